@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MGNet training hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run, one rank per
+GPU).  A step = one pass of the hot path (forward + backward) over one per-GPU batch of synthetic Cityscapes-shaped
+input that is already resident in HBM.  Rank 0 prints ONE JSON line.
+
+What is inside a step in this round: the self-supervised photometric reprojection loss of MGNet
+(MultiViewPhotometricLoss forward + backward, SURVEY.md 8a group G) at BASELINE.json's C4/C5 shape
+(1024x2048, 8 frames per GPU, 3 scales, 2 context frames).  The network rows (group N) are not in the step yet;
+`config.workload` says exactly what is timed.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
+FWD_BYTES_PER_PX = 49 + 12     # march kernel: reads 3 inv + 9 image floats + mask, writes 3 grad floats
+BWD_BYTES_PER_PX = 37 + 12     # streaming backward: 3 inv + 3 img + mask + 3 g (read) ; 3 d_inv (write)
+
+
+def synth_batch(B, H, W, seed, device):
+    """SURVEY.md 8(d) synthetic inputs, built on the GPU with torch (plumbing)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                            torch.arange(W + 16, device=device, dtype=torch.float32), indexing="ij")
+    img = torch.zeros(B, 3, H, W + 16, device=device)
+    for _ in range(8):
+        f = torch.rand(B, 3, 2, device=device, generator=g) * 0.2 + 0.005
+        ph = torch.rand(B, 3, 1, 1, device=device, generator=g) * 6.283
+        img += torch.sin(f[..., 0, None, None] * xx + f[..., 1, None, None] * yy + ph)
+    img = (img - img.amin((2, 3), keepdim=True)) / (img.amax((2, 3), keepdim=True) - img.amin((2, 3), keepdim=True))
+    img = (0.95 * img + 0.05 * torch.rand(img.shape, device=device, generator=g)).clamp(0, 1)
+    img = (img * 255).round() / 255  # uint8 frames / 255 like mg_net.py:320-335
+    cur = img[..., 8:8 + W].contiguous()
+    prev = torch.roll(img[..., 5:5 + W], 1, 2).contiguous()    # shifted by (+3,+1) px
+    nxt = torch.roll(img[..., 11:11 + W], -1, 2).contiguous()  # shifted by (-3,-1) px
+    inv = []
+    for s in (8, 16, 32):  # the heads predict at /8,/16,/32 and upsample bilinearly (mg_net.py:804-807)
+        lo = torch.rand(B, 1, H // s, W // s, device=device, generator=g) * 1.9 + 0.05
+        inv.append(torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=True).contiguous())
+    poses = 0.01 * torch.randn(B, 2, 6, device=device, generator=g)
+    mask = torch.rand(B, 1, H, W, device=device, generator=g) < 0.9
+    K = torch.eye(4, device=device).repeat(B, 1, 1)
+    sx, sy = W / 2048.0, H / 1024.0  # camera_utils.py:15-21 scale_intrinsics of the Cityscapes camera
+    K[:, 0, 0], K[:, 1, 1] = 2262.52 * sx, 2265.30 * sy
+    K[:, 0, 2], K[:, 1, 2] = (1096.98 + 0.5) * sx - 0.5, (513.137 + 0.5) * sy - 0.5
+    return dict(inv=inv, img=cur, prev=prev, nxt=nxt, poses=poses, mask=mask, K=K)
+
+
+class HipEvents:
+    """Raw hipEvent_t pair handed to the C-ABI (cfg.prof_begin/prof_end) so that the dominant kernel is timed on
+    the stream it is launched on."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.pairs = []
+        for _ in range(n):
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
+            self.pairs.append((a, b))
+
+    def elapsed_ms(self):
+        out = []
+        for a, b in self.pairs:
+            ms = ctypes.c_float()
+            assert self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+            out.append(ms.value)
+        return out
+
+
+def cpu_baseline(H, W):
+    """The pinned CPU oracle ("port" of the reference path) on a bounded sample: ONE frame of the workload."""
+    import oracle
+
+    oracle.build()
+    rs = np.random.RandomState(0)
+    B = 1
+    inv = [rs.uniform(0.05, 1.95, (B, 1, H, W)).astype(np.float32) for _ in range(3)]
+    img, prev, nxt = [rs.uniform(0, 1, (B, 3, H, W)).astype(np.float32) for _ in range(3)]
+    poses = (0.01 * rs.randn(B, 2, 6)).astype(np.float32)
+    mask = rs.uniform(size=(B, 1, H, W)) > 0.1
+    K = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = 2262.52, 2265.30, 1096.98, 513.137
+    t0 = time.time()
+    oracle.reproj_loss(inv, img, prev, nxt, mask, K, poses)
+    dt = time.time() - t0
+    return {"value": round(B / dt, 4), "unit": "img/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"1 frame {H}x{W}, reprojection loss fwd+bwd, oracle/reproj_oracle.c fp32 OpenMP, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU (C4/C5: 8)")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from mgnet_amd import _C
+    from mgnet_amd.modeling.loss import _ReprojLossFn
+
+    B, H, W = args.batch, args.height, args.width
+    d = synth_batch(B, H, W, 1234 + rank, dev)
+    inv = [x.requires_grad_(True) for x in d["inv"]]
+    poses = d["poses"].requires_grad_(True)
+    nsteps = args.warmup + args.steps
+    ev = HipEvents(args.steps)
+    cfgs = [_C.make_reproj_cfg(B, H, W, 3) for _ in range(nsteps)]
+    for k in range(args.steps):
+        cfgs[args.warmup + k].prof_begin, cfgs[args.warmup + k].prof_end = ev.pairs[k]
+    w = torch.ones(2, device=dev)
+
+    def step(k):
+        # data-parallel: each rank owns its B frames; the loss has no cross-rank term (per-rank means)
+        losses = _ReprojLossFn.apply(cfgs[k], d["img"], d["prev"], d["nxt"], d["mask"], d["K"], poses, *inv)
+        (losses * w).sum().backward()
+        for x in inv:
+            x.grad = None
+        poses.grad = None
+        return losses
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        last = step(args.warmup + k)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms = ev.elapsed_ms()
+        kern_ms = float(np.mean(ms))
+        npx = B * H * W
+        achieved = FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("B") == B and tj.get("H") == H and tj.get("W") == W:
+                traffic = tj.get("hbm_bytes_per_launch")
+        line = {
+            "metric": "training img/s at 1024x2048 Cityscapes, 1/2/4/8 MI355X; reprojection-loss HBM GB/s",
+            "value": round(world * B * args.steps / dt, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"MGNet-Cityscapes-VideoSequence (C4/C5 shape): photometric reprojection loss "
+                                   f"fwd+bwd only (SURVEY 8a group G; network rows N not in the step yet), "
+                                   f"{B} frames/GPU of {H}x{W}, 3 scales, 2 context frames",
+                       "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"dp{world}",
+                       "loss_photometric": float(last[0]), "loss_smoothness": float(last[1])},
+            "roofline": {"bound": "hbm", "kernel": "reproj_march<true> (fused loss + photometric gradient)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_launch": FWD_BYTES_PER_PX * npx, "avg_launch_ms": round(kern_ms, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(H, W)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,98 @@
+/*
+ * mgnet_hip.h -- C-ABI of libmgnet_hip.so: the MI355X (gfx950) kernels of MGNet's training hot path.
+ *
+ * The reference (uulm-mrm/MGNet) is pure Python on torch ops and has no FFI of its own; each entry
+ * point below replaces the chain of torch ops behind ONE reference function (cited per symbol), and
+ * is what a maintainer would bind with ctypes from that function.
+ *
+ * Conventions (all symbols):
+ *   - plain pointers and sizes only; no torch / C++ types; `stream` is a hipStream_t passed as void*
+ *   - every data pointer is a DEVICE pointer to a contiguous NCHW fp32 tensor unless stated otherwise
+ *   - returns 0 on success, a negative MGN_E* code on error; never throws, never allocates, never syncs
+ *   - stream-ordered, re-entrant; scratch space is caller-provided (`*_workspace_bytes` query per op)
+ */
+#ifndef MGNET_HIP_H
+#define MGNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGN_OK 0
+#define MGN_EINVAL (-22)     /* bad shape / null pointer / unsupported option value            */
+#define MGN_ENOSPC (-28)     /* workspace too small                                            */
+#define MGN_ENOTSUP (-95)    /* option exists in the reference but has no kernel yet           */
+#define MGN_ELAUNCH (-5)     /* hipLaunchKernel reported an error                              */
+
+#define MGN_MAX_SCALES 4
+
+/* library identification: "mgnet_hip <version> gfx950" */
+const char* mgn_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Self-supervised photometric reprojection loss
+ *   replaces mgnet/modeling/loss.py:111-154  MultiViewPhotometricLoss.forward  (+ its autograd backward)
+ *   and everything it calls in mgnet/geometry (camera.py:107-182, camera_utils.py:24-55, pose.py:40-95,
+ *   pose_utils.py:9-59, depth.py:11-51, image.py:42-69) and loss.py:156-294.
+ *
+ * Configuration supported by the kernels = the reference defaults (mgnet/config.py:109-117):
+ *   automask_loss=True, photometric_reduce_op="min", padding_mode="zeros", ssim_loss_weight>0.
+ *   Other values return MGN_ENOTSUP (no silent fallback).
+ *
+ * Inputs
+ *   inv_depth[n_scales] : [B,1,H,W] fp32 each (all scales already at full resolution, mg_net.py:804-807)
+ *   img, prev, next     : [B,3,H,W] fp32 in [0,1]   (image_orig, image_prev_orig, image_next_orig)
+ *   mask                : [B,1,H,W] uint8 (torch.bool storage) or NULL = all ones (loss.py:236-237)
+ *   cam                 : camera matrices, fp32; `cam_stride` floats between images and `cam_ld` floats between
+ *                         rows, so that camera_matrix[B,4,4] (cam_stride=16, cam_ld=4) is consumed in place
+ *                         (loss.py:122 takes [:, :3, :3])
+ *   pose                : [B,2,6] fp32 (tx,ty,tz,rx,ry,rz) for prev and next (loss.py:117-119)
+ * Outputs
+ *   losses              : device fp32[2] = { photometric_loss_weight * L_p , smoothing_loss_weight * L_s }
+ *   d_pose              : device fp32[B,2,6] = d losses[0] / d pose              (only if want_grad)
+ *   g_inv[n_scales]     : [B,1,H,W] fp32, UNSCALED photometric gradient wrt inv_depth (only if want_grad);
+ *                         mgn_reproj_loss_bwd turns it into the final gradient in place
+ *   dbg_minmap          : optional [n_scales][B,1,H,W] per-pixel min photometric map (tests), or NULL
+ *
+ * The forward launch computes the loss AND (want_grad!=0) the pixel-wise photometric gradient in the same
+ * pass over the inputs; mgn_reproj_loss_bwd is a light streaming kernel that applies the upstream gradients
+ * and adds the smoothness term.  Algorithmic HBM traffic: fwd 49 B/px read + 12 B/px written,
+ * bwd 37 B/px read + 12 B/px written (+12 B/px read of g_inv) = 110 B/px per training step.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int B, H, W;
+    int n_scales;             /* 1..MGN_MAX_SCALES */
+    float ssim_loss_weight;   /* 0.85 */
+    float photometric_loss_weight; /* 1.0 */
+    float smoothing_loss_weight;   /* 0.001 */
+    int automask_loss;        /* must be 1 */
+    int photometric_reduce_op;/* 0 = "min" (only supported value), 1 = "mean" */
+    int padding_mode;         /* 0 = "zeros" (only supported value), 1 = "border", 2 = "reflection" */
+    int rows_per_wave;        /* 0 = choose automatically; else rows each wavefront owns (>=4) */
+    void* prof_begin;         /* optional hipEvent_t recorded on `stream` right before the dominant kernel */
+    void* prof_end;           /* optional hipEvent_t recorded right after it (bench.py's roofline leg); NULL = off */
+} mgn_reproj_cfg;
+
+int mgn_reproj_workspace_bytes(const mgn_reproj_cfg* cfg, size_t* bytes);
+
+int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg,
+                        const float* const* inv_depth, const float* img, const float* prev, const float* next,
+                        const uint8_t* mask, const float* cam, int cam_stride, int cam_ld, const float* pose,
+                        int want_grad, float* losses, float* d_pose, float* const* g_inv, float* dbg_minmap,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* grad_losses: device fp32[2] = upstream gradients of {loss_photometric, loss_smoothness}.
+ * g_inv[i] (written by the forward with want_grad=1 and the SAME workspace) is overwritten with
+ * d(grad_losses . losses)/d inv_depth[i].  d_pose_out[B,2,6] = grad_losses[0] * d_pose. */
+int mgn_reproj_loss_bwd(const mgn_reproj_cfg* cfg,
+                        const float* const* inv_depth, const float* img, const uint8_t* mask,
+                        const float* grad_losses, const float* d_pose, float* const* g_inv, float* d_pose_out,
+                        const void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGNET_HIP_H */

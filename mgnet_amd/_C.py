@@ -1,0 +1,126 @@
+"""ctypes binding of include/mgnet_hip.h (libmgnet_hip.so).  Fails loudly when the extension is missing."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmgnet_hip.so")
+
+MGN_MAX_SCALES = 4
+_ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspace too small)",
+        -95: "MGN_ENOTSUP (option has no kernel)", -5: "MGN_ELAUNCH (kernel launch failed)"}
+
+# every symbol include/mgnet_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd"]
+
+
+class ReprojCfg(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("n_scales", ctypes.c_int),
+                ("ssim_loss_weight", ctypes.c_float), ("photometric_loss_weight", ctypes.c_float),
+                ("smoothing_loss_weight", ctypes.c_float), ("automask_loss", ctypes.c_int),
+                ("photometric_reduce_op", ctypes.c_int), ("padding_mode", ctypes.c_int), ("rows_per_wave", ctypes.c_int),
+                ("prof_begin", ctypes.c_void_p), ("prof_end", ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m mgnet_amd.build` "
+                "(needs hipcc). mgnet_amd has no CPU fallback by design.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+        L.mgn_version.restype = ctypes.c_char_p
+        L.mgn_reproj_workspace_bytes.restype = ci
+        L.mgn_reproj_workspace_bytes.argtypes = [ctypes.POINTER(ReprojCfg), ctypes.POINTER(sz)]
+        L.mgn_reproj_loss_fwd.restype = ci
+        L.mgn_reproj_loss_fwd.argtypes = [ctypes.POINTER(ReprojCfg), vp, vp, vp, vp, vp, vp, ci, ci, vp, ci, vp, vp, vp,
+                                          vp, vp, sz, vp]
+        L.mgn_reproj_loss_bwd.restype = ci
+        L.mgn_reproj_loss_bwd.argtypes = [ctypes.POINTER(ReprojCfg), vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        err = _ERR.get(rc, str(rc))
+        if rc == -95:
+            raise NotImplementedError(f"{what}: {err}")
+        raise RuntimeError(f"{what}: {err}")
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * MGN_MAX_SCALES)()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _dev_f32(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous float32 tensor on the GPU, got {t.dtype} {t.device} "
+                         f"contiguous={t.is_contiguous()}")
+    return t
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_PAD = {"zeros": 0, "border": 1, "reflection": 2}
+_RED = {"min": 0, "mean": 1}
+
+
+def make_reproj_cfg(B, H, W, n_scales, ssim_w=0.85, photo_w=1.0, smooth_w=0.001, automask=True, reduce_op="min",
+                    padding_mode="zeros", rows_per_wave=0):
+    return ReprojCfg(B, H, W, n_scales, ssim_w, photo_w, smooth_w, int(bool(automask)), _RED[reduce_op],
+                     _PAD[padding_mode], rows_per_wave, None, None)
+
+
+def reproj_workspace_bytes(cfg):
+    n = ctypes.c_size_t(0)
+    check(lib().mgn_reproj_workspace_bytes(ctypes.byref(cfg), ctypes.byref(n)), "mgn_reproj_workspace_bytes")
+    return n.value
+
+
+def reproj_loss_fwd(cfg, inv, img, prev, nxt, mask, cam, pose, want_grad=True, want_minmap=False):
+    """-> dict(losses[2], d_pose[B,2,6], g_inv[list], workspace, minmap)   (all device tensors, stream-ordered)"""
+    dev = img.device
+    inv = [_dev_f32(t, f"inv_depth[{i}]") for i, t in enumerate(inv)]
+    for n_, t in (("img", img), ("prev", prev), ("next", nxt), ("camera_matrix", cam), ("pose", pose)):
+        _dev_f32(t, n_)
+    if mask is not None:
+        if mask.dtype not in (torch.bool, torch.uint8) or not mask.is_contiguous() or not mask.is_cuda:
+            raise ValueError("reprojection_mask: expected a contiguous bool/uint8 GPU tensor")
+    cam_ld = cam.shape[-1]
+    cam_stride = cam.shape[-1] * cam.shape[-2]
+    ws = torch.empty(reproj_workspace_bytes(cfg), dtype=torch.uint8, device=dev)
+    losses = torch.empty(2, dtype=torch.float32, device=dev)
+    d_pose = torch.empty((cfg.B, 2, 6), dtype=torch.float32, device=dev) if want_grad else None
+    g_inv = [torch.empty_like(t) for t in inv] if want_grad else None
+    minmap = torch.zeros((cfg.n_scales, cfg.B, 1, cfg.H, cfg.W), dtype=torch.float32, device=dev) if want_minmap else None
+    rc = lib().mgn_reproj_loss_fwd(
+        ctypes.byref(cfg), _ptr_array(inv), img.data_ptr(), prev.data_ptr(), nxt.data_ptr(),
+        None if mask is None else mask.data_ptr(), cam.data_ptr(), cam_stride, cam_ld, pose.data_ptr(), int(want_grad),
+        losses.data_ptr(), None if d_pose is None else d_pose.data_ptr(), None if g_inv is None else _ptr_array(g_inv),
+        None if minmap is None else minmap.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "mgn_reproj_loss_fwd")
+    return {"losses": losses, "d_pose": d_pose, "g_inv": g_inv, "workspace": ws, "minmap": minmap}
+
+
+def reproj_loss_bwd(cfg, inv, img, mask, grad_losses, fwd):
+    """Finishes the backward IN PLACE on fwd['g_inv']; returns (d_inv list, d_pose)."""
+    _dev_f32(grad_losses, "grad_losses")
+    d_pose_out = torch.empty_like(fwd["d_pose"])
+    rc = lib().mgn_reproj_loss_bwd(
+        ctypes.byref(cfg), _ptr_array(inv), img.data_ptr(), None if mask is None else mask.data_ptr(),
+        grad_losses.data_ptr(), fwd["d_pose"].data_ptr(), _ptr_array(fwd["g_inv"]), d_pose_out.data_ptr(),
+        fwd["workspace"].data_ptr(), fwd["workspace"].numel(), _stream())
+    check(rc, "mgn_reproj_loss_bwd")
+    return fwd["g_inv"], d_pose_out

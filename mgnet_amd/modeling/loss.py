@@ -1,0 +1,82 @@
+"""Host-side mirror of mgnet/modeling/loss.py for the hot path: same class names, constructor arguments,
+`forward(predictions, targets)` contract and error behaviour; the arithmetic runs in libmgnet_hip.so."""
+import torch
+import torch.nn as nn
+
+from .. import _C
+
+__all__ = ["MultiViewPhotometricLoss"]
+
+
+class _ReprojLossFn(torch.autograd.Function):
+    """losses[2] = f(inv_depth_0..n-1, poses | images, mask, K).  Gradients flow to the inverse depths and the
+    poses only (reference: SURVEY 3.3 -- images, intrinsics and mask carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, cfg, img, prev, nxt, mask, cam, poses, *inv):
+        want_grad = any(t.requires_grad for t in inv) or poses.requires_grad
+        inv = [t.contiguous() for t in inv]
+        poses = poses.contiguous()
+        fwd = _C.reproj_loss_fwd(cfg, inv, img, prev, nxt, mask, cam, poses, want_grad=want_grad)
+        ctx.cfg, ctx.fwd, ctx.inv, ctx.img, ctx.mask = cfg, fwd, inv, img, mask
+        ctx.want_grad = want_grad
+        ctx.used = False
+        return fwd["losses"]
+
+    @staticmethod
+    def backward(ctx, grad_losses):
+        if not ctx.want_grad:
+            return (None,) * (7 + len(ctx.inv))
+        if ctx.used:
+            raise RuntimeError("MultiViewPhotometricLoss: backward called twice on the same forward; the fused "
+                               "gradient buffers are consumed in place (re-run the forward instead of retain_graph)")
+        ctx.used = True
+        d_inv, d_pose = _C.reproj_loss_bwd(ctx.cfg, ctx.inv, ctx.img, ctx.mask, grad_losses.contiguous().float(), ctx.fwd)
+        return (None, None, None, None, None, None, d_pose) + tuple(d_inv)
+
+
+class MultiViewPhotometricLoss(nn.Module):
+    """Drop-in for mgnet.modeling.loss.MultiViewPhotometricLoss (loss.py:84-154).
+
+    predictions = {"depth": [inv_depth_i [B,1,H,W]], "poses": [B,2,6]}
+    targets     = {"image_orig", "image_prev_orig", "image_next_orig": [B,3,H,W] in [0,1],
+                   "camera_matrix": [B,4,4] (or [B,3,3]), optional "reprojection_mask": [B,1,H,W] bool}
+    returns     {"loss_photometric", "loss_smoothness"}  (already multiplied by their weights, loss.py:151-154)
+    """
+
+    def __init__(self, ssim_loss_weight, photometric_loss_weight, smoothing_loss_weight, automask_loss,
+                 photometric_reduce_op, padding_mode):
+        super().__init__()
+        self.n = None
+        self.ssim_loss_weight = ssim_loss_weight
+        self.photometric_loss_weight = photometric_loss_weight
+        self.smoothing_loss_weight = smoothing_loss_weight
+        self.automask_loss = automask_loss
+        self.photometric_reduce_op = photometric_reduce_op
+        self.padding_mode = padding_mode
+        if self.automask_loss:  # loss.py:105-109
+            assert (
+                self.photometric_reduce_op == "min"
+            ), "For automasking only the min photometric_reduce_op is supported."
+
+    def forward(self, predictions, targets):
+        inv_depths = predictions["depth"]
+        pose_results = predictions["poses"]
+        self.n = len(inv_depths)
+        assert pose_results.shape[1] == 2, "Context and poses lists must be of same length"  # loss.py:120
+        img = targets["image_orig"]
+        B, _, H, W = img.shape
+        for x in inv_depths:  # match_scales would resize the image (image.py:101-135); the head already upsamples
+            if tuple(x.shape[-2:]) != (H, W):
+                raise NotImplementedError("inverse depths must already be at image resolution (mg_net.py:804-807)")
+        cfg = _C.make_reproj_cfg(B, H, W, self.n, self.ssim_loss_weight, self.photometric_loss_weight,
+                                 self.smoothing_loss_weight, self.automask_loss, self.photometric_reduce_op,
+                                 self.padding_mode)
+        mask = targets.get("reprojection_mask", None)
+        if mask is not None:
+            mask = mask.contiguous()
+        f32 = lambda t: t.float().contiguous()
+        losses = _ReprojLossFn.apply(cfg, f32(img), f32(targets["image_prev_orig"]), f32(targets["image_next_orig"]),
+                                     mask, f32(targets["camera_matrix"]), pose_results.float(),
+                                     *[x.float() for x in inv_depths])
+        return {"loss_photometric": losses[0], "loss_smoothness": losses[1]}

@@ -1,0 +1,232 @@
+"""GPU parity: the HIP reprojection loss (through the C-ABI) against the golden vectors of the reference and the
+pinned CPU oracle.  Tolerances follow SURVEY.md 8(d): fp32 kernels, different evaluation order."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import REPROJ_CASES, golden_case_inputs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(c):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d = {k: t(c[k]) for k in ("img", "prev", "nxt", "poses", "K")}
+    d["inv"] = [t(a) for a in c["inv"]]
+    d["mask"] = None if c["mask"] is None else t(c["mask"])
+    return d
+
+
+def run_hip(c, g=(1.0, 1.0), rows_per_wave=0, want_grad=True, want_minmap=False):
+    from mgnet_amd import _C
+
+    d = _dev(c)
+    B, _, H, W = c["img"].shape
+    cfg = _C.make_reproj_cfg(B, H, W, len(c["inv"]), rows_per_wave=rows_per_wave)
+    fwd = _C.reproj_loss_fwd(cfg, d["inv"], d["img"], d["prev"], d["nxt"], d["mask"], d["K"], d["poses"],
+                             want_grad=want_grad, want_minmap=want_minmap)
+    out = {"losses": fwd["losses"].cpu().numpy()}
+    if want_minmap:
+        out["minmap"] = fwd["minmap"].cpu().numpy()
+    if want_grad:
+        out["d_pose_unit"] = fwd["d_pose"].cpu().numpy()
+        gl = torch.tensor(g, dtype=torch.float32, device="cuda")
+        d_inv, d_pose = _C.reproj_loss_bwd(cfg, d["inv"], d["img"], d["mask"], gl, fwd)
+        out["d_inv"] = [x.cpu().numpy() for x in d_inv]
+        out["d_pose"] = d_pose.cpu().numpy()
+    torch.cuda.synchronize()
+    return out
+
+
+def grad_close(got, ref, name, rtol=2e-3, frac_tol=5e-3, agg_tol=2e-2):
+    scale = np.abs(ref).max() + 1e-30
+    if scale < 1e-10:
+        assert np.abs(got).max() < 1e-9, name
+        return
+    err = np.abs(got - ref) / scale
+    frac = float((err > rtol).mean())
+    assert frac < frac_tol, (name, "mismatching fraction", frac, float(err.max()))
+    agg = np.abs(got - ref).sum() / (np.abs(ref).sum() + 1e-30)
+    assert agg < agg_tol, (name, "aggregate rel err", agg)
+
+
+def test_dpp_wave_shift_semantics():
+    """The SSIM windows rely on DPP wave_shr:1/wave_shl:1 == neighbour lanes; a constant image must give the
+    analytic photometric value everywhere (any lane mix-up breaks the 9-tap sums at strip borders)."""
+    B, H, W = 1, 16, 150
+    c = dict(inv=[np.full((B, 1, H, W), 0.5, np.float32)] * 3, img=np.full((B, 3, H, W), 0.25, np.float32),
+             prev=np.full((B, 3, H, W), 0.75, np.float32), nxt=np.full((B, 3, H, W), 0.75, np.float32),
+             poses=np.zeros((B, 2, 6), np.float32), mask=None,
+             K=np.array([[[100.0, 0, 75, 0], [0, 100.0, 8, 0], [0, 0, 1, 0], [0, 0, 0, 1]]], np.float32))
+    r = run_hip(c, want_grad=False, want_minmap=True)
+    o = oracle.reproj_loss(c["inv"], c["img"], c["prev"], c["nxt"], None, c["K"], c["poses"], want_grad=False, want_minmap=True)
+    for i in range(3):
+        np.testing.assert_allclose(r["minmap"][i], o["minmap"][i], atol=2e-6)
+    assert np.ptp(r["minmap"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", REPROJ_CASES)
+def test_forward_matches_reference_and_oracle(name):
+    c = golden_case_inputs(name)
+    _, out = load_golden("reproj_" + name)
+    r = run_hip(c, want_grad=False, want_minmap=True)
+    lp, ls = float(out["loss_photometric"]), float(out["loss_smoothness"])
+    assert abs(r["losses"][0] - lp) <= 2e-5 * max(abs(lp), 1e-3), (r["losses"][0], lp)
+    assert abs(r["losses"][1] - ls) <= 2e-5 * abs(ls), (r["losses"][1], ls)
+    o = oracle.reproj_loss(c["inv"], c["img"], c["prev"], c["nxt"], c["mask"], c["K"], c["poses"], want_grad=False)
+    assert abs(r["losses"][0] - o["loss_photometric"]) <= 2e-5 * max(abs(lp), 1e-3)
+    assert abs(r["losses"][1] - o["loss_smoothness"]) <= 2e-5 * abs(ls)
+    for i in range(3):
+        err = np.abs(r["minmap"][i] - out[f"minmap{i}"])
+        assert float((err > 3e-5).mean()) < 3e-3 and err.max() < 2e-3, (name, i, float((err > 3e-5).mean()), err.max())
+
+
+@pytest.mark.parametrize("name", REPROJ_CASES)
+def test_gradients_match_reference(name):
+    c = golden_case_inputs(name)
+    _, out = load_golden("reproj_" + name)
+    rp = run_hip(c, g=(1.0, 0.0))
+    rs = run_hip(c, g=(0.0, 1.0))
+    for i in range(3):
+        grad_close(rp["d_inv"][i], out[f"dphot_dinv{i}"], f"{name}/dphot_dinv{i}")
+        ref_s = out[f"dsmooth_dinv{i}"]
+        np.testing.assert_allclose(rs["d_inv"][i], ref_s, rtol=1e-3, atol=1e-4 * np.abs(ref_s).max())
+    ref_p = out["dphot_dposes"]
+    if name == "identity_pose":
+        assert np.abs(rp["d_pose"]).max() < 1e-5
+    else:
+        np.testing.assert_allclose(rp["d_pose"], ref_p, rtol=5e-3, atol=5e-3 * np.abs(ref_p).max() + 1e-9)
+    assert np.all(rs["d_pose"] == 0)
+    # linearity in the upstream gradients
+    r2 = run_hip(c, g=(0.5, -2.0))
+    for i in range(3):
+        np.testing.assert_allclose(r2["d_inv"][i], 0.5 * rp["d_inv"][i] - 2.0 * rs["d_inv"][i], rtol=1e-5,
+                                   atol=1e-6 * (np.abs(rp["d_inv"][i]).max() + np.abs(rs["d_inv"][i]).max()))
+
+
+def test_survey_case_192x640():
+    c = golden_case_inputs("survey_192x640")
+    _, out = load_golden("reproj_survey_192x640")
+    rp = run_hip(c, g=(1.0, 0.0))
+    rs = run_hip(c, g=(0.0, 1.0))
+    lp, ls = float(out["loss_photometric"]), float(out["loss_smoothness"])
+    assert abs(rp["losses"][0] - lp) <= 1e-5 * lp and abs(rp["losses"][1] - ls) <= 1e-5 * ls
+    ref_p = out["dphot_dposes"]
+    np.testing.assert_allclose(rp["d_pose"], ref_p, rtol=2e-2, atol=2e-2 * np.abs(ref_p).max())
+    for i in range(3):
+        grad_close(rp["d_inv"][i][:, :, ::16, ::16], out[f"dphot_dinv{i}_s"], f"survey/dphot{i}")
+        got_abs = np.abs(rp["d_inv"][i].astype(np.float64)).sum()
+        assert abs(got_abs - float(out[f"dphot_dinv{i}_abssum"])) < 1e-2 * float(out[f"dphot_dinv{i}_abssum"])
+        ref_s = out[f"dsmooth_dinv{i}_s"]
+        np.testing.assert_allclose(rs["d_inv"][i][:, :, ::16, ::16], ref_s, rtol=1e-3, atol=1e-4 * np.abs(ref_s).max())
+
+
+@pytest.mark.parametrize("rows", [4, 5, 8, 16, 64])
+def test_tiling_invariance(rows):
+    """Row-segment height only changes which wavefront owns a pixel: results must agree with the default tiling
+    (catches halo / reflect / ownership errors at every segment border)."""
+    c = golden_case_inputs("smooth")
+    a = run_hip(c, rows_per_wave=0, want_minmap=True)
+    b = run_hip(c, rows_per_wave=rows, want_minmap=True)
+    np.testing.assert_allclose(a["losses"], b["losses"], rtol=2e-6)
+    np.testing.assert_array_equal(a["minmap"], b["minmap"])
+    for i in range(3):
+        np.testing.assert_array_equal(a["d_inv"][i], b["d_inv"][i])
+    np.testing.assert_allclose(a["d_pose"], b["d_pose"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 2), (1, 3, 5), (2, 7, 61), (1, 9, 121), (3, 33, 64)])
+def test_ragged_shapes_against_oracle(shape):
+    """Tiny / odd sizes: W below, at and just above one 60-column strip; H of 2 and 3 (reflect pad meets itself)."""
+    B, H, W = shape
+    rs_ = np.random.RandomState(B * 1000 + H * 37 + W)
+    c = dict(inv=[rs_.uniform(0.05, 1.95, (B, 1, H, W)).astype(np.float32) for _ in range(3)],
+             img=rs_.uniform(0, 1, (B, 3, H, W)).astype(np.float32), prev=rs_.uniform(0, 1, (B, 3, H, W)).astype(np.float32),
+             nxt=rs_.uniform(0, 1, (B, 3, H, W)).astype(np.float32), poses=(0.02 * rs_.randn(B, 2, 6)).astype(np.float32),
+             mask=rs_.uniform(0, 1, (B, 1, H, W)) > 0.2)
+    K = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = 0.6 * W, 1.9 * H, 0.5 * W, 0.5 * H
+    c["K"] = K
+    c["mask"][0, 0, 0, 0] = True
+    rp = run_hip(c, g=(1.0, 0.0), want_minmap=True)
+    rs = run_hip(c, g=(0.0, 1.0))
+    op = oracle.reproj_loss(c["inv"], c["img"], c["prev"], c["nxt"], c["mask"], c["K"], c["poses"], g_photo=1.0, g_smooth=0.0, want_minmap=True)
+    os_ = oracle.reproj_loss(c["inv"], c["img"], c["prev"], c["nxt"], c["mask"], c["K"], c["poses"], g_photo=0.0, g_smooth=1.0)
+    np.testing.assert_allclose(rp["losses"][0], op["loss_photometric"], rtol=3e-5)
+    if np.isfinite(op["loss_smoothness"]):
+        np.testing.assert_allclose(rp["losses"][1], op["loss_smoothness"], rtol=3e-5)
+    for i in range(3):
+        err = np.abs(rp["minmap"][i] - op["minmap"][i])
+        assert err.max() < 2e-3 and float((err > 3e-5).mean()) < 2e-2, (shape, i, err.max())
+        grad_close(rp["d_inv"][i], op["d_inv"][i], f"{shape}/dphot{i}", frac_tol=3e-2, agg_tol=5e-2)
+        if np.isfinite(op["loss_smoothness"]):
+            ref_s = os_["d_inv"][i]
+            np.testing.assert_allclose(rs["d_inv"][i], ref_s, rtol=2e-3, atol=2e-4 * np.abs(ref_s).max())
+    ref_p = op["d_poses"]
+    np.testing.assert_allclose(rp["d_pose"], ref_p, rtol=2e-2, atol=2e-2 * np.abs(ref_p).max() + 1e-9)
+
+
+def test_bitwise_deterministic():
+    c = golden_case_inputs("rand_small")
+    a, b = run_hip(c), run_hip(c)
+    assert np.array_equal(a["losses"], b["losses"]) and np.array_equal(a["d_pose"], b["d_pose"])
+    for i in range(3):
+        assert np.array_equal(a["d_inv"][i], b["d_inv"][i])
+
+
+def test_module_autograd_matches_reference():
+    """The nn.Module mirror (same ctor/forward contract as loss.py:84-154) under torch autograd."""
+    from mgnet_amd.modeling import MultiViewPhotometricLoss
+
+    c = golden_case_inputs("rand_small")
+    _, out = load_golden("reproj_rand_small")
+    d = _dev(c)
+    inv = [x.clone().requires_grad_(True) for x in d["inv"]]
+    poses = d["poses"].clone().requires_grad_(True)
+    crit = MultiViewPhotometricLoss(0.85, 1.0, 0.001, True, "min", "zeros")
+    res = crit({"depth": inv, "poses": poses}, {"image_orig": d["img"], "image_prev_orig": d["prev"],
+                                               "image_next_orig": d["nxt"], "camera_matrix": d["K"],
+                                               "reprojection_mask": d["mask"]})
+    assert set(res) == {"loss_photometric", "loss_smoothness"}
+    (res["loss_photometric"] + res["loss_smoothness"]).backward()
+    for i in range(3):
+        grad_close(inv[i].grad.cpu().numpy(), out[f"dphot_dinv{i}"] + out[f"dsmooth_dinv{i}"], f"module/dinv{i}")
+    np.testing.assert_allclose(poses.grad.cpu().numpy(), out["dphot_dposes"], rtol=5e-3,
+                               atol=5e-3 * np.abs(out["dphot_dposes"]).max())
+    with pytest.raises(AssertionError):
+        MultiViewPhotometricLoss(0.85, 1.0, 0.001, True, "mean", "zeros")  # loss.py:105-109
+    with pytest.raises(NotImplementedError):
+        bad = MultiViewPhotometricLoss(0.85, 1.0, 0.001, True, "min", "border")
+        bad({"depth": [x.detach() for x in inv], "poses": poses.detach()},
+            {"image_orig": d["img"], "image_prev_orig": d["prev"], "image_next_orig": d["nxt"], "camera_matrix": d["K"]})
+
+
+def test_full_size_properties():
+    """1024x2048, B=2 (BASELINE size per image): size-independent properties instead of an oracle run.
+    (a) identity pose + identical frames => photometric loss ~ 0;  (b) constant inverse depth => smoothness 0
+    (SURVEY section 4 KATs);  (c) loss equals the mean of the per-image losses when masks have equal counts;
+    (d) gradients are finite and linear in the upstream gradient."""
+    B, H, W = 2, 1024, 2048
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(1, 3, H, W, generator=g).repeat(B, 1, 1, 1)
+    K = torch.eye(4).repeat(B, 1, 1)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = 2262.52, 2265.30, 1096.98, 513.137
+    c = dict(inv=[np.full((B, 1, H, W), 0.7, np.float32)] * 3, img=img.numpy(), prev=img.numpy(), nxt=img.numpy(),
+             poses=np.zeros((B, 2, 6), np.float32), mask=None, K=K.numpy())
+    r = run_hip(c, want_grad=False)
+    assert abs(r["losses"][0]) < 1e-4 and r["losses"][1] == 0.0
+    rs_ = np.random.RandomState(11)
+    one = dict(inv=[rs_.uniform(0.05, 1.95, (1, 1, H, W)).astype(np.float32) for _ in range(3)],
+               img=rs_.uniform(0, 1, (1, 3, H, W)).astype(np.float32), prev=rs_.uniform(0, 1, (1, 3, H, W)).astype(np.float32),
+               nxt=rs_.uniform(0, 1, (1, 3, H, W)).astype(np.float32), poses=(0.01 * rs_.randn(1, 2, 6)).astype(np.float32),
+               mask=None, K=K.numpy()[:1])
+    two = {k: (np.concatenate([v, v]) if isinstance(v, np.ndarray) else v) for k, v in one.items()}
+    two["inv"] = [np.concatenate([a, a]) for a in one["inv"]]
+    r1, r2 = run_hip(one), run_hip(two)
+    np.testing.assert_allclose(r1["losses"], r2["losses"], rtol=2e-6)
+    for i in range(3):
+        assert np.isfinite(r2["d_inv"][i]).all()
+        np.testing.assert_allclose(r2["d_inv"][i][0], 0.5 * r1["d_inv"][i][0], rtol=1e-5, atol=1e-12)
+        np.testing.assert_array_equal(r2["d_inv"][i][0], r2["d_inv"][i][1])
+    np.testing.assert_allclose(r2["d_pose"][0], 0.5 * r1["d_pose"][0], rtol=1e-4, atol=1e-9)
