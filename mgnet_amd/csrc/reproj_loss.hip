@@ -82,17 +82,29 @@ __device__ __forceinline__ int reflect_clamp(int i, int n) {
 
 // loss.py:200-220 on window SUMS (9 taps).  Returns clamp((1-ssim)/2,0,1); if GRAD also the coefficients of
 // d ssim / d x[r] = alpha + beta*y[r] + gamma*x[r]  (valid for every tap r of the window).
+// Exactness contract: when x == y bitwise over the window, every intermediate below is bitwise symmetric in x and
+// y (explicit fmaf pattern for the products, no compiler contraction inside ssim_from_sums), so ssim == 1 and the
+// automask term of a static pixel is exactly 0 -- as in the reference, where the torch ops are rounded one by one.
+__device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
+    return fmaf(a0, b0, fmaf(a1, b1, a2 * b2));
+}
+
 template <bool GRAD>
 __device__ __forceinline__ float ssim_from_sums(float Sx, float Sy, float Sxx, float Syy, float Sxy, float& alpha,
                                                 float& beta, float& gamma, bool& gate) {
+#pragma clang fp contract(off)
     constexpr float r9 = 1.0f / 9.0f;
     const float mux = Sx * r9, muy = Sy * r9;
     const float mxx = mux * mux, myy = muy * muy, mxy = mux * muy;
     const float sgx = Sxx * r9 - mxx, sgy = Syy * r9 - myy, sgxy = Sxy * r9 - mxy;
     const float N1 = 2.f * mxy + SSIM_C1, N2 = 2.f * sgxy + SSIM_C2;
     const float D1 = mxx + myy + SSIM_C1, D2 = sgx + sgy + SSIM_C2;
-    const float i12 = frcp(D1 * D2);
-    const float s = N1 * N2 * i12;
+    // quotient = v_rcp_f32 + one Newton step: exactly 1 when numerator == denominator bitwise, so that
+    // ssim(x,x) == 1 and the automask term of identical frames is exactly 0 like the reference's true division
+    const float num = N1 * N2, den = D1 * D2;
+    const float i12 = frcp(den);
+    const float q0 = num * i12;
+    const float s = fmaf(fmaf(-den, q0, num), i12, q0);
     const float val = (1.f - s) * 0.5f;
     if (GRAD) {
         gate = (val >= 0.f) && (val <= 1.f);  // torch.clamp backward passes at the bounds
@@ -314,22 +326,22 @@ __global__ __launch_bounds__(WAVE* WPB) void reproj_march(Params p) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float Sy = hsum3(y2[c] + y1[c] + y0[c]);
-                        const float Syy = hsum3(y2[c] * y2[c] + y1[c] * y1[c] + y0[c] * y0[c]);
+                        const float Syy = hsum3(dot3(y2[c], y1[c], y0[c], y2[c], y1[c], y0[c]));
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             {   // warped image vs target
                                 const float a = xw2[j][c], bq = xw1[j][c], cc = xw0[j][c];
                                 const float Sx = hsum3(a + bq + cc);
-                                const float Sxx = hsum3(a * a + bq * bq + cc * cc);
-                                const float Sxy = hsum3(a * y2[c] + bq * y1[c] + cc * y0[c]);
+                                const float Sxx = hsum3(dot3(a, bq, cc, a, bq, cc));
+                                const float Sxy = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
                                 const float v = ssim_from_sums<GRAD>(Sx, Sy, Sxx, Syy, Sxy, al[j][c], be[j][c], ga[j][c], gt[j][c]);
                                 pw[j] += ssim_w3 * v + l1_w3 * fabsf(bq - y1[c]);
                             }
                             {   // un-warped context image vs target (automask, loss.py:139-144)
                                 const float a = rf2[j][c], bq = rf1[j][c], cc = rf0[j][c];
                                 const float Sx = hsum3(a + bq + cc);
-                                const float Sxx = hsum3(a * a + bq * bq + cc * cc);
-                                const float Sxy = hsum3(a * y2[c] + bq * y1[c] + cc * y0[c]);
+                                const float Sxx = hsum3(dot3(a, bq, cc, a, bq, cc));
+                                const float Sxy = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
                                 float d0, d1, d2;
                                 bool g0;
                                 const float v = ssim_from_sums<false>(Sx, Sy, Sxx, Syy, Sxy, d0, d1, d2, g0);
