@@ -199,7 +199,7 @@ __global__ void reproj_prep(const float* cam, int cam_stride, int cam_ld, const 
 // the row-march kernel
 // ---------------------------------------------------------------------------------------------------
 template <bool GRAD>
-__global__ __launch_bounds__(WAVE* WPB) void reproj_march(Params p) {
+__global__ __launch_bounds__(WAVE* WPB, 2) void reproj_march(Params p) {
     __shared__ float ring[WPB][RING][NSTATE][WAVE];
     __shared__ float red[WPB][NACC];
 
@@ -242,9 +242,14 @@ __global__ __launch_bounds__(WAVE* WPB) void reproj_march(Params p) {
     const float exp_to_left = (cu == W - 1) ? 2.f : 1.f;   // value exported to lane-1
 
     for (int i = 0; i < p.n; ++i) {
-        float acc[NACC];
+        float acc[A_POSE];        // scalar sums (slots 0..7)
+        float pacc[2][9];         // pose sums per context: sum s, sum s*row, sum dXc   (the column factor fu is per-lane constant)
 #pragma unroll
-        for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+        for (int k = 0; k < A_POSE; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) pacc[j][k] = 0.f;
 
         if (wave_active) {
             const float* invb = p.inv[i] + (size_t)b * HWp;
@@ -427,12 +432,10 @@ __global__ __launch_bounds__(WAVE* WPB) void reproj_march(Params p) {
                         const float a0 = base[j][0] + col1[j][0] * fr, a1 = base[j][1] + col1[j][1] * fr, a2 = base[j][2] + col1[j][2] * fr;
                         ddsum += dX * a0 + dY * a1 + dz * a2;
                         if (lane_own) {
-                            float* ap = &acc[A_POSE + j * 12];
                             const float sX = dd_ * dX, sY = dd_ * dY, sZ = dd_ * dz;
-                            ap[0] += sX * fu; ap[1] += sX * fr; ap[2] += sX;
-                            ap[3] += sY * fu; ap[4] += sY * fr; ap[5] += sY;
-                            ap[6] += sZ * fu; ap[7] += sZ * fr; ap[8] += sZ;
-                            ap[9] += dX; ap[10] += dY; ap[11] += dz;
+                            pacc[j][0] += sX; pacc[j][1] += sY; pacc[j][2] += sZ;
+                            pacc[j][3] += sX * fr; pacc[j][4] += sY * fr; pacc[j][5] += sZ * fr;
+                            pacc[j][6] += dX; pacc[j][7] += dY; pacc[j][8] += dz;
                         }
                     }
                     if (lane_own) gout[r * W + cu] = ddsum * ddf_;
@@ -463,7 +466,18 @@ __global__ __launch_bounds__(WAVE* WPB) void reproj_march(Params p) {
         // ---- block reduction of the accumulators -> partials[bid][i][:] (fixed order: deterministic) ----
 #pragma unroll
         for (int k = 0; k < NACC; ++k) {
-            float v = acc[k];
+            float v;
+            if (k < A_POSE) {
+                v = acc[k];
+            } else {  // expand to the 12-slot layout of the finalize kernel: dM[row][{u, v, 1}] (9), dKt (3)
+                const int j = (k - A_POSE) / 12, e = (k - A_POSE) % 12;
+                if (e < 9) {
+                    const int row = e / 3, col = e % 3;
+                    v = col == 0 ? pacc[j][row] * fu : (col == 1 ? pacc[j][3 + row] : pacc[j][row]);
+                } else {
+                    v = pacc[j][6 + (e - 9)];
+                }
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
             if (lane == 0) red[wave][k] = v;

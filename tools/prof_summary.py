@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd database (--kernel-trace --stats) into the per-kernel table kept under profiles/."""
+import sqlite3
+import sys
+
+
+def main(db, out=None):
+    c = sqlite3.connect(db)
+    rows = c.execute(
+        "select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels "
+        "group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    lines = [f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}"]
+    for n, k, s, a, mn, mx in rows:
+        lines.append(f"{n[:70]:70s} {k:6d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
+    txt = "\n".join(lines)
+    print(txt)
+    if out:
+        open(out, "w").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
