@@ -31,9 +31,9 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int HALO = 2;
 constexpr int STRIP = WAVE - 2 * HALO;  // 60 owned columns per wavefront
-constexpr int WPB = 4;                  // wavefronts per block
 constexpr int NACC = 32;                // accumulators per (block, scale)
-constexpr int NSTATE = 22;              // floats of per-pixel state kept for two rows
+constexpr int NSTATE = 19;              // floats of per-pixel state kept for two rows (per scale wave)
+constexpr int NSHARE = 11;              // floats per pixel and row published by the image wave
 constexpr int RING = 3;
 
 // accumulator slots
@@ -62,7 +62,7 @@ struct Params {
     const CamConst* cam;
     float* partials;
     float* dbg;
-    int B, H, W, n, RH, nseg, nsg, nstrips;
+    int B, H, W, n, RH, nseg, nstrips;
     float ssim_w;
 };
 
@@ -196,21 +196,26 @@ __global__ void reproj_prep(const float* cam, int cam_stride, int cam_ld, const 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// the row-march kernel
+// the row-march kernel.  Block = 1 "image" wavefront + n_scales "scale" wavefronts that walk down the SAME
+// 60-column strip in lock step (one barrier per row):
+//   image wave  : everything that depends on the images only -- window sums of the target, the un-warped
+//                 (automask) photometric maps, edge-aware smoothness weights, mask -- computed once and published
+//                 through LDS to the scale waves (it runs one row ahead)
+//   scale wave i: warp with depth scale i, SSIM vs target, per-pixel min, loss sums and the adjoint.
+// All waves of a block touch the same image rows at the same time, so the inputs stream from HBM once.
 // ---------------------------------------------------------------------------------------------------
+constexpr int SH_SY = 0, SH_SYY = 3, SH_PU = 6, SH_WX = 8, SH_WY = 9, SH_LIVE = 10;
+
 template <bool GRAD>
-__global__ __launch_bounds__(WAVE* WPB, 2) void reproj_march(Params p) {
-    __shared__ float ring[WPB][RING][NSTATE][WAVE];
-    __shared__ float red[WPB][NACC];
+__global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6;  // 0 = image wave, 1..n = scale waves
     const int bid = blockIdx.x;
-    const int sg = bid % p.nsg;
-    const int seg = (bid / p.nsg) % p.nseg;
-    const int b = bid / (p.nsg * p.nseg);
-    const int strip = sg * WPB + wave;
-    const bool wave_active = strip < p.nstrips;  // wave-uniform
+    const int strip = bid % p.nstrips;
+    const int seg = (bid / p.nstrips) % p.nseg;
+    const int b = bid / (p.nstrips * p.nseg);
 
     const int H = p.H, W = p.W, HWp = H * W;
     const int cu = strip * STRIP - HALO + lane;
@@ -220,7 +225,100 @@ __global__ __launch_bounds__(WAVE* WPB, 2) void reproj_march(Params p) {
     const int r0 = seg * p.RH;
     const int rend = min(r0 + p.RH, H);
     const float fu = (float)ucol;
+    const float* imgb = p.img + (size_t)b * 3 * HWp;
+    const float ssim_w = p.ssim_w;
+    const float l1_w3 = (1.f - ssim_w) * (1.f / 3.f), ssim_w3 = ssim_w * (1.f / 3.f);
+    float* share = smem + (size_t)p.n * RING * NSTATE * WAVE + lane;  // [2][NSHARE][WAVE]
 
+    if (wave == 0) {
+        // =========================================== image wave ===========================================
+        const float* refb[2] = {p.prev + (size_t)b * 3 * HWp, p.nxt + (size_t)b * 3 * HWp};
+        const uint8_t* maskb = p.mask ? p.mask + (size_t)b * HWp : nullptr;
+        float y1[3] = {0.f, 0.f, 0.f}, y2[3] = {0.f, 0.f, 0.f}, rf1[2][3], rf2[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rf1[j][c] = rf2[j][c] = 0.f;
+        bool m1 = false;
+        float nmask = 0.f, nmx = 0.f, nmy = 0.f;
+        for (int s = r0 - 3; s <= rend + 1; ++s) {
+            if (s <= rend) {  // wave-uniform
+                const int vrow = reflect_clamp(s + 1, H);
+                const int off = vrow * W + ucol;
+                float y0[3], rf0[2][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    y0[c] = imgb[c * HWp + off];
+                    rf0[0][c] = refb[0][c * HWp + off];
+                    rf0[1][c] = refb[1][c * HWp + off];
+                }
+                const bool m0 = maskb ? (maskb[off] != 0) : true;
+                if (s >= r0 - 1) {
+                    const int q = s;
+                    float* sh = share + (size_t)(s & 1) * NSHARE * WAVE;
+                    float pu[2] = {0.f, 0.f};
+                    float igx = 0.f, igy = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float Sy = hsum3(y2[c] + y1[c] + y0[c]);
+                        const float Syy = hsum3(dot3(y2[c], y1[c], y0[c], y2[c], y1[c], y0[c]));
+                        sh[(SH_SY + c) * WAVE] = Sy;
+                        sh[(SH_SYY + c) * WAVE] = Syy;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {  // un-warped context image vs target (automask, loss.py:139-144)
+                            const float a = rf2[j][c], bq = rf1[j][c], cc = rf0[j][c];
+                            const float Sx = hsum3(a + bq + cc);
+                            const float Sxx = hsum3(dot3(a, bq, cc, a, bq, cc));
+                            const float Sxy = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
+                            float d0, d1, d2;
+                            bool g0;
+                            const float v = ssim_from_sums<false>(Sx, Sy, Sxx, Syy, Sxy, d0, d1, d2, g0);
+                            pu[j] += ssim_w3 * v + l1_w3 * fabsf(bq - y1[c]);
+                        }
+                        igx += fabsf(y1[c] - dpp_from_right(y1[c]));
+                        igy += fabsf(y1[c] - y0[c]);
+                    }
+                    const bool row_in = (q >= 0) && (q < H);
+                    const bool live = row_in && col_in && m1;
+                    const bool hasx = cu + 1 < W, hasy = q + 1 < H;
+                    // smoothness weights exp(-mean_c |d img|) (depth.py:24-25), pre-masked (loss.py:284-285)
+                    sh[SH_PU * WAVE] = pu[0];
+                    sh[(SH_PU + 1) * WAVE] = pu[1];
+                    sh[SH_WX * WAVE] = (live && hasx) ? __expf(-igx * (1.f / 3.f)) : 0.f;
+                    sh[SH_WY * WAVE] = (live && hasy) ? __expf(-igy * (1.f / 3.f)) : 0.f;
+                    sh[SH_LIVE * WAVE] = live ? 1.f : 0.f;
+                    if (lane_own && m1 && q >= r0 && q < rend) {
+                        nmask += 1.f;
+                        if (hasx) nmx += 1.f;
+                        if (hasy) nmy += 1.f;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    y2[c] = y1[c]; y1[c] = y0[c];
+                    rf2[0][c] = rf1[0][c]; rf1[0][c] = rf0[0][c];
+                    rf2[1][c] = rf1[1][c]; rf1[1][c] = rf0[1][c];
+                }
+                m1 = m0;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            nmask += __shfl_xor(nmask, o);
+            nmx += __shfl_xor(nmx, o);
+            nmy += __shfl_xor(nmy, o);
+        }
+        if (lane == 0) {
+            float* pp = p.partials + (size_t)bid * p.n * NACC;
+            pp[A_NMASK] = nmask; pp[A_NMX] = nmx; pp[A_NMY] = nmy; pp[7] = 0.f;
+        }
+        return;
+    }
+
+    // ============================================= scale wave =============================================
+    const int i = wave - 1;
+    const bool active = i < p.n;  // wave-uniform (blockDim is 64*(n+1), so always true; kept for safety)
     const CamConst& cam = p.cam[b];
     // a_j(u,v) = M_j.[u,v,1] = base_j + col1_j * v
     float base[2][3], col1[2][3], kt[2][3];
@@ -232,244 +330,208 @@ __global__ __launch_bounds__(WAVE* WPB, 2) void reproj_march(Params p) {
             col1[j][k] = cam.M[j][k * 3 + 1];
             kt[j][k] = cam.Kt[j][k];
         }
-    const float* imgb = p.img + (size_t)b * 3 * HWp;
     const float* refb[2] = {p.prev + (size_t)b * 3 * HWp, p.nxt + (size_t)b * 3 * HWp};
-    const uint8_t* maskb = p.mask ? p.mask + (size_t)b * HWp : nullptr;
-    const float ssim_w = p.ssim_w;
-    const float l1_w3 = (1.f - ssim_w) * (1.f / 3.f), ssim_w3 = ssim_w * (1.f / 3.f);
     // weights realising the adjoint of F.pad(reflect): a border pixel's adjoint window is seen twice by its neighbour
     const float exp_to_right = (cu == 0) ? 2.f : 1.f;      // value exported to lane+1
     const float exp_to_left = (cu == W - 1) ? 2.f : 1.f;   // value exported to lane-1
+    const float* invb = p.inv[active ? i : 0] + (size_t)b * HWp;
+    float* gout = GRAD ? p.ginv[active ? i : 0] + (size_t)b * HWp : nullptr;
+    float* dbg = p.dbg ? p.dbg + ((size_t)i * p.B + b) * HWp : nullptr;
+    float* ringw = smem + (size_t)i * RING * NSTATE * WAVE + lane;
 
-    for (int i = 0; i < p.n; ++i) {
-        float acc[A_POSE];        // scalar sums (slots 0..7)
-        float pacc[2][9];         // pose sums per context: sum s, sum s*row, sum dXc   (the column factor fu is per-lane constant)
+    float a_psum = 0.f, a_sx = 0.f, a_sy = 0.f, a_sinv = 0.f;
+    float pacc[2][9];  // pose sums per context: sum s, sum s*row, sum dXc (the column factor fu is a per-lane constant)
 #pragma unroll
-        for (int k = 0; k < A_POSE; ++k) acc[k] = 0.f;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) pacc[j][k] = 0.f;
+        for (int k = 0; k < 9; ++k) pacc[j][k] = 0.f;
 
-        if (wave_active) {
-            const float* invb = p.inv[i] + (size_t)b * HWp;
-            float* gout = GRAD ? p.ginv[i] + (size_t)b * HWp : nullptr;
-            float* dbg = p.dbg ? p.dbg + ((size_t)i * p.B + b) * HWp : nullptr;
+    // rows t-1 (suffix 1) and t-2 (suffix 2)
+    float xw1[2][3], xw2[2][3], y1[3] = {0.f, 0.f, 0.f}, y2[3] = {0.f, 0.f, 0.f};
+    float inv1 = 0.f;
+    float cA1[2][3], cB1[2][3], cC1[2][3], cA2[2][3], cB2[2][3], cC2[2][3], l1g1[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xw1[j][c] = xw2[j][c] = 0.f;
+            cA1[j][c] = cB1[j][c] = cC1[j][c] = cA2[j][c] = cB2[j][c] = cC2[j][c] = l1g1[j][c] = 0.f;
+        }
 
-            // rows t-1 (suffix 1) and t-2 (suffix 2)
-            float xw1[2][3], xw2[2][3], rf1[2][3], rf2[2][3], y1[3], y2[3];
-            float inv1 = 0.f;
-            bool m1 = false;
-            float cA1[2][3], cB1[2][3], cC1[2][3], cA2[2][3], cB2[2][3], cC2[2][3], l1g1[2][3];
+    int slot = 0;  // ring slot of row t
+    // the inverse depth row is first touched by this wave (HBM latency): keep it one row ahead of its use
+    float inv_pre = invb[reflect_clamp(r0 - 2, H) * W + ucol];
+    for (int t = r0 - 3; t <= rend + 1; ++t) {
+        if (t >= r0 - 2 && active) {  // wave-uniform
+            // ------------------------------ stage R: row t ------------------------------
+            const int vrow = reflect_clamp(t, H);
+            const int off = vrow * W + ucol;
+            const float fv = (float)vrow;
+            float y0[3], xw0[2][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) y0[c] = imgb[c * HWp + off];
+            const float inv0 = inv_pre;
+            inv_pre = invb[reflect_clamp(t + 1, H) * W + ucol];
+            const float d = frcp(fmaxf(inv0, 1e-6f));  // depth.py:15
+            float* st = ringw + (size_t)slot * NSTATE * WAVE;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float a0 = base[j][0] + col1[j][0] * fv, a1 = base[j][1] + col1[j][1] * fv, a2 = base[j][2] + col1[j][2] * fv;
+                const float X = d * a0 + kt[j][0], Y = d * a1 + kt[j][1], z = d * a2 + kt[j][2];
+                const bool zf = z >= 1e-5f;             // camera.py:172 clamp(min=1e-5)
+                const float rz = frcp(fmaxf(z, 1e-5f));
+                const float ix = X * rz, iy = Y * rz;   // == ((Xn+1)/2)(W-1) of grid_sample
+                float ex[3], ey[3];
+                bilinear3<GRAD>(refb[j], HWp, W, H, ix, iy, xw0[j], ex, ey);
+                if (GRAD) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        st[(j * 9 + c) * WAVE] = ex[c];
+                        st[(j * 9 + 3 + c) * WAVE] = ey[c];
+                    }
+                    st[(j * 9 + 6) * WAVE] = zf ? rz : -rz;  // rz > 0: the sign carries the clamp flag
+                    st[(j * 9 + 7) * WAVE] = ix;
+                    st[(j * 9 + 8) * WAVE] = iy;
+                }
+            }
+            if (GRAD) st[18 * WAVE] = (inv0 >= 1e-6f) ? d : -d;  // d > 0: the sign carries "inverse depth not clamped"
+
+            // ------------------------------ stage S: row q = t-1 ------------------------------
+            float cA0[2][3], cB0[2][3], cC0[2][3], l1g0[2][3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) cA0[j][c] = cB0[j][c] = cC0[j][c] = l1g0[j][c] = 0.f;
+            if (t >= r0) {  // wave-uniform
+                const int q = t - 1;
+                const float* sh = share + (size_t)(q & 1) * NSHARE * WAVE;
+                const bool row_own = (q >= r0) && (q < rend);
+                float pw[2] = {0.f, 0.f};
+                float al[2][3], be[2][3], ga[2][3];
+                bool gt[2][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float Sy = sh[(SH_SY + c) * WAVE], Syy = sh[(SH_SYY + c) * WAVE];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float a = xw2[j][c], bq = xw1[j][c], cc = xw0[j][c];
+                        const float Sx = hsum3(a + bq + cc);
+                        const float Sxx = hsum3(dot3(a, bq, cc, a, bq, cc));
+                        const float Sxy = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
+                        const float v = ssim_from_sums<GRAD>(Sx, Sy, Sxx, Syy, Sxy, al[j][c], be[j][c], ga[j][c], gt[j][c]);
+                        pw[j] += ssim_w3 * v + l1_w3 * fabsf(bq - y1[c]);
+                    }
+                }
+                const float pu0 = sh[SH_PU * WAVE], pu1 = sh[(SH_PU + 1) * WAVE];
+                const float wxm = sh[SH_WX * WAVE], wym = sh[SH_WY * WAVE];
+                const bool live = sh[SH_LIVE * WAVE] != 0.f;
+                // loss.py:241-246: min over [warp_prev, unwarp_prev, warp_next, unwarp_next]; first index wins ties
+                float best = pw[0];
+                int win = 0;
+                if (pu0 < best) { best = pu0; win = 1; }
+                if (pw[1] < best) { best = pw[1]; win = 2; }
+                if (pu1 < best) { best = pu1; win = 3; }
+                const bool own = row_own && lane_own;
+                // smoothness (depth.py:18-51, loss.py:257-294), un-normalised: |d inv| * exp(-mean_c |d img|)
+                const float sxv = fabsf(inv1 - dpp_from_right(inv1)) * wxm;
+                const float syv = fabsf(inv1 - inv0) * wym;
+                if (own) {
+                    if (live) a_psum += best;
+                    a_sinv += inv1;
+                    a_sx += sxv;
+                    a_sy += syv;
+                    if (dbg) dbg[q * W + cu] = best;
+                }
+                if (GRAD) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bool G = live && (win == 2 * j);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float k = (G && gt[j][c]) ? -0.5f * ssim_w3 : 0.f;
+                            cA0[j][c] = k * al[j][c];
+                            cB0[j][c] = k * be[j][c];
+                            cC0[j][c] = k * ga[j][c];
+                            const float df = xw1[j][c] - y1[c];
+                            l1g0[j][c] = G ? l1_w3 * (float)((df > 0.f) - (df < 0.f)) : 0.f;
+                        }
+                    }
+                }
+            }
+
+            // ------------------------------ stage G: row r = t-2 ------------------------------
+            if (GRAD && t >= r0 + 2 && t - 2 < rend) {  // wave-uniform
+                const int r = t - 2;
+                const float wu = (r == 1) ? 2.f : 1.f, wd = (r == H - 2) ? 2.f : 1.f;
+                const float* sr = ringw + (size_t)((slot + 1) % RING) * NSTATE * WAVE;  // slot of row t-2
+                const float ds = sr[18 * WAVE];
+                const float dd_ = fabsf(ds), ddf_ = ds > 0.f ? -ds * ds : 0.f;  // d depth / d inv (0 where clamped)
+                const float fr = (float)r;
+                float ddsum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float gix = 0.f, giy = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float vA = wu * cA2[j][c] + cA1[j][c] + wd * cA0[j][c];
+                        const float vB = wu * cB2[j][c] + cB1[j][c] + wd * cB0[j][c];
+                        const float vC = wu * cC2[j][c] + cC1[j][c] + wd * cC0[j][c];
+                        const float sA = dpp_from_left(vA * exp_to_right) + vA + dpp_from_right(vA * exp_to_left);
+                        const float sB = dpp_from_left(vB * exp_to_right) + vB + dpp_from_right(vB * exp_to_left);
+                        const float sC = dpp_from_left(vC * exp_to_right) + vC + dpp_from_right(vC * exp_to_left);
+                        const float g = sA + y2[c] * sB + xw2[j][c] * sC + l1g1[j][c];  // d L / d warped_c(r)
+                        gix += g * sr[(j * 9 + c) * WAVE];
+                        giy += g * sr[(j * 9 + 3 + c) * WAVE];
+                    }
+                    const float rzs = sr[(j * 9 + 6) * WAVE], ix = sr[(j * 9 + 7) * WAVE], iy = sr[(j * 9 + 8) * WAVE];
+                    const float rz = fabsf(rzs);
+                    const float dX = gix * rz, dY = giy * rz;
+                    const float dz = rzs > 0.f ? -(gix * ix + giy * iy) * rz : 0.f;
+                    const float a0 = base[j][0] + col1[j][0] * fr, a1 = base[j][1] + col1[j][1] * fr, a2 = base[j][2] + col1[j][2] * fr;
+                    ddsum += dX * a0 + dY * a1 + dz * a2;
+                    if (lane_own) {
+                        const float sX = dd_ * dX, sY = dd_ * dY, sZ = dd_ * dz;
+                        pacc[j][0] += sX; pacc[j][1] += sY; pacc[j][2] += sZ;
+                        pacc[j][3] += sX * fr; pacc[j][4] += sY * fr; pacc[j][5] += sZ * fr;
+                        pacc[j][6] += dX; pacc[j][7] += dY; pacc[j][8] += dz;
+                    }
+                }
+                if (lane_own) gout[r * W + cu] = ddsum * ddf_;
+            }
+
+            // ------------------------------ shift the row pipeline ------------------------------
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    xw1[j][c] = xw2[j][c] = rf1[j][c] = rf2[j][c] = 0.f;
-                    cA1[j][c] = cB1[j][c] = cC1[j][c] = cA2[j][c] = cB2[j][c] = cC2[j][c] = l1g1[j][c] = 0.f;
-                }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) y1[c] = y2[c] = 0.f;
-
-            int slot = 0;  // ring slot of row t
-            for (int t = r0 - 2; t <= rend + 1; ++t) {
-                // ------------------------------ stage R: row t ------------------------------
-                const int vrow = reflect_clamp(t, H);
-                const int off = vrow * W + ucol;
-                const float fv = (float)vrow;
-                float y0[3], rf0[2][3], xw0[2][3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    y0[c] = imgb[c * HWp + off];
-                    rf0[0][c] = refb[0][c * HWp + off];
-                    rf0[1][c] = refb[1][c * HWp + off];
-                }
-                const float inv0 = invb[off];
-                const bool m0 = maskb ? (maskb[off] != 0) : true;
-                const float d = frcp(fmaxf(inv0, 1e-6f));              // depth.py:15
-                const float ddf = (inv0 >= 1e-6f) ? -d * d : 0.f;      // d depth / d inv (0 where clamped)
-                float* st = &ring[wave][slot][0][lane];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float a0 = base[j][0] + col1[j][0] * fv, a1 = base[j][1] + col1[j][1] * fv, a2 = base[j][2] + col1[j][2] * fv;
-                    const float X = d * a0 + kt[j][0], Y = d * a1 + kt[j][1], z = d * a2 + kt[j][2];
-                    const bool zf = z >= 1e-5f;                         // camera.py:172 clamp(min=1e-5)
-                    const float rz = frcp(fmaxf(z, 1e-5f));
-                    const float ix = X * rz, iy = Y * rz;               // == ((Xn+1)/2)(W-1) of grid_sample
-                    float ex[3], ey[3];
-                    bilinear3<GRAD>(refb[j], HWp, W, H, ix, iy, xw0[j], ex, ey);
+                    xw2[j][c] = xw1[j][c]; xw1[j][c] = xw0[j][c];
                     if (GRAD) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            st[(j * 10 + c) * WAVE] = ex[c];
-                            st[(j * 10 + 3 + c) * WAVE] = ey[c];
-                        }
-                        st[(j * 10 + 6) * WAVE] = rz;
-                        st[(j * 10 + 7) * WAVE] = ix;
-                        st[(j * 10 + 8) * WAVE] = iy;
-                        st[(j * 10 + 9) * WAVE] = zf ? 1.f : 0.f;
+                        cA2[j][c] = cA1[j][c]; cA1[j][c] = cA0[j][c];
+                        cB2[j][c] = cB1[j][c]; cB1[j][c] = cB0[j][c];
+                        cC2[j][c] = cC1[j][c]; cC1[j][c] = cC0[j][c];
+                        l1g1[j][c] = l1g0[j][c];
                     }
                 }
-                if (GRAD) {
-                    st[20 * WAVE] = d;
-                    st[21 * WAVE] = ddf;
-                }
-
-                // ------------------------------ stage S: row q = t-1 ------------------------------
-                float cA0[2][3], cB0[2][3], cC0[2][3], l1g0[2][3];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) cA0[j][c] = cB0[j][c] = cC0[j][c] = l1g0[j][c] = 0.f;
-                if (t >= r0) {  // wave-uniform
-                    const int q = t - 1;
-                    const bool row_in = (q >= 0) && (q < H);
-                    const bool row_own = (q >= r0) && (q < rend);
-                    float pw[2] = {0.f, 0.f}, pu[2] = {0.f, 0.f};
-                    float al[2][3], be[2][3], ga[2][3];
-                    bool gt[2][3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float Sy = hsum3(y2[c] + y1[c] + y0[c]);
-                        const float Syy = hsum3(dot3(y2[c], y1[c], y0[c], y2[c], y1[c], y0[c]));
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            {   // warped image vs target
-                                const float a = xw2[j][c], bq = xw1[j][c], cc = xw0[j][c];
-                                const float Sx = hsum3(a + bq + cc);
-                                const float Sxx = hsum3(dot3(a, bq, cc, a, bq, cc));
-                                const float Sxy = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
-                                const float v = ssim_from_sums<GRAD>(Sx, Sy, Sxx, Syy, Sxy, al[j][c], be[j][c], ga[j][c], gt[j][c]);
-                                pw[j] += ssim_w3 * v + l1_w3 * fabsf(bq - y1[c]);
-                            }
-                            {   // un-warped context image vs target (automask, loss.py:139-144)
-                                const float a = rf2[j][c], bq = rf1[j][c], cc = rf0[j][c];
-                                const float Sx = hsum3(a + bq + cc);
-                                const float Sxx = hsum3(dot3(a, bq, cc, a, bq, cc));
-                                const float Sxy = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
-                                float d0, d1, d2;
-                                bool g0;
-                                const float v = ssim_from_sums<false>(Sx, Sy, Sxx, Syy, Sxy, d0, d1, d2, g0);
-                                pu[j] += ssim_w3 * v + l1_w3 * fabsf(bq - y1[c]);
-                            }
-                        }
-                    }
-                    // loss.py:241-246: min over [warp_prev, unwarp_prev, warp_next, unwarp_next]; first index wins ties
-                    float best = pw[0];
-                    int win = 0;
-                    if (pu[0] < best) { best = pu[0]; win = 1; }
-                    if (pw[1] < best) { best = pw[1]; win = 2; }
-                    if (pu[1] < best) { best = pu[1]; win = 3; }
-                    const bool own = row_own && lane_own;
-                    if (own && m1) acc[A_PSUM] += best;
-                    if (dbg && own) dbg[q * W + cu] = best;
-
-                    // smoothness (depth.py:18-51, loss.py:257-294), un-normalised: |d inv| * exp(-mean_c |d img|)
-                    {
-                        const float invr = dpp_from_right(inv1);
-                        float igx = 0.f, igy = 0.f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            igx += fabsf(y1[c] - dpp_from_right(y1[c]));
-                            igy += fabsf(y1[c] - y0[c]);
-                        }
-                        const float sxv = fabsf(inv1 - invr) * __expf(-igx * (1.f / 3.f));
-                        const float syv = fabsf(inv1 - inv0) * __expf(-igy * (1.f / 3.f));
-                        if (own) {
-                            acc[A_SINV] += inv1;
-                            if (m1) {
-                                acc[A_NMASK] += 1.f;
-                                if (cu + 1 < W) { acc[A_SX] += sxv; acc[A_NMX] += 1.f; }
-                                if (q + 1 < H) { acc[A_SY] += syv; acc[A_NMY] += 1.f; }
-                            }
-                        }
-                    }
-                    if (GRAD) {
-                        const bool live = row_in && col_in && m1;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const bool G = live && (win == 2 * j);
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const float k = (G && gt[j][c]) ? -0.5f * ssim_w3 : 0.f;
-                                cA0[j][c] = k * al[j][c];
-                                cB0[j][c] = k * be[j][c];
-                                cC0[j][c] = k * ga[j][c];
-                                const float df = xw1[j][c] - y1[c];
-                                l1g0[j][c] = G ? l1_w3 * (float)((df > 0.f) - (df < 0.f)) : 0.f;
-                            }
-                        }
-                    }
-                }
-
-                // ------------------------------ stage G: row r = t-2 ------------------------------
-                if (GRAD && t >= r0 + 2 && t - 2 < rend) {  // wave-uniform
-                    const int r = t - 2;
-                    const float wu = (r == 1) ? 2.f : 1.f, wd = (r == H - 2) ? 2.f : 1.f;
-                    const float* sr = &ring[wave][(slot + 1) % RING][0][lane];  // slot of row t-2
-                    const float dd_ = sr[20 * WAVE], ddf_ = sr[21 * WAVE];
-                    const float fr = (float)r;
-                    float ddsum = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        float gix = 0.f, giy = 0.f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float vA = wu * cA2[j][c] + cA1[j][c] + wd * cA0[j][c];
-                            const float vB = wu * cB2[j][c] + cB1[j][c] + wd * cB0[j][c];
-                            const float vC = wu * cC2[j][c] + cC1[j][c] + wd * cC0[j][c];
-                            const float sA = dpp_from_left(vA * exp_to_right) + vA + dpp_from_right(vA * exp_to_left);
-                            const float sB = dpp_from_left(vB * exp_to_right) + vB + dpp_from_right(vB * exp_to_left);
-                            const float sC = dpp_from_left(vC * exp_to_right) + vC + dpp_from_right(vC * exp_to_left);
-                            const float g = sA + y2[c] * sB + xw2[j][c] * sC + l1g1[j][c];  // d L / d warped_c(r)
-                            gix += g * sr[(j * 10 + c) * WAVE];
-                            giy += g * sr[(j * 10 + 3 + c) * WAVE];
-                        }
-                        const float rz = sr[(j * 10 + 6) * WAVE], ix = sr[(j * 10 + 7) * WAVE], iy = sr[(j * 10 + 8) * WAVE];
-                        const float zf = sr[(j * 10 + 9) * WAVE];
-                        const float dX = gix * rz, dY = giy * rz;
-                        const float dz = -(gix * ix + giy * iy) * rz * zf;
-                        const float a0 = base[j][0] + col1[j][0] * fr, a1 = base[j][1] + col1[j][1] * fr, a2 = base[j][2] + col1[j][2] * fr;
-                        ddsum += dX * a0 + dY * a1 + dz * a2;
-                        if (lane_own) {
-                            const float sX = dd_ * dX, sY = dd_ * dY, sZ = dd_ * dz;
-                            pacc[j][0] += sX; pacc[j][1] += sY; pacc[j][2] += sZ;
-                            pacc[j][3] += sX * fr; pacc[j][4] += sY * fr; pacc[j][5] += sZ * fr;
-                            pacc[j][6] += dX; pacc[j][7] += dY; pacc[j][8] += dz;
-                        }
-                    }
-                    if (lane_own) gout[r * W + cu] = ddsum * ddf_;
-                }
-
-                // ------------------------------ shift the row pipeline ------------------------------
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        xw2[j][c] = xw1[j][c]; xw1[j][c] = xw0[j][c];
-                        rf2[j][c] = rf1[j][c]; rf1[j][c] = rf0[j][c];
-                        if (GRAD) {
-                            cA2[j][c] = cA1[j][c]; cA1[j][c] = cA0[j][c];
-                            cB2[j][c] = cB1[j][c]; cB1[j][c] = cB0[j][c];
-                            cC2[j][c] = cC1[j][c]; cC1[j][c] = cC0[j][c];
-                            l1g1[j][c] = l1g0[j][c];
-                        }
-                    }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { y2[c] = y1[c]; y1[c] = y0[c]; }
-                inv1 = inv0;
-                m1 = m0;
-                slot = (slot + 1) % RING;
-            }
+            for (int c = 0; c < 3; ++c) { y2[c] = y1[c]; y1[c] = y0[c]; }
+            inv1 = inv0;
+            slot = (slot + 1) % RING;
         }
+        __syncthreads();
+    }
 
-        // ---- block reduction of the accumulators -> partials[bid][i][:] (fixed order: deterministic) ----
+    // ---- wave reduction -> partials[bid][i][:]  (every slot written: the finalize kernels read all of them) ----
+    if (active) {
+        float* pp = p.partials + ((size_t)bid * p.n + i) * NACC;
 #pragma unroll
         for (int k = 0; k < NACC; ++k) {
             float v;
-            if (k < A_POSE) {
-                v = acc[k];
-            } else {  // expand to the 12-slot layout of the finalize kernel: dM[row][{u, v, 1}] (9), dKt (3)
+            if (k == A_PSUM) v = a_psum;
+            else if (k == A_SX) v = a_sx;
+            else if (k == A_SY) v = a_sy;
+            else if (k == A_SINV) v = a_sinv;
+            else if (k < A_POSE) v = 0.f;
+            else {  // expand to the 12-slot layout of the finalize kernel: dM[row][{u, v, 1}] (9), dKt (3)
                 const int j = (k - A_POSE) / 12, e = (k - A_POSE) % 12;
                 if (e < 9) {
                     const int row = e / 3, col = e % 3;
@@ -478,16 +540,11 @@ __global__ __launch_bounds__(WAVE* WPB, 2) void reproj_march(Params p) {
                     v = pacc[j][6 + (e - 9)];
                 }
             }
+            if (k >= A_NMASK && k < A_POSE && i == 0) continue;  // written by the image wave
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0) red[wave][k] = v;
+            if (lane == 0) pp[k] = v;
         }
-        __syncthreads();
-        if (threadIdx.x < NACC) {
-            const int k = threadIdx.x;
-            p.partials[((size_t)bid * p.n + i) * NACC + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-        }
-        __syncthreads();
     }
 }
 
@@ -661,7 +718,8 @@ __global__ __launch_bounds__(256) void reproj_bwd(BwdParams p) {
 // host side
 // ---------------------------------------------------------------------------------------------------
 struct Layout {
-    int RH, nseg, nstrips, nsg, nblocks;
+    int RH, nseg, nstrips, nblocks;
+    size_t lds_bytes;
     size_t off_cam, off_partials, off_persum, off_hdr, off_stats, total;
 };
 
@@ -671,17 +729,17 @@ int make_layout(const mgn_reproj_cfg* c, Layout* L) {
     if (!c || c->B < 1 || c->H < 2 || c->W < 2 || c->n_scales < 1 || c->n_scales > MGN_MAX_SCALES) return MGN_EINVAL;
     if ((long long)c->H * c->W > (1LL << 30)) return MGN_EINVAL;
     L->nstrips = (c->W + STRIP - 1) / STRIP;
-    L->nsg = (L->nstrips + WPB - 1) / WPB;
     int RH = c->rows_per_wave;
     if (RH <= 0) {
         RH = 64;
-        const long long target = 4096;  // ~2 waves per SIMD over 256 CUs x 4 SIMDs, two rounds
-        while (RH > 8 && (long long)c->B * L->nsg * WPB * ((c->H + RH - 1) / RH) < target) RH >>= 1;
+        const long long target = 1536;  // blocks: 256 CUs x 3 resident blocks x 2 rounds
+        while (RH > 8 && (long long)c->B * L->nstrips * ((c->H + RH - 1) / RH) < target) RH >>= 1;
     }
     if (RH < 4) return MGN_EINVAL;
     L->RH = RH;
     L->nseg = (c->H + RH - 1) / RH;
-    L->nblocks = c->B * L->nseg * L->nsg;
+    L->nblocks = c->B * L->nseg * L->nstrips;
+    L->lds_bytes = sizeof(float) * WAVE * ((size_t)c->n_scales * RING * NSTATE + 2 * NSHARE);
     size_t o = 0;
     L->off_cam = o;      o = align_up(o + sizeof(CamConst) * c->B, 256);
     L->off_partials = o; o = align_up(o + sizeof(float) * NACC * c->n_scales * (size_t)L->nblocks, 256);
@@ -741,19 +799,19 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
     p.partials = (float*)(ws + L.off_partials);
     p.dbg = dbg_minmap;
     p.B = cfg->B; p.H = cfg->H; p.W = cfg->W; p.n = cfg->n_scales;
-    p.RH = L.RH; p.nseg = L.nseg; p.nsg = L.nsg; p.nstrips = L.nstrips;
+    p.RH = L.RH; p.nseg = L.nseg; p.nstrips = L.nstrips;
     p.ssim_w = cfg->ssim_loss_weight;
 
     hipLaunchKernelGGL(reproj_prep, dim3((cfg->B + 63) / 64), dim3(64), 0, stream, cam, cam_stride, cam_ld, pose, cfg->B,
                        (CamConst*)(ws + L.off_cam));
     if (cfg->prof_begin) (void)hipEventRecord((hipEvent_t)cfg->prof_begin, stream);
     if (want_grad)
-        hipLaunchKernelGGL(reproj_march<true>, dim3(L.nblocks), dim3(WAVE * WPB), 0, stream, p);
+        hipLaunchKernelGGL(reproj_march<true>, dim3(L.nblocks), dim3(WAVE * (cfg->n_scales + 1)), L.lds_bytes, stream, p);
     else
-        hipLaunchKernelGGL(reproj_march<false>, dim3(L.nblocks), dim3(WAVE * WPB), 0, stream, p);
+        hipLaunchKernelGGL(reproj_march<false>, dim3(L.nblocks), dim3(WAVE * (cfg->n_scales + 1)), L.lds_bytes, stream, p);
     if (cfg->prof_end) (void)hipEventRecord((hipEvent_t)cfg->prof_end, stream);
     hipLaunchKernelGGL(reproj_fin1, dim3(cfg->B, cfg->n_scales), dim3(256), 0, stream, (const float*)(ws + L.off_partials),
-                       cfg->n_scales, L.nseg * L.nsg, (double*)(ws + L.off_persum));
+                       cfg->n_scales, L.nseg * L.nstrips, (double*)(ws + L.off_persum));
     hipLaunchKernelGGL(reproj_fin2, dim3(1), dim3(256), 0, stream, (const double*)(ws + L.off_persum),
                        (const CamConst*)(ws + L.off_cam), pose, cfg->B, cfg->H, cfg->W, cfg->n_scales,
                        cfg->photometric_loss_weight, cfg->smoothing_loss_weight, want_grad, losses, d_pose,
