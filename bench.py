@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true", help="diagnostic: loss only (no gradient); NOT the benchmark")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,8 +126,8 @@ def main():
 
     B, H, W = args.batch, args.height, args.width
     d = synth_batch(B, H, W, 1234 + rank, dev)
-    inv = [x.requires_grad_(True) for x in d["inv"]]
-    poses = d["poses"].requires_grad_(True)
+    inv = [x.requires_grad_(not args.fwd_only) for x in d["inv"]]
+    poses = d["poses"].requires_grad_(not args.fwd_only)
     nsteps = args.warmup + args.steps
     ev = HipEvents(args.steps)
     cfgs = [_C.make_reproj_cfg(B, H, W, 3) for _ in range(nsteps)]
@@ -137,6 +138,8 @@ def main():
     def step(k):
         # data-parallel: each rank owns its B frames; the loss has no cross-rank term (per-rank means)
         losses = _ReprojLossFn.apply(cfgs[k], d["img"], d["prev"], d["nxt"], d["mask"], d["K"], poses, *inv)
+        if args.fwd_only:
+            return losses
         (losses * w).sum().backward()
         for x in inv:
             x.grad = None

@@ -5,7 +5,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmgnet_hip.so")
+LIB_PATH = os.environ.get("MGNET_HIP_LIB", os.path.join(_HERE, "lib", "libmgnet_hip.so"))  # env override: A/B builds
 
 MGN_MAX_SCALES = 4
 _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspace too small)",

@@ -66,11 +66,14 @@ struct Params {
     float ssim_w;
 };
 
+// bound_ctrl=1: lanes without a source read 0, so no "old" operand has to be materialised (saves a v_mov per shift)
 __device__ __forceinline__ float dpp_from_left(float x) {  // lane i <- lane i-1 (lane 0 <- 0)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float dpp_from_right(float x) {  // lane i <- lane i+1 (lane 63 <- 0)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float hsum3(float v) { return dpp_from_left(v) + v + dpp_from_right(v); }
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -714,6 +717,89 @@ __global__ __launch_bounds__(256) void reproj_bwd(BwdParams p) {
     }
 }
 
+// Same computation, 4 pixels per thread with 16-byte loads/stores (W % 4 == 0).
+__global__ __launch_bounds__(256) void reproj_bwd4(BwdParams p) {
+    const int W = p.W, H = p.H, HWp = H * W;
+    const int u = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int v = blockIdx.y, b = blockIdx.z;
+    const float gp = p.grad_losses[0] * p.hdr->pscale, gs = p.grad_losses[1];
+    if (blockIdx.x == 0 && v == 0 && b == 0)
+        for (int k = threadIdx.x; k < p.B * 12; k += blockDim.x) p.d_pose_out[k] = p.grad_losses[0] * p.d_pose[k];
+    if (u >= W) return;
+    const int off = v * W + u;
+    const float* im = p.img + (size_t)b * 3 * HWp;
+    const uint8_t* mk = p.mask ? p.mask + (size_t)b * HWp : nullptr;
+    const bool hasL = u > 0, hasR4 = u + 4 < W, hasD = v + 1 < H, hasU = v > 0;
+    // image gradient magnitudes of the pairs (k-1,k) for k=0..4 along x, and (up,ctr), (ctr,down) per pixel
+    float gx[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, gu[4] = {0.f, 0.f, 0.f, 0.f}, gd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* ic = im + c * HWp + off;
+        const float4 ctr = *reinterpret_cast<const float4*>(ic);
+        const float cv[4] = {ctr.x, ctr.y, ctr.z, ctr.w};
+        const float l = hasL ? ic[-1] : 0.f, r = hasR4 ? ic[4] : 0.f;
+        gx[0] += fabsf(l - cv[0]);
+        gx[1] += fabsf(cv[0] - cv[1]);
+        gx[2] += fabsf(cv[1] - cv[2]);
+        gx[3] += fabsf(cv[2] - cv[3]);
+        gx[4] += fabsf(cv[3] - r);
+        if (hasU) {
+            const float4 up = *reinterpret_cast<const float4*>(ic - W);
+            gu[0] += fabsf(up.x - cv[0]); gu[1] += fabsf(up.y - cv[1]); gu[2] += fabsf(up.z - cv[2]); gu[3] += fabsf(up.w - cv[3]);
+        }
+        if (hasD) {
+            const float4 dn = *reinterpret_cast<const float4*>(ic + W);
+            gd[0] += fabsf(cv[0] - dn.x); gd[1] += fabsf(cv[1] - dn.y); gd[2] += fabsf(cv[2] - dn.z); gd[3] += fabsf(cv[3] - dn.w);
+        }
+    }
+    bool mC[4] = {true, true, true, true}, mU[4] = {hasU, hasU, hasU, hasU};
+    bool mL = hasL;
+    if (mk) {
+        const uchar4 m4 = *reinterpret_cast<const uchar4*>(mk + off);
+        mC[0] = m4.x != 0; mC[1] = m4.y != 0; mC[2] = m4.z != 0; mC[3] = m4.w != 0;
+        if (hasU) {
+            const uchar4 u4 = *reinterpret_cast<const uchar4*>(mk + off - W);
+            mU[0] = u4.x != 0; mU[1] = u4.y != 0; mU[2] = u4.z != 0; mU[3] = u4.w != 0;
+        }
+        if (hasL) mL = mk[off - 1] != 0;
+    }
+    // pair weights: the pair (p, p+1) belongs to p and is masked by mask[p] (loss.py:284-285)
+    float wx[5], wd[4], wu[4];
+    wx[0] = mL ? __expf(-gx[0] * (1.f / 3.f)) : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool pair_exists = (k < 3) || hasR4;
+        wx[k + 1] = (mC[k] && pair_exists) ? __expf(-gx[k + 1] * (1.f / 3.f)) : 0.f;
+        wd[k] = (mC[k] && hasD) ? __expf(-gd[k] * (1.f / 3.f)) : 0.f;
+        wu[k] = mU[k] ? __expf(-gu[k] * (1.f / 3.f)) : 0.f;
+    }
+    auto sgn = [](float x) { return (float)((x > 0.f) - (x < 0.f)); };
+    for (int i = 0; i < p.n; ++i) {
+        const float* iv = p.inv[i] + (size_t)b * HWp + off;
+        const Stats s = p.stats[b * p.n + i];
+        const float4 c4 = *reinterpret_cast<const float4*>(iv);
+        const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+        const float l = hasL ? iv[-1] : 0.f, r = hasR4 ? iv[4] : 0.f;
+        float upv[4] = {0.f, 0.f, 0.f, 0.f}, dnv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (hasU) { const float4 t4 = *reinterpret_cast<const float4*>(iv - W); upv[0] = t4.x; upv[1] = t4.y; upv[2] = t4.z; upv[3] = t4.w; }
+        if (hasD) { const float4 t4 = *reinterpret_cast<const float4*>(iv + W); dnv[0] = t4.x; dnv[1] = t4.y; dnv[2] = t4.z; dnv[3] = t4.w; }
+        const float e[6] = {l, cv[0], cv[1], cv[2], cv[3], r};
+        float* g = p.ginv[i] + (size_t)b * HWp + off;
+        const float4 g4 = *reinterpret_cast<const float4*>(g);
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // pairs: (k-1,k) has weight wx[k], (k,k+1) has weight wx[k+1]
+            const float ddx = wx[k + 1] * sgn(e[k + 1] - e[k + 2]) - wx[k] * sgn(e[k] - e[k + 1]);
+            const float ddy = wd[k] * sgn(cv[k] - dnv[k]) - wu[k] * sgn(upv[k] - cv[k]);
+            const float ddn = s.cxs * ddx + s.cys * ddy;
+            o[k] = gp * gv[k] + gs * (ddn * s.inv_mc + s.dmean);
+        }
+        *reinterpret_cast<float4*>(g) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -841,7 +927,13 @@ int mgn_reproj_loss_bwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
     p.stats = (const Stats*)(ws + L.off_stats);
     p.d_pose = d_pose; p.d_pose_out = d_pose_out;
     p.B = cfg->B; p.H = cfg->H; p.W = cfg->W; p.n = cfg->n_scales;
-    hipLaunchKernelGGL(reproj_bwd, dim3((cfg->W + 255) / 256, cfg->H, cfg->B), dim3(256), 0, (hipStream_t)stream_, p);
+    const bool vec4 = (cfg->W % 4 == 0) && (((uintptr_t)img | (uintptr_t)mask) % 16 == 0);
+    bool aligned = vec4;
+    for (int i = 0; i < cfg->n_scales; ++i) aligned = aligned && (((uintptr_t)inv_depth[i] | (uintptr_t)g_inv[i]) % 16 == 0);
+    if (aligned)
+        hipLaunchKernelGGL(reproj_bwd4, dim3((cfg->W / 4 + 255) / 256, cfg->H, cfg->B), dim3(256), 0, (hipStream_t)stream_, p);
+    else
+        hipLaunchKernelGGL(reproj_bwd, dim3((cfg->W + 255) / 256, cfg->H, cfg->B), dim3(256), 0, (hipStream_t)stream_, p);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
