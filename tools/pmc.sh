@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/pmc.sh <tag>   -- collects PMC passes for bench.py (short run) into gpurun_out/pmc_<tag>/
+# usage: tools/pmc.sh <tag>   -- collects PMC passes for bench.py (short run) into gpurun_out/pmc_<tag>/
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/pmc2.sh <tag> <bench args...>  -- FETCH/WRITE/TCC + timing only
+# usage: tools/pmc2.sh <tag> <bench args...>  -- FETCH/WRITE/TCC + timing only
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift
