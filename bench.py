@@ -99,16 +99,94 @@ def cpu_baseline(H, W):
             "sample": f"1 frame {H}x{W}, reprojection loss fwd+bwd, oracle/reproj_oracle.c fp32 OpenMP, {dt:.1f} s"}
 
 
+def full_step_bench(args, world, rank, dev):
+    """The benchmark: one full MGNet training step (SURVEY 3.1 hot loop) per per-GPU batch of synthetic frames."""
+    from mgnet_amd import add_mgnet_config, get_cfg
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.engine import Trainer
+    from mgnet_amd.registry import build_model
+
+    B, H, W = args.batch, args.height, args.width
+    cfg = get_cfg()
+    add_mgnet_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "bench-c4-cityscapes-videosequence.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", str(dev), "SOLVER.IMS_PER_BATCH", B * world,
+                         "MODEL.SEM_SEG_HEAD.OHEM_N_MIN", min(524287, B * H * W // 4 - 1)])
+    torch.manual_seed(0)  # identical initial weights on every rank (DDP broadcasts rank 0's; same seed is equivalent)
+    model = build_model(cfg)
+    trainer = Trainer(cfg, model)
+    batch = synthetic_batch(B, H, W, dev, seed=1234 + rank)
+    ev = HipEvents(args.steps)
+    depth_loss = model.depth_head.loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.run_step(batch)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        depth_loss.prof_events = ev.pairs[k]
+        last = trainer.run_step(batch)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        kern_ms = float(np.mean(ev.elapsed_ms()))
+        npx = B * H * W
+        achieved = FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if (tj.get("B"), tj.get("H"), tj.get("W")) == (B, H, W):
+                traffic = tj.get("hbm_bytes_per_launch")
+        img_s = world * B * args.steps / dt
+        # forward conv FLOPs per image (SURVEY Appendix A) scale with the pixel count; training ~ 3x forward
+        gflop_fwd = 560.2 * (H * W) / (1024 * 2048)
+        line = {
+            "metric": "training img/s at 1024x2048 Cityscapes, 1/2/4/8 MI355X; reprojection-loss HBM GB/s",
+            "value": round(img_s, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"MGNet-Cityscapes-VideoSequence recipe (BASELINE C4/C5): full multi-task training step "
+                                   f"(2x ResNet-18 + 3 decoders/heads fwd+bwd, OHEM CE, centre/offset, photometric "
+                                   f"reprojection + smoothness, uncertainty weighting, grad all-reduce, clip, Adam), "
+                                   f"{B} frames/GPU of {H}x{W}",
+                       "frames_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
+                       "parallelism": f"dp{world}", "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
+                       "losses": {k: round(float(v.detach()), 5) for k, v in last.items()}},
+            "roofline": {"bound": "hbm", "kernel": "reproj_march<true> (fused reprojection loss + photometric gradient)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_launch": FWD_BYTES_PER_PX * npx, "avg_launch_ms": round(kern_ms, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(H, W)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU (C4/C5: 8)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="diagnostic: loss only (no gradient); NOT the benchmark")
+    ap.add_argument("--loss-only", action="store_true",
+                    help="diagnostic: time only the reprojection loss fwd+bwd (round-1 v2 workload); NOT the benchmark")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,6 +203,8 @@ def main():
     from mgnet_amd.modeling.loss import _ReprojLossFn
 
     B, H, W = args.batch, args.height, args.width
+    if not (args.loss_only or args.fwd_only):
+        return full_step_bench(args, world, rank, dev)
     d = synth_batch(B, H, W, 1234 + rank, dev)
     inv = [x.requires_grad_(not args.fwd_only) for x in d["inv"]]
     poses = d["poses"].requires_grad_(not args.fwd_only)

@@ -5,3 +5,8 @@ binding of that ABI) and the host-side mirror of the reference's interface for t
 There is no CPU fallback: importing an op without the built extension raises.
 """
 __version__ = "0.1.0"
+
+from .config import add_mgnet_config, get_cfg  # noqa: E402,F401
+from . import modeling  # noqa: E402,F401  (registers MGNet, the heads and the backbone builder)
+
+__all__ = ["add_mgnet_config", "get_cfg", "modeling"]

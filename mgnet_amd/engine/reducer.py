@@ -1,0 +1,81 @@
+"""Data-parallel gradient reduction for one process per GPU over RCCL/xGMI (torch.distributed backend "nccl" on ROCm;
+"gloo" in the CPU tests).  Replaces detectron2's `create_ddp_model` -> torch DDP.
+
+* parameters are packed, in REVERSE registration order (= roughly the order in which backward produces gradients:
+  heads -> decoders -> res5 .. stem), into flat fp32 buckets; `param.grad` are views into the bucket, so there is no
+  gather/scatter copy around the collective
+* a post-accumulate-grad hook counts a bucket's ready gradients and launches ONE asynchronous all-reduce per bucket as
+  soon as it is complete, so the collective overlaps with the rest of backward
+* xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound, ~2*(N-1)/N*bytes/153 GB/s
+  (1.4 ms for the 123.8 MB of MGNet at N=8); 32 MB buckets keep each call far above the latency floor while leaving
+  >= 4 calls to pipeline behind backward
+* gradients are averaged (sum, then 1/world) like DDP
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, params, bucket_bytes=32 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        params = [p for p in params if p.requires_grad]
+        self.buckets = []          # list of dict(flat, params, pending)
+        self._bucket_of = {}
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            nb = p.numel() * 4
+            if cur and cur_bytes + nb > bucket_bytes:
+                self._seal(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            self._seal(cur)
+        self._handles = []
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    def _seal(self, plist):
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
+        off = 0
+        for p in plist:
+            assert p.dtype == torch.float32
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        b = dict(flat=flat, params=plist, pending=len(plist), n=len(plist))
+        self.buckets.append(b)
+        for p in plist:
+            self._bucket_of[p] = b
+
+    def zero_grad(self):
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"] = b["n"]
+            off = 0
+            for p in b["params"]:  # restore the views if someone replaced .grad
+                if p.grad is None or p.grad.data_ptr() != b["flat"].data_ptr() + off * 4:
+                    p.grad = b["flat"][off:off + p.numel()].view_as(p)
+                off += p.numel()
+
+    def _hook(self, p):
+        b = self._bucket_of[p]
+        b["pending"] -= 1
+        if b["pending"] == 0 and self.world > 1:
+            self._handles.append(dist.all_reduce(b["flat"], group=self.group, async_op=True))
+
+    def finish(self):
+        """Wait for the in-flight buckets, launch the ones whose parameters got no gradient this step, average."""
+        if self.world > 1:
+            for b in self.buckets:
+                if b["pending"] > 0:  # unused parameters this iteration: still reduce (zeros) to stay in lock step
+                    self._handles.append(dist.all_reduce(b["flat"], group=self.group, async_op=True))
+            for h in self._handles:
+                h.wait()
+            self._handles.clear()
+            for b in self.buckets:
+                b["flat"].mul_(1.0 / self.world)
+
+    def grad_bytes(self):
+        return sum(b["flat"].numel() * 4 for b in self.buckets)

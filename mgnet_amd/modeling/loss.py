@@ -5,7 +5,57 @@ import torch.nn as nn
 
 from .. import _C
 
-__all__ = ["MultiViewPhotometricLoss"]
+__all__ = ["DeepLabCE", "OhemCE", "MultiViewPhotometricLoss"]
+
+
+def _pixel_ce(logits, labels, weights, ignore_label):
+    """[torch-staging] per-pixel cross entropy (reduction none, ignore_index) times the per-pixel weights."""
+    ce = torch.nn.functional.cross_entropy(logits.float(), labels, ignore_index=ignore_label, reduction="none")
+    if weights is not None:
+        ce = ce * weights
+    return ce.contiguous().view(-1)
+
+
+class DeepLabCE(nn.Module):
+    """Hard pixel mining CE: mean of the top-k percent pixel losses (mirror of loss.py:9-42)."""
+
+    def __init__(self, ignore_label=-1, top_k_percent_pixels=1.0, weight=None):
+        super().__init__()
+        assert weight is None, "class weights are not used by any MGNet config"
+        self.top_k_percent_pixels = top_k_percent_pixels
+        self.ignore_label = ignore_label
+
+    def forward(self, logits, labels, weights=None):
+        pixel_losses = _pixel_ce(logits, labels, weights, self.ignore_label)
+        if self.top_k_percent_pixels == 1.0:
+            return pixel_losses.mean()
+        top_k_pixels = int(self.top_k_percent_pixels * pixel_losses.numel())
+        return torch.topk(pixel_losses, top_k_pixels)[0].mean()
+
+
+class OhemCE(nn.Module):
+    """Online hard example mining CE (mirror of loss.py:45-81).  The reference sorts ALL pixel losses; the selection
+    rule only needs (a) how many losses exceed the threshold and (b), when fewer than n_min+1 do, the n_min largest:
+        sorted[n_min] > thr  <=>  count(loss > thr) > n_min      -> mean of {loss > thr}
+        otherwise                                                 -> mean of the n_min largest
+    which is result-identical without a full sort.  Like the reference it raises IndexError if n_min >= #pixels."""
+
+    def __init__(self, ignore_label=-1, ohem_threshold=0.7, n_min=100000, weight=None):
+        super().__init__()
+        assert weight is None, "class weights are not used by any MGNet config"
+        self.ohem_threshold = float(-torch.log(torch.tensor(ohem_threshold, dtype=torch.float)))
+        self.n_min = n_min
+        self.ignore_label = ignore_label
+
+    def forward(self, logits, labels, weights=None):
+        pixel_losses = _pixel_ce(logits, labels, weights, self.ignore_label)
+        if self.n_min >= pixel_losses.numel():
+            raise IndexError(f"index {self.n_min} is out of bounds for dimension 0 with size {pixel_losses.numel()}")
+        hard = pixel_losses > self.ohem_threshold
+        n_hard = hard.sum()
+        if int(n_hard) > self.n_min:  # one host sync, as in the reference (loss.py:76)
+            return (pixel_losses * hard).sum() / n_hard
+        return torch.topk(pixel_losses, self.n_min)[0].mean()
 
 
 class _ReprojLossFn(torch.autograd.Function):
@@ -54,6 +104,7 @@ class MultiViewPhotometricLoss(nn.Module):
         self.automask_loss = automask_loss
         self.photometric_reduce_op = photometric_reduce_op
         self.padding_mode = padding_mode
+        self.prof_events = None  # optional (hipEvent_t begin, hipEvent_t end) for the next forward (bench.py roofline leg)
         if self.automask_loss:  # loss.py:105-109
             assert (
                 self.photometric_reduce_op == "min"
@@ -72,6 +123,9 @@ class MultiViewPhotometricLoss(nn.Module):
         cfg = _C.make_reproj_cfg(B, H, W, self.n, self.ssim_loss_weight, self.photometric_loss_weight,
                                  self.smoothing_loss_weight, self.automask_loss, self.photometric_reduce_op,
                                  self.padding_mode)
+        if self.prof_events is not None:
+            cfg.prof_begin, cfg.prof_end = self.prof_events
+            self.prof_events = None
         mask = targets.get("reprojection_mask", None)
         if mask is not None:
             mask = mask.contiguous()

@@ -1,0 +1,267 @@
+"""MGNet meta-architecture and its three heads -- host-side mirror of mgnet/modeling/mg_net.py for the TRAINING
+path (mg_net.py:220-373) with the same registries, `@configurable`/`from_config` protocol, attribute names
+(=> state-dict keys) and loss dict keys.  The inference branch (mg_net.py:375-520: post-processing, multi-scale flip)
+is outside the hot path: eval mode returns the raw head outputs."""
+from typing import Dict, List
+
+import torch
+from torch import nn
+
+from ..data.metadata import MetadataCatalog
+from ..events import get_event_storage
+from ..registry import (DEPTH_HEADS_REGISTRY, INS_EMBED_HEADS_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY,
+                        ShapeSpec, build_backbone, build_depth_head, build_ins_embed_head, build_sem_seg_head,
+                        configurable)
+from ..structures import ImageList
+from . import ops
+from .layers import GlobalContextModule, MGNetDecoder, MGNetHead, PoseCNN
+from .loss import DeepLabCE, MultiViewPhotometricLoss, OhemCE
+
+__all__ = ["MGNet", "INS_EMBED_HEADS_REGISTRY", "build_ins_embed_head", "DEPTH_HEADS_REGISTRY", "build_depth_head",
+           "MGNetSemSegHead", "MGNetInsEmbedHead", "MGNetSelfSupervisedDepthHead"]
+
+
+def _decoder_kwargs(node, input_shape, feature_node=None):
+    feats = (feature_node or node).IN_FEATURES
+    return dict(input_shape={k: v for k, v in input_shape.items() if k in feats}, common_stride=node.COMMON_STRIDE,
+                arm_channels=node.ARM_CHANNELS, refine_channels=node.REFINE_CHANNELS, ffm_channels=node.FFM_CHANNELS,
+                head_channels=node.HEAD_CHANNELS, init_method=node.INIT_METHOD)
+
+
+@META_ARCH_REGISTRY.register()
+class MGNet(nn.Module):
+    @configurable
+    def __init__(self, *, size_divisibility, pixel_mean, pixel_std, backbone, global_context, sem_seg_head,
+                 ins_embed_head, depth_head, pose_net, with_panoptic, with_depth, with_uncertainty, msc_flip_eval=False,
+                 amp_dtype=None, **unused_inference_kwargs):
+        super().__init__()
+        self.size_divisibility = size_divisibility
+        self.register_buffer("pixel_mean", torch.tensor([x / 255.0 for x in pixel_mean]).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor([x / 255.0 for x in pixel_std]).view(-1, 1, 1), False)
+        self.backbone = backbone
+        self.bb_features = list(backbone.output_shape().keys())
+        self.global_context = global_context
+        self.sem_seg_head, self.ins_embed_head = sem_seg_head, ins_embed_head
+        self.depth_head, self.pose_net = depth_head, pose_net
+        self.with_panoptic, self.with_depth, self.with_uncertainty = with_panoptic, with_depth, with_uncertainty
+        if with_uncertainty:  # mg_net.py:104-107
+            self.register_parameter("log_vars", nn.Parameter(torch.zeros(5), requires_grad=True))
+        self.msc_flip_eval = msc_flip_eval
+        self.amp_dtype = amp_dtype  # activation dtype of the conv trunk (None = fp32); SOLVER.AMP.ENABLED -> bf16
+
+    @classmethod
+    def from_config(cls, cfg):
+        backbone = build_backbone(cfg)
+        shapes = backbone.output_shape()
+        gcm = GlobalContextModule(in_channels=list(shapes.values())[-1].channels, out_channels=cfg.MODEL.GCM.GCM_CHANNELS,
+                                  init_method=cfg.MODEL.GCM.INIT_METHOD)
+        sem = ins = dep = pose = None
+        if cfg.WITH_PANOPTIC:
+            sem, ins = build_sem_seg_head(cfg, shapes), build_ins_embed_head(cfg, shapes)
+        if cfg.WITH_DEPTH:
+            dep, pose = build_depth_head(cfg, shapes), PoseCNN(cfg)
+        MetadataCatalog.get(cfg.DATASETS.TRAIN[0] if len(cfg.DATASETS.TRAIN) else "cityscapes")  # mg_net.py:147
+        return dict(size_divisibility=cfg.MODEL.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN,
+                    pixel_std=cfg.MODEL.PIXEL_STD, backbone=backbone, global_context=gcm, sem_seg_head=sem,
+                    ins_embed_head=ins, depth_head=dep, pose_net=pose, with_panoptic=cfg.WITH_PANOPTIC,
+                    with_depth=cfg.WITH_DEPTH, with_uncertainty=cfg.WITH_UNCERTAINTY, msc_flip_eval=cfg.TEST.MSC_FLIP_EVAL,
+                    amp_dtype=torch.bfloat16 if cfg.SOLVER.AMP.ENABLED else None)
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    # ---- batching helpers (mg_net.py:250-345) --------------------------------------------------------------
+    def _stack(self, batched_inputs, key, scale=None):
+        ts = [x[key].to(self.device) for x in batched_inputs]
+        if scale is not None:
+            ts = [t.float() / scale for t in ts]
+        return ImageList.from_tensors(ts, self.size_divisibility).tensor
+
+    def _net_input(self, batched_inputs, key):
+        x = (self._stack(batched_inputs, key, 255.0) - self.pixel_mean) / self.pixel_std
+        if self.amp_dtype is not None:
+            x = x.to(self.amp_dtype)
+        return x.contiguous(memory_format=torch.channels_last) if x.is_cuda else x.contiguous()
+
+    def forward(self, batched_inputs):
+        inputs, outputs, targets = {}, {}, {}
+        inputs["image"] = self._net_input(batched_inputs, "image")
+        if self.training and self.with_depth:
+            inputs["image_prev"] = self._net_input(batched_inputs, "image_prev")
+            inputs["image_next"] = self._net_input(batched_inputs, "image_next")
+            outputs["poses"] = self.pose_net(torch.cat(list(inputs.values()), 1))  # mg_net.py:264
+
+        if self.msc_flip_eval and not self.training:
+            raise NotImplementedError("multi-scale flip inference (mg_net.py:427-520) is outside the training hot path")
+        features = self.backbone(inputs["image"])
+        features["global_context"] = self.global_context(features[self.bb_features[-1]])
+        if self.with_panoptic:
+            outputs["sem_seg"] = self.sem_seg_head(features)
+            outputs["center"], outputs["offset"] = self.ins_embed_head(features)
+        if self.with_depth:
+            outputs["depth"] = self.depth_head(features)
+        if not self.training:
+            return outputs  # raw head outputs; post-processing (mg_net.py:375-425) is row f2
+
+        if self.with_panoptic:
+            targets.update({
+                "sem_seg": self._stack(batched_inputs, "sem_seg"),
+                "sem_seg_weights": self._stack(batched_inputs, "sem_seg_weights"),
+                "center": self._stack(batched_inputs, "center").unsqueeze(1),
+                "center_weights": self._stack(batched_inputs, "center_weights"),
+                "offset": self._stack(batched_inputs, "offset"),
+                "offset_weights": self._stack(batched_inputs, "offset_weights"),
+            })
+        if self.with_depth:
+            targets.update({
+                "image_orig": self._stack(batched_inputs, "image_orig", 255.0),  # NOT mean/std normalised (:320-335)
+                "image_prev_orig": self._stack(batched_inputs, "image_prev_orig", 255.0),
+                "image_next_orig": self._stack(batched_inputs, "image_next_orig", 255.0),
+                "camera_matrix": torch.stack([x["camera_matrix"] for x in batched_inputs], 0).to(self.device),
+                "reprojection_mask": self._stack(batched_inputs, "reprojection_mask").unsqueeze(1),
+            })
+
+        losses = {}
+        if self.with_panoptic:
+            losses.update(self.sem_seg_head.losses(outputs, targets))
+            losses.update(self.ins_embed_head.losses(outputs, targets))
+        if self.with_depth:
+            losses.update(self.depth_head.losses(outputs, targets))
+
+        if self.with_uncertainty:  # mg_net.py:360-372 -- same scalar names, but no .item() host syncs inside forward
+            storage = get_event_storage()
+            for idx, (key, value) in enumerate(list(losses.items())):
+                storage.put_scalar(key + "_raw", value.detach())
+                tau = 1.0 if key == "loss_sem_seg" else 0.5
+                losses[key] = tau * torch.exp(-self.log_vars[idx]) * value + 0.5 * self.log_vars[idx]
+                storage.put_scalar(key + "_uncertainty", torch.exp(self.log_vars[idx].detach()))
+        return losses
+
+
+@SEM_SEG_HEADS_REGISTRY.register()
+class MGNetSemSegHead(MGNetDecoder):  # mg_net.py:523-610
+    @configurable
+    def __init__(self, input_shape: Dict[str, ShapeSpec], *, common_stride, arm_channels, refine_channels, ffm_channels,
+                 head_channels, init_method, loss_weight, loss_type, loss_top_k, ohem_threshold, ohem_n_min,
+                 ignore_value, num_classes):
+        super().__init__(input_shape=input_shape, common_stride=common_stride, arm_channels=arm_channels,
+                         refine_channels=refine_channels, ffm_channels=ffm_channels, init_method=init_method)
+        self.ignore_value, self.loss_weight, self.loss_type = ignore_value, loss_weight, loss_type
+        self.decoder_only = num_classes is None
+        self.head = MGNetHead(ffm_channels, head_channels, num_classes, init_method)
+        if loss_type == "cross_entropy":
+            self.loss = DeepLabCE(ignore_label=ignore_value, top_k_percent_pixels=1.0)
+            self._plain_ce = True
+        elif loss_type == "hard_pixel_mining":
+            self.loss = DeepLabCE(ignore_label=ignore_value, top_k_percent_pixels=loss_top_k)
+        elif loss_type == "ohem":
+            self.loss = OhemCE(ignore_label=ignore_value, ohem_threshold=ohem_threshold, n_min=ohem_n_min)
+        else:
+            raise ValueError("Unexpected loss type: %s" % loss_type)
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        n = cfg.MODEL.SEM_SEG_HEAD
+        ret = _decoder_kwargs(n, input_shape)
+        ret.update(loss_weight=n.LOSS_WEIGHT, loss_type=n.LOSS_TYPE, loss_top_k=n.LOSS_TOP_K,
+                   ohem_threshold=n.OHEM_THRESHOLD, ohem_n_min=n.OHEM_N_MIN, ignore_value=n.IGNORE_VALUE,
+                   num_classes=n.NUM_CLASSES)
+        return ret
+
+    def forward(self, features):
+        return ops.upsample_bilinear(self.layers(features), self.common_stride)
+
+    def layers(self, features):
+        y, _ = super().forward(features)
+        return self.head(y)
+
+    def losses(self, predictions, targets):
+        if self.loss_type == "cross_entropy":  # nn.CrossEntropyLoss(mean, ignore_index): mean over non-ignored pixels
+            ce = torch.nn.functional.cross_entropy(predictions["sem_seg"].float(), targets["sem_seg"],
+                                                   ignore_index=self.ignore_value, reduction="mean")
+            return {"loss_sem_seg": ce * self.loss_weight}
+        loss = self.loss(predictions["sem_seg"], targets["sem_seg"], targets["sem_seg_weights"])
+        return {"loss_sem_seg": loss * self.loss_weight}
+
+
+@INS_EMBED_HEADS_REGISTRY.register()
+class MGNetInsEmbedHead(MGNetDecoder):  # mg_net.py:621-715
+    @configurable
+    def __init__(self, input_shape: Dict[str, ShapeSpec], *, common_stride, arm_channels, refine_channels, ffm_channels,
+                 head_channels, init_method, center_loss_weight, offset_loss_weight):
+        super().__init__(input_shape=input_shape, common_stride=common_stride, arm_channels=arm_channels,
+                         refine_channels=refine_channels, ffm_channels=ffm_channels, init_method=init_method)
+        self.center_loss_weight, self.offset_loss_weight = center_loss_weight, offset_loss_weight
+        self.center_head = MGNetHead(ffm_channels, head_channels, 1, init_method)
+        self.offset_head = MGNetHead(ffm_channels, head_channels, 2, init_method)
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        n = cfg.MODEL.INS_EMBED_HEAD
+        ret = _decoder_kwargs(n, input_shape)
+        ret.update(center_loss_weight=n.CENTER_LOSS_WEIGHT, offset_loss_weight=n.OFFSET_LOSS_WEIGHT)
+        return ret
+
+    def forward(self, features):
+        center, offset = self.layers(features)
+        center = ops.upsample_bilinear(center, self.common_stride)
+        offset = ops.upsample_bilinear(offset, self.common_stride) * self.common_stride  # pixel offsets (:682-694)
+        return center, offset
+
+    def layers(self, features):
+        y, _ = super().forward(features)
+        center = torch.sigmoid(self.center_head(y).float())  # mg_net.py:694 (sigmoid_ before the upsample)
+        return center, self.offset_head(y)
+
+    def losses(self, predictions, targets):
+        """[torch-staging] weighted MSE / L1 (mg_net.py:697-715) without the two `.sum() > 0` host syncs:
+        sum/max(wsum, tiny) * (wsum > 0) is identical in value and gradient."""
+        cw, ow = targets["center_weights"], targets["offset_weights"]
+        lc = ((predictions["center"].float() - targets["center"]) ** 2 * cw).sum()
+        cws = cw.sum()
+        lc = torch.where(cws > 0, lc / cws.clamp_min(1e-30), lc * 0)
+        lo = ((predictions["offset"].float() - targets["offset"]).abs() * ow).sum()
+        ows = ow.sum()
+        lo = torch.where(ows > 0, lo / ows.clamp_min(1e-30), lo * 0)
+        return {"loss_center": lc * self.center_loss_weight, "loss_offset": lo * self.offset_loss_weight}
+
+
+@DEPTH_HEADS_REGISTRY.register()
+class MGNetSelfSupervisedDepthHead(MGNetDecoder):  # mg_net.py:726-829
+    @configurable
+    def __init__(self, input_shape: Dict[str, ShapeSpec], *, common_stride, arm_channels, refine_channels, ffm_channels,
+                 head_channels, init_method, msc_loss, loss):
+        super().__init__(input_shape=input_shape, common_stride=common_stride, arm_channels=arm_channels,
+                         refine_channels=refine_channels, ffm_channels=ffm_channels, init_method=init_method)
+        self.n, self.msc_loss, self.loss = None, msc_loss, loss
+        in_ch = [ffm_channels, arm_channels[1], arm_channels[0]] if self.training and msc_loss else [ffm_channels]
+        self.heads = nn.ModuleList([MGNetHead(c, head_channels, 1, init_method) for c in in_ch])
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        n = cfg.MODEL.DEPTH_HEAD
+        loss = MultiViewPhotometricLoss(ssim_loss_weight=n.SSIM_LOSS_WEIGHT, photometric_loss_weight=n.PHOTOMETRIC_LOSS_WEIGHT,
+                                        smoothing_loss_weight=n.SMOOTHING_LOSS_WEIGHT, automask_loss=n.AUTOMASK_LOSS,
+                                        photometric_reduce_op=n.PHOTOMETRIC_REDUCE_OP, padding_mode=n.PADDING_MODE)
+        ret = _decoder_kwargs(n, input_shape, feature_node=cfg.MODEL.INS_EMBED_HEAD)  # sic: mg_net.py:783-785
+        ret.update(msc_loss=n.MSC_LOSS, loss=loss)
+        return ret
+
+    def forward(self, features):
+        y = self.layers(features)
+        s = self.common_stride
+        strides = [s, 2 * s, 4 * s] if self.training and self.msc_loss else [s]
+        inv_depths = [ops.upsample_bilinear(x, st) for x, st in zip(y, strides)]
+        if not self.training:
+            return 1.0 / inv_depths[0].clamp(min=1e-6)  # inv2depth, depth.py:15
+        return inv_depths
+
+    def layers(self, features):
+        y, msc = super().forward(features)
+        feats = [y, msc[1], msc[0]] if self.training and self.msc_loss else [y]
+        # sigmoid / 0.5 -> inverse depth in (0, 2) (mg_net.py:819-823)
+        return [torch.sigmoid(head(f).float()) / 0.5 for head, f in zip(self.heads, feats)]
+
+    def losses(self, predictions, targets):  # fp32 by contract (custom_fwd(cast_inputs=float32), mg_net.py:827)
+        return self.loss(predictions, targets)
