@@ -92,6 +92,38 @@ int mgn_reproj_loss_bwd(const mgn_reproj_cfg* cfg,
                         const float* grad_losses, const float* d_pose, float* const* g_inv, float* d_pose_out,
                         const void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * In-place activated batch norm with cross-rank statistics
+ *   replaces inplace_abn.InPlaceABNSync (68 call sites: mgnet/modeling/res_net.py:35,49,59,103 and
+ *   layers.py:63,71,117,209,242,253,291; always momentum=0.01, group=WORLD, activation leaky_relu(0.01)|identity).
+ *   y = act((|weight|+eps) * (x-mean)/sqrt(var+eps) + bias); backward recovers x_hat from the OUTPUT y.
+ *
+ * x/y/dy/dx: [M = N*H*W, C] channels-last activations, dtype 0 = fp32, 1 = bf16; C % (16/sizeof) == 0, C <= 1024.
+ * The cross-rank exchange is the caller's (RCCL via torch.distributed): all_gather of `stats` between
+ * mgn_iabn_stats and mgn_iabn_combine (forward), all_reduce of `sums` between mgn_iabn_bwd_reduce and
+ * mgn_iabn_bwd_apply (backward) -- the same two exchanges inplace_abn performs.
+ *   forward : stats -> [all_gather] -> combine (Chan's formula; running stats; scale/offset; saved={mean,rstd}) -> apply
+ *   backward: bwd_reduce (sums[2][C] = {sum dz, sum dz*x_hat}; d_bias = sums[0], d_weight = sign(weight)*sums[1])
+ *             -> [all_reduce sums] -> bwd_apply
+ * activation: 0 = identity, 1 = leaky_relu(slope).
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_iabn_workspace_bytes(long M, int C, int dtype, size_t* bytes);
+int mgn_iabn_stats(const void* x, int dtype, long M, int C, float* stats /*[3][C]: count, mean, M2*/,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int mgn_iabn_combine(const float* gathered /*[n_ranks][3][C]*/, int n_ranks, int C, const float* weight, const float* bias,
+                     float eps, float momentum, float* running_mean /*nullable*/, float* running_var,
+                     float* scale, float* offset, float* saved /*[2][C]: mean, rstd*/, void* stream);
+int mgn_iabn_eval_coeffs(int C, const float* weight, const float* bias, const float* running_mean,
+                         const float* running_var, float eps, float* scale, float* offset, void* stream);
+int mgn_iabn_apply(const void* x, void* y /*may alias x*/, int dtype, long M, int C, const float* scale,
+                   const float* offset, int activation, float slope, void* stream);
+int mgn_iabn_bwd_reduce(const void* y, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
+                        float eps, int activation, float slope, float* sums /*[2][C]*/,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int mgn_iabn_bwd_apply(const void* y, const void* dy, void* dx /*may alias dy*/, int dtype, long M, int C,
+                       const float* weight, const float* bias, const float* saved, const float* sums,
+                       float total_count, float eps, int activation, float slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,9 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
         -95: "MGN_ENOTSUP (option has no kernel)", -5: "MGN_ELAUNCH (kernel launch failed)"}
 
 # every symbol include/mgnet_hip.h declares (tests check that the library exports all of them)
-SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd"]
+SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
+           "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
+           "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply"]
 
 
 class ReprojCfg(ctypes.Structure):
@@ -43,6 +45,16 @@ def lib():
                                           vp, vp, sz, vp]
         L.mgn_reproj_loss_bwd.restype = ci
         L.mgn_reproj_loss_bwd.argtypes = [ctypes.POINTER(ReprojCfg), vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        cl, cf = ctypes.c_long, ctypes.c_float
+        L.mgn_iabn_workspace_bytes.argtypes = [cl, ci, ci, ctypes.POINTER(sz)]
+        L.mgn_iabn_stats.argtypes = [vp, ci, cl, ci, vp, vp, sz, vp]
+        L.mgn_iabn_combine.argtypes = [vp, ci, ci, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp]
+        L.mgn_iabn_eval_coeffs.argtypes = [ci, vp, vp, vp, vp, cf, vp, vp, vp]
+        L.mgn_iabn_apply.argtypes = [vp, vp, ci, cl, ci, vp, vp, ci, cf, vp]
+        L.mgn_iabn_bwd_reduce.argtypes = [vp, vp, ci, cl, ci, vp, vp, cf, ci, cf, vp, vp, sz, vp]
+        L.mgn_iabn_bwd_apply.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, cf, ci, cf, vp]
+        for n in SYMBOLS[4:]:
+            getattr(L, n).restype = ci
         _lib = L
     return _lib
 
@@ -124,3 +136,72 @@ def reproj_loss_bwd(cfg, inv, img, mask, grad_losses, fwd):
         fwd["workspace"].data_ptr(), fwd["workspace"].numel(), _stream())
     check(rc, "mgn_reproj_loss_bwd")
     return fwd["g_inv"], d_pose_out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# activated batch norm
+# ---------------------------------------------------------------------------------------------------------------
+_IABN_WS = {}
+
+
+def _iabn_ws(device):
+    ws = _IABN_WS.get(device)
+    if ws is None:
+        ws = _IABN_WS[device] = torch.empty(2 * 1024 * 1024, dtype=torch.float32, device=device)  # 2*C*1024 floats, C<=1024
+    return ws
+
+
+def _act_dtype(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise ValueError(f"activations must be float32 or bfloat16, got {t.dtype}")
+
+
+def iabn_stats(x2d_like, M, C):
+    """x: channels-last activation storage -> stats[3,C] = (count, mean, M2) of this rank."""
+    stats = torch.empty((3, C), dtype=torch.float32, device=x2d_like.device)
+    ws = _iabn_ws(x2d_like.device)
+    check(lib().mgn_iabn_stats(x2d_like.data_ptr(), _act_dtype(x2d_like), M, C, stats.data_ptr(), ws.data_ptr(),
+                               ws.numel() * 4, _stream()), "mgn_iabn_stats")
+    return stats
+
+
+def iabn_combine(gathered, weight, bias, eps, momentum, running_mean, running_var):
+    R, _, C = gathered.shape
+    out = torch.empty((4, C), dtype=torch.float32, device=gathered.device)  # scale, offset, mean, rstd
+    check(lib().mgn_iabn_combine(gathered.data_ptr(), R, C, weight.data_ptr(), bias.data_ptr(), eps, momentum,
+                                 None if running_mean is None else running_mean.data_ptr(),
+                                 None if running_var is None else running_var.data_ptr(), out[0].data_ptr(),
+                                 out[1].data_ptr(), out[2].data_ptr(), _stream()), "mgn_iabn_combine")
+    return out
+
+
+def iabn_eval_coeffs(weight, bias, running_mean, running_var, eps):
+    C = weight.numel()
+    out = torch.empty((2, C), dtype=torch.float32, device=weight.device)
+    check(lib().mgn_iabn_eval_coeffs(C, weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(),
+                                     running_var.data_ptr(), eps, out[0].data_ptr(), out[1].data_ptr(), _stream()),
+          "mgn_iabn_eval_coeffs")
+    return out
+
+
+def iabn_apply(x, y, M, C, scale, offset, activation, slope):
+    check(lib().mgn_iabn_apply(x.data_ptr(), y.data_ptr(), _act_dtype(x), M, C, scale.data_ptr(), offset.data_ptr(),
+                               activation, slope, _stream()), "mgn_iabn_apply")
+
+
+def iabn_bwd_reduce(y, dy, M, C, weight, bias, eps, activation, slope):
+    sums = torch.empty((2, C), dtype=torch.float32, device=y.device)
+    ws = _iabn_ws(y.device)
+    check(lib().mgn_iabn_bwd_reduce(y.data_ptr(), dy.data_ptr(), _act_dtype(y), M, C, weight.data_ptr(), bias.data_ptr(),
+                                    eps, activation, slope, sums.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()),
+          "mgn_iabn_bwd_reduce")
+    return sums
+
+
+def iabn_bwd_apply(y, dy, dx, M, C, weight, bias, saved, sums, total_count, eps, activation, slope):
+    check(lib().mgn_iabn_bwd_apply(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), _act_dtype(y), M, C, weight.data_ptr(),
+                                   bias.data_ptr(), saved.data_ptr(), sums.data_ptr(), float(total_count), eps,
+                                   activation, slope, _stream()), "mgn_iabn_bwd_apply")
