@@ -124,6 +124,23 @@ int mgn_iabn_bwd_apply(const void* y, const void* dy, void* dx /*may alias dy*/,
                        const float* weight, const float* bias, const float* saved, const float* sums,
                        float total_count, float eps, int activation, float slope, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Full-model gradient clipping + Adam over flat fp32 buckets
+ *   replaces tools/train_net.py:108-154: torch.optim.Adam wrapped in FullModelGradientClippingOptimizer
+ *   (clip_grad_norm_(all params, CLIP_VALUE=0.01, L2) then Adam.step), parameter groups of mgnet/solver/build.py:9-116.
+ * Buckets are padded so that every tensor starts at a multiple of mgn_optim_chunk() elements; chunk_lr / chunk_wd hold
+ * the learning rate / weight decay of the tensor that owns each chunk (device arrays, n / chunk entries).
+ *   mgn_sqnorm     : partials[0..n_partials) = block sums of g^2 (call once per bucket, consecutive partial ranges)
+ *   mgn_clip_coef  : coef_and_norm = { min(1, max_norm/(norm+1e-6)), norm } with norm = sqrt(sum partials)*grad_scale
+ *   mgn_adam_step  : torch.optim.Adam (no amsgrad) on g*grad_scale*coef, bias correction for `step` (1-based)
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_optim_chunk(void);
+int mgn_sqnorm(const float* g, long n, float* partials, int max_partials, int* n_partials, void* stream);
+int mgn_clip_coef(const float* partials, int n_partials, float max_norm, float grad_scale, float* coef_and_norm,
+                  void* stream);
+int mgn_adam_step(float* p, const float* g, float* m, float* v, long n, const float* chunk_lr, const float* chunk_wd,
+                  float beta1, float beta2, float eps, int step, const float* clip_coef, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,8 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 # every symbol include/mgnet_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
-           "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply"]
+           "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step"]
 
 
 class ReprojCfg(ctypes.Structure):
@@ -53,6 +54,9 @@ def lib():
         L.mgn_iabn_apply.argtypes = [vp, vp, ci, cl, ci, vp, vp, ci, cf, vp]
         L.mgn_iabn_bwd_reduce.argtypes = [vp, vp, ci, cl, ci, vp, vp, cf, ci, cf, vp, vp, sz, vp]
         L.mgn_iabn_bwd_apply.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, cf, ci, cf, vp]
+        L.mgn_sqnorm.argtypes = [vp, cl, vp, ci, ctypes.POINTER(ci), vp]
+        L.mgn_clip_coef.argtypes = [vp, ci, cf, cf, vp, vp]
+        L.mgn_adam_step.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, ci, vp, cf, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
         _lib = L
@@ -205,3 +209,28 @@ def iabn_bwd_apply(y, dy, dx, M, C, weight, bias, saved, sums, total_count, eps,
     check(lib().mgn_iabn_bwd_apply(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), _act_dtype(y), M, C, weight.data_ptr(),
                                    bias.data_ptr(), saved.data_ptr(), sums.data_ptr(), float(total_count), eps,
                                    activation, slope, _stream()), "mgn_iabn_bwd_apply")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# clip + Adam over flat buckets
+# ---------------------------------------------------------------------------------------------------------------
+def optim_chunk():
+    return lib().mgn_optim_chunk()
+
+
+def sqnorm(g, partials, offset):
+    """block partials of sum g^2 into partials[offset:]; returns the number of partials written"""
+    n = ctypes.c_int(0)
+    check(lib().mgn_sqnorm(g.data_ptr(), g.numel(), partials.data_ptr() + 4 * offset, partials.numel() - offset,
+                           ctypes.byref(n), _stream()), "mgn_sqnorm")
+    return n.value
+
+
+def clip_coef(partials, n_partials, max_norm, grad_scale, out):
+    check(lib().mgn_clip_coef(partials.data_ptr(), n_partials, max_norm, grad_scale, out.data_ptr(), _stream()), "mgn_clip_coef")
+
+
+def adam_step(p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, step, coef, grad_scale):
+    check(lib().mgn_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), chunk_lr.data_ptr(),
+                              chunk_wd.data_ptr(), beta1, beta2, eps, step, coef.data_ptr(), grad_scale, _stream()),
+          "mgn_adam_step")

@@ -116,16 +116,30 @@ __global__ __launch_bounds__(TPB) void iabn_stats_partial(const T* __restrict__ 
     });
 }
 
-// stats[3][C] = {count, mean, M2} of THIS rank
+// sum the block partials [nblk][2][C] for 32 channels per block: 8 slices of blocks in parallel, then LDS (fixed order)
+__device__ __forceinline__ void reduce_partials(const float* partials, int nblk, int C, int c, int slice, float& s1, float& s2) {
+    __shared__ float r1[8][32], r2[8][32];
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int k = slice; k < nblk; k += 8) {
+            a += partials[((size_t)k * 2 + 0) * C + c];
+            b += partials[((size_t)k * 2 + 1) * C + c];
+        }
+    r1[slice][threadIdx.x] = a;
+    r2[slice][threadIdx.x] = b;
+    __syncthreads();
+    s1 = s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
+}
+
+// stats[3][C] = {count, mean, M2} of THIS rank.  block (32, 8), grid C/32
 template <typename T>
 __global__ void iabn_stats_final(const T* __restrict__ x, const float* partials, int nblk, long M, int C, float* stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += partials[((size_t)b * 2 + 0) * C + c];
-        s2 += partials[((size_t)b * 2 + 1) * C + c];
-    }
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    float s1, s2;
+    reduce_partials(partials, nblk, C, c, threadIdx.y, s1, s2);
+    if (c >= C || threadIdx.y != 0) return;
     float sv[Vec<T>::N];
     Vec<T>::load(x + (c / Vec<T>::N) * Vec<T>::N, sv);
     const float shift = sv[c % Vec<T>::N];
@@ -220,13 +234,10 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_partial(const T* __restrict__ y,
 }
 
 __global__ void iabn_bwd_final(const float* partials, int nblk, int C, float* sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += partials[((size_t)b * 2 + 0) * C + c];
-        s2 += partials[((size_t)b * 2 + 1) * C + c];
-    }
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    float s1, s2;
+    reduce_partials(partials, nblk, C, c, threadIdx.y, s1, s2);
+    if (c >= C || threadIdx.y != 0) return;
     sums[c] = s1;
     sums[C + c] = s2;
 }
@@ -276,7 +287,7 @@ inline int stat_blocks(long M, int C, int dtype) {
     const int V = dtype == 1 ? 8 : 4;
     const int rpb = TPB / (C / V);
     long b = (M + (long)rpb * 8 - 1) / ((long)rpb * 8);  // >= 8 rows per thread before adding blocks
-    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 
 }  // namespace
@@ -300,10 +311,10 @@ int mgn_iabn_stats(const void* x, int dtype, long M, int C, float* stats, void* 
     const int nb = stat_blocks(M, C, dtype);
     if (dtype == 1) {
         hipLaunchKernelGGL(iabn_stats_partial<__hip_bfloat16>, dim3(nb), dim3(TPB), 0, s, (const __hip_bfloat16*)x, M, C, (float*)ws);
-        hipLaunchKernelGGL(iabn_stats_final<__hip_bfloat16>, dim3((C + 63) / 64), dim3(64), 0, s, (const __hip_bfloat16*)x, (const float*)ws, nb, M, C, stats);
+        hipLaunchKernelGGL(iabn_stats_final<__hip_bfloat16>, dim3((C + 31) / 32), dim3(32, 8), 0, s, (const __hip_bfloat16*)x, (const float*)ws, nb, M, C, stats);
     } else {
         hipLaunchKernelGGL(iabn_stats_partial<float>, dim3(nb), dim3(TPB), 0, s, (const float*)x, M, C, (float*)ws);
-        hipLaunchKernelGGL(iabn_stats_final<float>, dim3((C + 63) / 64), dim3(64), 0, s, (const float*)x, (const float*)ws, nb, M, C, stats);
+        hipLaunchKernelGGL(iabn_stats_final<float>, dim3((C + 31) / 32), dim3(32, 8), 0, s, (const float*)x, (const float*)ws, nb, M, C, stats);
     }
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
@@ -354,7 +365,7 @@ int mgn_iabn_bwd_reduce(const void* y, const void* dy, int dtype, long M, int C,
     else
         hipLaunchKernelGGL(iabn_bwd_partial<float>, dim3(nb), dim3(TPB), 0, s, (const float*)y, (const float*)dy, M, C, weight, bias,
                            eps, activation, slope, (float*)ws);
-    hipLaunchKernelGGL(iabn_bwd_final, dim3((C + 63) / 64), dim3(64), 0, s, (const float*)ws, nb, C, sums);
+    hipLaunchKernelGGL(iabn_bwd_final, dim3((C + 31) / 32), dim3(32, 8), 0, s, (const float*)ws, nb, C, sums);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

@@ -3,79 +3,91 @@
 
 * parameters are packed, in REVERSE registration order (= roughly the order in which backward produces gradients:
   heads -> decoders -> res5 .. stem), into flat fp32 buckets; `param.grad` are views into the bucket, so there is no
-  gather/scatter copy around the collective
+  gather/scatter copy around the collective.  With `flatten_params=True` the parameters themselves (and later the Adam
+  moments) live in flat buffers of the same layout, which is what the fused clip+Adam kernels consume.
 * a post-accumulate-grad hook counts a bucket's ready gradients and launches ONE asynchronous all-reduce per bucket as
   soon as it is complete, so the collective overlaps with the rest of backward
 * xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound, ~2*(N-1)/N*bytes/153 GB/s
   (1.4 ms for the 123.8 MB of MGNet at N=8); 32 MB buckets keep each call far above the latency floor while leaving
   >= 4 calls to pipeline behind backward
-* gradients are averaged (sum, then 1/world) like DDP
+* gradients are averaged (sum, then 1/world) like DDP -- by `finish()` or, when `average=False`, by the consumer
+  (the fused optimizer folds 1/world into its clipping pass)
 """
 import torch
 import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, group=None):
-        self.group = group
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, align=1, flatten_params=False, average=True):
+        self.group, self.align, self.average = group, align, average
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         params = [p for p in params if p.requires_grad]
-        self.buckets = []          # list of dict(flat, params, pending)
+        self.buckets = []          # dict(flat_g, flat_p, params, offsets, pending, n)
         self._bucket_of = {}
         cur, cur_bytes = [], 0
         for p in reversed(params):
-            nb = p.numel() * 4
+            nb = self._padded(p.numel()) * 4
             if cur and cur_bytes + nb > bucket_bytes:
-                self._seal(cur)
+                self._seal(cur, flatten_params)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nb
         if cur:
-            self._seal(cur)
+            self._seal(cur, flatten_params)
         self._handles = []
         for p in params:
             p.register_post_accumulate_grad_hook(self._hook)
 
-    def _seal(self, plist):
-        n = sum(p.numel() for p in plist)
-        flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
-        off = 0
+    def _padded(self, n):
+        return (n + self.align - 1) // self.align * self.align
+
+    def _seal(self, plist, flatten_params):
+        offsets, off = [], 0
         for p in plist:
             assert p.dtype == torch.float32
-            p.grad = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        b = dict(flat=flat, params=plist, pending=len(plist), n=len(plist))
+            offsets.append(off)
+            off += self._padded(p.numel())
+        dev = plist[0].device
+        flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        flat_p = None
+        if flatten_params:
+            flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+            for p, o in zip(plist, offsets):
+                flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = flat_p[o:o + p.numel()].view(p.shape)
+        for p, o in zip(plist, offsets):
+            p.grad = flat_g[o:o + p.numel()].view(p.shape)
+        b = dict(flat_g=flat_g, flat_p=flat_p, params=plist, offsets=offsets, pending=len(plist), n=len(plist))
         self.buckets.append(b)
         for p in plist:
             self._bucket_of[p] = b
 
     def zero_grad(self):
         for b in self.buckets:
-            b["flat"].zero_()
+            b["flat_g"].zero_()
             b["pending"] = b["n"]
-            off = 0
-            for p in b["params"]:  # restore the views if someone replaced .grad
-                if p.grad is None or p.grad.data_ptr() != b["flat"].data_ptr() + off * 4:
-                    p.grad = b["flat"][off:off + p.numel()].view_as(p)
-                off += p.numel()
+            for p, o in zip(b["params"], b["offsets"]):  # restore the views if someone replaced .grad
+                if p.grad is None or p.grad.data_ptr() != b["flat_g"].data_ptr() + o * 4:
+                    p.grad = b["flat_g"][o:o + p.numel()].view(p.shape)
 
     def _hook(self, p):
         b = self._bucket_of[p]
         b["pending"] -= 1
         if b["pending"] == 0 and self.world > 1:
-            self._handles.append(dist.all_reduce(b["flat"], group=self.group, async_op=True))
+            self._handles.append(dist.all_reduce(b["flat_g"], group=self.group, async_op=True))
 
     def finish(self):
         """Wait for the in-flight buckets, launch the ones whose parameters got no gradient this step, average."""
         if self.world > 1:
             for b in self.buckets:
                 if b["pending"] > 0:  # unused parameters this iteration: still reduce (zeros) to stay in lock step
-                    self._handles.append(dist.all_reduce(b["flat"], group=self.group, async_op=True))
+                    self._handles.append(dist.all_reduce(b["flat_g"], group=self.group, async_op=True))
             for h in self._handles:
                 h.wait()
             self._handles.clear()
-            for b in self.buckets:
-                b["flat"].mul_(1.0 / self.world)
+            if self.average:
+                for b in self.buckets:
+                    b["flat_g"].mul_(1.0 / self.world)
 
     def grad_bytes(self):
-        return sum(b["flat"].numel() * 4 for b in self.buckets)
+        return sum(b["flat_g"].numel() * 4 for b in self.buckets)

@@ -11,9 +11,18 @@ from .reducer import GradReducer
 class Trainer:
     def __init__(self, cfg, model, bucket_bytes=32 << 20):
         self.cfg, self.model = cfg, model
-        self.optimizer = build_optimizer(cfg, model)
+        on_gpu = next(model.parameters()).is_cuda
+        if on_gpu and cfg.SOLVER.OPTIMIZER == "ADAM":
+            from .. import _C
+            from ..solver import get_mgnet_optimizer_params
+            groups = get_mgnet_optimizer_params(model, cfg.SOLVER.BASE_LR, head_lr_factor=cfg.SOLVER.HEAD_LR_FACTOR)
+            self.reducer = GradReducer([p for g in groups for p in (g["params"] if isinstance(g["params"], list) else [g["params"]])],
+                                       bucket_bytes, align=_C.optim_chunk(), flatten_params=True, average=False)
+            self.optimizer = build_optimizer(cfg, model, reducer=self.reducer)
+        else:
+            self.optimizer = build_optimizer(cfg, model)
+            self.reducer = GradReducer([p for g in self.optimizer.param_groups for p in g["params"]], bucket_bytes)
         self.scheduler = build_lr_scheduler(cfg, self.optimizer)
-        self.reducer = GradReducer([p for g in self.optimizer.param_groups for p in g["params"]], bucket_bytes)
         self.storage = EventStorage()
         self.iter = 0
 

@@ -53,14 +53,19 @@ def _with_full_model_clipping(optim_cls, clip_value, norm_type=2.0):
     return FullModelGradientClippingOptimizer
 
 
-def build_optimizer(cfg, model):
-    """[torch-staging: torch.optim step] Adam/AdamW/SGD over the MGNet param groups, clip_grad_norm_(all, 0.01)."""
+def build_optimizer(cfg, model, reducer=None):
+    """Adam/AdamW/SGD over the MGNet param groups with clip_grad_norm_(all, 0.01).
+    With a flat-bucket `reducer` on a CUDA model and OPTIMIZER == "ADAM": [HIP] fused clip+Adam (solver/fused_adam.py);
+    otherwise (CPU host-logic tests, SGD/AdamW) the torch optimizers."""
     s = cfg.SOLVER
     groups = get_mgnet_optimizer_params(model, base_lr=s.BASE_LR, head_lr_factor=s.HEAD_LR_FACTOR,
                                         weight_decay=s.WEIGHT_DECAY, weight_decay_norm=s.WEIGHT_DECAY_NORM)
     clip = s.CLIP_GRADIENTS
     enable = clip.ENABLED and clip.CLIP_TYPE == "full_model" and clip.CLIP_VALUE > 0.0
     wrap = (lambda c: _with_full_model_clipping(c, clip.CLIP_VALUE, clip.NORM_TYPE)) if enable else (lambda c: c)
+    if reducer is not None and s.OPTIMIZER == "ADAM":
+        from .fused_adam import FusedAdam
+        return FusedAdam(groups, s.BASE_LR, reducer, max_grad_norm=clip.CLIP_VALUE if enable else 0.0)
     if s.OPTIMIZER == "SGD":
         return wrap(torch.optim.SGD)(groups, s.BASE_LR, momentum=s.MOMENTUM, nesterov=s.NESTEROV)
     if s.OPTIMIZER == "ADAM":

@@ -1,0 +1,59 @@
+"""[HIP] Adam + full-model gradient-norm clipping on the flat buckets of GradReducer (mgnet_amd/csrc/optim.hip).
+Same update rule as torch.optim.Adam behind FullModelGradientClippingOptimizer (tools/train_net.py:129-148); a
+torch.optim.Optimizer subclass so that the LR scheduler and `param_groups` work unchanged."""
+import numpy as np
+import torch
+
+from .. import _C
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr, reducer, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.reducer, self.max_grad_norm = reducer, float(max_grad_norm)
+        assert reducer.align == _C.optim_chunk() and all(b["flat_p"] is not None for b in reducer.buckets)
+        self.chunk = reducer.align
+        dev = reducer.buckets[0]["flat_g"].device
+        self._t = 0
+        self._m = [torch.zeros_like(b["flat_g"]) for b in reducer.buckets]
+        self._v = [torch.zeros_like(b["flat_g"]) for b in reducer.buckets]
+        self._lr_dev = [torch.zeros(b["flat_g"].numel() // self.chunk, device=dev) for b in reducer.buckets]
+        self._wd_dev = [torch.zeros(b["flat_g"].numel() // self.chunk, device=dev) for b in reducer.buckets]
+        self._host = [[torch.zeros(2, t.numel(), pin_memory=True) for _ in range(2)] for t in self._lr_dev]
+        self._partials = torch.zeros(1024 * len(reducer.buckets), device=dev)
+        self._coef = torch.zeros(2, device=dev)
+        self._group_of = {p: g for g in self.param_groups for p in g["params"]}
+        # chunks owned by each parameter
+        self._reps = [np.array([(p.numel() + self.chunk - 1) // self.chunk for p in b["params"]]) for b in reducer.buckets]
+
+    def _upload_tables(self):
+        for k, b in enumerate(self.reducer.buckets):
+            lr = np.repeat(np.array([self._group_of[p]["lr"] for p in b["params"]], np.float32), self._reps[k])
+            wd = np.repeat(np.array([self._group_of[p]["weight_decay"] or 0.0 for p in b["params"]], np.float32), self._reps[k])
+            host = self._host[k][self._t % 2]
+            host[0].copy_(torch.from_numpy(lr))
+            host[1].copy_(torch.from_numpy(wd))
+            self._lr_dev[k].copy_(host[0], non_blocking=True)
+            self._wd_dev[k].copy_(host[1], non_blocking=True)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        self._t += 1
+        self._upload_tables()
+        grad_scale = 1.0 / self.reducer.world
+        n = 0
+        for b in self.reducer.buckets:
+            n += _C.sqnorm(b["flat_g"], self._partials, n)
+        _C.clip_coef(self._partials, n, self.max_grad_norm, grad_scale, self._coef)
+        g0 = self.param_groups[0]
+        for k, b in enumerate(self.reducer.buckets):
+            _C.adam_step(b["flat_p"], b["flat_g"], self._m[k], self._v[k], self._lr_dev[k], self._wd_dev[k],
+                         g0["betas"][0], g0["betas"][1], g0["eps"], self._t, self._coef, grad_scale)
+
+    def grad_norm(self):
+        """total gradient norm of the last step (device scalar; no sync)"""
+        return self._coef[1]
+
+    def zero_grad(self, set_to_none=False):
+        self.reducer.zero_grad()
