@@ -141,6 +141,23 @@ int mgn_clip_coef(const float* partials, int n_partials, float max_norm, float g
 int mgn_adam_step(float* p, const float* g, float* m, float* v, long n, const float* chunk_lr, const float* chunk_wd,
                   float beta1, float beta2, float eps, int step, const float* clip_coef, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Convolutions as implicit GEMM on the bf16 matrix cores
+ *   replaces F.conv2d (cuDNN/MIOpen) behind detectron2.layers.Conv2d / nn.Conv2d in mgnet/modeling/res_net.py:28-60,
+ *   96-104 and layers.py:53-72,110-118,146-149,201-210,234-256,283-311.
+ * in  : [N, IH, IW, Cin]  bf16 (channels-last);  w : [Cout, KH, KW, Cin] bf16;  out : [N, OH, OW, Cout] bf16 | fp32
+ * mgn_conv_igemm: out[n,oh,ow,co] = bias[co] + sum_{kh,kw,ci} in[n, t(oh,kh), t(ow,kw), ci] * w[co,kh,kw,ci], optional ReLU,
+ *   t(o,k) = o*stride + k - pad, and when up > 1 the tap only contributes where t is divisible by `up` (then t /= up):
+ *   with (w flipped+transposed, stride=1, pad=K-1-pad, up=forward stride) this is the data gradient.
+ *   Cin must be a multiple of 32 (MGN_ENOTSUP otherwise: the 3/9-channel 7x7 stems).
+ * mgn_conv_wgrad: dw[co,kh,kw,ci] += sum_{n,oh,ow} dout[n,oh,ow,co] * in[n, oh*stride+kh-pad, ow*stride+kw-pad, ci]
+ *   (fp32 atomics: zero dw first; Cin, Cout multiples of 8)
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH,
+                   int OW, int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, void* stream);
+int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout,
+                   int KH, int KW, int stride, int pad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step"]
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad"]
 
 
 class ReprojCfg(ctypes.Structure):
@@ -57,6 +57,8 @@ def lib():
         L.mgn_sqnorm.argtypes = [vp, cl, vp, ci, ctypes.POINTER(ci), vp]
         L.mgn_clip_coef.argtypes = [vp, ci, cf, cf, vp, vp]
         L.mgn_adam_step.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, ci, vp, cf, vp]
+        L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp]
+        L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 11 + [vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
         _lib = L
@@ -234,3 +236,32 @@ def adam_step(p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, step, coef, gra
     check(lib().mgn_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), chunk_lr.data_ptr(),
                               chunk_wd.data_ptr(), beta1, beta2, eps, step, coef.data_ptr(), grad_scale, _stream()),
           "mgn_adam_step")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# convolution (implicit GEMM, bf16 MFMA).  Tensors are logical NCHW in channels_last memory format.
+# ---------------------------------------------------------------------------------------------------------------
+def conv_supported(x, weight):
+    return x.is_cuda and x.dtype == torch.bfloat16 and weight.shape[1] % 32 == 0
+
+
+def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=torch.bfloat16):
+    """x [N,Cin,IH,IW] channels_last bf16; w_ohwi [Cout,KH,KW,Cin] bf16 contiguous -> out [N,Cout,OH,OW] channels_last"""
+    N, Cin, IH, IW = x.shape
+    Cout, KH, KW, _ = w_ohwi.shape
+    OH, OW = out_shape
+    out = torch.empty((N, Cout, OH, OW), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
+    check(lib().mgn_conv_igemm(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(),
+                               N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, int(relu),
+                               int(out_dtype == torch.float32), _stream()), "mgn_conv_igemm")
+    return out
+
+
+def conv_wgrad(dy, x, kh, kw, stride, pad):
+    """dy [N,Cout,OH,OW], x [N,Cin,IH,IW] (channels_last bf16) -> dw [Cout,KH,KW,Cin] fp32"""
+    N, Cout, OH, OW = dy.shape
+    _, Cin, IH, IW = x.shape
+    dw = torch.zeros((Cout, kh, kw, Cin), dtype=torch.float32, device=x.device)
+    check(lib().mgn_conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, IH, IW, Cin, OH, OW, Cout, kh, kw, stride, pad,
+                               _stream()), "mgn_conv_wgrad")
+    return dw

@@ -1,0 +1,300 @@
+// conv.hip -- convolutions of the MGNet trunk as implicit GEMM on the bf16 matrix cores of gfx950.
+//
+// Replaces torch.nn.functional.conv2d -> cuDNN/MIOpen behind detectron2.layers.Conv2d / nn.Conv2d in
+// mgnet/modeling/res_net.py:28-60,96-104 and layers.py:53-72,110-118,146-149,201-210,234-256,283-311 (84 convs; 1x1,
+// 3x3 stride 1/2; the 7x7 stems with 3/9 input channels stay on the staging path).
+//
+// Layout: activations NHWC (torch channels_last) bf16, weights [Cout][KH][KW][Cin] bf16 (K = tap-major, channel-minor),
+// fp32 accumulation in the MFMA accumulators.  A 1x1 conv is the plain GEMM [N*H*W, Cin] x [Cin, Cout]; a 3x3 conv is
+// the same contraction with K = 9*Cin: the A operand is gathered tap by tap with zero fill for the padding.
+//
+//   forward / data-gradient : conv_igemm   C[m, co] = sum_{tap, ci} In[pix(m, tap), ci] * W[co, tap, ci]
+//        (data gradient = the same kernel over dOut with flipped/transposed weights; stride-2 layers use `up`:
+//         a tap contributes only where (o + k - pad) is divisible by the forward stride)
+//   weight gradient          : conv_wgrad   dW[co, tap, ci] = sum_m dOut[m, co] * In[pix(m, tap), ci]
+//        (K = pixels; split over blockIdx.z, fp32 atomics into the [Cout][KH][KW][Cin] fp32 gradient)
+//
+// Tiling (wave64, v_mfma_f32_32x32x16_bf16): block 128(M) x 128(N) x 32(K), 4 wavefronts as 2x2, each 64x64 =
+// 2x2 MFMA tiles -> 8 MFMAs per wavefront per k-step; LDS tiles [row][32 k] with an 80-byte row pitch (conflict-free
+// ds_read_b128 fragment reads); register-staged double buffering (global loads of step s+1 in flight during the MFMAs
+// of step s), one barrier per k-step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mgnet_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int PITCH = 80;  // bytes per LDS row (64 data + 16 pad)
+constexpr int TILE_BYTES = 128 * PITCH;
+
+struct ConvParams {
+    const uint16_t* in;   // [N, IH, IW, Cin] bf16
+    const uint16_t* w;    // [Cout, KH, KW, Cin] bf16
+    void* out;            // [N, OH, OW, Cout] bf16 or fp32
+    const float* bias;    // [Cout] or null
+    int N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32;
+};
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+__device__ __forceinline__ void mma_tile(const unsigned char* sA, const unsigned char* sB, int wm, int wn, int lane,
+                                         f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int koff = (kk * 16 + (lane >> 5) * 8) * 2;
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[i] = *reinterpret_cast<const bf16x8*>(sA + (wm * 64 + i * 32 + (lane & 31)) * PITCH + koff);
+            b[i] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + i * 32 + (lane & 31)) * PITCH + koff);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int bm = blockIdx.x, bn = blockIdx.y;
+    const long M = (long)p.N * p.OH * p.OW;
+    const int lrow = tid >> 2, seg = tid & 3;  // loader: rows lrow and lrow+64, 16-byte segment `seg` of the 64-byte k-slab
+
+    int nb[2], ihb[2], iwb[2];
+    bool vm[2], vco[2];
+    const uint16_t* wrow[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const long m = (long)bm * BM + lrow + r * 64;
+        vm[r] = m < M;
+        const long mm = vm[r] ? m : 0;
+        const int n = (int)(mm / ((long)p.OH * p.OW));
+        const int rem = (int)(mm - (long)n * p.OH * p.OW);
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        nb[r] = n;
+        ihb[r] = oh * p.stride - p.pad;
+        iwb[r] = ow * p.stride - p.pad;
+        const int co = bn * BN + lrow + r * 64;
+        vco[r] = co < p.Cout;
+        wrow[r] = p.w + (size_t)(vco[r] ? co : 0) * p.KH * p.KW * p.Cin + seg * 8;
+    }
+    const int cpt = p.Cin / BK;  // k-steps per tap
+    const int ksteps = p.KH * p.KW * cpt;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 ra[2], rb[2];
+    int kh = 0, kw = 0, cc = 0;  // state of the NEXT k-step to load
+    auto load_next = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int th = ihb[r] + kh, tw = iwb[r] + kw;
+            bool ok = vm[r];
+            if (p.up > 1) {
+                ok = ok && (th % p.up == 0) && (tw % p.up == 0) && th >= 0 && tw >= 0;
+                th /= p.up;
+                tw /= p.up;
+            }
+            ok = ok && th >= 0 && th < p.IH && tw >= 0 && tw < p.IW;
+            ra[r] = make_uint4(0, 0, 0, 0);
+            if (ok) ra[r] = *reinterpret_cast<const uint4*>(p.in + (((size_t)nb[r] * p.IH + th) * p.IW + tw) * p.Cin + cc * BK + seg * 8);
+            rb[r] = make_uint4(0, 0, 0, 0);
+            if (vco[r]) rb[r] = *reinterpret_cast<const uint4*>(wrow[r] + ((size_t)kh * p.KW + kw) * p.Cin + cc * BK);
+        }
+        if (++cc == cpt) { cc = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            *reinterpret_cast<uint4*>(&smem[buf][0][(lrow + r * 64) * PITCH + seg * 16]) = ra[r];
+            *reinterpret_cast<uint4*>(&smem[buf][1][(lrow + r * 64) * PITCH + seg * 16]) = rb[r];
+        }
+    };
+
+    load_next();
+    store_tile(0);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < ksteps) load_next();
+        mma_tile(smem[buf][0], smem[buf][1], wm, wn, lane, acc);
+        if (ks + 1 < ksteps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of v_mfma_f32_32x32x*: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = bn * BN + wn * 64 + j * 32 + (lane & 31);
+        if (co >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long m = (long)bm * BM + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (m >= M) continue;
+                float v = acc[i][j][e] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.out_f32)
+                    reinterpret_cast<float*>(p.out)[m * p.Cout + co] = v;
+                else
+                    reinterpret_cast<uint16_t*>(p.out)[m * p.Cout + co] = f2bf(v);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------------
+struct WgradParams {
+    const uint16_t* dout;  // [N, OH, OW, Cout] bf16
+    const uint16_t* in;    // [N, IH, IW, Cin] bf16
+    float* dw;             // [Cout, KH, KW, Cin] fp32, accumulated with atomics
+    int N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
+    int ci_tiles;          // ceil(Cin / 128)
+    long m_per_split;      // pixels per blockIdx.z
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int bco = blockIdx.x;
+    const int tap = blockIdx.y / p.ci_tiles, bci = blockIdx.y % p.ci_tiles;
+    const int kh = tap / p.KW, kw = tap % p.KW;
+    const long M = (long)p.N * p.OH * p.OW;
+    const long m_begin = (long)blockIdx.z * p.m_per_split;
+    const long m_end = m_begin + p.m_per_split < M ? m_begin + p.m_per_split : M;
+    if (m_begin >= M) return;
+    // loader: pixel row prow (and +16) of the 32-pixel k-slab, 16-byte segment `cseg` of the 128 channels (8 channels)
+    const int prow = tid >> 4, cseg = tid & 15;
+    const int co0 = bco * 128 + cseg * 8, ci0 = bci * 128 + cseg * 8;
+    const bool vco = co0 < p.Cout, vci = ci0 < p.Cin;  // Cout, Cin are multiples of 8
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 ra[2], rb[2];
+    auto load = [&](long m0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const long m = m0 + prow + r * 16;
+            ra[r] = make_uint4(0, 0, 0, 0);
+            rb[r] = make_uint4(0, 0, 0, 0);
+            if (m < m_end) {
+                if (vco) ra[r] = *reinterpret_cast<const uint4*>(p.dout + m * p.Cout + co0);
+                const int n = (int)(m / ((long)p.OH * p.OW));
+                const int rem = (int)(m - (long)n * p.OH * p.OW);
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                if (vci && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
+                    rb[r] = *reinterpret_cast<const uint4*>(p.in + (((size_t)n * p.IH + ih) * p.IW + iw) * p.Cin + ci0);
+            }
+        }
+    };
+    // transposed store: LDS tile is [channel row][32 pixels]; a thread owns 8 channels of pixel k -> 8 two-byte writes
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int k = prow + r * 16;
+            const uint32_t wa[4] = {ra[r].x, ra[r].y, ra[r].z, ra[r].w}, wb[4] = {rb[r].x, rb[r].y, rb[r].z, rb[r].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint16_t va = (uint16_t)(wa[e >> 1] >> ((e & 1) * 16)), vb = (uint16_t)(wb[e >> 1] >> ((e & 1) * 16));
+                *reinterpret_cast<uint16_t*>(&smem[buf][0][(cseg * 8 + e) * PITCH + k * 2]) = va;
+                *reinterpret_cast<uint16_t*>(&smem[buf][1][(cseg * 8 + e) * PITCH + k * 2]) = vb;
+            }
+        }
+    };
+
+    load(m_begin);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (long m0 = m_begin; m0 < m_end; m0 += BK) {
+        const bool more = m0 + BK < m_end;
+        if (more) load(m0 + BK);
+        mma_tile(smem[buf][0], smem[buf][1], wm, wn, lane, acc);
+        if (more) store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = bci * 128 + wn * 64 + j * 32 + (lane & 31);
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = bco * 128 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                atomicAdd(p.dw + (((size_t)co * p.KH + kh) * p.KW + kw) * p.Cin + ci, acc[i][j][e]);
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
+                   int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, void* stream) {
+    if (!in || !w || !out || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || up < 1)
+        return MGN_EINVAL;
+    if (Cin < BK || Cin % BK != 0) return MGN_ENOTSUP;  // k-slab = 32 input channels of one tap
+    ConvParams p;
+    p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = out; p.bias = bias;
+    p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
+    p.stride = stride; p.pad = pad; p.up = up; p.relu = relu; p.out_f32 = out_f32;
+    const long M = (long)N * OH * OW;
+    const long gx = (M + BM - 1) / BM;
+    if (gx > 0x7fffffffL) return MGN_EINVAL;
+    hipLaunchKernelGGL(conv_igemm, dim3((unsigned)gx, (Cout + BN - 1) / BN), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
+                   int KW, int stride, int pad, void* stream) {
+    if (!dout || !in || !dw || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || KH < 1 || KW < 1 || stride < 1) return MGN_EINVAL;
+    if (Cin % 8 != 0 || Cout % 8 != 0) return MGN_ENOTSUP;
+    WgradParams p;
+    p.dout = (const uint16_t*)dout; p.in = (const uint16_t*)in; p.dw = dw;
+    p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.ci_tiles = (Cin + 127) / 128;
+    const long M = (long)N * OH * OW;
+    const int tiles = ((Cout + 127) / 128) * KH * KW * p.ci_tiles;
+    long splits = (2048 + tiles - 1) / tiles;             // aim at >= 2048 blocks
+    const long max_splits = (M + 1023) / 1024;            // >= 1024 pixels (32 k-steps) per block
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    p.m_per_split = ((M + splits - 1) / splits + BK - 1) / BK * BK;
+    const long gz = (M + p.m_per_split - 1) / p.m_per_split;
+    hipLaunchKernelGGL(conv_wgrad, dim3((Cout + 127) / 128, KH * KW * p.ci_tiles, (unsigned)gz), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+}  // extern "C"

@@ -127,11 +127,67 @@ def iabn(x, weight, bias, running_mean, running_var, training, momentum, eps, ac
     return y.to(x.dtype)
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0):
-    """[torch-staging] convolution in the activation dtype (bf16 under AMP), fp32 master weights cast per call."""
+class _ConvFn(torch.autograd.Function):
+    """[HIP] mgnet_amd/csrc/conv.hip: implicit-GEMM forward, data gradient (same kernel, flipped weights) and weight
+    gradient on the bf16 matrix cores.  Master weights stay fp32 OIHW; the kernel layouts are derived per call."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, relu):
+        from .. import _C
+
+        N, Cin, IH, IW = x.shape
+        Cout, _, KH, KW = weight.shape
+        OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
+        xs = x.contiguous(memory_format=torch.channels_last)
+        w = weight.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+        b = None if bias is None else bias.detach().float().contiguous()
+        out = _C.conv_igemm(xs, w, (OH, OW), b, stride, pad, 1, relu)
+        ctx.save_for_backward(xs, weight, out if relu else None)
+        ctx.cfg = (stride, pad, relu, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _C
+
+        xs, weight, out = ctx.saved_tensors
+        stride, pad, relu, has_bias = ctx.cfg
+        Cout, Cin, KH, KW = weight.shape
+        dy = dy.to(torch.bfloat16)
+        if relu:
+            dy = dy * (out > 0)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)  # [Cin][KH][KW][Cout]
+            dx = _C.conv_igemm(dy, wt, xs.shape[2:], None, 1, KH - 1 - pad, up=stride)
+        if ctx.needs_input_grad[1]:
+            dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad).permute(0, 3, 1, 2).to(weight.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum((0, 2, 3))
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
+    """Convolution in the activation dtype (bf16 under AMP) from fp32 master weights.
+    bf16 CUDA activations with Cin % 32 == 0: [HIP] implicit GEMM (Cout is zero-padded to a multiple of 32 for the
+    few-class predictors).  Otherwise (fp32 activations, the 3/9-channel 7x7 stems, CPU tests): [torch-staging]."""
+    stride = stride[0] if isinstance(stride, (tuple, list)) else stride
+    padding = padding[0] if isinstance(padding, (tuple, list)) else padding
+    from .. import _C
+    if _C.conv_supported(x, weight):
+        Cout = weight.shape[0]
+        if Cout % 32:
+            padc = 32 - Cout % 32
+            weight = torch.cat([weight, weight.new_zeros((padc,) + tuple(weight.shape[1:]))], 0)
+            if bias is not None:
+                bias = torch.cat([bias, bias.new_zeros(padc)], 0)
+            return _ConvFn.apply(x, weight, bias, stride, padding, relu)[:, :Cout]
+        return _ConvFn.apply(x, weight, bias, stride, padding, relu)
     w = weight.to(x.dtype)
     b = None if bias is None else bias.to(x.dtype)
-    return F.conv2d(x, w, b, stride=stride, padding=padding)
+    y = F.conv2d(x, w, b, stride=stride, padding=padding)
+    return torch.relu_(y) if relu else y
 
 
 def max_pool_3x3_s2(x):

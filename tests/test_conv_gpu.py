@@ -1,0 +1,67 @@
+"""GPU: implicit-GEMM convolution kernels (mgnet_amd/csrc/conv.hip) against F.conv2d evaluated in fp64 on the CPU
+from the same bf16-rounded inputs (the oracle's restatement of every conv is F.conv2d, oracle/network_oracle.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+#        N  Cin Cout  H   W  k  s  p  bias  relu
+CASES = [(2, 64, 128, 16, 24, 1, 1, 0, False, False),
+         (1, 64, 128, 17, 23, 1, 2, 0, False, False),     # shortcut 1x1 stride 2, odd sizes
+         (2, 128, 128, 12, 20, 3, 1, 1, False, False),
+         (2, 64, 128, 16, 24, 3, 2, 1, False, False),     # 3x3 stride 2
+         (1, 64, 128, 15, 21, 3, 2, 1, False, False),     # odd sizes, stride 2
+         (2, 256, 20, 9, 13, 1, 1, 0, False, False),      # predictor: Cout padded to 32
+         (2, 512, 256, 4, 6, 1, 1, 0, True, True),        # pose conv1: bias + ReLU
+         (1, 256, 256, 8, 8, 3, 1, 1, True, True),
+         (3, 32, 64, 5, 7, 3, 1, 1, False, False),
+         (2, 128, 1, 6, 10, 1, 1, 0, False, False)]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    from mgnet_amd.modeling import ops
+
+    N, Cin, Cout, H, W, k, s, p, has_bias, relu = case
+    torch.manual_seed(sum(case[:8]))
+    x0 = torch.randn(N, Cin, H, W).to(torch.bfloat16)
+    w0 = (torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5)
+    b0 = torch.randn(Cout) * 0.1 if has_bias else None
+    w_r = w0.to(torch.bfloat16).double().requires_grad_(True)  # the kernel consumes bf16-rounded weights
+    x_r = x0.double().requires_grad_(True)
+    b_r = None if b0 is None else b0.double().requires_grad_(True)
+    y_r = F.conv2d(x_r, w_r, b_r, stride=s, padding=p)
+    if relu:
+        y_r = F.relu(y_r)
+    g0 = torch.randn(*y_r.shape).to(torch.bfloat16)
+    (y_r * g0.double()).sum().backward()
+
+    x = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = w0.cuda().requires_grad_(True)
+    b = None if b0 is None else b0.cuda().requires_grad_(True)
+    y = ops.conv2d(x, w, b, stride=s, padding=p, relu=relu)
+    assert y.shape == y_r.shape and y.dtype == torch.bfloat16
+    (y.float() * g0.cuda().float()).sum().backward()
+
+    def rel(a, r):
+        return float((a.float().cpu().double() - r).abs().max() / (r.abs().max() + 1e-12))
+    assert rel(y, y_r.detach()) < 1e-2, ("fwd", rel(y, y_r.detach()))            # output rounded to bf16 (2^-8)
+    assert rel(x.grad, x_r.grad) < 1e-2, ("dgrad", rel(x.grad, x_r.grad))        # dx rounded to bf16
+    assert rel(w.grad, w_r.grad) < 2e-3, ("wgrad", rel(w.grad, w_r.grad))        # fp32 accumulation of bf16 products
+    if has_bias:
+        assert rel(b.grad, b_r.grad) < 2e-3
+
+
+def test_mfma_fragment_layout_is_not_transposed():
+    """A = identity-like, asymmetric B (guide rule: symmetric operands hide a row/col swap)."""
+    from mgnet_amd import _C
+
+    Cin, Cout = 64, 96
+    x = torch.zeros(1, Cin, 1, 40, dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
+    for m in range(40):
+        x[0, m % Cin, 0, m] = 1.0
+    w = torch.arange(Cout * Cin, dtype=torch.float32, device="cuda").reshape(Cout, 1, 1, Cin) % 251
+    y = _C.conv_igemm(x, w.to(torch.bfloat16).contiguous(), (1, 40), None, 1, 0, out_dtype=torch.float32)
+    ref = torch.stack([w[:, 0, 0, m % Cin] for m in range(40)], 1)  # [Cout, 40]
+    assert torch.equal(y[0, :, 0, :], ref)
