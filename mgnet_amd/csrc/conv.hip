@@ -28,7 +28,7 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BK = 32;
 constexpr int PITCH = 80;  // bytes per LDS row (64 data + 16 pad)
 constexpr int TILE_BYTES = 128 * PITCH;
 
@@ -46,25 +46,38 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+// XOR swizzle of the 16-byte slot inside a 128-byte LDS row (found by exhaustive search: conflict-free for both the
+// 8-lane ds_write_b128 groups of the transposing loader and the 16-lane ds_read_b128 groups of the fragment reads)
+__device__ __forceinline__ int swz(int row) { return ((row >> 3) & 1) | (((row >> 4) & 1) << 1) | (((row ^ (row >> 1) ^ (row >> 5)) & 1) << 2); }
+
+// one k-slab of KS*16 reduction elements: wave tile (32*MT) x (32*NT); LDS rows are LPITCH bytes apart
+template <int MT, int NT, int KS, int LPITCH, bool SWZ>
 __device__ __forceinline__ void mma_tile(const unsigned char* sA, const unsigned char* sB, int wm, int wn, int lane,
-                                         f32x16 (&acc)[2][2]) {
+                                         f32x16 (&acc)[MT][NT]) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int koff = (kk * 16 + (lane >> 5) * 8) * 2;
-        bf16x8 a[2], b[2];
+    for (int kk = 0; kk < KS; ++kk) {
+        const int slot = kk * 2 + (lane >> 5);
+        bf16x8 a[MT], b[NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            a[i] = *reinterpret_cast<const bf16x8*>(sA + (wm * 64 + i * 32 + (lane & 31)) * PITCH + koff);
-            b[i] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + i * 32 + (lane & 31)) * PITCH + koff);
+        for (int i = 0; i < MT; ++i) {
+            const int row = wm * 32 * MT + i * 32 + (lane & 31);
+            a[i] = *reinterpret_cast<const bf16x8*>(sA + row * LPITCH + ((SWZ ? (slot ^ swz(row)) : slot) << 4));
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NT; ++j) {
+            const int row = wn * 32 * NT + j * 32 + (lane & 31);
+            b[j] = *reinterpret_cast<const bf16x8*>(sB + row * LPITCH + ((SWZ ? (slot ^ swz(row)) : slot) << 4));
+        }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
 }
 
+template <int NT>
 __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
+    constexpr int BN = 64 * NT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int bm = blockIdx.x, bn = blockIdx.y;
@@ -86,17 +99,17 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
         ihb[r] = oh * p.stride - p.pad;
         iwb[r] = ow * p.stride - p.pad;
         const int co = bn * BN + lrow + r * 64;
-        vco[r] = co < p.Cout;
+        vco[r] = co < p.Cout && (r < NT);
         wrow[r] = p.w + (size_t)(vco[r] ? co : 0) * p.KH * p.KW * p.Cin + seg * 8;
     }
     const int cpt = p.Cin / BK;  // k-steps per tap
     const int ksteps = p.KH * p.KW * cpt;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -115,8 +128,10 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
             ok = ok && th >= 0 && th < p.IH && tw >= 0 && tw < p.IW;
             ra[r] = make_uint4(0, 0, 0, 0);
             if (ok) ra[r] = *reinterpret_cast<const uint4*>(p.in + (((size_t)nb[r] * p.IH + th) * p.IW + tw) * p.Cin + cc * BK + seg * 8);
-            rb[r] = make_uint4(0, 0, 0, 0);
-            if (vco[r]) rb[r] = *reinterpret_cast<const uint4*>(wrow[r] + ((size_t)kh * p.KW + kw) * p.Cin + cc * BK);
+            if (r < NT) {
+                rb[r] = make_uint4(0, 0, 0, 0);
+                if (vco[r]) rb[r] = *reinterpret_cast<const uint4*>(wrow[r] + ((size_t)kh * p.KW + kw) * p.Cin + cc * BK);
+            }
         }
         if (++cc == cpt) { cc = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             *reinterpret_cast<uint4*>(&smem[buf][0][(lrow + r * 64) * PITCH + seg * 16]) = ra[r];
-            *reinterpret_cast<uint4*>(&smem[buf][1][(lrow + r * 64) * PITCH + seg * 16]) = rb[r];
+            if (r < NT) *reinterpret_cast<uint4*>(&smem[buf][1][(lrow + r * 64) * PITCH + seg * 16]) = rb[r];
         }
     };
 
@@ -134,15 +149,15 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
     for (int ks = 0; ks < ksteps; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < ksteps) load_next();
-        mma_tile(smem[buf][0], smem[buf][1], wm, wn, lane, acc);
+        mma_tile<2, NT, 2, PITCH, false>(smem[buf][0], smem[buf][1], wm, wn, lane, acc);
         if (ks + 1 < ksteps) store_tile(buf ^ 1);
         __syncthreads();
     }
 
     // epilogue: C/D layout of v_mfma_f32_32x32x*: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = bn * BN + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NT; ++j) {
+        const int co = bn * BN + wn * 32 * NT + j * 32 + (lane & 31);
         if (co >= p.Cout) continue;
         const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
@@ -169,12 +184,35 @@ struct WgradParams {
     const uint16_t* in;    // [N, IH, IW, Cin] bf16
     float* dw;             // [Cout, KH, KW, Cin] fp32, accumulated with atomics
     int N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
-    int ci_tiles;          // ceil(Cin / 128)
-    long m_per_split;      // pixels per blockIdx.z
+    int ci_tiles;          // ceil(Cin / (64*NT))
+    long m_per_split;      // pixels per blockIdx.z (multiple of 64)
 };
 
+constexpr int WBK = 64;            // pixels per k-step
+constexpr int WPITCH = 128;        // 64 pixels x 2 bytes per channel row, XOR-swizzled (no padding)
+constexpr int WTILE = 128 * WPITCH;
+
+// 8 pixels x 8 channels (one uint4 per pixel) -> 8 channels x 8 pixels (one uint4 per channel), in registers
+__device__ __forceinline__ void transpose8x8(const uint4 (&in)[8], uint4 (&out)[8]) {
+    const uint32_t* I = reinterpret_cast<const uint32_t*>(in);   // I[p*4 + d]
+    uint32_t* O = reinterpret_cast<uint32_t*>(out);              // O[c*4 + q]
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t x = I[(2 * q) * 4 + d], y = I[(2 * q + 1) * 4 + d];
+            O[(2 * d) * 4 + q] = (x & 0xffffu) | (y << 16);
+            O[(2 * d + 1) * 4 + q] = (x >> 16) | (y & 0xffff0000u);
+        }
+}
+
+// Block: (64*MT) output channels x (64*NT) input channels of one tap, a slice of the pixels.  Waves 0,1 stream dOut,
+// waves 2,3 stream (gathered) In: each thread loads 8 pixels x 8 channels with 16-byte loads, transposes in registers
+// and writes 8 x 16 bytes into the [channel][pixel] LDS tile that the MFMA fragments read.  Pixel coordinates advance
+// incrementally (no integer division in the loop).
+template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TILE_BYTES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];  // [2 buffers][A | B][WTILE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int bco = blockIdx.x;
     const int tap = blockIdx.y / p.ci_tiles, bci = blockIdx.y % p.ci_tiles;
@@ -183,73 +221,80 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
     const long m_begin = (long)blockIdx.z * p.m_per_split;
     const long m_end = m_begin + p.m_per_split < M ? m_begin + p.m_per_split : M;
     if (m_begin >= M) return;
-    // loader: pixel row prow (and +16) of the 32-pixel k-slab, 16-byte segment `cseg` of the 128 channels (8 channels)
-    const int prow = tid >> 4, cseg = tid & 15;
-    const int co0 = bco * 128 + cseg * 8, ci0 = bci * 128 + cseg * 8;
-    const bool vco = co0 < p.Cout, vci = ci0 < p.Cin;  // Cout, Cin are multiples of 8
+    const bool isB = tid >= 128;
+    const int t = tid & 127;
+    const int cseg = t & 15, pg = t >> 4;  // 8-channel segment, 8-pixel group
+    const int c0 = (isB ? bci * 64 * NT : bco * 64 * MT) + cseg * 8;
+    const bool vc = c0 < (isB ? p.Cin : p.Cout) && cseg * 8 < 64 * (isB ? NT : MT);
+    // coordinates of this thread's first pixel of the current k-step
+    long mcur = m_begin + pg * 8;
+    int pn = (int)(mcur / ((long)p.OH * p.OW));
+    int prem = (int)(mcur - (long)pn * p.OH * p.OW);
+    int poh = prem / p.OW, pow_ = prem - poh * p.OW;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    uint4 ra[2], rb[2];
-    auto load = [&](long m0) {
+    uint4 rg[8];
+    auto load = [&]() {  // loads the k-step starting at pixel mcur, then advances mcur by WBK
+        if (!isB) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const long m = m0 + prow + r * 16;
-            ra[r] = make_uint4(0, 0, 0, 0);
-            rb[r] = make_uint4(0, 0, 0, 0);
-            if (m < m_end) {
-                if (vco) ra[r] = *reinterpret_cast<const uint4*>(p.dout + m * p.Cout + co0);
-                const int n = (int)(m / ((long)p.OH * p.OW));
-                const int rem = (int)(m - (long)n * p.OH * p.OW);
-                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            for (int q = 0; q < 8; ++q) {
+                rg[q] = make_uint4(0, 0, 0, 0);
+                if (vc && mcur + q < m_end) rg[q] = *reinterpret_cast<const uint4*>(p.dout + (mcur + q) * p.Cout + c0);
+            }
+        } else {
+            int n = pn, oh = poh, ow = pow_;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                rg[q] = make_uint4(0, 0, 0, 0);
                 const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
-                if (vci && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
-                    rb[r] = *reinterpret_cast<const uint4*>(p.in + (((size_t)n * p.IH + ih) * p.IW + iw) * p.Cin + ci0);
+                if (vc && mcur + q < m_end && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
+                    rg[q] = *reinterpret_cast<const uint4*>(p.in + (((size_t)n * p.IH + ih) * p.IW + iw) * p.Cin + c0);
+                if (++ow == p.OW) { ow = 0; if (++oh == p.OH) { oh = 0; ++n; } }
             }
+            pow_ += WBK;
+            while (pow_ >= p.OW) { pow_ -= p.OW; if (++poh == p.OH) { poh = 0; ++pn; } }
         }
+        mcur += WBK;
     };
-    // transposed store: LDS tile is [channel row][32 pixels]; a thread owns 8 channels of pixel k -> 8 two-byte writes
     auto store = [&](int buf) {
+        uint4 tr[8];
+        transpose8x8(rg, tr);
+        unsigned char* base = wsm + (size_t)(buf * 2 + (isB ? 1 : 0)) * WTILE;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int k = prow + r * 16;
-            const uint32_t wa[4] = {ra[r].x, ra[r].y, ra[r].z, ra[r].w}, wb[4] = {rb[r].x, rb[r].y, rb[r].z, rb[r].w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint16_t va = (uint16_t)(wa[e >> 1] >> ((e & 1) * 16)), vb = (uint16_t)(wb[e >> 1] >> ((e & 1) * 16));
-                *reinterpret_cast<uint16_t*>(&smem[buf][0][(cseg * 8 + e) * PITCH + k * 2]) = va;
-                *reinterpret_cast<uint16_t*>(&smem[buf][1][(cseg * 8 + e) * PITCH + k * 2]) = vb;
-            }
+        for (int e = 0; e < 8; ++e) {
+            const int row = cseg * 8 + e;
+            *reinterpret_cast<uint4*>(base + row * WPITCH + ((pg ^ swz(row)) << 4)) = tr[e];
         }
     };
 
-    load(m_begin);
+    load();
     store(0);
     __syncthreads();
     int buf = 0;
-    for (long m0 = m_begin; m0 < m_end; m0 += BK) {
-        const bool more = m0 + BK < m_end;
-        if (more) load(m0 + BK);
-        mma_tile(smem[buf][0], smem[buf][1], wm, wn, lane, acc);
+    for (long m0 = m_begin; m0 < m_end; m0 += WBK) {
+        const bool more = m0 + WBK < m_end;
+        if (more) load();
+        mma_tile<MT, NT, 4, WPITCH, true>(wsm + (size_t)(buf * 2) * WTILE, wsm + (size_t)(buf * 2 + 1) * WTILE, wm, wn, lane, acc);
         if (more) store(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int ci = bci * 128 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NT; ++j) {
+        const int ci = bci * 64 * NT + wn * 32 * NT + j * 32 + (lane & 31);
         if (ci >= p.Cin) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = bco * 128 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int co = bco * 64 * MT + wm * 32 * MT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
                 atomicAdd(p.dw + (((size_t)co * p.KH + kh) * p.KW + kw) * p.Cin + ci, acc[i][j][e]);
             }
@@ -272,7 +317,10 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
     const long M = (long)N * OH * OW;
     const long gx = (M + BM - 1) / BM;
     if (gx > 0x7fffffffL) return MGN_EINVAL;
-    hipLaunchKernelGGL(conv_igemm, dim3((unsigned)gx, (Cout + BN - 1) / BN), dim3(256), 0, (hipStream_t)stream, p);
+    if (Cout <= 64)
+        hipLaunchKernelGGL(conv_igemm<1>, dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv_igemm<2>, dim3((unsigned)gx, (Cout + 127) / 128), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -283,17 +331,33 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
     WgradParams p;
     p.dout = (const uint16_t*)dout; p.in = (const uint16_t*)in; p.dw = dw;
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
-    p.ci_tiles = (Cin + 127) / 128;
+    const int NT = Cin <= 64 ? 1 : 2, MT = Cout <= 64 ? 1 : 2;
+    p.ci_tiles = (Cin + 64 * NT - 1) / (64 * NT);
+    const int co_tiles = (Cout + 64 * MT - 1) / (64 * MT);
     const long M = (long)N * OH * OW;
-    const int tiles = ((Cout + 127) / 128) * KH * KW * p.ci_tiles;
-    long splits = (2048 + tiles - 1) / tiles;             // aim at >= 2048 blocks
-    const long max_splits = (M + 1023) / 1024;            // >= 1024 pixels (32 k-steps) per block
+    const int tiles = co_tiles * KH * KW * p.ci_tiles;
+    long splits = (768 + tiles - 1) / tiles;              // ~768 blocks: 3 resident per CU on 256 CUs
+    const long max_splits = (M + 2047) / 2048;            // >= 2048 pixels (32 k-steps) per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
-    p.m_per_split = ((M + splits - 1) / splits + BK - 1) / BK * BK;
+    p.m_per_split = ((M + splits - 1) / splits + WBK - 1) / WBK * WBK;
     const long gz = (M + p.m_per_split - 1) / p.m_per_split;
-    hipLaunchKernelGGL(conv_wgrad, dim3((Cout + 127) / 128, KH * KW * p.ci_tiles, (unsigned)gz), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 grid(co_tiles, KH * KW * p.ci_tiles, (unsigned)gz);
+    const size_t lds = 4 * (size_t)WTILE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (MT == 1 && NT == 1) hipLaunchKernelGGL((conv_wgrad<1, 1>), grid, dim3(256), lds, st, p);
+    else if (MT == 1) hipLaunchKernelGGL((conv_wgrad<1, 2>), grid, dim3(256), lds, st, p);
+    else if (NT == 1) hipLaunchKernelGGL((conv_wgrad<2, 1>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_wgrad<2, 2>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
