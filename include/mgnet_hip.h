@@ -158,6 +158,32 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
 int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout,
                    int KH, int KW, int stride, int pad, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Panoptic-head losses fused with the bilinear (align_corners=True) upsampling of the low-resolution head outputs
+ *   mgn_upce_*     replace mg_net.py:597-610 (F.interpolate x8 of the logits) + loss.py:45-81 OhemCE / :9-42 DeepLabCE:
+ *                  per-pixel weighted CE map (fp32 [B,H,W]) and sums3 = {count(ce>thr), sum(ce|ce>thr), sum(ce)};
+ *                  the caller applies the OHEM rule (count > n_min ? mean of {ce>thr} : mean of the n_min largest).
+ *                  backward: sel3 = {tau, tie_weight, scale}: dL/dce = scale*(ce>tau ? 1 : ce==tau ? tie_weight : 0);
+ *                  dlogits [B,h,w,Kp] fp32 must be zero-initialised.
+ *   mgn_ins_loss_* replace mg_net.py:676-715: centre map (low-res AFTER sigmoid, fp32) and offset map (low-res bf16)
+ *                  upsampled on the fly; out4 = {sum w(c-t)^2 / sum w, sum w|o*s-t| / sum w, sum w_c, sum w_o};
+ *                  backward dco [B,h,w,4] fp32 (zero-initialised) = {d centre_lr, d offset_lr[0], d offset_lr[1], 0}.
+ * Low-res maps: bf16 (logits/offset) with channel stride 1 and element strides (sb, sh, sw) multiples of 8.
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_upce_partials(int B, int H, int W);
+int mgn_upce_fwd(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K,
+                 const long* labels, const float* weights, int ignore, float thr, float* ce_map, float* partials,
+                 float* sums3, void* stream);
+int mgn_upce_bwd(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K, int Kp,
+                 const long* labels, const float* weights, int ignore, const float* ce_map, const float* sel3,
+                 const float* gout, float* dlogits, void* stream);
+int mgn_ins_loss_fwd(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh,
+                     long osw, int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot,
+                     const float* ow, float oscale, float* partials, float* out4, void* stream);
+int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh,
+                     long osw, int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot,
+                     const float* ow, float oscale, const float* out4, const float* gout2, float* dco, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

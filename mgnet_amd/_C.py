@@ -15,7 +15,8 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad"]
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad",
+           "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd"]
 
 
 class ReprojCfg(ctypes.Structure):
@@ -59,6 +60,11 @@ def lib():
         L.mgn_adam_step.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, ci, vp, cf, vp]
         L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp]
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 11 + [vp]
+        L.mgn_upce_partials.argtypes = [ci, ci, ci]
+        L.mgn_upce_fwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp, vp]
+        L.mgn_upce_bwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
+        L.mgn_ins_loss_fwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp]
+        L.mgn_ins_loss_bwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
         _lib = L
@@ -265,3 +271,61 @@ def conv_wgrad(dy, x, kh, kw, stride, pad):
     check(lib().mgn_conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, IH, IW, Cin, OH, OW, Cout, kh, kw, stride, pad,
                                _stream()), "mgn_conv_wgrad")
     return dw
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# head losses fused with the bilinear upsampling
+# ---------------------------------------------------------------------------------------------------------------
+def _lr_strides(t):
+    """(sb, sh, sw) element strides of a logical [B,C,h,w] low-res map whose channel stride is 1"""
+    assert t.stride(1) == 1 or t.shape[1] == 1, "low-res map must be channels-last"
+    return t.stride(0), t.stride(2), t.stride(3)
+
+
+def upce_supported(lr):
+    sb, sh, sw = lr.stride(0), lr.stride(2), lr.stride(3)
+    return (lr.is_cuda and lr.dtype == torch.bfloat16 and lr.stride(1) == 1 and lr.shape[1] <= 32 and sb % 8 == 0 and sh % 8 == 0
+            and sw % 8 == 0 and sw >= (lr.shape[1] + 7) // 8 * 8 and lr.shape[2] >= 2 and lr.shape[3] >= 2)
+
+
+def upce_fwd(lr, labels, weights, H, W, ignore, thr):
+    B, K, h, w = lr.shape
+    sb, sh, sw = _lr_strides(lr)
+    ce = torch.empty((B, H, W), dtype=torch.float32, device=lr.device)
+    partials = torch.empty(lib().mgn_upce_partials(B, H, W) * 3, dtype=torch.float32, device=lr.device)
+    sums = torch.empty(3, dtype=torch.float32, device=lr.device)
+    check(lib().mgn_upce_fwd(lr.data_ptr(), sb, sh, sw, B, h, w, H, W, K, labels.data_ptr(),
+                             None if weights is None else weights.data_ptr(), ignore, thr, ce.data_ptr(), partials.data_ptr(),
+                             sums.data_ptr(), _stream()), "mgn_upce_fwd")
+    return ce, sums
+
+
+def upce_bwd(lr, labels, weights, H, W, ignore, ce, sel3, gout, Kp):
+    B, K, h, w = lr.shape
+    sb, sh, sw = _lr_strides(lr)
+    dlg = torch.zeros((B, h, w, Kp), dtype=torch.float32, device=lr.device)
+    check(lib().mgn_upce_bwd(lr.data_ptr(), sb, sh, sw, B, h, w, H, W, K, Kp, labels.data_ptr(),
+                             None if weights is None else weights.data_ptr(), ignore, ce.data_ptr(), sel3.data_ptr(),
+                             gout.data_ptr(), dlg.data_ptr(), _stream()), "mgn_upce_bwd")
+    return dlg
+
+
+def ins_loss_fwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale):
+    B, _, h, w = center_lr.shape
+    partials = torch.empty(lib().mgn_upce_partials(B, H, W) * 4, dtype=torch.float32, device=ct.device)
+    out4 = torch.empty(4, dtype=torch.float32, device=ct.device)
+    cs, os_ = _lr_strides(center_lr), _lr_strides(offset_lr)
+    check(lib().mgn_ins_loss_fwd(center_lr.data_ptr(), *cs, offset_lr.data_ptr(), *os_, B, h, w, H, W, ct.data_ptr(), cw.data_ptr(),
+                                 ot.data_ptr(), ow.data_ptr(), oscale, partials.data_ptr(), out4.data_ptr(), _stream()),
+          "mgn_ins_loss_fwd")
+    return out4
+
+
+def ins_loss_bwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale, out4, gout2):
+    B, _, h, w = center_lr.shape
+    dco = torch.zeros((B, h, w, 4), dtype=torch.float32, device=ct.device)
+    cs, os_ = _lr_strides(center_lr), _lr_strides(offset_lr)
+    check(lib().mgn_ins_loss_bwd(center_lr.data_ptr(), *cs, offset_lr.data_ptr(), *os_, B, h, w, H, W, ct.data_ptr(), cw.data_ptr(),
+                                 ot.data_ptr(), ow.data_ptr(), oscale, out4.data_ptr(), gout2.data_ptr(), dco.data_ptr(), _stream()),
+          "mgn_ins_loss_bwd")
+    return dco

@@ -1,0 +1,427 @@
+// headloss.hip -- losses of the panoptic heads fused with the x8 bilinear upsampling of their low-resolution outputs.
+//
+// Replaces (reference file:line)
+//   mgnet/modeling/mg_net.py:597-610  MGNetSemSegHead.forward/.losses: F.interpolate(logits, x8, bilinear,
+//       align_corners=True) -> [B,20,H,W] fp32 (1.34 GB at B=8 1024x2048) -> loss.py:45-81 OhemCE (per-pixel CE x weights,
+//       FULL torch.sort over B*H*W values, threshold / top-n_min selection, mean)
+//   mgnet/modeling/mg_net.py:676-715  MGNetInsEmbedHead.forward/.losses: x8 upsampling of centre (after sigmoid) and
+//       offset (then x8), weighted MSE / L1 sums divided by the weight sums.
+// Here the full-resolution maps are never materialised: every output pixel interpolates its 4 low-resolution
+// neighbours on the fly (the low-res maps are 64x smaller and stay in L2), both in the forward and in the backward.
+//
+// OHEM without a sort (result-identical selection): sorted[n_min] > thr  <=>  count(loss > thr) > n_min, then the mean of
+// {loss > thr}; otherwise the mean of the n_min largest losses, which only needs the n_min-th largest VALUE (host side:
+// torch.topk on the per-pixel loss map this kernel writes; rare late-training branch).
+//
+// Backward = gather-free two-phase tile kernel: phase 1 recomputes softmax / residuals of a 16x32 pixel tile into LDS,
+// phase 2 lets each (low-res cell, channel) of the tile's footprint sum its bilinear-weighted contributions in a fixed
+// order; only the footprint cells shared between tiles are combined with global fp32 atomics.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mgnet_hip.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int TX = 32, TY = 16;      // backward pixel tile
+
+struct UpGeom {
+    int B, h, w, H, W;
+    long sb, sh, sw;   // element strides of the low-res map (channel stride 1)
+    float ry, rx;      // (h-1)/(H-1), (w-1)/(W-1)   (align_corners=True)
+};
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+
+struct Corner {
+    long o00, o10, o01, o11;
+    float w00, w10, w01, w11;
+    int x0, y0, x1, y1;
+    float tx, ty;
+};
+
+__device__ __forceinline__ Corner corners(const UpGeom& g, int b, int Y, int X) {
+    Corner c;
+    const float sy = Y * g.ry, sx = X * g.rx;  // torch area_pixel_compute_source_index(align_corners=True)
+    c.y0 = min((int)sy, g.h - 1);
+    c.x0 = min((int)sx, g.w - 1);
+    c.y1 = min(c.y0 + 1, g.h - 1);
+    c.x1 = min(c.x0 + 1, g.w - 1);
+    c.ty = sy - c.y0;
+    c.tx = sx - c.x0;
+    c.w00 = (1.f - c.ty) * (1.f - c.tx);
+    c.w10 = (1.f - c.ty) * c.tx;
+    c.w01 = c.ty * (1.f - c.tx);
+    c.w11 = c.ty * c.tx;
+    const long base = (long)b * g.sb;
+    c.o00 = base + c.y0 * g.sh + c.x0 * g.sw;
+    c.o10 = base + c.y0 * g.sh + c.x1 * g.sw;
+    c.o01 = base + c.y1 * g.sh + c.x0 * g.sw;
+    c.o11 = base + c.y1 * g.sh + c.x1 * g.sw;
+    return c;
+}
+
+// interpolated logits of one pixel (K <= 32 classes, bf16 low-res map); returns log-sum-exp
+template <int K8>
+__device__ __forceinline__ float interp_logits(const uint16_t* __restrict__ lg, const Corner& c, int K, float (&z)[K8 * 8]) {
+    float m = -3.0e38f;
+#pragma unroll
+    for (int v = 0; v < K8; ++v) {
+        const uint4 a = *reinterpret_cast<const uint4*>(lg + c.o00 + v * 8), b = *reinterpret_cast<const uint4*>(lg + c.o10 + v * 8);
+        const uint4 d = *reinterpret_cast<const uint4*>(lg + c.o01 + v * 8), e = *reinterpret_cast<const uint4*>(lg + c.o11 + v * 8);
+        const uint32_t A[4] = {a.x, a.y, a.z, a.w}, Bv[4] = {b.x, b.y, b.z, b.w}, D[4] = {d.x, d.y, d.z, d.w}, E[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int sh = (q & 1) * 16;
+            const float va = bf2f((uint16_t)(A[q >> 1] >> sh)), vb = bf2f((uint16_t)(Bv[q >> 1] >> sh));
+            const float vd = bf2f((uint16_t)(D[q >> 1] >> sh)), ve = bf2f((uint16_t)(E[q >> 1] >> sh));
+            const float val = c.w00 * va + c.w10 * vb + c.w01 * vd + c.w11 * ve;
+            z[v * 8 + q] = val;
+            if (v * 8 + q < K) m = fmaxf(m, val);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K8 * 8; ++k)
+        if (k < K) s += __expf(z[k] - m);
+    return m + __logf(s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// semantic head forward: per-pixel weighted CE map + block partials {count(ce>thr), sum(ce | ce>thr), sum(ce)}
+// ---------------------------------------------------------------------------------------------------------------
+template <int K8>
+__global__ __launch_bounds__(TPB) void upce_fwd(const uint16_t* __restrict__ lg, UpGeom g, int K, const long* __restrict__ labels,
+                                                const float* __restrict__ weights, int ignore, float thr,
+                                                float* __restrict__ ce_map, float* partials) {
+    __shared__ float red[3][TPB / 64];
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    float ce = 0.f;
+    const bool in = X < g.W && Y < g.H;
+    if (in) {
+        const long p = ((long)b * g.H + Y) * g.W + X;
+        const long lab = labels[p];
+        if (lab != ignore) {
+            float z[K8 * 8];
+            const Corner c = corners(g, b, Y, X);
+            const float lse = interp_logits<K8>(lg, c, K, z);
+            float zl = 0.f;
+#pragma unroll
+            for (int k = 0; k < K8 * 8; ++k)
+                if (k == (int)lab) zl = z[k];
+            ce = (lse - zl) * (weights ? weights[p] : 1.f);
+        }
+        ce_map[p] = ce;
+    }
+    float cnt = (in && ce > thr) ? 1.f : 0.f, sh = (in && ce > thr) ? ce : 0.f, sa = in ? ce : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); sh += __shfl_xor(sh, o); sa += __shfl_xor(sa, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cnt; red[1][threadIdx.x >> 6] = sh; red[2][threadIdx.x >> 6] = sa; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partials[(size_t)blk * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
+}
+
+// out[0]=n_hard, out[1]=sum_hard, out[2]=sum_all  (fp64 accumulation, fixed order)
+__global__ void sum3_kernel(const float* partials, int nblk, float* out) {
+    __shared__ double sh[3][TPB];
+    double a[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < nblk; i += TPB)
+        for (int k = 0; k < 3; ++k) a[k] += (double)partials[(size_t)i * 3 + k];
+    for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] = a[k];
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) out[threadIdx.x] = (float)sh[threadIdx.x][0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// semantic head backward.  sel = {tau, tie_weight, scale}: d loss / d ce(p) = scale * (ce > tau ? 1 : (ce == tau ? tie_weight : 0))
+// dlg: [B, h, w, Kp] fp32 (zero-initialised), accumulates d loss / d low-res logits
+// ---------------------------------------------------------------------------------------------------------------
+template <int K8>
+__global__ __launch_bounds__(TPB) void upce_bwd(const uint16_t* __restrict__ lg, UpGeom g, int K, int Kp, const long* __restrict__ labels,
+                                                const float* __restrict__ weights, int ignore, const float* __restrict__ ce_map,
+                                                const float* __restrict__ sel, const float* __restrict__ gout, float* dlg) {
+    extern __shared__ float res[];  // [TY*TX][K8*8] residuals g*(p_k - onehot)
+    constexpr int KK = K8 * 8;
+    const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY, b = blockIdx.z;
+    const float tau = sel[0], tie_w = sel[1], scale = sel[2] * gout[0];
+    // ---- phase 1: residual vectors of the tile's pixels
+    for (int t = threadIdx.x; t < TX * TY; t += TPB) {
+        const int X = X0 + (t % TX), Y = Y0 + (t / TX);
+        float z[KK];
+        float gpx = 0.f;
+        long lab = ignore;
+        float lse = 0.f;
+        if (X < g.W && Y < g.H) {
+            const long p = ((long)b * g.H + Y) * g.W + X;
+            lab = labels[p];
+            const float ce = ce_map[p];
+            const float sw = ce > tau ? 1.f : (ce == tau ? tie_w : 0.f);
+            if (lab != ignore && sw != 0.f) {
+                gpx = sw * scale * (weights ? weights[p] : 1.f);
+                const Corner c = corners(g, b, Y, X);
+                lse = interp_logits<K8>(lg, c, K, z);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            float r = 0.f;
+            if (gpx != 0.f && k < K) r = gpx * (__expf(z[k] - lse) - (k == (int)lab ? 1.f : 0.f));
+            res[t * KK + k] = r;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: each (footprint cell, channel) sums its bilinear-weighted pixels in a fixed order
+    const int ly0 = min((int)(Y0 * g.ry), g.h - 1), lx0 = min((int)(X0 * g.rx), g.w - 1);
+    const int Yl = min(Y0 + TY, g.H) - 1, Xl = min(X0 + TX, g.W) - 1;
+    const int ly1 = min(min((int)(Yl * g.ry), g.h - 1) + 1, g.h - 1), lx1 = min(min((int)(Xl * g.rx), g.w - 1) + 1, g.w - 1);
+    const int nr = ly1 - ly0 + 1, nc = lx1 - lx0 + 1;
+    for (int o = threadIdx.x; o < nr * nc * KK; o += TPB) {
+        const int k = o % KK, cell = o / KK;
+        if (k >= K) continue;
+        const int cy = ly0 + cell / nc, cx = lx0 + cell % nc;
+        float acc = 0.f;
+        for (int yy = 0; yy < TY; ++yy) {
+            const int Y = Y0 + yy;
+            if (Y >= g.H) break;
+            const float sy = Y * g.ry;
+            const int y0 = min((int)sy, g.h - 1), y1 = min(y0 + 1, g.h - 1);
+            const float ty = sy - y0;
+            const float wy = (y0 == cy ? 1.f - ty : 0.f) + (y1 == cy ? ty : 0.f);
+            if (wy == 0.f) continue;
+            for (int xx = 0; xx < TX; ++xx) {
+                const int X = X0 + xx;
+                if (X >= g.W) break;
+                const float sx = X * g.rx;
+                const int x0 = min((int)sx, g.w - 1), x1 = min(x0 + 1, g.w - 1);
+                const float tx = sx - x0;
+                const float wx = (x0 == cx ? 1.f - tx : 0.f) + (x1 == cx ? tx : 0.f);
+                if (wx != 0.f) acc += wy * wx * res[(yy * TX + xx) * KK + k];
+            }
+        }
+        if (acc != 0.f) atomicAdd(dlg + (((long)b * g.h + cy) * g.w + cx) * Kp + k, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// instance head: centre (sigmoid at low res, then x8) weighted MSE and offset (x8, then *scale) weighted L1
+//   forward : partial sums {sum w_c*(c-t)^2, sum w_c, sum w_o*|o-t| (both channels), sum w_o}
+//   backward: same two-phase tile scheme; dco [B,h,w,4] fp32 = {d/d centre_lowres(after sigmoid), d/d off0, d/d off1, 0}
+// ---------------------------------------------------------------------------------------------------------------
+struct InsMaps {
+    const uint16_t* center;  // low-res, bf16 or null if f32
+    const float* center_f;   // low-res fp32 (after sigmoid)
+    const uint16_t* offset;  // low-res [.., 2+] bf16
+    UpGeom gc, go;
+    const float* ct;   // [B,1,H,W]
+    const float* cw;   // [B,1,H,W]
+    const float* ot;   // [B,2,H,W]
+    const float* ow;   // [B,1,H,W]
+    float oscale;      // common_stride multiplier applied after the upsampling (mg_net.py:682-694)
+};
+
+__device__ __forceinline__ float interp1f(const float* m, const Corner& c) {
+    return c.w00 * m[c.o00] + c.w10 * m[c.o10] + c.w01 * m[c.o01] + c.w11 * m[c.o11];
+}
+__device__ __forceinline__ float interp1b(const uint16_t* m, const Corner& c, int ch) {
+    return c.w00 * bf2f(m[c.o00 + ch]) + c.w10 * bf2f(m[c.o10 + ch]) + c.w01 * bf2f(m[c.o01 + ch]) + c.w11 * bf2f(m[c.o11 + ch]);
+}
+
+__global__ __launch_bounds__(TPB) void ins_fwd(InsMaps m, float* partials) {
+    __shared__ float red[4][TPB / 64];
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int H = m.gc.H, W = m.gc.W;
+    if (X < W && Y < H) {
+        const long p = ((long)b * H + Y) * W + X;
+        const Corner cc = corners(m.gc, b, Y, X);
+        const float c = interp1f(m.center_f, cc);
+        const float wc = m.cw[p], d = c - m.ct[p];
+        v[0] = wc * d * d;
+        v[1] = wc;
+        const Corner co = corners(m.go, b, Y, X);
+        const float wo = m.ow[p];
+        const long p2 = ((long)b * 2 * H + Y) * W + X;
+        const float o0 = interp1b(m.offset, co, 0) * m.oscale, o1 = interp1b(m.offset, co, 1) * m.oscale;
+        v[2] = wo * (fabsf(o0 - m.ot[p2]) + fabsf(o1 - m.ot[p2 + (long)H * W]));
+        v[3] = wo;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partials[(size_t)blk * 4 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
+}
+
+__global__ void sum4_kernel(const float* partials, int nblk, float* out) {
+    __shared__ double sh[4][TPB];
+    double a[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nblk; i += TPB)
+        for (int k = 0; k < 4; ++k) a[k] += (double)partials[(size_t)i * 4 + k];
+    for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = a[k];
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    // out = {loss_center (sum/wsum or 0), loss_offset, wsum_c, wsum_o}   (mg_net.py:697-715)
+    if (threadIdx.x == 0) {
+        out[0] = sh[1][0] > 0 ? (float)(sh[0][0] / sh[1][0]) : 0.f;
+        out[1] = sh[3][0] > 0 ? (float)(sh[2][0] / sh[3][0]) : 0.f;
+        out[2] = (float)sh[1][0];
+        out[3] = (float)sh[3][0];
+    }
+}
+
+// gout = {d/d loss_center, d/d loss_offset}; sums = output of sum4_kernel
+__global__ __launch_bounds__(TPB) void ins_bwd(InsMaps m, const float* __restrict__ sums, const float* __restrict__ gout, float* dco) {
+    __shared__ float res[TY * TX][3];
+    const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY, b = blockIdx.z;
+    const UpGeom& g = m.gc;  // centre and offset maps share the geometry
+    const float sc = sums[2] > 0.f ? gout[0] / sums[2] : 0.f, so = sums[3] > 0.f ? gout[1] / sums[3] : 0.f;
+    for (int t = threadIdx.x; t < TX * TY; t += TPB) {
+        const int X = X0 + (t % TX), Y = Y0 + (t / TX);
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        if (X < g.W && Y < g.H) {
+            const long p = ((long)b * g.H + Y) * g.W + X;
+            const Corner cc = corners(m.gc, b, Y, X);
+            r0 = sc * m.cw[p] * 2.f * (interp1f(m.center_f, cc) - m.ct[p]);
+            const Corner co = corners(m.go, b, Y, X);
+            const long p2 = ((long)b * 2 * g.H + Y) * g.W + X;
+            const float d0 = interp1b(m.offset, co, 0) * m.oscale - m.ot[p2], d1 = interp1b(m.offset, co, 1) * m.oscale - m.ot[p2 + (long)g.H * g.W];
+            const float wo = so * m.ow[p] * m.oscale;
+            r1 = wo * (float)((d0 > 0.f) - (d0 < 0.f));
+            r2 = wo * (float)((d1 > 0.f) - (d1 < 0.f));
+        }
+        res[t][0] = r0; res[t][1] = r1; res[t][2] = r2;
+    }
+    __syncthreads();
+    const int ly0 = min((int)(Y0 * g.ry), g.h - 1), lx0 = min((int)(X0 * g.rx), g.w - 1);
+    const int Yl = min(Y0 + TY, g.H) - 1, Xl = min(X0 + TX, g.W) - 1;
+    const int ly1 = min(min((int)(Yl * g.ry), g.h - 1) + 1, g.h - 1), lx1 = min(min((int)(Xl * g.rx), g.w - 1) + 1, g.w - 1);
+    const int nr = ly1 - ly0 + 1, nc = lx1 - lx0 + 1;
+    for (int o = threadIdx.x; o < nr * nc * 3; o += TPB) {
+        const int k = o % 3, cell = o / 3;
+        const int cy = ly0 + cell / nc, cx = lx0 + cell % nc;
+        float acc = 0.f;
+        for (int yy = 0; yy < TY; ++yy) {
+            const int Y = Y0 + yy;
+            if (Y >= g.H) break;
+            const float sy = Y * g.ry;
+            const int y0 = min((int)sy, g.h - 1), y1 = min(y0 + 1, g.h - 1);
+            const float ty = sy - y0;
+            const float wy = (y0 == cy ? 1.f - ty : 0.f) + (y1 == cy ? ty : 0.f);
+            if (wy == 0.f) continue;
+            for (int xx = 0; xx < TX; ++xx) {
+                const int X = X0 + xx;
+                if (X >= g.W) break;
+                const float sx = X * g.rx;
+                const int x0 = min((int)sx, g.w - 1), x1 = min(x0 + 1, g.w - 1);
+                const float tx = sx - x0;
+                const float wx = (x0 == cx ? 1.f - tx : 0.f) + (x1 == cx ? tx : 0.f);
+                if (wx != 0.f) acc += wy * wx * res[yy * TX + xx][k];
+            }
+        }
+        if (acc != 0.f) atomicAdd(dco + (((long)b * g.h + cy) * g.w + cx) * 4 + k, acc);
+    }
+}
+
+inline int geom_ok(int B, int h, int w, int H, int W) { return B >= 1 && h >= 2 && w >= 2 && H >= h && W >= w; }
+
+inline UpGeom make_geom(int B, int h, int w, int H, int W, long sb, long sh, long sw) {
+    UpGeom g;
+    g.B = B; g.h = h; g.w = w; g.H = H; g.W = W; g.sb = sb; g.sh = sh; g.sw = sw;
+    g.ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    g.rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mgn_upce_partials(int B, int H, int W) { return B * ((H + 3) / 4) * ((W + 63) / 64); }
+
+int mgn_upce_fwd(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K, const long* labels,
+                 const float* weights, int ignore, float thr, float* ce_map, float* partials, float* sums3, void* stream) {
+    if (!logits_bf16 || !labels || !ce_map || !partials || !sums3 || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
+    if (K < 1 || K > 32 || sw % 8 != 0 || sh % 8 != 0 || sb % 8 != 0 || sw < ((K + 7) / 8) * 8) return MGN_ENOTSUP;
+    const UpGeom g = make_geom(B, h, w, H, W, sb, sh, sw);
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+    hipStream_t s = (hipStream_t)stream;
+    const uint16_t* lg = (const uint16_t*)logits_bf16;
+    switch ((K + 7) / 8) {
+        case 1: hipLaunchKernelGGL(upce_fwd<1>, grid, dim3(TPB), 0, s, lg, g, K, labels, weights, ignore, thr, ce_map, partials); break;
+        case 2: hipLaunchKernelGGL(upce_fwd<2>, grid, dim3(TPB), 0, s, lg, g, K, labels, weights, ignore, thr, ce_map, partials); break;
+        case 3: hipLaunchKernelGGL(upce_fwd<3>, grid, dim3(TPB), 0, s, lg, g, K, labels, weights, ignore, thr, ce_map, partials); break;
+        default: hipLaunchKernelGGL(upce_fwd<4>, grid, dim3(TPB), 0, s, lg, g, K, labels, weights, ignore, thr, ce_map, partials); break;
+    }
+    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(TPB), 0, s, partials, (int)(grid.x * grid.y * grid.z), sums3);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_upce_bwd(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K, int Kp,
+                 const long* labels, const float* weights, int ignore, const float* ce_map, const float* sel3, const float* gout,
+                 float* dlogits, void* stream) {
+    if (!logits_bf16 || !labels || !ce_map || !sel3 || !gout || !dlogits || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
+    if (K < 1 || K > 32 || Kp < K || sw % 8 != 0 || sh % 8 != 0 || sb % 8 != 0) return MGN_ENOTSUP;
+    const UpGeom g = make_geom(B, h, w, H, W, sb, sh, sw);
+    const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
+    hipStream_t s = (hipStream_t)stream;
+    const uint16_t* lg = (const uint16_t*)logits_bf16;
+    const int k8 = (K + 7) / 8;
+    const size_t lds = sizeof(float) * TX * TY * k8 * 8;
+    switch (k8) {
+        case 1: hipLaunchKernelGGL(upce_bwd<1>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
+        case 2: hipLaunchKernelGGL(upce_bwd<2>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
+        case 3: hipLaunchKernelGGL(upce_bwd<3>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
+        default: hipLaunchKernelGGL(upce_bwd<4>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
+    }
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_ins_loss_fwd(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh, long osw,
+                     int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot, const float* ow,
+                     float oscale, float* partials, float* out4, void* stream) {
+    if (!center_lr || !offset_lr_bf16 || !ct || !cw || !ot || !ow || !partials || !out4 || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
+    InsMaps m;
+    m.center = nullptr; m.center_f = center_lr; m.offset = (const uint16_t*)offset_lr_bf16;
+    m.gc = make_geom(B, h, w, H, W, csb, csh, csw);
+    m.go = make_geom(B, h, w, H, W, osb, osh, osw);
+    m.ct = ct; m.cw = cw; m.ot = ot; m.ow = ow; m.oscale = oscale;
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+    hipLaunchKernelGGL(ins_fwd, grid, dim3(TPB), 0, (hipStream_t)stream, m, partials);
+    hipLaunchKernelGGL(sum4_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)stream, partials, (int)(grid.x * grid.y * grid.z), out4);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh, long osw,
+                     int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot, const float* ow,
+                     float oscale, const float* out4, const float* gout2, float* dco, void* stream) {
+    if (!center_lr || !offset_lr_bf16 || !ct || !cw || !ot || !ow || !out4 || !gout2 || !dco || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
+    InsMaps m;
+    m.center = nullptr; m.center_f = center_lr; m.offset = (const uint16_t*)offset_lr_bf16;
+    m.gc = make_geom(B, h, w, H, W, csb, csh, csw);
+    m.go = make_geom(B, h, w, H, W, osb, osh, osw);
+    m.ct = ct; m.cw = cw; m.ot = ot; m.ow = ow; m.oscale = oscale;
+    const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
+    hipLaunchKernelGGL(ins_bwd, grid, dim3(TPB), 0, (hipStream_t)stream, m, out4, gout2, dco);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+}  // extern "C"

@@ -26,6 +26,12 @@ class DeepLabCE(nn.Module):
         self.ignore_label = ignore_label
 
     def forward(self, logits, labels, weights=None):
+        from . import ops
+        if isinstance(logits, ops.LazyUpsample):  # [HIP] fused upsampling + CE (+ top-k)
+            if self.top_k_percent_pixels == 1.0:
+                return ops.upsampled_ce(logits, labels, weights, self.ignore_label, "mean")
+            return ops.upsampled_ce(logits, labels, weights, self.ignore_label, "topk",
+                                    n_sel=int(self.top_k_percent_pixels * labels.numel()))
         pixel_losses = _pixel_ce(logits, labels, weights, self.ignore_label)
         if self.top_k_percent_pixels == 1.0:
             return pixel_losses.mean()
@@ -48,6 +54,9 @@ class OhemCE(nn.Module):
         self.ignore_label = ignore_label
 
     def forward(self, logits, labels, weights=None):
+        from . import ops
+        if isinstance(logits, ops.LazyUpsample):  # [HIP] fused upsampling + CE + OHEM selection
+            return ops.upsampled_ce(logits, labels, weights, self.ignore_label, "ohem", self.ohem_threshold, self.n_min)
         pixel_losses = _pixel_ce(logits, labels, weights, self.ignore_label)
         if self.n_min >= pixel_losses.numel():
             raise IndexError(f"index {self.n_min} is out of bounds for dimension 0 with size {pixel_losses.numel()}")

@@ -170,7 +170,11 @@ class MGNetSemSegHead(MGNetDecoder):  # mg_net.py:523-610
         return ret
 
     def forward(self, features):
-        return ops.upsample_bilinear(self.layers(features), self.common_stride)
+        from .. import _C
+        y = self.layers(features)
+        if self.training and _C.upce_supported(y):   # the loss kernel interpolates the low-res logits on the fly
+            return ops.LazyUpsample(y, self.common_stride)
+        return ops.upsample_bilinear(y, self.common_stride)
 
     def layers(self, features):
         y, _ = super().forward(features)
@@ -178,7 +182,7 @@ class MGNetSemSegHead(MGNetDecoder):  # mg_net.py:523-610
 
     def losses(self, predictions, targets):
         if self.loss_type == "cross_entropy":  # nn.CrossEntropyLoss(mean, ignore_index): mean over non-ignored pixels
-            ce = torch.nn.functional.cross_entropy(predictions["sem_seg"].float(), targets["sem_seg"],
+            ce = torch.nn.functional.cross_entropy(ops.materialize(predictions["sem_seg"]).float(), targets["sem_seg"],
                                                    ignore_index=self.ignore_value, reduction="mean")
             return {"loss_sem_seg": ce * self.loss_weight}
         loss = self.loss(predictions["sem_seg"], targets["sem_seg"], targets["sem_seg_weights"])
@@ -205,9 +209,11 @@ class MGNetInsEmbedHead(MGNetDecoder):  # mg_net.py:621-715
 
     def forward(self, features):
         center, offset = self.layers(features)
-        center = ops.upsample_bilinear(center, self.common_stride)
-        offset = ops.upsample_bilinear(offset, self.common_stride) * self.common_stride  # pixel offsets (:682-694)
-        return center, offset
+        lc = ops.LazyUpsample(center, self.common_stride)
+        lo = ops.LazyUpsample(offset, self.common_stride, mult=float(self.common_stride))  # pixel offsets (:682-694)
+        if self.training and ops.ins_losses_supported(lc, lo):
+            return lc, lo
+        return lc.materialize(), lo.materialize()
 
     def layers(self, features):
         y, _ = super().forward(features)
@@ -217,6 +223,9 @@ class MGNetInsEmbedHead(MGNetDecoder):  # mg_net.py:621-715
     def losses(self, predictions, targets):
         """[torch-staging] weighted MSE / L1 (mg_net.py:697-715) without the two `.sum() > 0` host syncs:
         sum/max(wsum, tiny) * (wsum > 0) is identical in value and gradient."""
+        if isinstance(predictions["center"], ops.LazyUpsample):  # [HIP] fused upsampling + weighted MSE / L1
+            l2 = ops.upsampled_ins_losses(predictions["center"], predictions["offset"], targets)
+            return {"loss_center": l2[0] * self.center_loss_weight, "loss_offset": l2[1] * self.offset_loss_weight}
         cw, ow = targets["center_weights"], targets["offset_weights"]
         lc = ((predictions["center"].float() - targets["center"]) ** 2 * cw).sum()
         cws = cw.sum()

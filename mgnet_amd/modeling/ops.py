@@ -208,3 +208,117 @@ def upsample_nearest(x, size):
 def upsample_bilinear(x, scale_factor):
     """[torch-staging] F.interpolate(bilinear, align_corners=True) (mg_net.py:599, :678-687, :804-806)"""
     return F.interpolate(x.float(), scale_factor=scale_factor, mode="bilinear", align_corners=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# head losses fused with the bilinear upsampling of the low-resolution head outputs
+# ---------------------------------------------------------------------------------------------------------------
+class LazyUpsample:
+    """`F.interpolate(lr, scale_factor=scale, bilinear, align_corners=True) * mult`, not materialised: the fused loss
+    kernels interpolate on the fly.  `materialize()` gives the tensor the reference would have produced."""
+
+    def __init__(self, lr, scale, mult=1.0):
+        self.lr, self.scale, self.mult = lr, scale, mult
+
+    @property
+    def shape(self):
+        return tuple(self.lr.shape[:2]) + (self.lr.shape[2] * self.scale, self.lr.shape[3] * self.scale)
+
+    def materialize(self):
+        y = upsample_bilinear(self.lr, self.scale)
+        return y * self.mult if self.mult != 1.0 else y
+
+
+def materialize(x):
+    return x.materialize() if isinstance(x, LazyUpsample) else x
+
+
+class _UpCEFn(torch.autograd.Function):
+    """[HIP] mgnet_amd/csrc/headloss.hip: x`scale` upsampling + weighted per-pixel CE + OHEM / top-k / mean selection."""
+
+    @staticmethod
+    def forward(ctx, lr, labels, weights, H, W, ignore, mode, thr, n_sel):
+        from .. import _C
+
+        labels = labels.contiguous()
+        weights = None if weights is None else weights.float().contiguous()
+        ce, sums = _C.upce_fwd(lr, labels, weights, H, W, ignore, thr if mode == "ohem" else 3.0e38)
+        n_px = ce.numel()
+        if mode == "mean":          # DeepLabCE(top_k=1.0): mean over ALL pixels (ignored ones count with loss 0)
+            loss = sums[2] / n_px
+            sel = torch.stack([sums.new_tensor(-1.0), sums.new_tensor(0.0), sums.new_tensor(1.0 / n_px)])
+        else:
+            use_thr = mode == "ohem" and int(sums[0]) > n_sel   # one host sync, as in the reference (loss.py:76)
+            if use_thr:
+                loss = sums[1] / sums[0]
+                sel = torch.stack([sums.new_tensor(thr), sums.new_tensor(0.0), 1.0 / sums[0]])
+            else:                   # mean of the n_sel largest: [torch-staging] torch.topk for the n_sel-th value
+                flat = ce.view(-1)
+                vals = torch.topk(flat, n_sel)[0]
+                vk = vals[-1]
+                n_gt, n_eq = (flat > vk).sum(), (flat == vk).sum()
+                loss = vals.mean()
+                sel = torch.stack([vk, (n_sel - n_gt).float() / n_eq.float(), sums.new_tensor(1.0 / n_sel)])
+        ctx.save_for_backward(lr, labels, weights, ce, sel.float().contiguous())
+        ctx.cfg = (H, W, ignore)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+
+        lr, labels, weights, ce, sel = ctx.saved_tensors
+        H, W, ignore = ctx.cfg
+        K = lr.shape[1]
+        dlg = _C.upce_bwd(lr, labels, weights, H, W, ignore, ce, sel, g.float().reshape(1).contiguous(), (K + 7) // 8 * 8)
+        return dlg[..., :K].permute(0, 3, 1, 2).to(lr.dtype), None, None, None, None, None, None, None, None
+
+
+def upsampled_ce(lazy, labels, weights, ignore, mode, thr=0.0, n_sel=0):
+    """loss of the semantic head on a LazyUpsample of the low-res logits (mode: ohem | topk | mean)."""
+    from .. import _C
+
+    lr = lazy.lr
+    H, W = lazy.shape[2:]
+    if mode != "mean" and n_sel >= labels.numel():
+        raise IndexError(f"index {n_sel} is out of bounds for dimension 0 with size {labels.numel()}")
+    assert lazy.mult == 1.0 and _C.upce_supported(lr)
+    return _UpCEFn.apply(lr, labels, weights, H, W, ignore, mode, float(thr), int(n_sel))
+
+
+class _InsLossFn(torch.autograd.Function):
+    """[HIP] centre (weighted MSE) and offset (weighted L1) losses on the fly-upsampled low-res maps."""
+
+    @staticmethod
+    def forward(ctx, center_lr, offset_lr, ct, cw, ot, ow, H, W, oscale):
+        from .. import _C
+
+        center_lr = center_lr.float().contiguous()
+        ct, cw, ot, ow = ct.float().contiguous(), cw.float().contiguous(), ot.float().contiguous(), ow.float().contiguous()
+        out4 = _C.ins_loss_fwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale)
+        ctx.save_for_backward(center_lr, offset_lr, ct, cw, ot, ow, out4)
+        ctx.cfg = (H, W, oscale)
+        return out4[:2].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+
+        center_lr, offset_lr, ct, cw, ot, ow, out4 = ctx.saved_tensors
+        H, W, oscale = ctx.cfg
+        dco = _C.ins_loss_bwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale, out4, g.float().contiguous())
+        d_center = dco[..., 0].unsqueeze(1)
+        d_offset = dco[..., 1:3].permute(0, 3, 1, 2).to(offset_lr.dtype)
+        return d_center, d_offset, None, None, None, None, None, None, None
+
+
+def ins_losses_supported(center, offset):
+    from .. import _C
+    return (isinstance(center, LazyUpsample) and isinstance(offset, LazyUpsample) and center.lr.is_cuda
+            and center.lr.dtype == torch.float32 and _C.upce_supported(offset.lr) and center.scale == offset.scale)
+
+
+def upsampled_ins_losses(center, offset, targets):
+    H, W = center.shape[2:]
+    return _InsLossFn.apply(center.lr, offset.lr, targets["center"], targets["center_weights"], targets["offset"],
+                            targets["offset_weights"], H, W, float(offset.mult))
