@@ -20,6 +20,7 @@
 // of step s), one barrier per k-step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mgnet_hip.h"
 
@@ -28,9 +29,7 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int BM = 128, BK = 32;
-constexpr int PITCH = 80;  // bytes per LDS row (64 data + 16 pad)
-constexpr int TILE_BYTES = 128 * PITCH;
+constexpr int BM = 128;
 
 struct ConvParams {
     const uint16_t* in;   // [N, IH, IW, Cin] bf16
@@ -51,7 +50,8 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 __device__ __forceinline__ int swz(int row) { return ((row >> 3) & 1) | (((row >> 4) & 1) << 1) | (((row ^ (row >> 1) ^ (row >> 5)) & 1) << 2); }
 
 // one k-slab of KS*16 reduction elements: wave tile (32*MT) x (32*NT); LDS rows are LPITCH bytes apart
-template <int MT, int NT, int KS, int LPITCH, bool SWZ>
+// SWAP: D = B-rows x A-rows (the accumulator's 4 consecutive registers then run along the B-row index)
+template <int MT, int NT, int KS, int LPITCH, bool SWZ, bool SWAP = false>
 __device__ __forceinline__ void mma_tile(const unsigned char* sA, const unsigned char* sB, int wm, int wn, int lane,
                                          f32x16 (&acc)[MT][NT]) {
 #pragma unroll
@@ -71,36 +71,47 @@ __device__ __forceinline__ void mma_tile(const unsigned char* sA, const unsigned
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
 }
 
-template <int NT>
+// KS = k-slab in units of 16 channels (BK = 16*KS input channels of one tap per k-step); LDS rows are padded by 16 bytes
+template <int NT, int KS>
 __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
-    constexpr int BN = 64 * NT;
+    constexpr int BN = 64 * NT, BK = 16 * KS, PITCH = BK * 2 + 16, TILE_BYTES = 128 * PITCH;
+    constexpr int SEGS = BK / 8;          // 16-byte segments per row
+    constexpr int RPP = 256 / SEGS;       // rows covered per loader pass
+    constexpr int NR = 128 / RPP;         // loader passes (rows per thread)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int bm = blockIdx.x, bn = blockIdx.y;
     const long M = (long)p.N * p.OH * p.OW;
-    const int lrow = tid >> 2, seg = tid & 3;  // loader: rows lrow and lrow+64, 16-byte segment `seg` of the 64-byte k-slab
+    const int lrow = tid / SEGS, seg = tid % SEGS;  // loader: rows lrow + r*RPP, 16-byte segment `seg` of the k-slab
 
-    int nb[2], ihb[2], iwb[2];
-    bool vm[2], vco[2];
-    const uint16_t* wrow[2];
+    // Buffer descriptors: an out-of-range voffset makes the hardware return 0, which realises the zero padding and the
+    // M / Cout tails without divergent branches around the loads.
+    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * p.KH * p.KW * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, w_bytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+
+    int ihb[NR], iwb[NR], abase[NR], wbase[NR];
+    bool vm[NR];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const long m = (long)bm * BM + lrow + r * 64;
+    for (int r = 0; r < NR; ++r) {
+        const long m = (long)bm * BM + lrow + r * RPP;
         vm[r] = m < M;
         const long mm = vm[r] ? m : 0;
         const int n = (int)(mm / ((long)p.OH * p.OW));
         const int rem = (int)(mm - (long)n * p.OH * p.OW);
         const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        nb[r] = n;
         ihb[r] = oh * p.stride - p.pad;
         iwb[r] = ow * p.stride - p.pad;
-        const int co = bn * BN + lrow + r * 64;
-        vco[r] = co < p.Cout && (r < NT);
-        wrow[r] = p.w + (size_t)(vco[r] ? co : 0) * p.KH * p.KW * p.Cin + seg * 8;
+        abase[r] = (n * p.IH * p.IW * p.Cin + seg * 8) * 2;  // byte offset of image n (+ this thread's 16-byte segment)
+        const int co = bn * BN + lrow + r * RPP;
+        wbase[r] = (co < p.Cout && lrow + r * RPP < BN) ? (co * p.KH * p.KW * p.Cin + seg * 8) * 2 : OOB;
     }
     const int cpt = p.Cin / BK;  // k-steps per tap
     const int ksteps = p.KH * p.KW * cpt;
@@ -113,33 +124,45 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    uint4 ra[2], rb[2];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[NR], rb[NR];
     int kh = 0, kw = 0, cc = 0;  // state of the NEXT k-step to load
-    auto load_next = [&]() {
+    int avoff[NR], wvoff[NR];    // per-tap byte offsets (OOB when the tap falls into the padding)
+    auto set_tap = [&]() {
+        const int wtap = (kh * p.KW + kw) * p.Cin * 2;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < NR; ++r) {
             int th = ihb[r] + kh, tw = iwb[r] + kw;
             bool ok = vm[r];
             if (p.up > 1) {
-                ok = ok && (th % p.up == 0) && (tw % p.up == 0) && th >= 0 && tw >= 0;
+                ok = ok && th >= 0 && tw >= 0 && (th % p.up == 0) && (tw % p.up == 0);
                 th /= p.up;
                 tw /= p.up;
             }
             ok = ok && th >= 0 && th < p.IH && tw >= 0 && tw < p.IW;
-            ra[r] = make_uint4(0, 0, 0, 0);
-            if (ok) ra[r] = *reinterpret_cast<const uint4*>(p.in + (((size_t)nb[r] * p.IH + th) * p.IW + tw) * p.Cin + cc * BK + seg * 8);
-            if (r < NT) {
-                rb[r] = make_uint4(0, 0, 0, 0);
-                if (vco[r]) rb[r] = *reinterpret_cast<const uint4*>(wrow[r] + ((size_t)kh * p.KW + kw) * p.Cin + cc * BK);
-            }
+            avoff[r] = ok ? abase[r] + (th * p.IW + tw) * p.Cin * 2 : OOB;
+            wvoff[r] = wbase[r] == OOB ? OOB : wbase[r] + wtap;
         }
-        if (++cc == cpt) { cc = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    };
+    set_tap();
+    auto load_next = [&]() {
+        const int soff = cc * BK * 2;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            ra[r] = __builtin_amdgcn_raw_buffer_load_b128(rsA, avoff[r], soff, 0);
+            rb[r] = __builtin_amdgcn_raw_buffer_load_b128(rsB, wvoff[r], soff, 0);
+        }
+        if (++cc == cpt) {
+            cc = 0;
+            if (++kw == p.KW) { kw = 0; ++kh; }
+            set_tap();
+        }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            *reinterpret_cast<uint4*>(&smem[buf][0][(lrow + r * 64) * PITCH + seg * 16]) = ra[r];
-            if (r < NT) *reinterpret_cast<uint4*>(&smem[buf][1][(lrow + r * 64) * PITCH + seg * 16]) = rb[r];
+        for (int r = 0; r < NR; ++r) {
+            *reinterpret_cast<u32x4*>(&smem[buf][0][(lrow + r * RPP) * PITCH + seg * 16]) = ra[r];
+            if (lrow + r * RPP < BN) *reinterpret_cast<u32x4*>(&smem[buf][1][(lrow + r * RPP) * PITCH + seg * 16]) = rb[r];
         }
     };
 
@@ -149,29 +172,45 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
     for (int ks = 0; ks < ksteps; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < ksteps) load_next();
-        mma_tile<2, NT, 2, PITCH, false>(smem[buf][0], smem[buf][1], wm, wn, lane, acc);
+        mma_tile<2, NT, KS, PITCH, false, true>(smem[buf][0], smem[buf][1], wm, wn, lane, acc);
         if (ks + 1 < ksteps) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    // epilogue: C/D layout of v_mfma_f32_32x32x*: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    // epilogue.  Operands are swapped in the MFMA (D = W-rows x pixel-rows), so in the C/D layout
+    //   col = lane & 31 -> pixel,  row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel:
+    // the 4 registers e..e+3 are 4 CONSECUTIVE channels of one pixel = one 8-byte (bf16) / 16-byte (fp32) store.
+    const bool vec_ok = (p.Cout % 4) == 0;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = bn * BN + wn * 32 * NT + j * 32 + (lane & 31);
-        if (co >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[co] : 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const long m = (long)bm * BM + wm * 64 + i * 32 + (lane & 31);
+        if (m >= M) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const long m = (long)bm * BM + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (m >= M) continue;
-                float v = acc[i][j][e] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.out_f32)
-                    reinterpret_cast<float*>(p.out)[m * p.Cout + co] = v;
-                else
-                    reinterpret_cast<uint16_t*>(p.out)[m * p.Cout + co] = f2bf(v);
+            for (int q = 0; q < 4; ++q) {
+                const int co = bn * BN + wn * 32 * NT + j * 32 + 8 * q + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][q * 4 + e] + ((p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f);
+                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (vec_ok) {
+                    if (p.out_f32)
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * p.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + m * p.Cout + co) =
+                            make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= p.Cout) break;
+                        if (p.out_f32) reinterpret_cast<float*>(p.out)[m * p.Cout + co + e] = v[e];
+                        else reinterpret_cast<uint16_t*>(p.out)[m * p.Cout + co + e] = f2bf(v[e]);
+                    }
+                }
             }
     }
 }
@@ -240,23 +279,33 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dout), 0, (uint32_t)((size_t)M * p.Cout * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), 0x00020000);
+    constexpr int OOB = (int)0x80000000;
     uint4 rg[8];
-    auto load = [&]() {  // loads the k-step starting at pixel mcur, then advances mcur by WBK
+    auto load = [&]() {  // loads the k-step starting at pixel mcur (out-of-range -> 0 via the buffer bounds), advances by WBK
         if (!isB) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                rg[q] = make_uint4(0, 0, 0, 0);
-                if (vc && mcur + q < m_end) rg[q] = *reinterpret_cast<const uint4*>(p.dout + (mcur + q) * p.Cout + c0);
+                const int off = (vc && mcur + q < m_end) ? (int)(((mcur + q) * p.Cout + c0) * 2) : OOB;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+                rg[q] = make_uint4(v.x, v.y, v.z, v.w);
             }
         } else {
             int n = pn, oh = poh, ow = pow_;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                rg[q] = make_uint4(0, 0, 0, 0);
                 const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
-                if (vc && mcur + q < m_end && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
-                    rg[q] = *reinterpret_cast<const uint4*>(p.in + (((size_t)n * p.IH + ih) * p.IW + iw) * p.Cin + c0);
-                if (++ow == p.OW) { ow = 0; if (++oh == p.OH) { oh = 0; ++n; } }
+                const bool ok = vc && mcur + q < m_end && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+                const int off = ok ? (((n * p.IH + ih) * p.IW + iw) * p.Cin + c0) * 2 : OOB;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
+                rg[q] = make_uint4(v.x, v.y, v.z, v.w);
+                const bool wrap = (ow + 1 == p.OW);
+                ow = wrap ? 0 : ow + 1;
+                const bool wrap2 = wrap && (oh + 1 == p.OH);
+                oh = wrap ? (wrap2 ? 0 : oh + 1) : oh;
+                n += wrap2 ? 1 : 0;
             }
             pow_ += WBK;
             while (pow_ >= p.OW) { pow_ -= p.OW; if (++poh == p.OH) { poh = 0; ++pn; } }
@@ -309,7 +358,7 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
                    int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, void* stream) {
     if (!in || !w || !out || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || up < 1)
         return MGN_EINVAL;
-    if (Cin < BK || Cin % BK != 0) return MGN_ENOTSUP;  // k-slab = 32 input channels of one tap
+    if (Cin < 32 || Cin % 32 != 0) return MGN_ENOTSUP;  // k-slab = 32 or 64 input channels of one tap
     ConvParams p;
     p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = out; p.bias = bias;
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
@@ -317,10 +366,17 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
     const long M = (long)N * OH * OW;
     const long gx = (M + BM - 1) / BM;
     if (gx > 0x7fffffffL) return MGN_EINVAL;
-    if (Cout <= 64)
-        hipLaunchKernelGGL(conv_igemm<1>, dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(conv_igemm<2>, dim3((unsigned)gx, (Cout + 127) / 128), dim3(256), 0, (hipStream_t)stream, p);
+    const bool k64 = (Cin % 64 == 0) && getenv("MGN_CONV_BK64");  // measured: no gain over BK=32 (LDS halves the residency)
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout <= 64) {
+        const dim3 grid((unsigned)gx, (Cout + 63) / 64);
+        if (k64) hipLaunchKernelGGL((conv_igemm<1, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm<1, 2>), grid, dim3(256), 0, st, p);
+    } else {
+        const dim3 grid((unsigned)gx, (Cout + 127) / 128);
+        if (k64) hipLaunchKernelGGL((conv_igemm<2, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm<2, 2>), grid, dim3(256), 0, st, p);
+    }
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
