@@ -88,6 +88,50 @@ __device__ __forceinline__ float interp_logits(const uint16_t* __restrict__ lg, 
     return m + __logf(s);
 }
 
+// Phase 2 of the backward tile kernels, separable: rows first (sum over the tile's x with the horizontal bilinear weight
+// of every footprint column), then columns.  res: [TY*TX][KK] residuals in LDS; rowsum: [TY][MAXC][KK] scratch in LDS.
+constexpr int MAXC = 8, MAXR = 6;  // footprint bound of a 32x16 tile for scale >= 4 (checked on the host)
+
+template <int KK>
+__device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int Y0, int K, const float* res, float* rowsum,
+                                             float* out, int out_stride) {
+    const int ly0 = min((int)(Y0 * g.ry), g.h - 1), lx0 = min((int)(X0 * g.rx), g.w - 1);
+    const int Yl = min(Y0 + TY, g.H) - 1, Xl = min(X0 + TX, g.W) - 1;
+    const int ly1 = min(min((int)(Yl * g.ry), g.h - 1) + 1, g.h - 1), lx1 = min(min((int)(Xl * g.rx), g.w - 1) + 1, g.w - 1);
+    const int nr = min(ly1 - ly0 + 1, MAXR), nc = min(lx1 - lx0 + 1, MAXC);
+    const int ny = Yl - Y0 + 1, nx = Xl - X0 + 1;
+    for (int o = threadIdx.x; o < ny * nc * KK; o += TPB) {
+        const int k = o % KK, cxi = (o / KK) % nc, yy = o / (KK * nc);
+        float acc = 0.f;
+        if (k < K) {
+            const int cx = lx0 + cxi;
+            for (int xx = 0; xx < nx; ++xx) {
+                const float sx = (X0 + xx) * g.rx;
+                const int x0 = min((int)sx, g.w - 1), x1 = min(x0 + 1, g.w - 1);
+                const float tx = sx - x0;
+                const float wx = (x0 == cx ? 1.f - tx : 0.f) + (x1 == cx ? tx : 0.f);
+                acc += wx * res[(yy * TX + xx) * KK + k];
+            }
+        }
+        rowsum[(yy * MAXC + cxi) * KK + k] = acc;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nr * nc * KK; o += TPB) {
+        const int k = o % KK, cxi = (o / KK) % nc, cyi = o / (KK * nc);
+        if (k >= K) continue;
+        const int cy = ly0 + cyi;
+        float acc = 0.f;
+        for (int yy = 0; yy < ny; ++yy) {
+            const float sy = (Y0 + yy) * g.ry;
+            const int y0 = min((int)sy, g.h - 1), y1 = min(y0 + 1, g.h - 1);
+            const float ty = sy - y0;
+            const float wy = (y0 == cy ? 1.f - ty : 0.f) + (y1 == cy ? ty : 0.f);
+            acc += wy * rowsum[(yy * MAXC + cxi) * KK + k];
+        }
+        if (acc != 0.f) atomicAdd(out + (((long)b * g.h + cy) * g.w + lx0 + cxi) * out_stride + k, acc);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // semantic head forward: per-pixel weighted CE map + block partials {count(ce>thr), sum(ce | ce>thr), sum(ce)}
 // ---------------------------------------------------------------------------------------------------------------
@@ -179,36 +223,8 @@ __global__ __launch_bounds__(TPB) void upce_bwd(const uint16_t* __restrict__ lg,
         }
     }
     __syncthreads();
-    // ---- phase 2: each (footprint cell, channel) sums its bilinear-weighted pixels in a fixed order
-    const int ly0 = min((int)(Y0 * g.ry), g.h - 1), lx0 = min((int)(X0 * g.rx), g.w - 1);
-    const int Yl = min(Y0 + TY, g.H) - 1, Xl = min(X0 + TX, g.W) - 1;
-    const int ly1 = min(min((int)(Yl * g.ry), g.h - 1) + 1, g.h - 1), lx1 = min(min((int)(Xl * g.rx), g.w - 1) + 1, g.w - 1);
-    const int nr = ly1 - ly0 + 1, nc = lx1 - lx0 + 1;
-    for (int o = threadIdx.x; o < nr * nc * KK; o += TPB) {
-        const int k = o % KK, cell = o / KK;
-        if (k >= K) continue;
-        const int cy = ly0 + cell / nc, cx = lx0 + cell % nc;
-        float acc = 0.f;
-        for (int yy = 0; yy < TY; ++yy) {
-            const int Y = Y0 + yy;
-            if (Y >= g.H) break;
-            const float sy = Y * g.ry;
-            const int y0 = min((int)sy, g.h - 1), y1 = min(y0 + 1, g.h - 1);
-            const float ty = sy - y0;
-            const float wy = (y0 == cy ? 1.f - ty : 0.f) + (y1 == cy ? ty : 0.f);
-            if (wy == 0.f) continue;
-            for (int xx = 0; xx < TX; ++xx) {
-                const int X = X0 + xx;
-                if (X >= g.W) break;
-                const float sx = X * g.rx;
-                const int x0 = min((int)sx, g.w - 1), x1 = min(x0 + 1, g.w - 1);
-                const float tx = sx - x0;
-                const float wx = (x0 == cx ? 1.f - tx : 0.f) + (x1 == cx ? tx : 0.f);
-                if (wx != 0.f) acc += wy * wx * res[(yy * TX + xx) * KK + k];
-            }
-        }
-        if (acc != 0.f) atomicAdd(dlg + (((long)b * g.h + cy) * g.w + cx) * Kp + k, acc);
-    }
+    // ---- phase 2: separable bilinear adjoint of the tile into its low-res footprint
+    scatter_tile<KK>(g, b, X0, Y0, K, res, res + TX * TY * KK, dlg, Kp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -290,7 +306,7 @@ __global__ void sum4_kernel(const float* partials, int nblk, float* out) {
 
 // gout = {d/d loss_center, d/d loss_offset}; sums = output of sum4_kernel
 __global__ __launch_bounds__(TPB) void ins_bwd(InsMaps m, const float* __restrict__ sums, const float* __restrict__ gout, float* dco) {
-    __shared__ float res[TY * TX][3];
+    __shared__ float res[TY * TX * 4 + TY * MAXC * 4];
     const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY, b = blockIdx.z;
     const UpGeom& g = m.gc;  // centre and offset maps share the geometry
     const float sc = sums[2] > 0.f ? gout[0] / sums[2] : 0.f, so = sums[3] > 0.f ? gout[1] / sums[3] : 0.f;
@@ -308,37 +324,16 @@ __global__ __launch_bounds__(TPB) void ins_bwd(InsMaps m, const float* __restric
             r1 = wo * (float)((d0 > 0.f) - (d0 < 0.f));
             r2 = wo * (float)((d1 > 0.f) - (d1 < 0.f));
         }
-        res[t][0] = r0; res[t][1] = r1; res[t][2] = r2;
+        res[t * 4 + 0] = r0; res[t * 4 + 1] = r1; res[t * 4 + 2] = r2; res[t * 4 + 3] = 0.f;
     }
     __syncthreads();
-    const int ly0 = min((int)(Y0 * g.ry), g.h - 1), lx0 = min((int)(X0 * g.rx), g.w - 1);
-    const int Yl = min(Y0 + TY, g.H) - 1, Xl = min(X0 + TX, g.W) - 1;
-    const int ly1 = min(min((int)(Yl * g.ry), g.h - 1) + 1, g.h - 1), lx1 = min(min((int)(Xl * g.rx), g.w - 1) + 1, g.w - 1);
-    const int nr = ly1 - ly0 + 1, nc = lx1 - lx0 + 1;
-    for (int o = threadIdx.x; o < nr * nc * 3; o += TPB) {
-        const int k = o % 3, cell = o / 3;
-        const int cy = ly0 + cell / nc, cx = lx0 + cell % nc;
-        float acc = 0.f;
-        for (int yy = 0; yy < TY; ++yy) {
-            const int Y = Y0 + yy;
-            if (Y >= g.H) break;
-            const float sy = Y * g.ry;
-            const int y0 = min((int)sy, g.h - 1), y1 = min(y0 + 1, g.h - 1);
-            const float ty = sy - y0;
-            const float wy = (y0 == cy ? 1.f - ty : 0.f) + (y1 == cy ? ty : 0.f);
-            if (wy == 0.f) continue;
-            for (int xx = 0; xx < TX; ++xx) {
-                const int X = X0 + xx;
-                if (X >= g.W) break;
-                const float sx = X * g.rx;
-                const int x0 = min((int)sx, g.w - 1), x1 = min(x0 + 1, g.w - 1);
-                const float tx = sx - x0;
-                const float wx = (x0 == cx ? 1.f - tx : 0.f) + (x1 == cx ? tx : 0.f);
-                if (wx != 0.f) acc += wy * wx * res[yy * TX + xx][k];
-            }
-        }
-        if (acc != 0.f) atomicAdd(dco + (((long)b * g.h + cy) * g.w + cx) * 4 + k, acc);
-    }
+    scatter_tile<4>(g, b, X0, Y0, 3, res, res + TX * TY * 4, dco, 4);
+}
+
+// a 32x16 pixel tile must fall into at most MAXC x MAXR low-res cells
+inline bool footprint_ok(int h, int w, int H, int W) {
+    const double rx = W > 1 ? (double)(w - 1) / (W - 1) : 0.0, ry = H > 1 ? (double)(h - 1) / (H - 1) : 0.0;
+    return (TX - 1) * rx + 3 <= MAXC && (TY - 1) * ry + 3 <= MAXR;
 }
 
 inline int geom_ok(int B, int h, int w, int H, int W) { return B >= 1 && h >= 2 && w >= 2 && H >= h && W >= w; }
@@ -380,12 +375,13 @@ int mgn_upce_bwd(const void* logits_bf16, long sb, long sh, long sw, int B, int 
                  float* dlogits, void* stream) {
     if (!logits_bf16 || !labels || !ce_map || !sel3 || !gout || !dlogits || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
     if (K < 1 || K > 32 || Kp < K || sw % 8 != 0 || sh % 8 != 0 || sb % 8 != 0) return MGN_ENOTSUP;
+    if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
     const UpGeom g = make_geom(B, h, w, H, W, sb, sh, sw);
     const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* lg = (const uint16_t*)logits_bf16;
     const int k8 = (K + 7) / 8;
-    const size_t lds = sizeof(float) * TX * TY * k8 * 8;
+    const size_t lds = sizeof(float) * (TX * TY + TY * MAXC) * k8 * 8;
     switch (k8) {
         case 1: hipLaunchKernelGGL(upce_bwd<1>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
         case 2: hipLaunchKernelGGL(upce_bwd<2>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
@@ -414,6 +410,7 @@ int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const
                      int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot, const float* ow,
                      float oscale, const float* out4, const float* gout2, float* dco, void* stream) {
     if (!center_lr || !offset_lr_bf16 || !ct || !cw || !ot || !ow || !out4 || !gout2 || !dco || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
+    if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
     InsMaps m;
     m.center = nullptr; m.center_f = center_lr; m.offset = (const uint16_t*)offset_lr_bf16;
     m.gc = make_geom(B, h, w, H, W, csb, csh, csw);
