@@ -184,6 +184,17 @@ int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const
                      long osw, int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot,
                      const float* ow, float oscale, const float* out4, const float* gout2, float* dco, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Network input assembly -- replaces mg_net.py:250-264 (`.float()/255`, mean/std normalisation of image, image_prev,
+ * image_next and their channel concatenation for PoseCNN).
+ * frames_u8: HOST array of n_frames (1..3) device pointers to [B,3,H,W] uint8; pixel_mean3/std3: HOST floats in the 0..1
+ * domain (cfg value / 255); out: [B,H,W,Cp] bf16 channels-last, Cp = 8 or 16, channels 3f..3f+2 = frame f, rest zero.
+ * mgn_conv_igemm / mgn_conv_wgrad accept such Cin = 8 | 16 inputs ("packed taps": k = tap*Cin + c, weights
+ * [Cout][ceil(KH*KW*Cin/32)*32] bf16, dw [Cout][KH*KW*Cin] fp32).
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
+                   const float* pixel_std3, void* out_bf16, int Cp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

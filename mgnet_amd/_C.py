@@ -16,7 +16,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
            "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad",
-           "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd"]
+           "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input"]
 
 
 class ReprojCfg(ctypes.Structure):
@@ -65,6 +65,7 @@ def lib():
         L.mgn_upce_bwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
         L.mgn_ins_loss_fwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp]
         L.mgn_ins_loss_bwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
+        L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
         _lib = L
@@ -248,13 +249,30 @@ def adam_step(p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, step, coef, gra
 # convolution (implicit GEMM, bf16 MFMA).  Tensors are logical NCHW in channels_last memory format.
 # ---------------------------------------------------------------------------------------------------------------
 def conv_supported(x, weight):
-    return x.is_cuda and x.dtype == torch.bfloat16 and weight.shape[1] % 32 == 0
+    """Cin % 32 == 0, or a channel-padded stem input (Cin 8/16 holding the weight's 3/9 real channels)"""
+    return x.is_cuda and x.dtype == torch.bfloat16 and (weight.shape[1] % 32 == 0 or (x.shape[1] in (8, 16) and weight.shape[1] <= x.shape[1]))
 
 
-def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=torch.bfloat16):
-    """x [N,Cin,IH,IW] channels_last bf16; w_ohwi [Cout,KH,KW,Cin] bf16 contiguous -> out [N,Cout,OH,OW] channels_last"""
+def prep_input(frames_u8, mean3, std3, Cp):
+    """frames: list of [B,3,H,W] uint8 CUDA tensors -> [B,Cp,H,W] bf16 channels_last (normalised, zero-padded channels)"""
+    B, _, H, W = frames_u8[0].shape
+    frames_u8 = [f.contiguous() for f in frames_u8]
+    out = torch.empty((B, Cp, H, W), dtype=torch.bfloat16, device=frames_u8[0].device, memory_format=torch.channels_last)
+    ptrs = (ctypes.c_void_p * 3)(*[f.data_ptr() for f in frames_u8])
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean3])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std3])
+    check(lib().mgn_prep_input(ptrs, len(frames_u8), B, H, W, m, sd, out.data_ptr(), Cp, _stream()), "mgn_prep_input")
+    return out
+
+
+def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=torch.bfloat16, khw=None):
+    """x [N,Cin,IH,IW] channels_last bf16; w_ohwi [Cout,KH,KW,Cin] bf16 contiguous (or, for Cin 8/16, the packed
+    [Cout, Kpad] layout with khw=(KH,KW)) -> out [N,Cout,OH,OW] channels_last"""
     N, Cin, IH, IW = x.shape
-    Cout, KH, KW, _ = w_ohwi.shape
+    if khw is None:
+        Cout, KH, KW, _ = w_ohwi.shape
+    else:
+        Cout, (KH, KW) = w_ohwi.shape[0], khw
     OH, OW = out_shape
     out = torch.empty((N, Cout, OH, OW), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
     check(lib().mgn_conv_igemm(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(),

@@ -78,7 +78,9 @@ __device__ __forceinline__ void mma_tile(const unsigned char* sA, const unsigned
 }
 
 // KS = k-slab in units of 16 channels (BK = 16*KS input channels of one tap per k-step); LDS rows are padded by 16 bytes
-template <int NT, int KS>
+// PACK (small Cin = 8 or 16, the 7x7 stems): the reduction index is k = tap*Cin + c with several taps per 32-wide
+// k-slab; every 16-byte loader segment then belongs to its own tap.  Weights are [Cout][Kpad], Kpad = ksteps*32.
+template <int NT, int KS, bool PACK = false>
 __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
     constexpr int BN = 64 * NT, BK = 16 * KS, PITCH = BK * 2 + 16, TILE_BYTES = 128 * PITCH;
     constexpr int SEGS = BK / 8;          // 16-byte segments per row
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
 
     // Buffer descriptors: an out-of-range voffset makes the hardware return 0, which realises the zero padding and the
     // M / Cout tails without divergent branches around the loads.
-    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * p.KH * p.KW * p.Cin * 2);
+    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * (PACK ? ((p.KH * p.KW * p.Cin + BK - 1) / BK) * BK : p.KH * p.KW * p.Cin) * 2);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, w_bytes, 0x00020000);
     constexpr int OOB = (int)0x80000000;
@@ -109,12 +111,14 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
         const int oh = rem / p.OW, ow = rem - oh * p.OW;
         ihb[r] = oh * p.stride - p.pad;
         iwb[r] = ow * p.stride - p.pad;
-        abase[r] = (n * p.IH * p.IW * p.Cin + seg * 8) * 2;  // byte offset of image n (+ this thread's 16-byte segment)
+        abase[r] = (n * p.IH * p.IW * p.Cin + (PACK ? 0 : seg * 8)) * 2;  // byte offset of image n (+ the 16-byte segment)
         const int co = bn * BN + lrow + r * RPP;
-        wbase[r] = (co < p.Cout && lrow + r * RPP < BN) ? (co * p.KH * p.KW * p.Cin + seg * 8) * 2 : OOB;
+        const int wrow = PACK ? ((p.KH * p.KW * p.Cin + BK - 1) / BK) * BK : p.KH * p.KW * p.Cin;
+        wbase[r] = (co < p.Cout && lrow + r * RPP < BN) ? (co * wrow + seg * 8) * 2 : OOB;
     }
-    const int cpt = p.Cin / BK;  // k-steps per tap
-    const int ksteps = p.KH * p.KW * cpt;
+    const int cpt = PACK ? 1 : p.Cin / BK;  // k-steps per tap
+    const int ksteps = PACK ? (p.KH * p.KW * p.Cin + BK - 1) / BK : p.KH * p.KW * cpt;
+    int ksl = 0;  // PACK: k-step being loaded
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -129,18 +133,29 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
     int kh = 0, kw = 0, cc = 0;  // state of the NEXT k-step to load
     int avoff[NR], wvoff[NR];    // per-tap byte offsets (OOB when the tap falls into the padding)
     auto set_tap = [&]() {
-        const int wtap = (kh * p.KW + kw) * p.Cin * 2;
+        int wtap = (kh * p.KW + kw) * p.Cin * 2;
+        int tkh = kh, tkw = kw, coff = 0;
+        bool tap_ok = true;
+        if (PACK) {  // this thread's segment of the k-slab: k = ksl*BK + seg*8 -> (tap, channel offset)
+            const int k = ksl * BK + seg * 8;
+            const int tap = k / p.Cin;
+            coff = (k - tap * p.Cin) * 2;
+            tkh = tap / p.KW;
+            tkw = tap - tkh * p.KW;
+            tap_ok = tap < p.KH * p.KW;
+            wtap = ksl * BK * 2;
+        }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            int th = ihb[r] + kh, tw = iwb[r] + kw;
-            bool ok = vm[r];
+            int th = ihb[r] + tkh, tw = iwb[r] + tkw;
+            bool ok = vm[r] && tap_ok;
             if (p.up > 1) {
                 ok = ok && th >= 0 && tw >= 0 && (th % p.up == 0) && (tw % p.up == 0);
                 th /= p.up;
                 tw /= p.up;
             }
             ok = ok && th >= 0 && th < p.IH && tw >= 0 && tw < p.IW;
-            avoff[r] = ok ? abase[r] + (th * p.IW + tw) * p.Cin * 2 : OOB;
+            avoff[r] = ok ? abase[r] + (th * p.IW + tw) * p.Cin * 2 + coff : OOB;
             wvoff[r] = wbase[r] == OOB ? OOB : wbase[r] + wtap;
         }
     };
@@ -152,7 +167,10 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
             ra[r] = __builtin_amdgcn_raw_buffer_load_b128(rsA, avoff[r], soff, 0);
             rb[r] = __builtin_amdgcn_raw_buffer_load_b128(rsB, wvoff[r], soff, 0);
         }
-        if (++cc == cpt) {
+        if (PACK) {
+            ++ksl;
+            set_tap();
+        } else if (++cc == cpt) {
             cc = 0;
             if (++kw == p.KW) { kw = 0; ++kh; }
             set_tap();
@@ -249,13 +267,15 @@ __device__ __forceinline__ void transpose8x8(const uint4 (&in)[8], uint4 (&out)[
 // waves 2,3 stream (gathered) In: each thread loads 8 pixels x 8 channels with 16-byte loads, transposes in registers
 // and writes 8 x 16 bytes into the [channel][pixel] LDS tile that the MFMA fragments read.  Pixel coordinates advance
 // incrementally (no integer division in the loop).
-template <int MT, int NT>
+// PACK (Cin = 8 or 16): the column index of dW is n' = tap*Cin + c, a 64*NT-column tile spans several taps and every
+// loader thread owns the tap of its 8-channel segment.
+template <int MT, int NT, bool PACK = false>
 __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];  // [2 buffers][A | B][WTILE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int bco = blockIdx.x;
-    const int tap = blockIdx.y / p.ci_tiles, bci = blockIdx.y % p.ci_tiles;
-    const int kh = tap / p.KW, kw = tap % p.KW;
+    const int tap_blk = PACK ? 0 : blockIdx.y / p.ci_tiles, bci = PACK ? blockIdx.y : blockIdx.y % p.ci_tiles;
+    int kh = tap_blk / p.KW, kw = tap_blk % p.KW;
     const long M = (long)p.N * p.OH * p.OW;
     const long m_begin = (long)blockIdx.z * p.m_per_split;
     const long m_end = m_begin + p.m_per_split < M ? m_begin + p.m_per_split : M;
@@ -263,8 +283,15 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
     const bool isB = tid >= 128;
     const int t = tid & 127;
     const int cseg = t & 15, pg = t >> 4;  // 8-channel segment, 8-pixel group
-    const int c0 = (isB ? bci * 64 * NT : bco * 64 * MT) + cseg * 8;
-    const bool vc = c0 < (isB ? p.Cin : p.Cout) && cseg * 8 < 64 * (isB ? NT : MT);
+    int c0 = (isB ? bci * 64 * NT : bco * 64 * MT) + cseg * 8;
+    bool vc = c0 < (isB ? p.Cin : p.Cout) && cseg * 8 < 64 * (isB ? NT : MT);
+    if (PACK && isB) {  // c0 is a packed column: split into (tap, channel)
+        const int tap = c0 / p.Cin;
+        vc = tap < p.KH * p.KW && cseg * 8 < 64 * NT;
+        c0 -= tap * p.Cin;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+    }
     // coordinates of this thread's first pixel of the current k-step
     long mcur = m_begin + pg * 8;
     int pn = (int)(mcur / ((long)p.OH * p.OW));
@@ -335,17 +362,19 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
         __syncthreads();
         buf ^= 1;
     }
+    const int ncols = PACK ? p.KH * p.KW * p.Cin : p.Cin;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int ci = bci * 64 * NT + wn * 32 * NT + j * 32 + (lane & 31);
-        if (ci >= p.Cin) continue;
+        if (ci >= ncols) continue;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = bco * 64 * MT + wm * 32 * MT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
-                atomicAdd(p.dw + (((size_t)co * p.KH + kh) * p.KW + kw) * p.Cin + ci, acc[i][j][e]);
+                if (PACK) atomicAdd(p.dw + (size_t)co * ncols + ci, acc[i][j][e]);
+                else atomicAdd(p.dw + (((size_t)co * p.KH + tap_blk / p.KW) * p.KW + tap_blk % p.KW) * p.Cin + ci, acc[i][j][e]);
             }
     }
 }
@@ -358,7 +387,9 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
                    int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, void* stream) {
     if (!in || !w || !out || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || up < 1)
         return MGN_EINVAL;
-    if (Cin < 32 || Cin % 32 != 0) return MGN_ENOTSUP;  // k-slab = 32 or 64 input channels of one tap
+    const bool pack = (Cin == 8 || Cin == 16);            // small-Cin stems: taps packed into the k-slab
+    if (!pack && (Cin < 32 || Cin % 32 != 0)) return MGN_ENOTSUP;  // k-slab = 32 or 64 input channels of one tap
+    if (pack && up != 1) return MGN_ENOTSUP;
     ConvParams p;
     p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = out; p.bias = bias;
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
@@ -368,7 +399,10 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
     if (gx > 0x7fffffffL) return MGN_EINVAL;
     const bool k64 = (Cin % 64 == 0) && getenv("MGN_CONV_BK64");  // measured: no gain over BK=32 (LDS halves the residency)
     hipStream_t st = (hipStream_t)stream;
-    if (Cout <= 64) {
+    if (pack) {
+        if (Cout <= 64) hipLaunchKernelGGL((conv_igemm<1, 2, true>), dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm<2, 2, true>), dim3((unsigned)gx, (Cout + 127) / 128), dim3(256), 0, st, p);
+    } else if (Cout <= 64) {
         const dim3 grid((unsigned)gx, (Cout + 63) / 64);
         if (k64) hipLaunchKernelGGL((conv_igemm<1, 4>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm<1, 2>), grid, dim3(256), 0, st, p);
@@ -387,11 +421,13 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
     WgradParams p;
     p.dout = (const uint16_t*)dout; p.in = (const uint16_t*)in; p.dw = dw;
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
-    const int NT = Cin <= 64 ? 1 : 2, MT = Cout <= 64 ? 1 : 2;
-    p.ci_tiles = (Cin + 64 * NT - 1) / (64 * NT);
+    const bool pack = (Cin == 8 || Cin == 16);
+    const int ncols = pack ? KH * KW * Cin : Cin;
+    const int NT = ncols <= 64 ? 1 : 2, MT = Cout <= 64 ? 1 : 2;
+    p.ci_tiles = (ncols + 64 * NT - 1) / (64 * NT);
     const int co_tiles = (Cout + 64 * MT - 1) / (64 * MT);
     const long M = (long)N * OH * OW;
-    const int tiles = co_tiles * KH * KW * p.ci_tiles;
+    const int tiles = co_tiles * (pack ? 1 : KH * KW) * p.ci_tiles;
     long splits = (768 + tiles - 1) / tiles;              // ~768 blocks: 3 resident per CU on 256 CUs
     const long max_splits = (M + 2047) / 2048;            // >= 2048 pixels (32 k-steps) per block
     if (splits > max_splits) splits = max_splits;
@@ -399,7 +435,7 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
     if (splits > 65535) splits = 65535;
     p.m_per_split = ((M + splits - 1) / splits + WBK - 1) / WBK * WBK;
     const long gz = (M + p.m_per_split - 1) / p.m_per_split;
-    const dim3 grid(co_tiles, KH * KW * p.ci_tiles, (unsigned)gz);
+    const dim3 grid(co_tiles, (pack ? 1 : KH * KW) * p.ci_tiles, (unsigned)gz);
     const size_t lds = 4 * (size_t)WTILE;
     static bool attr_done = false;
     if (!attr_done) {
@@ -407,10 +443,14 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<1, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (MT == 1 && NT == 1) hipLaunchKernelGGL((conv_wgrad<1, 1>), grid, dim3(256), lds, st, p);
+    if (pack && MT == 1) hipLaunchKernelGGL((conv_wgrad<1, 2, true>), grid, dim3(256), lds, st, p);
+    else if (pack) hipLaunchKernelGGL((conv_wgrad<2, 2, true>), grid, dim3(256), lds, st, p);
+    else if (MT == 1 && NT == 1) hipLaunchKernelGGL((conv_wgrad<1, 1>), grid, dim3(256), lds, st, p);
     else if (MT == 1) hipLaunchKernelGGL((conv_wgrad<1, 2>), grid, dim3(256), lds, st, p);
     else if (NT == 1) hipLaunchKernelGGL((conv_wgrad<2, 1>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((conv_wgrad<2, 2>), grid, dim3(256), lds, st, p);

@@ -1,0 +1,62 @@
+// prep.hip -- network input assembly: uint8 frames -> normalised, channel-padded NHWC bf16.
+//
+// Replaces mgnet/modeling/mg_net.py:250-264: `x.float()/255`, `(x - pixel_mean)/pixel_std` for image / image_prev /
+// image_next and the channel concatenation fed to PoseCNN -- ~12 elementwise torch kernels and three fp32 copies of every
+// frame in the reference.  One pass: reads 3 bytes per frame and pixel, writes one 16- or 32-byte NHWC pixel whose padding
+// channels are zero (the layout the packed-tap stem convolution consumes).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mgnet_hip.h"
+
+namespace {
+
+struct PrepParams {
+    const uint8_t* frames[3];  // each [B, 3, H, W] uint8
+    float scale[3], shift[3];  // y = u8 * scale[c] + shift[c]  ( = (u8/255 - mean_c) / std_c )
+    int nf, B, H, W, Cp;
+    uint16_t* out;             // [B, H, W, Cp] bf16
+};
+
+__device__ __forceinline__ uint32_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
+    const long hw = (long)p.H * p.W;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)p.B * hw) return;
+    const long b = i / hw, px = i - b * hw;
+    uint32_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = 0;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        if (f >= p.nf) break;
+        const uint8_t* src = p.frames[f] + (b * 3) * hw + px;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[f * 3 + c] = f2bf((float)src[c * hw] * p.scale[c] + p.shift[c]);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(p.out + i * p.Cp);
+    dst[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    if (p.Cp == 16) dst[1] = make_uint4(v[8] | (v[9] << 16), v[10] | (v[11] << 16), v[12] | (v[13] << 16), v[14] | (v[15] << 16));
+}
+
+}  // namespace
+
+extern "C" int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
+                              const float* pixel_std3, void* out_bf16, int Cp, void* stream) {
+    if (!frames_u8 || n_frames < 1 || n_frames > 3 || B < 1 || H < 1 || W < 1 || !pixel_mean3 || !pixel_std3 || !out_bf16) return MGN_EINVAL;
+    if ((Cp != 8 && Cp != 16) || n_frames * 3 > Cp) return MGN_EINVAL;
+    PrepParams p;
+    for (int f = 0; f < 3; ++f) p.frames[f] = f < n_frames ? (const uint8_t*)frames_u8[f] : nullptr;
+    for (int c = 0; c < 3; ++c) {  // pixel_mean / pixel_std are in the 0..1 domain (mg_net.py:86-91: cfg value / 255)
+        p.scale[c] = 1.0f / (255.0f * pixel_std3[c]);
+        p.shift[c] = -pixel_mean3[c] / pixel_std3[c];
+    }
+    p.nf = n_frames; p.B = B; p.H = H; p.W = W; p.Cp = Cp; p.out = (uint16_t*)out_bf16;
+    const long n = (long)B * H * W;
+    hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}

@@ -86,11 +86,21 @@ class MGNet(nn.Module):
 
     def forward(self, batched_inputs):
         inputs, outputs, targets = {}, {}, {}
-        inputs["image"] = self._net_input(batched_inputs, "image")
-        if self.training and self.with_depth:
-            inputs["image_prev"] = self._net_input(batched_inputs, "image_prev")
-            inputs["image_next"] = self._net_input(batched_inputs, "image_next")
-            outputs["poses"] = self.pose_net(torch.cat(list(inputs.values()), 1))  # mg_net.py:264
+        fused_prep = self.pixel_mean.is_cuda and self.amp_dtype == torch.bfloat16 and batched_inputs[0]["image"].dtype == torch.uint8
+        if fused_prep:  # [HIP] uint8 frames -> normalised, channel-padded NHWC bf16 in one pass (csrc/prep.hip)
+            from .. import _C
+            mean, std = self.pixel_mean.flatten().tolist(), self.pixel_std.flatten().tolist()
+            frames = [self._stack(batched_inputs, "image")]
+            inputs["image"] = _C.prep_input(frames, mean, std, 8)
+            if self.training and self.with_depth:
+                frames += [self._stack(batched_inputs, "image_prev"), self._stack(batched_inputs, "image_next")]
+                outputs["poses"] = self.pose_net(_C.prep_input(frames, mean, std, 16))  # channels: image, prev, next (:264)
+        else:
+            inputs["image"] = self._net_input(batched_inputs, "image")
+            if self.training and self.with_depth:
+                inputs["image_prev"] = self._net_input(batched_inputs, "image_prev")
+                inputs["image_next"] = self._net_input(batched_inputs, "image_next")
+                outputs["poses"] = self.pose_net(torch.cat(list(inputs.values()), 1))  # mg_net.py:264
 
         if self.msc_flip_eval and not self.training:
             raise NotImplementedError("multi-scale flip inference (mg_net.py:427-520) is outside the training hot path")

@@ -135,13 +135,21 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, pad, relu):
         from .. import _C
 
-        N, Cin, IH, IW = x.shape
+        N, Cin, IH, IW = x.shape   # Cin of the ACTIVATION (8/16 = channel-padded stem input)
         Cout, _, KH, KW = weight.shape
         OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
         xs = x.contiguous(memory_format=torch.channels_last)
-        w = weight.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
         b = None if bias is None else bias.detach().float().contiguous()
-        out = _C.conv_igemm(xs, w, (OH, OW), b, stride, pad, 1, relu)
+        packed = Cin in (8, 16)
+        if packed:  # stem on a channel-padded input: k = tap*Cin + c, row padded to a multiple of 32
+            wp = weight.new_zeros((Cout, KH, KW, Cin))
+            wp[..., :weight.shape[1]] = weight.detach().permute(0, 2, 3, 1)
+            kpad = (KH * KW * Cin + 31) // 32 * 32
+            w = torch.nn.functional.pad(wp.reshape(Cout, -1), (0, kpad - KH * KW * Cin)).to(torch.bfloat16).contiguous()
+            out = _C.conv_igemm(xs, w, (OH, OW), b, stride, pad, 1, relu, khw=(KH, KW))
+        else:
+            w = weight.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+            out = _C.conv_igemm(xs, w, (OH, OW), b, stride, pad, 1, relu)
         ctx.save_for_backward(xs, weight, out if relu else None)
         ctx.cfg = (stride, pad, relu, bias is not None)
         return out
@@ -153,16 +161,18 @@ class _ConvFn(torch.autograd.Function):
         xs, weight, out = ctx.saved_tensors
         stride, pad, relu, has_bias = ctx.cfg
         Cout, Cin, KH, KW = weight.shape
+        Cx = xs.shape[1]
         dy = dy.to(torch.bfloat16)
         if relu:
             dy = dy * (out > 0)
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
+            assert Cx == Cin, "no data gradient for the channel-padded stem input"
             wt = weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)  # [Cin][KH][KW][Cout]
             dx = _C.conv_igemm(dy, wt, xs.shape[2:], None, 1, KH - 1 - pad, up=stride)
         if ctx.needs_input_grad[1]:
-            dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad).permute(0, 3, 1, 2).to(weight.dtype)
+            dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad)[..., :Cin].permute(0, 3, 1, 2).to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum((0, 2, 3))
         return dx, dw, db, None, None, None

@@ -65,3 +65,47 @@ def test_mfma_fragment_layout_is_not_transposed():
     y = _C.conv_igemm(x, w.to(torch.bfloat16).contiguous(), (1, 40), None, 1, 0, out_dtype=torch.float32)
     ref = torch.stack([w[:, 0, 0, m % Cin] for m in range(40)], 1)  # [Cout, 40]
     assert torch.equal(y[0, :, 0, :], ref)
+
+
+@pytest.mark.parametrize("cfg", [(2, 3, 8, 64, 40, 56), (1, 9, 16, 64, 33, 47), (2, 3, 8, 128, 32, 32)])
+def test_stem_7x7_packed_taps(cfg):
+    """7x7 stride-2 stems on the channel-padded input of csrc/prep.hip (3 -> 8, 9 -> 16 channels): forward + wgrad."""
+    from mgnet_amd.modeling import ops
+
+    N, Creal, Cp, Cout, H, W = cfg
+    torch.manual_seed(N + Creal + H)
+    x0 = torch.zeros(N, Cp, H, W)
+    x0[:, :Creal] = torch.randn(N, Creal, H, W)
+    x0 = x0.to(torch.bfloat16)
+    w0 = torch.randn(Cout, Creal, 7, 7) / (Creal * 49) ** 0.5
+    w_r = w0.to(torch.bfloat16).double().requires_grad_(True)
+    y_r = F.conv2d(x0[:, :Creal].double(), w_r, None, stride=2, padding=3)
+    g0 = torch.randn(*y_r.shape).to(torch.bfloat16)
+    (y_r * g0.double()).sum().backward()
+    x = x0.cuda().contiguous(memory_format=torch.channels_last)
+    w = w0.cuda().requires_grad_(True)
+    y = ops.conv2d(x, w, None, stride=2, padding=3)
+    (y.float() * g0.cuda().float()).sum().backward()
+
+    def rel(a, r):
+        return float((a.float().cpu().double() - r).abs().max() / (r.abs().max() + 1e-12))
+    assert y.shape == y_r.shape
+    assert rel(y, y_r.detach()) < 1e-2, rel(y, y_r.detach())
+    assert rel(w.grad, w_r.grad) < 2e-3, rel(w.grad, w_r.grad)
+
+
+def test_prep_input_matches_reference_normalisation():
+    """mg_net.py:250-264: x/255, (x-mean)/std, cat(image, prev, next) -- against torch ops."""
+    from mgnet_amd import _C
+
+    g = torch.Generator().manual_seed(0)
+    frames = [torch.randint(0, 256, (2, 3, 24, 40), generator=g, dtype=torch.uint8) for _ in range(3)]
+    mean = [123.675 / 255, 116.28 / 255, 103.53 / 255]
+    std = [58.395 / 255, 57.12 / 255, 57.375 / 255]
+    ref = torch.cat([(f.float() / 255 - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1) for f in frames], 1)
+    out16 = _C.prep_input([f.cuda() for f in frames], mean, std, 16)
+    assert out16.shape == (2, 16, 24, 40) and out16.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(out16[:, :9].float().cpu(), ref, atol=2e-2, rtol=1e-2)          # bf16 rounding
+    assert float(out16[:, 9:].abs().max()) == 0.0
+    out8 = _C.prep_input([frames[0].cuda()], mean, std, 8)
+    assert torch.equal(out8[:, :3], out16[:, :3]) and float(out8[:, 3:].abs().max()) == 0.0
