@@ -119,6 +119,7 @@ int mgn_iabn_apply(const void* x, void* y /*may alias x*/, int dtype, long M, in
                    const float* offset, int activation, float slope, void* stream);
 int mgn_iabn_bwd_reduce(const void* y, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
                         float eps, int activation, float slope, float* sums /*[2][C]*/,
+                        float* dwb /*nullable [2][C]: d_weight, d_bias of this rank*/,
                         void* workspace, size_t workspace_bytes, void* stream);
 int mgn_iabn_bwd_apply(const void* y, const void* dy, void* dx /*may alias dy*/, int dtype, long M, int C,
                        const float* weight, const float* bias, const float* saved, const float* sums,
@@ -150,13 +151,19 @@ int mgn_adam_step(float* p, const float* g, float* m, float* v, long n, const fl
  *   t(o,k) = o*stride + k - pad, and when up > 1 the tap only contributes where t is divisible by `up` (then t /= up):
  *   with (w flipped+transposed, stride=1, pad=K-1-pad, up=forward stride) this is the data gradient.
  *   Cin must be a multiple of 32 (MGN_ENOTSUP otherwise: the 3/9-channel 7x7 stems).
- * mgn_conv_wgrad: dw[co,kh,kw,ci] += sum_{n,oh,ow} dout[n,oh,ow,co] * in[n, oh*stride+kh-pad, ow*stride+kw-pad, ci]
- *   (fp32 atomics: zero dw first; Cin, Cout multiples of 8)
+ * mgn_conv_wgrad: dw[co,kh,kw,ci] = sum_{n,oh,ow} dout[n,oh,ow,co] * in[n, oh*stride+kh-pad, ow*stride+kw-pad, ci]
+ *   (pixels are split over blocks; per-split partial tiles go to the workspace with plain stores and a second kernel
+ *    sums them in a fixed order -- deterministic, no atomics; Cin, Cout multiples of 8)
  * ---------------------------------------------------------------------------------------------- */
 int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH,
                    int OW, int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, void* stream);
 int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout,
-                   int KH, int KW, int stride, int pad, void* stream);
+                   int KH, int KW, int stride, int pad, int oihw_cin /* >0: dw is [Cout][oihw_cin][KH][KW] */,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, size_t* bytes);
+/* fp32 OIHW master weights -> bf16 kernel layout. mode 0: [Cout][KH][KW][Cin]; 1: [Cin][KH][KW][Cout] with flipped taps
+ * (data gradient); 2: packed-tap stem layout [Cout][ceil(KH*KW*Cp/32)*32] for a Cp-channel (8|16) padded input */
+int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Panoptic-head losses fused with the bilinear (align_corners=True) upsampling of the low-resolution head outputs

@@ -15,7 +15,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input"]
 
 
@@ -53,13 +53,15 @@ def lib():
         L.mgn_iabn_combine.argtypes = [vp, ci, ci, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp]
         L.mgn_iabn_eval_coeffs.argtypes = [ci, vp, vp, vp, vp, cf, vp, vp, vp]
         L.mgn_iabn_apply.argtypes = [vp, vp, ci, cl, ci, vp, vp, ci, cf, vp]
-        L.mgn_iabn_bwd_reduce.argtypes = [vp, vp, ci, cl, ci, vp, vp, cf, ci, cf, vp, vp, sz, vp]
+        L.mgn_iabn_bwd_reduce.argtypes = [vp, vp, ci, cl, ci, vp, vp, cf, ci, cf, vp, vp, vp, sz, vp]
         L.mgn_iabn_bwd_apply.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, cf, ci, cf, vp]
         L.mgn_sqnorm.argtypes = [vp, cl, vp, ci, ctypes.POINTER(ci), vp]
         L.mgn_clip_coef.argtypes = [vp, ci, cf, cf, vp, vp]
         L.mgn_adam_step.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, ci, vp, cf, vp]
         L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp]
-        L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 11 + [vp]
+        L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
+        L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
+        L.mgn_weight_layout.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.mgn_upce_partials.argtypes = [ci, ci, ci]
         L.mgn_upce_fwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp, vp]
         L.mgn_upce_bwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
@@ -206,12 +208,12 @@ def iabn_apply(x, y, M, C, scale, offset, activation, slope):
 
 
 def iabn_bwd_reduce(y, dy, M, C, weight, bias, eps, activation, slope):
-    sums = torch.empty((2, C), dtype=torch.float32, device=y.device)
+    out = torch.empty((4, C), dtype=torch.float32, device=y.device)  # sums[2], d_weight, d_bias
     ws = _iabn_ws(y.device)
     check(lib().mgn_iabn_bwd_reduce(y.data_ptr(), dy.data_ptr(), _act_dtype(y), M, C, weight.data_ptr(), bias.data_ptr(),
-                                    eps, activation, slope, sums.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()),
-          "mgn_iabn_bwd_reduce")
-    return sums
+                                    eps, activation, slope, out.data_ptr(), out[2].data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                    _stream()), "mgn_iabn_bwd_reduce")
+    return out[:2], out[2], out[3]
 
 
 def iabn_bwd_apply(y, dy, dx, M, C, weight, bias, saved, sums, total_count, eps, activation, slope):
@@ -281,14 +283,34 @@ def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dt
     return out
 
 
-def conv_wgrad(dy, x, kh, kw, stride, pad):
-    """dy [N,Cout,OH,OW], x [N,Cin,IH,IW] (channels_last bf16) -> dw [Cout,KH,KW,Cin] fp32"""
+def conv_wgrad(dy, x, kh, kw, stride, pad, cin_real=None):
+    """dy [N,Cout,OH,OW], x [N,Cin,IH,IW] (channels_last bf16) -> dw fp32 in the torch parameter layout
+    [Cout, cin_real, KH, KW] (cin_real < Cin for the channel-padded stem inputs)"""
     N, Cout, OH, OW = dy.shape
     _, Cin, IH, IW = x.shape
-    dw = torch.zeros((Cout, kh, kw, Cin), dtype=torch.float32, device=x.device)
+    cin_real = Cin if cin_real is None else cin_real
+    dw = torch.empty((Cout, cin_real, kh, kw), dtype=torch.float32, device=x.device)
+    nb = ctypes.c_size_t(0)
+    check(lib().mgn_conv_wgrad_workspace_bytes(N, OH, OW, Cin, Cout, kh, kw, ctypes.byref(nb)), "mgn_conv_wgrad_workspace_bytes")
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device)
     check(lib().mgn_conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, IH, IW, Cin, OH, OW, Cout, kh, kw, stride, pad,
-                               _stream()), "mgn_conv_wgrad")
+                               cin_real, ws.data_ptr(), nb.value, _stream()), "mgn_conv_wgrad")
     return dw
+
+
+def weight_layout(w, mode, Cp=0):
+    """fp32 OIHW parameter -> bf16 kernel layout (0: OHWI, 1: flipped IHWO for the data gradient, 2: packed stem)"""
+    Cout, Cin, KH, KW = w.shape
+    if mode == 0:
+        out = torch.empty((Cout, KH, KW, Cin), dtype=torch.bfloat16, device=w.device)
+    elif mode == 1:
+        out = torch.empty((Cin, KH, KW, Cout), dtype=torch.bfloat16, device=w.device)
+    else:
+        out = torch.empty((Cout, (KH * KW * Cp + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
+    wc = w.detach()
+    wc = wc if (wc.dtype == torch.float32 and wc.is_contiguous()) else wc.float().contiguous()
+    check(lib().mgn_weight_layout(wc.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, mode, Cp, _stream()), "mgn_weight_layout")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -243,6 +243,8 @@ struct WgradParams {
     int N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
     int ci_tiles;          // ceil(Cin / (64*NT))
     long m_per_split;      // pixels per blockIdx.z (multiple of 64)
+    int oihw, cin_real;    // final layout of dw: [Cout][cin_real][KH][KW] (torch parameter layout) or [Cout][KH][KW][Cin]
+    float* partial;        // [gridDim.z][Cout][taps*Cin] per-split partial results (plain stores, no atomics)
 };
 
 constexpr int WBK = 64;            // pixels per k-step
@@ -373,15 +375,69 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
             for (int e = 0; e < 16; ++e) {
                 const int co = bco * 64 * MT + wm * 32 * MT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
-                if (PACK) atomicAdd(p.dw + (size_t)co * ncols + ci, acc[i][j][e]);
-                else atomicAdd(p.dw + (((size_t)co * p.KH + tap_blk / p.KW) * p.KW + tap_blk % p.KW) * p.Cin + ci, acc[i][j][e]);
+                // per-split partial tile in [Cout][tap][Cin] order: coalesced plain stores; conv_wgrad_reduce sums the splits
+                const size_t wsize = (size_t)p.Cout * p.KH * p.KW * p.Cin;
+                const size_t idx = PACK ? (size_t)co * ncols + ci : (((size_t)co * p.KH * p.KW + tap_blk) * p.Cin + ci);
+                p.partial[(size_t)blockIdx.z * wsize + idx] = acc[i][j][e];
             }
     }
+}
+
+// dw = sum over the pixel splits (fixed order: deterministic), written in the requested layout
+__global__ void conv_wgrad_reduce(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw, int cin_real,
+                                  float* __restrict__ dw) {
+    const long wsize = (long)Cout * taps * Cin;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= wsize) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partial[(long)z * wsize + i];
+    if (!oihw) { dw[i] = s; return; }
+    const int ci = (int)(i % Cin);
+    const int tap = (int)((i / Cin) % taps);
+    const int co = (int)(i / ((long)Cin * taps));
+    if (ci < cin_real) dw[((long)co * cin_real + ci) * taps + tap] = s;
+}
+
+// fp32 OIHW master weights -> bf16 kernel layouts, one launch per conv
+//   mode 0: [Cout][KH][KW][Cin]                      (forward)
+//   mode 1: [Cin][KH][KW][Cout], taps flipped        (data gradient: w'[ci][kh][kw][co] = w[co][ci][KH-1-kh][KW-1-kw])
+//   mode 2: [Cout][Kpad], k = tap*Cp + c, zero padded (packed-tap stems; Cp = padded input channels)
+__global__ void weight_layout_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin, int KH, int KW,
+                                     int mode, int Cp, int Kpad, long n_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    float v = 0.f;
+    if (mode == 0) {
+        const int ci = (int)(i % Cin); long r = i / Cin;
+        const int kw = (int)(r % KW); r /= KW;
+        const int kh = (int)(r % KH); const int co = (int)(r / KH);
+        v = w[(((long)co * Cin + ci) * KH + kh) * KW + kw];
+    } else if (mode == 1) {
+        const int co = (int)(i % Cout); long r = i / Cout;
+        const int kw = (int)(r % KW); r /= KW;
+        const int kh = (int)(r % KH); const int ci = (int)(r / KH);
+        v = w[(((long)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+    } else {
+        const int k = (int)(i % Kpad), co = (int)(i / Kpad);
+        const int tap = k / Cp, c = k - tap * Cp;
+        if (tap < KH * KW && c < Cin) v = w[(((long)co * Cin + c) * KH + tap / KW) * KW + tap % KW];
+    }
+    out[i] = f2bf(v);
 }
 
 }  // namespace
 
 extern "C" {
+
+int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp, void* stream) {
+    if (!w_oihw || !out_bf16 || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || mode < 0 || mode > 2) return MGN_EINVAL;
+    const int Kpad = mode == 2 ? (KH * KW * Cp + 31) / 32 * 32 : 0;
+    if (mode == 2 && (Cp < Cin || (Cp != 8 && Cp != 16))) return MGN_EINVAL;
+    const long n = mode == 2 ? (long)Cout * Kpad : (long)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(weight_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                       (uint16_t*)out_bf16, Cout, Cin, KH, KW, mode, Cp, Kpad, n);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
 
 int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
                    int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, void* stream) {
@@ -414,27 +470,47 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
-                   int KW, int stride, int pad, void* stream) {
-    if (!dout || !in || !dw || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || KH < 1 || KW < 1 || stride < 1) return MGN_EINVAL;
-    if (Cin % 8 != 0 || Cout % 8 != 0) return MGN_ENOTSUP;
-    WgradParams p;
-    p.dout = (const uint16_t*)dout; p.in = (const uint16_t*)in; p.dw = dw;
-    p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
-    const bool pack = (Cin == 8 || Cin == 16);
-    const int ncols = pack ? KH * KW * Cin : Cin;
-    const int NT = ncols <= 64 ? 1 : 2, MT = Cout <= 64 ? 1 : 2;
-    p.ci_tiles = (ncols + 64 * NT - 1) / (64 * NT);
-    const int co_tiles = (Cout + 64 * MT - 1) / (64 * MT);
+static void wgrad_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, bool* pack, int* NT, int* MT, int* ci_tiles,
+                       int* co_tiles, long* m_per_split, long* gz) {
+    *pack = (Cin == 8 || Cin == 16);
+    const int ncols = *pack ? KH * KW * Cin : Cin;
+    *NT = ncols <= 64 ? 1 : 2;
+    *MT = Cout <= 64 ? 1 : 2;
+    *ci_tiles = (ncols + 64 * *NT - 1) / (64 * *NT);
+    *co_tiles = (Cout + 64 * *MT - 1) / (64 * *MT);
     const long M = (long)N * OH * OW;
-    const int tiles = co_tiles * (pack ? 1 : KH * KW) * p.ci_tiles;
+    const int tiles = *co_tiles * (*pack ? 1 : KH * KW) * *ci_tiles;
     long splits = (768 + tiles - 1) / tiles;              // ~768 blocks: 3 resident per CU on 256 CUs
     const long max_splits = (M + 2047) / 2048;            // >= 2048 pixels (32 k-steps) per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
-    p.m_per_split = ((M + splits - 1) / splits + WBK - 1) / WBK * WBK;
-    const long gz = (M + p.m_per_split - 1) / p.m_per_split;
+    *m_per_split = ((M + splits - 1) / splits + WBK - 1) / WBK * WBK;
+    *gz = (M + *m_per_split - 1) / *m_per_split;
+}
+
+int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, size_t* bytes) {
+    if (!bytes || N < 1 || OH < 1 || OW < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1) return MGN_EINVAL;
+    bool pack; int NT, MT, cit, cot; long mps, gz;
+    wgrad_plan(N, OH, OW, Cin, Cout, KH, KW, &pack, &NT, &MT, &cit, &cot, &mps, &gz);
+    *bytes = sizeof(float) * (size_t)gz * Cout * KH * KW * Cin;
+    return MGN_OK;
+}
+
+int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
+                   int KW, int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dout || !in || !dw || !workspace || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || KH < 1 || KW < 1 || stride < 1) return MGN_EINVAL;
+    if (Cin % 8 != 0 || Cout % 8 != 0) return MGN_ENOTSUP;
+    WgradParams p;
+    p.dout = (const uint16_t*)dout; p.in = (const uint16_t*)in; p.dw = dw;
+    p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.oihw = oihw_cin > 0; p.cin_real = oihw_cin > 0 ? oihw_cin : Cin;
+    if (oihw_cin > Cin) return MGN_EINVAL;
+    bool pack; int NT, MT, co_tiles; long gz;
+    wgrad_plan(N, OH, OW, Cin, Cout, KH, KW, &pack, &NT, &MT, &p.ci_tiles, &co_tiles, &p.m_per_split, &gz);
+    const size_t wsize = (size_t)Cout * KH * KW * Cin;
+    if (workspace_bytes < sizeof(float) * gz * wsize) return MGN_ENOSPC;
+    p.partial = (float*)workspace;
     const dim3 grid(co_tiles, (pack ? 1 : KH * KW) * p.ci_tiles, (unsigned)gz);
     const size_t lds = 4 * (size_t)WTILE;
     static bool attr_done = false;
@@ -454,6 +530,8 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
     else if (MT == 1) hipLaunchKernelGGL((conv_wgrad<1, 2>), grid, dim3(256), lds, st, p);
     else if (NT == 1) hipLaunchKernelGGL((conv_wgrad<2, 1>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((conv_wgrad<2, 2>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((wsize + 255) / 256)), dim3(256), 0, st, (const float*)workspace, (int)gz, Cout,
+                       KH * KW, Cin, p.oihw, p.cin_real, dw);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

@@ -233,13 +233,18 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_partial(const T* __restrict__ y,
     });
 }
 
-__global__ void iabn_bwd_final(const float* partials, int nblk, int C, float* sums) {
+__global__ void iabn_bwd_final(const float* partials, int nblk, int C, const float* weight, float* sums, float* dwb) {
     const int c = blockIdx.x * 32 + threadIdx.x;
     float s1, s2;
     reduce_partials(partials, nblk, C, c, threadIdx.y, s1, s2);
     if (c >= C || threadIdx.y != 0) return;
     sums[c] = s1;
     sums[C + c] = s2;
+    if (dwb) {  // local parameter gradients: d bias = sum dz ; d weight = sign(weight) * sum dz*x_hat  (gamma' = |weight| + eps)
+        const float w = weight[c];
+        dwb[c] = s2 * (float)((w > 0.f) - (w < 0.f));
+        dwb[C + c] = s1;
+    }
 }
 
 // backward pass 2: dx = gamma' * rstd * (dz - sum_dz/n - x_hat * sum_dzxh/n)     (sums are GLOBAL over ranks, n too)
@@ -352,7 +357,7 @@ int mgn_iabn_apply(const void* x, void* y, int dtype, long M, int C, const float
 }
 
 int mgn_iabn_bwd_reduce(const void* y, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
-                        float eps, int activation, float slope, float* sums, void* ws, size_t ws_bytes, void* stream_) {
+                        float eps, int activation, float slope, float* sums, float* dwb, void* ws, size_t ws_bytes, void* stream_) {
     int rc = check_shape(M, C, dtype);
     if (rc != MGN_OK) return rc;
     if (!y || !dy || !weight || !bias || !sums || !ws) return MGN_EINVAL;
@@ -365,7 +370,7 @@ int mgn_iabn_bwd_reduce(const void* y, const void* dy, int dtype, long M, int C,
     else
         hipLaunchKernelGGL(iabn_bwd_partial<float>, dim3(nb), dim3(TPB), 0, s, (const float*)y, (const float*)dy, M, C, weight, bias,
                            eps, activation, slope, (float*)ws);
-    hipLaunchKernelGGL(iabn_bwd_final, dim3((C + 31) / 32), dim3(32, 8), 0, s, (const float*)ws, nb, C, sums);
+    hipLaunchKernelGGL(iabn_bwd_final, dim3((C + 31) / 32), dim3(32, 8), 0, s, (const float*)ws, nb, C, weight, sums, dwb);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

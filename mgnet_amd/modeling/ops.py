@@ -83,9 +83,7 @@ class _IABNFn(torch.autograd.Function):
         dx = torch.empty_like(y)
         if not training:  # eval: plain affine + activation
             raise NotImplementedError("backward through eval-mode InPlaceABNSync is not on the training path")
-        sums = _C.iabn_bwd_reduce(y, dy, M, C, w32, b32, eps, act, slope)
-        d_bias = sums[0].clone()
-        d_weight = sums[1] * torch.sign(w32)
+        sums, d_weight, d_bias = _C.iabn_bwd_reduce(y, dy, M, C, w32, b32, eps, act, slope)
         if world > 1:
             dist.all_reduce(sums, group=group)
         _C.iabn_bwd_apply(y, dy, dx, M, C, w32, b32, coef[2:], sums, total, eps, act, slope)
@@ -142,14 +140,9 @@ class _ConvFn(torch.autograd.Function):
         b = None if bias is None else bias.detach().float().contiguous()
         packed = Cin in (8, 16)
         if packed:  # stem on a channel-padded input: k = tap*Cin + c, row padded to a multiple of 32
-            wp = weight.new_zeros((Cout, KH, KW, Cin))
-            wp[..., :weight.shape[1]] = weight.detach().permute(0, 2, 3, 1)
-            kpad = (KH * KW * Cin + 31) // 32 * 32
-            w = torch.nn.functional.pad(wp.reshape(Cout, -1), (0, kpad - KH * KW * Cin)).to(torch.bfloat16).contiguous()
-            out = _C.conv_igemm(xs, w, (OH, OW), b, stride, pad, 1, relu, khw=(KH, KW))
+            out = _C.conv_igemm(xs, _C.weight_layout(weight, 2, Cin), (OH, OW), b, stride, pad, 1, relu, khw=(KH, KW))
         else:
-            w = weight.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
-            out = _C.conv_igemm(xs, w, (OH, OW), b, stride, pad, 1, relu)
+            out = _C.conv_igemm(xs, _C.weight_layout(weight, 0), (OH, OW), b, stride, pad, 1, relu)
         ctx.save_for_backward(xs, weight, out if relu else None)
         ctx.cfg = (stride, pad, relu, bias is not None)
         return out
@@ -169,10 +162,9 @@ class _ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             assert Cx == Cin, "no data gradient for the channel-padded stem input"
-            wt = weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)  # [Cin][KH][KW][Cout]
-            dx = _C.conv_igemm(dy, wt, xs.shape[2:], None, 1, KH - 1 - pad, up=stride)
+            dx = _C.conv_igemm(dy, _C.weight_layout(weight, 1), xs.shape[2:], None, 1, KH - 1 - pad, up=stride)
         if ctx.needs_input_grad[1]:
-            dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad)[..., :Cin].permute(0, 3, 1, 2).to(weight.dtype)
+            dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad, cin_real=Cin)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum((0, 2, 3))
         return dx, dw, db, None, None, None

@@ -38,7 +38,7 @@ for name, Cin, Cout, H, W, k, s in SHAPES:
     gf = 2.0 * B * OH * OW * Cout * Cin * k * k / 1e9
     t_f = timeit(lambda: _C.conv_igemm(x, wo, (OH, OW), None, s, p))
     t_d = timeit(lambda: _C.conv_igemm(dy, wt, (H, W), None, 1, k - 1 - p, up=s))
-    t_w = timeit(lambda: _C.conv_wgrad(dy, x, k, k, s, p))
+    t_w = timeit(lambda: _C.conv_wgrad(dy, x, k, k, s, p))  # incl. zero-init of dw
     wb = w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     xr = x.detach().requires_grad_(True); wr = wb.detach().requires_grad_(True)
     t_tf = timeit(lambda: F.conv2d(x, wb, None, s, p))
