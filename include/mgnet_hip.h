@@ -178,6 +178,10 @@ int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, in
  * Low-res maps: bf16 (logits/offset) with channel stride 1 and element strides (sb, sh, sw) multiples of 8.
  * ---------------------------------------------------------------------------------------------- */
 int mgn_upce_partials(int B, int H, int W);
+/* single-channel fp32 bilinear (align_corners=True) upsampling [B,1,h,w] -> [B,1,H,W] and its adjoint (dlr zero-initialised);
+ * replaces F.interpolate at mg_net.py:804-807 (depth head, x8/x16/x32). The adjoint needs an upsampling factor >= 7. */
+int mgn_upsample1_fwd(const float* lr, int B, int h, int w, int H, int W, float* out, void* stream);
+int mgn_upsample1_bwd(const float* dfull, int B, int h, int w, int H, int W, float* dlr_zeroed, void* stream);
 int mgn_upce_fwd(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K,
                  const long* labels, const float* weights, int ignore, float thr, float* ce_map, float* partials,
                  float* sums3, void* stream);

@@ -16,7 +16,8 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
            "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout",
-           "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input"]
+           "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
+           "mgn_upsample1_fwd", "mgn_upsample1_bwd"]
 
 
 class ReprojCfg(ctypes.Structure):
@@ -67,6 +68,8 @@ def lib():
         L.mgn_upce_bwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
         L.mgn_ins_loss_fwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp]
         L.mgn_ins_loss_bwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
+        L.mgn_upsample1_fwd.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
+        L.mgn_upsample1_bwd.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
@@ -369,3 +372,17 @@ def ins_loss_bwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale, out4, gout2
                                  ot.data_ptr(), ow.data_ptr(), oscale, out4.data_ptr(), gout2.data_ptr(), dco.data_ptr(), _stream()),
           "mgn_ins_loss_bwd")
     return dco
+
+
+def upsample1_fwd(lr, H, W):
+    B, _, h, w = lr.shape
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=lr.device)
+    check(lib().mgn_upsample1_fwd(lr.data_ptr(), B, h, w, H, W, out.data_ptr(), _stream()), "mgn_upsample1_fwd")
+    return out
+
+
+def upsample1_bwd(dfull, h, w):
+    B, _, H, W = dfull.shape
+    dlr = torch.zeros((B, 1, h, w), dtype=torch.float32, device=dfull.device)
+    check(lib().mgn_upsample1_bwd(dfull.data_ptr(), B, h, w, H, W, dlr.data_ptr(), _stream()), "mgn_upsample1_bwd")
+    return dlr

@@ -336,6 +336,28 @@ inline bool footprint_ok(int h, int w, int H, int W) {
     return (TX - 1) * rx + 3 <= MAXC && (TY - 1) * ry + 3 <= MAXR;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// plain bilinear (align_corners=True) upsampling of single-channel fp32 maps and its adjoint (depth head,
+// mg_net.py:804-807: x8 / x16 / x32 of the three inverse-depth predictions)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void up1_fwd(const float* __restrict__ lr, UpGeom g, float* __restrict__ out) {
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (X >= g.W || Y >= g.H) return;
+    const Corner c = corners(g, b, Y, X);
+    out[((long)b * g.H + Y) * g.W + X] = interp1f(lr, c);
+}
+
+__global__ __launch_bounds__(TPB) void up1_bwd(const float* __restrict__ dfull, UpGeom g, float* dlr) {
+    __shared__ float res[TY * TX + TY * MAXC];
+    const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY, b = blockIdx.z;
+    for (int t = threadIdx.x; t < TX * TY; t += TPB) {
+        const int X = X0 + (t % TX), Y = Y0 + (t / TX);
+        res[t] = (X < g.W && Y < g.H) ? dfull[((long)b * g.H + Y) * g.W + X] : 0.f;
+    }
+    __syncthreads();
+    scatter_tile<1>(g, b, X0, Y0, 1, res, res + TX * TY, dlr, 1);
+}
+
 inline int geom_ok(int B, int h, int w, int H, int W) { return B >= 1 && h >= 2 && w >= 2 && H >= h && W >= w; }
 
 inline UpGeom make_geom(int B, int h, int w, int H, int W, long sb, long sh, long sw) {
@@ -418,6 +440,21 @@ int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const
     m.ct = ct; m.cw = cw; m.ot = ot; m.ow = ow; m.oscale = oscale;
     const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
     hipLaunchKernelGGL(ins_bwd, grid, dim3(TPB), 0, (hipStream_t)stream, m, out4, gout2, dco);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_upsample1_fwd(const float* lr, int B, int h, int w, int H, int W, float* out, void* stream) {
+    if (!lr || !out || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
+    const UpGeom g = make_geom(B, h, w, H, W, (long)h * w, w, 1);
+    hipLaunchKernelGGL(up1_fwd, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(TPB), 0, (hipStream_t)stream, lr, g, out);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_upsample1_bwd(const float* dfull, int B, int h, int w, int H, int W, float* dlr_zeroed, void* stream) {
+    if (!dfull || !dlr_zeroed || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
+    if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
+    const UpGeom g = make_geom(B, h, w, H, W, (long)h * w, w, 1);
+    hipLaunchKernelGGL(up1_bwd, dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B), dim3(TPB), 0, (hipStream_t)stream, dfull, g, dlr_zeroed);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

@@ -207,8 +207,27 @@ def upsample_nearest(x, size):
     return F.interpolate(x, size=tuple(size), mode="nearest")
 
 
+class _Up1Fn(torch.autograd.Function):
+    """[HIP] single-channel fp32 bilinear upsampling (depth head) and its separable adjoint (csrc/headloss.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        from .. import _C
+        ctx.hw = x.shape[2:]
+        return _C.upsample1_fwd(x.contiguous(), x.shape[2] * scale, x.shape[3] * scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+        return _C.upsample1_bwd(g.float().contiguous(), *ctx.hw), None
+
+
 def upsample_bilinear(x, scale_factor):
-    """[torch-staging] F.interpolate(bilinear, align_corners=True) (mg_net.py:599, :678-687, :804-806)"""
+    """F.interpolate(bilinear, align_corners=True) (mg_net.py:599, :678-687, :804-806).
+    Single-channel fp32 CUDA maps with factor >= 8 (the depth head): [HIP]; everything else: [torch-staging]."""
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[1] == 1 and int(scale_factor) == scale_factor and scale_factor >= 8 \
+            and x.shape[2] >= 2 and x.shape[3] >= 2:
+        return _Up1Fn.apply(x, int(scale_factor))
     return F.interpolate(x.float(), scale_factor=scale_factor, mode="bilinear", align_corners=True)
 
 

@@ -116,3 +116,21 @@ def test_fused_instance_losses(shape):
     z2 = ops.upsampled_ins_losses(ops.LazyUpsample(c2, s), ops.LazyUpsample(offset_lr.detach(), s, mult=float(s)), tg0)
     z2.sum().backward()
     assert float(z2.abs().sum()) == 0.0 and float(c2.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [(2, 6, 10, 8), (1, 5, 7, 16), (2, 3, 4, 32)])
+def test_depth_upsample_fwd_bwd(cfg):
+    from mgnet_amd.modeling import ops
+
+    B, h, w, s = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x0 = torch.rand(B, 1, h, w, generator=g) * 2
+    xr = x0.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=s, mode="bilinear", align_corners=True)
+    gy = torch.randn(*yr.shape, generator=g)
+    (yr * gy).sum().backward()
+    x = x0.cuda().requires_grad_(True)
+    y = ops.upsample_bilinear(x, s)
+    (y * gy.cuda()).sum().backward()
+    assert torch.allclose(y.cpu(), yr, atol=1e-6, rtol=1e-6)
+    assert torch.allclose(x.grad.cpu(), xr.grad, atol=1e-4, rtol=1e-5)
