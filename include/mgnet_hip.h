@@ -206,6 +206,11 @@ int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const
 int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
                    const float* pixel_std3, void* out_bf16, int Cp, void* stream);
 
+/* 3x3 / stride 2 / pad 1 max pooling of the ResNet stems (res_net.py:109) on channels-last bf16 [N,IH,IW,C] (C % 8 == 0);
+ * argmax: 1 byte per output element (winning tap 0..8); backward is a deterministic gather. */
+int mgn_maxpool3x3s2_fwd(const void* x_bf16, void* y_bf16, uint8_t* argmax, int N, int IH, int IW, int C, void* stream);
+int mgn_maxpool3x3s2_bwd(const void* dy_bf16, const uint8_t* argmax, void* dx_bf16, int N, int IH, int IW, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
            "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
-           "mgn_upsample1_fwd", "mgn_upsample1_bwd"]
+           "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd"]
 
 
 class ReprojCfg(ctypes.Structure):
@@ -70,6 +70,8 @@ def lib():
         L.mgn_ins_loss_bwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
         L.mgn_upsample1_fwd.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_upsample1_bwd.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
+        L.mgn_maxpool3x3s2_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
+        L.mgn_maxpool3x3s2_bwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
         L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
@@ -386,3 +388,19 @@ def upsample1_bwd(dfull, h, w):
     dlr = torch.zeros((B, 1, h, w), dtype=torch.float32, device=dfull.device)
     check(lib().mgn_upsample1_bwd(dfull.data_ptr(), B, h, w, H, W, dlr.data_ptr(), _stream()), "mgn_upsample1_bwd")
     return dlr
+
+
+def maxpool_fwd(x):
+    N, C, IH, IW = x.shape
+    OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
+    y = torch.empty((N, C, OH, OW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
+    check(lib().mgn_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), arg.data_ptr(), N, IH, IW, C, _stream()), "mgn_maxpool3x3s2_fwd")
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, in_shape):
+    N, C, IH, IW = in_shape
+    dx = torch.empty((N, C, IH, IW), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    check(lib().mgn_maxpool3x3s2_bwd(dy.data_ptr(), arg.data_ptr(), dx.data_ptr(), N, IH, IW, C, _stream()), "mgn_maxpool3x3s2_bwd")
+    return dx

@@ -192,8 +192,28 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
     return torch.relu_(y) if relu else y
 
 
+class _MaxPoolFn(torch.autograd.Function):
+    """[HIP] csrc/pool.hip"""
+
+    @staticmethod
+    def forward(ctx, x):
+        from .. import _C
+        y, arg = _C.maxpool_fwd(x.contiguous(memory_format=torch.channels_last))
+        ctx.save_for_backward(arg)
+        ctx.in_shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _C
+        (arg,) = ctx.saved_tensors
+        return _C.maxpool_bwd(dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), arg, ctx.in_shape)
+
+
 def max_pool_3x3_s2(x):
-    """[torch-staging] res_net.py:109"""
+    """F.max_pool2d(x, 3, stride 2, padding 1) (res_net.py:109).  bf16 CUDA: [HIP]; otherwise [torch-staging]."""
+    if x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0:
+        return _MaxPoolFn.apply(x)
     return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
 
 
