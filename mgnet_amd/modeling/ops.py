@@ -53,7 +53,7 @@ class _IABNFn(torch.autograd.Function):
             stats = _C.iabn_stats(xs, M, C)
             if world > 1:
                 gathered = torch.empty((world, 3, C), dtype=torch.float32, device=x.device)
-                dist.all_gather_into_tensor(gathered, stats, group=group)
+                dist.all_gather(list(gathered.unbind(0)), stats, group=group)  # (list form: also available on gloo)
             else:
                 gathered = stats.unsqueeze(0)
             coef = _C.iabn_combine(gathered, w32, b32, eps, momentum, running_mean, running_var)
