@@ -61,12 +61,12 @@ __device__ __forceinline__ void mma_tile(const unsigned char* sA, const unsigned
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = wm * 32 * MT + i * 32 + (lane & 31);
-            a[i] = *reinterpret_cast<const bf16x8*>(sA + row * LPITCH + ((SWZ ? (slot ^ swz(row)) : slot) << 4));
+            a[i] = *reinterpret_cast<const bf16x8*>(sA + row * LPITCH + ((SWZ ? (slot ^ (LPITCH == 64 ? ((row >> 2) & 3) : swz(row))) : slot) << 4));
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int row = wn * 32 * NT + j * 32 + (lane & 31);
-            b[j] = *reinterpret_cast<const bf16x8*>(sB + row * LPITCH + ((SWZ ? (slot ^ swz(row)) : slot) << 4));
+            b[j] = *reinterpret_cast<const bf16x8*>(sB + row * LPITCH + ((SWZ ? (slot ^ (LPITCH == 64 ? ((row >> 2) & 3) : swz(row))) : slot) << 4));
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -82,7 +82,7 @@ __device__ __forceinline__ void mma_tile(const unsigned char* sA, const unsigned
 // k-slab; every 16-byte loader segment then belongs to its own tap.  Weights are [Cout][Kpad], Kpad = ksteps*32.
 template <int NT, int KS, bool PACK = false>
 __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
-    constexpr int BN = 64 * NT, BK = 16 * KS, PITCH = BK * 2 + 16, TILE_BYTES = 128 * PITCH;
+    constexpr int BN = 64 * NT, BK = 16 * KS, PITCH = BK * 2, TILE_BYTES = 128 * PITCH;  // XOR-swizzled rows, no padding
     constexpr int SEGS = BK / 8;          // 16-byte segments per row
     constexpr int RPP = 256 / SEGS;       // rows covered per loader pass
     constexpr int NR = 128 / RPP;         // loader passes (rows per thread)
@@ -179,8 +179,10 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            *reinterpret_cast<u32x4*>(&smem[buf][0][(lrow + r * RPP) * PITCH + seg * 16]) = ra[r];
-            if (lrow + r * RPP < BN) *reinterpret_cast<u32x4*>(&smem[buf][1][(lrow + r * RPP) * PITCH + seg * 16]) = rb[r];
+            const int row = lrow + r * RPP;
+            const int sw = (KS == 2 ? (seg ^ ((row >> 2) & 3)) : (seg ^ swz(row))) * 16;
+            *reinterpret_cast<u32x4*>(&smem[buf][0][row * PITCH + sw]) = ra[r];
+            if (row < BN) *reinterpret_cast<u32x4*>(&smem[buf][1][row * PITCH + sw]) = rb[r];
         }
     };
 
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
     for (int ks = 0; ks < ksteps; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < ksteps) load_next();
-        mma_tile<2, NT, KS, PITCH, false, true>(smem[buf][0], smem[buf][1], wm, wn, lane, acc);
+        mma_tile<2, NT, KS, PITCH, true, true>(smem[buf][0], smem[buf][1], wm, wn, lane, acc);
         if (ks + 1 < ksteps) store_tile(buf ^ 1);
         __syncthreads();
     }

@@ -14,9 +14,9 @@ def main(root, filt="reproj"):
             k = r["Kernel_Name"]
             if filt not in k:
                 continue
-            short = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
-            if "march<true>" in k: short = "reproj_march<true>"
-            if "march<false>" in k: short = "reproj_march<false>"
+            import re
+            m = re.search(r"(?:\(anonymous namespace\)::)?(\w+(?:<[^>]*>)?)\(", k.replace("void ", ""))
+            short = m.group(1) if m else k[:60]
             acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in acc.items():
         print(k)
