@@ -236,6 +236,143 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// conv_igemm_glds: same tiling, but the tiles go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds, no VGPR staging)
+// into a ring of three LDS buffers, so the loads of k-step s+2 are in flight while k-step s is on the matrix cores
+// (counted s_waitcnt vmcnt + raw s_barrier; guide: "glds spanning the barrier").  LDS-DMA writes lane-linearly
+// (wave base + lane*16), which is exactly the unpadded [row][64 B] tile; the XOR swizzle is therefore applied to the
+// SOURCE segment each lane fetches.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
+    constexpr int BN = 64 * NT, BK = 32, PITCH = 64, TILE = 128 * PITCH;  // 8 KB per operand tile
+    constexpr int LPT = 2 + NT;  // LDS-DMA instructions per thread and tile (2 A passes + NT B passes)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3][2][TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int bm = blockIdx.x, bn = blockIdx.y;
+    const long M = (long)p.N * p.OH * p.OW;
+    const int lrow = tid >> 2, seg = tid & 3;
+
+    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * p.KH * p.KW * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, w_bytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+
+    int ihb[2], iwb[2], abase[2], wbase[2];
+    bool vm[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = lrow + r * 64;
+        const int sseg = seg ^ ((row >> 2) & 3);  // source segment that lands in LDS slot `seg` of this row
+        const long m = (long)bm * BM + row;
+        vm[r] = m < M;
+        const long mm = vm[r] ? m : 0;
+        const int n = (int)(mm / ((long)p.OH * p.OW));
+        const int rem = (int)(mm - (long)n * p.OH * p.OW);
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        ihb[r] = oh * p.stride - p.pad;
+        iwb[r] = ow * p.stride - p.pad;
+        abase[r] = (n * p.IH * p.IW * p.Cin + sseg * 8) * 2;
+        const int co = bn * BN + row;
+        wbase[r] = (co < p.Cout && row < BN) ? (co * p.KH * p.KW * p.Cin + sseg * 8) * 2 : OOB;
+    }
+    const int cpt = p.Cin / BK;
+    const int ksteps = p.KH * p.KW * cpt;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int kh = 0, kw = 0, cc = 0;
+    int avoff[2], wvoff[2];
+    auto set_tap = [&]() {
+        const int wtap = (kh * p.KW + kw) * p.Cin * 2;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int th = ihb[r] + kh, tw = iwb[r] + kw;
+            bool ok = vm[r];
+            if (p.up > 1) {
+                ok = ok && th >= 0 && tw >= 0 && (th % p.up == 0) && (tw % p.up == 0);
+                th /= p.up;
+                tw /= p.up;
+            }
+            ok = ok && th >= 0 && th < p.IH && tw >= 0 && tw < p.IW;
+            avoff[r] = ok ? abase[r] + (th * p.IW + tw) * p.Cin * 2 : OOB;
+            wvoff[r] = wbase[r] == OOB ? OOB : wbase[r] + wtap;
+        }
+    };
+    set_tap();
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue = [&](int buf) {  // this wave's 1 KB pieces: rows [wave*16, wave*16+16) (+64) of the A and B tiles
+        const int soff = cc * BK * 2;
+        unsigned char* a0 = &smem[buf][0][wave * 1024];
+        unsigned char* b0 = &smem[buf][1][wave * 1024];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)a0, 16, avoff[0], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a0 + 4096), 16, avoff[1], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)b0, 16, wvoff[0], soff, 0, 0);
+        if (NT == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b0 + 4096), 16, wvoff[1], soff, 0, 0);
+        if (++cc == cpt) {
+            cc = 0;
+            if (++kw == p.KW) { kw = 0; ++kh; }
+            set_tap();
+        }
+    };
+
+    issue(0);
+    if (ksteps > 1) issue(1);
+    int buf = 0;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        if (ks + 1 < ksteps) {
+            if (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (ks + 2 < ksteps) issue(buf == 0 ? 2 : buf - 1);  // (ks+2) % 3
+        mma_tile<2, NT, 2, PITCH, true, true>(smem[buf][0], smem[buf][1], wm, wn, lane, acc);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    const bool vec_ok = (p.Cout % 4) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long m = (long)bm * BM + wm * 64 + i * 32 + (lane & 31);
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = bn * BN + wn * 32 * NT + j * 32 + 8 * q + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][q * 4 + e] + ((p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f);
+                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (vec_ok) {
+                    if (p.out_f32)
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * p.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + m * p.Cout + co) =
+                            make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= p.Cout) break;
+                        if (p.out_f32) reinterpret_cast<float*>(p.out)[m * p.Cout + co + e] = v[e];
+                        else reinterpret_cast<uint16_t*>(p.out)[m * p.Cout + co + e] = f2bf(v[e]);
+                    }
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------------
 struct WgradParams {
@@ -460,6 +597,9 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
     if (pack) {
         if (Cout <= 64) hipLaunchKernelGGL((conv_igemm<1, 2, true>), dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm<2, 2, true>), dim3((unsigned)gx, (Cout + 127) / 128), dim3(256), 0, st, p);
+    } else if (!getenv("MGN_CONV_NOGLDS")) {
+        if (Cout <= 64) hipLaunchKernelGGL((conv_igemm_glds<1>), dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_glds<2>), dim3((unsigned)gx, (Cout + 127) / 128), dim3(256), 0, st, p);
     } else if (Cout <= 64) {
         const dim3 grid((unsigned)gx, (Cout + 63) / 64);
         if (k64) hipLaunchKernelGGL((conv_igemm<1, 4>), grid, dim3(256), 0, st, p);
