@@ -460,6 +460,19 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
                 rg[q] = make_uint4(v.x, v.y, v.z, v.w);
             }
+        } else if (pow_ + 8 <= p.OW) {
+            // fast path: the 8 pixels lie in one output row -> one row test, offsets differ by a constant step
+            const int ih = poh * p.stride - p.pad + kh, iw0 = pow_ * p.stride - p.pad + kw;
+            const bool rowok = vc && ih >= 0 && ih < p.IH;
+            const int base = (((pn * p.IH + ih) * p.IW + iw0) * p.Cin + c0) * 2, step = p.stride * p.Cin * 2;
+            const int rem = (int)(m_end - mcur < 8 ? m_end - mcur : 8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int iw = iw0 + q * p.stride;
+                const bool ok = rowok && q < rem && iw >= 0 && iw < p.IW;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? base + q * step : OOB, 0, 0);
+                rg[q] = make_uint4(v.x, v.y, v.z, v.w);
+            }
         } else {
             int n = pn, oh = poh, ow = pow_;
 #pragma unroll
@@ -475,6 +488,8 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
                 oh = wrap ? (wrap2 ? 0 : oh + 1) : oh;
                 n += wrap2 ? 1 : 0;
             }
+        }
+        if (isB) {
             pow_ += WBK;
             while (pow_ >= p.OW) { pow_ -= p.OW; if (++poh == p.OH) { poh = 0; ++pn; } }
         }
