@@ -79,11 +79,30 @@ class HipEvents:
         return out
 
 
-def cpu_baseline(H, W):
-    """The pinned CPU oracle ("port" of the reference path) on a bounded sample: ONE frame of the workload."""
+def cpu_baseline(H, W, state_dict=None, cfg=None):
+    """CPU baseline on a bounded sample (ONE frame of the workload), `kind: "port"`:
+    with a state_dict: the full training step (network forward + five losses + backward) of oracle/network_oracle.py
+    (plain-torch fp32 restatement of the reference network + the pinned C oracle of the reprojection loss);
+    without: only the reprojection loss (used by --loss-only)."""
     import oracle
 
     oracle.build()
+    if state_dict is not None:
+        from mgnet_amd.data import synthetic_batch
+        from oracle import network_oracle as NO
+
+        torch.manual_seed(0)
+        nb = 2  # F.batch_norm refuses a single value per channel (the 1x1-spatial GCM / attention layers need B >= 2)
+        batch = synthetic_batch(nb, H, W, "cpu", seed=99)
+        sd = {k: v.detach().float().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in state_dict.items()}
+        t0 = time.time()
+        losses = NO.mgnet_losses(sd, batch, pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD,
+                                 ohem_n_min=min(cfg.MODEL.SEM_SEG_HEAD.OHEM_N_MIN, H * W // 4 - 1))
+        sum(losses.values()).backward()
+        dt = time.time() - t0
+        return {"value": round(nb / dt, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{nb} frames {H}x{W}: full MGNet training step fwd+bwd (no optimizer), oracle/network_oracle.py "
+                          f"(torch fp32 CPU, {torch.get_num_threads()} threads) + oracle/reproj_oracle.c, {dt:.1f} s"}
     rs = np.random.RandomState(0)
     B = 1
     inv = [rs.uniform(0.05, 1.95, (B, 1, H, W)).astype(np.float32) for _ in range(3)]
@@ -169,7 +188,7 @@ def full_step_bench(args, world, rank, dev):
                          "bytes_per_launch": FWD_BYTES_PER_PX * npx, "avg_launch_ms": round(kern_ms, 4)},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(H, W)
+            line["cpu_baseline"] = cpu_baseline(H, W, model.state_dict(), cfg)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
