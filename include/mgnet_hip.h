@@ -211,6 +211,27 @@ int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int
 int mgn_maxpool3x3s2_fwd(const void* x_bf16, void* y_bf16, uint8_t* argmax, int N, int IH, int IW, int C, void* stream);
 int mgn_maxpool3x3s2_bwd(const void* dy_bf16, const uint8_t* argmax, void* dx_bf16, int N, int IH, int IW, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise / broadcast / pooling glue of the blocks, channels-last bf16 [N, H*W, C], C % 8 == 0
+ *   mgn_add_relu_fwd / mgn_relu_mask_bwd : res_net.py:77-78 (out + shortcut, relu_)
+ *   mgn_colsum                          : out[n,c] = scale * sum_r x[n,r,c] (* x2[n,r,c]); layers.py:170-184 global
+ *                                         average pool (scale = 1/HW) and the d/d attention reduction; deterministic
+ *   mgn_bcast_rows                      : dx[n,r,c] = g[n,c] * scale (adjoint of the pool)
+ *   mgn_scale_channels                  : y = x * s[n,c] (mode 0, layers.py:262-267) | x * (1 + s[n,c]) (mode 1, :315-322)
+ *   mgn_nearest_fwd / _bwd              : F.interpolate(mode="nearest") (layers.py:90, :217) and its adjoint
+ *   mgn_concat2 / mgn_split2            : torch.cat([a, b], dim=1) (layers.py:316) and the split of its gradient
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_add_relu_fwd(const void* a, const void* b, void* y, long n_elems, void* stream);
+int mgn_relu_mask_bwd(const void* dy, const void* y, void* dx, long n_elems, void* stream);
+int mgn_colsum(const void* x, const void* x2 /*nullable*/, int N, long HW, int C, float scale, float* out, float* workspace,
+               size_t workspace_bytes /* >= N*64*C*4 */, void* stream);
+int mgn_bcast_rows(const float* g, int N, long HW, int C, float scale, void* dx, void* stream);
+int mgn_scale_channels(const void* x, const float* s, int N, long HW, int C, int mode, void* y, void* stream);
+int mgn_nearest_fwd(const void* x, int N, int h, int w, int H, int W, int C, void* y, void* stream);
+int mgn_nearest_bwd(const void* dy, int N, int h, int w, int H, int W, int C, void* dx, void* stream);
+int mgn_concat2(const void* a, const void* b, long rows, int Ca, int Cb, void* y, void* stream);
+int mgn_split2(const void* dy, long rows, int Ca, int Cb, void* da, void* db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,9 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
            "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
-           "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd"]
+           "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
+           "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
+           "mgn_nearest_bwd", "mgn_concat2", "mgn_split2"]
 
 
 class ReprojCfg(ctypes.Structure):
@@ -72,6 +74,15 @@ def lib():
         L.mgn_upsample1_bwd.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_maxpool3x3s2_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
         L.mgn_maxpool3x3s2_bwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
+        L.mgn_add_relu_fwd.argtypes = [vp, vp, vp, cl, vp]
+        L.mgn_relu_mask_bwd.argtypes = [vp, vp, vp, cl, vp]
+        L.mgn_colsum.argtypes = [vp, vp, ci, cl, ci, cf, vp, vp, sz, vp]
+        L.mgn_bcast_rows.argtypes = [vp, ci, cl, ci, cf, vp, vp]
+        L.mgn_scale_channels.argtypes = [vp, vp, ci, cl, ci, ci, vp, vp]
+        L.mgn_nearest_fwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp]
+        L.mgn_nearest_bwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp]
+        L.mgn_concat2.argtypes = [vp, vp, cl, ci, ci, vp, vp]
+        L.mgn_split2.argtypes = [vp, cl, ci, ci, vp, vp, vp]
         L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
@@ -404,3 +415,80 @@ def maxpool_bwd(dy, arg, in_shape):
     dx = torch.empty((N, C, IH, IW), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     check(lib().mgn_maxpool3x3s2_bwd(dy.data_ptr(), arg.data_ptr(), dx.data_ptr(), N, IH, IW, C, _stream()), "mgn_maxpool3x3s2_bwd")
     return dx
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# element-wise / broadcast / pooling glue (channels-last bf16)
+# ---------------------------------------------------------------------------------------------------------------
+def elt_supported(x):
+    C = x.shape[1]
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and C % 8 == 0 and C // 8 <= 256 and 256 % (C // 8) == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _cl_like(x, shape=None):
+    return torch.empty(tuple(x.shape) if shape is None else shape, dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+
+
+def add_relu_fwd(a, b):
+    y = _cl_like(a)
+    check(lib().mgn_add_relu_fwd(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mgn_add_relu_fwd")
+    return y
+
+
+def relu_mask_bwd(dy, y):
+    dx = _cl_like(y)
+    check(lib().mgn_relu_mask_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), _stream()), "mgn_relu_mask_bwd")
+    return dx
+
+
+def colsum(x, x2, scale):
+    N, C, H, W = x.shape
+    out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    ws = torch.empty(N * 64 * C, dtype=torch.float32, device=x.device)
+    check(lib().mgn_colsum(x.data_ptr(), None if x2 is None else x2.data_ptr(), N, H * W, C, scale, out.data_ptr(), ws.data_ptr(),
+                           ws.numel() * 4, _stream()), "mgn_colsum")
+    return out
+
+
+def bcast_rows(g, shape, scale):
+    N, C, H, W = shape
+    dx = _cl_like(g, shape)
+    check(lib().mgn_bcast_rows(g.data_ptr(), N, H * W, C, scale, dx.data_ptr(), _stream()), "mgn_bcast_rows")
+    return dx
+
+
+def scale_channels(x, s, mode):
+    N, C, H, W = x.shape
+    y = _cl_like(x)
+    check(lib().mgn_scale_channels(x.data_ptr(), s.data_ptr(), N, H * W, C, mode, y.data_ptr(), _stream()), "mgn_scale_channels")
+    return y
+
+
+def nearest_fwd(x, H, W):
+    N, C, h, w = x.shape
+    y = _cl_like(x, (N, C, H, W))
+    check(lib().mgn_nearest_fwd(x.data_ptr(), N, h, w, H, W, C, y.data_ptr(), _stream()), "mgn_nearest_fwd")
+    return y
+
+
+def nearest_bwd(dy, h, w):
+    N, C, H, W = dy.shape
+    dx = _cl_like(dy, (N, C, h, w))
+    check(lib().mgn_nearest_bwd(dy.data_ptr(), N, h, w, H, W, C, dx.data_ptr(), _stream()), "mgn_nearest_bwd")
+    return dx
+
+
+def concat2(a, b):
+    N, Ca, H, W = a.shape
+    Cb = b.shape[1]
+    y = _cl_like(a, (N, Ca + Cb, H, W))
+    check(lib().mgn_concat2(a.data_ptr(), b.data_ptr(), N * H * W, Ca, Cb, y.data_ptr(), _stream()), "mgn_concat2")
+    return y
+
+
+def split2(dy, Ca, Cb):
+    N, _, H, W = dy.shape
+    da, db = _cl_like(dy, (N, Ca, H, W)), _cl_like(dy, (N, Cb, H, W))
+    check(lib().mgn_split2(dy.data_ptr(), N * H * W, Ca, Cb, da.data_ptr(), db.data_ptr(), _stream()), "mgn_split2")
+    return da, db

@@ -112,7 +112,7 @@ class AttentionRefinementModule(nn.Module):  # layers.py:221-267
 
     def forward(self, x):
         fm = self.conv(x)
-        return fm * self.channel_attention(fm)
+        return ops.scale_channels(fm, self.channel_attention(fm))
 
 
 class FeatureFusionModule(nn.Module):  # layers.py:270-322
@@ -130,8 +130,8 @@ class FeatureFusionModule(nn.Module):  # layers.py:270-322
             mgnet_xavier_fill(self.channel_attention[2])
 
     def forward(self, fsp, fcp):
-        fm = self.conv(torch.cat([fsp, fcp], dim=1))
-        return fm + fm * self.channel_attention(fm)
+        fm = self.conv(ops.concat_channels(fsp, fcp))
+        return ops.scale_channels(fm, self.channel_attention(fm), residual=True)
 
 
 class MGNetDecoder(nn.Module):  # layers.py:22-94

@@ -217,14 +217,128 @@ def max_pool_3x3_s2(x):
     return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
 
 
+def _cl(t):
+    return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+
+class _GapFn(torch.autograd.Function):
+    """[HIP] csrc/eltwise.hip: two-stage column mean over H*W and its broadcast adjoint"""
+
+    @staticmethod
+    def forward(ctx, x):
+        from .. import _C
+        ctx.shape = tuple(x.shape)
+        N, C, H, W = x.shape
+        return _C.colsum(x, None, 1.0 / (H * W)).to(x.dtype).view(N, C, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+        N, C, H, W = ctx.shape
+        return _C.bcast_rows(g.float().reshape(N, C).contiguous(), ctx.shape, 1.0 / (H * W))
+
+
 def global_avg_pool(x):
-    """[torch-staging] layers.py:170-184 FastGlobalAvgPool2d (flatten=False): [B,C,H,W] -> [B,C,1,1]"""
+    """layers.py:170-184 FastGlobalAvgPool2d (flatten=False): [B,C,H,W] -> [B,C,1,1].  bf16 CUDA: [HIP]"""
+    from .. import _C
+    if _C.elt_supported(x):
+        return _GapFn.apply(x)
     return x.float().mean((2, 3), keepdim=True).to(x.dtype)
 
 
+class _NearestFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        from .. import _C
+        ctx.hw = x.shape[2:]
+        return _C.nearest_fwd(x, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+        return _C.nearest_bwd(_cl(g), *ctx.hw), None, None
+
+
 def upsample_nearest(x, size):
-    """[torch-staging] F.interpolate(mode='nearest') (layers.py:90, :217)"""
-    return F.interpolate(x, size=tuple(size), mode="nearest")
+    """F.interpolate(mode='nearest') (layers.py:90, :217).  bf16 CUDA: [HIP]"""
+    from .. import _C
+    H, W = int(size[0]), int(size[1])
+    if _C.elt_supported(x) and H >= x.shape[2] and W >= x.shape[3]:
+        return _NearestFn.apply(x, H, W)
+    return F.interpolate(x, size=(H, W), mode="nearest")
+
+
+class _AddReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        from .. import _C
+        y = _C.add_relu_fwd(a, b)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+        (y,) = ctx.saved_tensors
+        dx = _C.relu_mask_bwd(_cl(g), y)
+        return dx, dx
+
+
+def add_relu(a, b):
+    """res_net.py:77-78: relu_(out + shortcut).  bf16 CUDA: [HIP]"""
+    from .. import _C
+    if _C.elt_supported(a) and _C.elt_supported(b) and a.shape == b.shape:
+        return _AddReluFn.apply(a, b)
+    return torch.relu_(a + b)
+
+
+class _ScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s, mode):
+        from .. import _C
+        s32 = s.float().reshape(x.shape[0], x.shape[1]).contiguous()
+        ctx.save_for_backward(x, s32)
+        ctx.mode, ctx.sdtype, ctx.sshape = mode, s.dtype, tuple(s.shape)
+        return _C.scale_channels(x, s32, mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+        x, s32 = ctx.saved_tensors
+        g = _cl(g)
+        dx = _C.scale_channels(g, s32, ctx.mode)
+        ds = _C.colsum(g, x, 1.0).to(ctx.sdtype).view(ctx.sshape)
+        return dx, ds, None
+
+
+def scale_channels(x, s, residual=False):
+    """x * s (AttentionRefinementModule, layers.py:262-267) or x + x * s (FeatureFusionModule, :315-322) with a
+    per-(image, channel) factor s [B,C,1,1].  bf16 CUDA: [HIP]"""
+    from .. import _C
+    if _C.elt_supported(x):
+        return _ScaleFn.apply(x, s, 1 if residual else 0)
+    return x + x * s if residual else x * s
+
+
+class _CatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        from .. import _C
+        ctx.c = (a.shape[1], b.shape[1])
+        return _C.concat2(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+        return _C.split2(_cl(g), *ctx.c)
+
+
+def concat_channels(a, b):
+    """torch.cat([a, b], dim=1) (layers.py:316).  bf16 CUDA: [HIP]"""
+    from .. import _C
+    if _C.elt_supported(a) and _C.elt_supported(b) and a.shape[0] == b.shape[0] and a.shape[2:] == b.shape[2:]:
+        return _CatFn.apply(a, b)
+    return torch.cat([a, b], dim=1)
 
 
 class _Up1Fn(torch.autograd.Function):

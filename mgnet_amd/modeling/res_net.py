@@ -35,7 +35,7 @@ class BasicBlock(nn.Module):  # res_net.py:11-79
     def forward(self, x):
         out = self.conv2(self.conv1(x))
         sc = x if self.shortcut is None else self.shortcut(x)
-        return torch.relu_(out + sc)
+        return ops.add_relu(out, sc)
 
 
 class BasicStem(nn.Module):  # res_net.py:82-110

@@ -1,0 +1,76 @@
+"""GPU: element-wise / broadcast / pooling glue kernels (csrc/eltwise.hip) against the torch formulation of the reference
+lines they replace, on the same bf16 values."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _x(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(torch.bfloat16)
+
+
+def _pair(x0):
+    return x0.float().requires_grad_(True), x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+
+
+def _close(a, b, tol=2e-2):
+    return float((a.detach().float().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-9)) < tol
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 9, 13), (1, 512, 4, 6)])
+def test_add_relu(shape):
+    from mgnet_amd.modeling import ops
+    (ar, a), (br, b) = _pair(_x(shape, 1)), _pair(_x(shape, 2))
+    g = _x(shape, 3)
+    yr = F.relu(ar + br); (yr * g.float()).sum().backward()
+    y = ops.add_relu(a, b); (y.float() * g.cuda().float()).sum().backward()
+    assert _close(y, yr) and _close(a.grad, ar.grad) and _close(b.grad, br.grad)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 32, 64), (3, 256, 7, 5), (2, 512, 1, 1)])
+def test_global_avg_pool(shape):
+    from mgnet_amd.modeling import ops
+    xr, x = _pair(_x(shape, 4))
+    g = _x(shape[:2] + (1, 1), 5)
+    yr = xr.mean((2, 3), keepdim=True); (yr * g.float()).sum().backward()
+    y = ops.global_avg_pool(x); (y.float() * g.cuda().float()).sum().backward()
+    assert y.shape == yr.shape and _close(y, yr) and _close(x.grad, xr.grad)
+
+
+@pytest.mark.parametrize("cfg", [((2, 128, 4, 6), (8, 12)), ((1, 64, 1, 1), (5, 7)), ((2, 128, 3, 5), (7, 11))])
+def test_nearest_upsample(cfg):
+    from mgnet_amd.modeling import ops
+    shape, size = cfg
+    xr, x = _pair(_x(shape, 6))
+    yr = F.interpolate(xr, size=size, mode="nearest")
+    g = _x(tuple(yr.shape), 7)
+    (yr * g.float()).sum().backward()
+    y = ops.upsample_nearest(x, size); (y.float() * g.cuda().float()).sum().backward()
+    assert torch.equal(y.float().cpu(), yr.detach()) and _close(x.grad, xr.grad)
+
+
+@pytest.mark.parametrize("residual", [False, True])
+def test_scale_channels(residual):
+    from mgnet_amd.modeling import ops
+    shape = (2, 128, 6, 10)
+    xr, x = _pair(_x(shape, 8))
+    s0 = torch.sigmoid(_x((2, 128, 1, 1), 9).float())
+    sr, s = s0.clone().requires_grad_(True), s0.cuda().requires_grad_(True)
+    g = _x(shape, 10)
+    yr = xr + xr * sr if residual else xr * sr
+    (yr * g.float()).sum().backward()
+    y = ops.scale_channels(x, s, residual=residual); (y.float() * g.cuda().float()).sum().backward()
+    assert _close(y, yr) and _close(x.grad, xr.grad) and _close(s.grad, sr.grad)
+
+
+def test_concat_channels():
+    from mgnet_amd.modeling import ops
+    (ar, a), (br, b) = _pair(_x((2, 128, 5, 7), 11)), _pair(_x((2, 64, 5, 7), 12))
+    yr = torch.cat([ar, br], 1)
+    g = _x(tuple(yr.shape), 13)
+    (yr * g.float()).sum().backward()
+    y = ops.concat_channels(a, b); (y.float() * g.cuda().float()).sum().backward()
+    assert torch.equal(y.float().cpu(), yr.detach()) and torch.equal(a.grad.float().cpu(), ar.grad) and torch.equal(b.grad.float().cpu(), br.grad)
