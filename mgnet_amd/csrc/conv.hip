@@ -537,6 +537,207 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// conv_wgrad3x3: weight gradient of the 3x3 / stride 1 / pad 1 layers (the bulk of the trunk), all 9 taps in one block.
+//
+// Block = one 64(co) x 64(ci) tile of dW for ALL 9 taps over a slice of pixels (image n, a 64-column strip, a run of
+// rows).  The block marches down its rows; LDS holds a ring of 4 input rows (72 pixels: the strip + halo) and 2 dOut
+// rows in the NATURAL NHWC order [pixel][64 channels], filled by LDS-DMA (no VGPR staging, no register transpose);
+// the zero padding and every tail come from the buffer bounds check.  The MFMA fragments (K = pixels) are gathered
+// with ds_read_b64_tr_b16, the transposing LDS read of gfx950: a 16-lane group reads 4 pixels x 16 channels and every
+// lane receives the 4 pixels of its channel.  A tap (kh, kw) is only an address offset of the In fragment (row slot,
+// +kw pixels), so dOut and In are read from HBM ONCE for the 9 taps (the per-tap kernel read them 9 times), and the
+// dOut fragment is reused by 9 MFMAs.  Each wave owns a 32x32 corner of the tile for the 9 taps (9 accumulators).
+// 16-byte slot swizzle: slot ^= 4 * bit1(pixel): any 4 consecutive pixels x 4 slots then cover all 64 banks once.
+// Blocks that share a pixel slice (the other co/ci tiles) are placed on the same XCD back to back (shared L2).
+// ---------------------------------------------------------------------------------------------------------------
+struct Wgrad3Params {
+    const uint16_t* dout;  // [N, H, W, Cout] bf16
+    const uint16_t* in;    // [N, H, W, Cin] bf16
+    float* partial;        // [nslices][Cout][9][Cin]
+    int N, H, W, Cin, Cout;
+    int co_tiles, ci_tiles, strips, chunks, rows_per_chunk, nslices, ng;
+};
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {  // 8 k-values (pixels p, p+4 rows apart by 128 B) of this lane's channel
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + 512));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// NG = number of 4-wave groups: the strip is 64*NG pixels wide, group q owns pixels [64q, 64q+64) of every row and the
+// groups' accumulators are summed through LDS at the end (half the split partials for NG = 2).
+// Rows are prefetched W3_D = 2 steps ahead (ring of 5 In rows and 3 dOut rows) with a counted s_waitcnt.
+template <int NG>
+struct W3 {
+    static constexpr int SW = 64 * NG, INROW = (SW + 8) * 128, OUTROW = SW * 128;
+    static constexpr int NIN = 5, NOUT = 3, LDS = NIN * INROW + NOUT * OUTROW;
+    static constexpr int PIN = SW / 8 + 1, POUT = SW / 8, NW = 4 * NG;      // 1-KB DMA pieces per row, waves
+    static constexpr int IMAX = (PIN + POUT + NW - 1) / NW;                 // pieces per wave and row step (upper bound)
+};
+
+template <int NG>
+__device__ __forceinline__ void wgrad3x3_body(const Wgrad3Params& p) {
+    using C = W3<NG>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char w3sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int tiles = p.co_tiles * p.ci_tiles;
+    const int L = blockIdx.x, q = L >> 3;
+    const int slice = (q / tiles) * 8 + (L & 7), tile = q % tiles;
+    if (slice >= p.nslices) return;
+    const int co0 = (tile / p.ci_tiles) * 64, ci0 = (tile % p.ci_tiles) * 64;
+    int s = slice;
+    const int chunk = s % p.chunks; s /= p.chunks;
+    const int strip = s % p.strips, n = s / p.strips;
+    const int ow0 = strip * C::SW;
+    const int r0 = chunk * p.rows_per_chunk, r1 = r0 + p.rows_per_chunk < p.H ? r0 + p.rows_per_chunk : p.H;
+
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dout), 0, (uint32_t)((size_t)p.N * p.H * p.W * p.Cout * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, (uint32_t)((size_t)p.N * p.H * p.W * p.Cin * 2), 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    // LDS-DMA plan: PIN + POUT one-KB pieces per row step; wave w issues pieces w, w + NW, ...
+    int voff[C::IMAX];
+#pragma unroll
+    for (int i = 0; i < C::IMAX; ++i) {
+        const int j = wave + C::NW * i;
+        const int px = 8 * (j < C::PIN ? j : j - C::PIN) + (lane >> 3);
+        const int seg = (lane & 7) ^ (((px >> 1) & 1) << 2);
+        if (j < C::PIN) {
+            const int iw = ow0 - 1 + px;
+            voff[i] = (iw >= 0 && iw < p.W) ? (iw * p.Cin + ci0 + seg * 8) * 2 : OOB;
+        } else {
+            const int ow = ow0 + px;
+            voff[i] = (j < C::PIN + C::POUT && ow < p.W) ? (ow * p.Cout + co0 + seg * 8) * 2 : OOB;
+        }
+    }
+    auto issue_in = [&](int ih, int slot) {
+        const bool ok = ih >= 0 && ih < p.H;
+        const int soff = ok ? ((n * p.H + ih) * p.W) * p.Cin * 2 : 0;
+        unsigned char* base = w3sm + slot * C::INROW;
+#pragma unroll
+        for (int i = 0; i < C::IMAX; ++i) {
+            const int j = wave + C::NW * i;
+            if (j < C::PIN) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(base + j * 1024), 16, ok ? voff[i] : OOB, soff, 0, 0);
+        }
+    };
+    auto issue_out = [&](int oh, int slot) {
+        const bool ok = oh < p.H;
+        const int soff = ok ? ((n * p.H + oh) * p.W) * p.Cout * 2 : 0;
+        unsigned char* base = w3sm + C::NIN * C::INROW + slot * C::OUTROW;
+#pragma unroll
+        for (int i = 0; i < C::IMAX; ++i) {
+            const int j = wave + C::NW * i;
+            if (j >= C::PIN && j < C::PIN + C::POUT)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lds_ptr)(base + (j - C::PIN) * 1024), 16, ok ? voff[i] : OOB, soff, 0, 0);
+        }
+    };
+    // pieces this wave issues per row step (for the counted wait)
+    const int my_cnt = (C::PIN + C::POUT - wave + C::NW - 1) / C::NW;
+
+    // fragment gather addresses (ds_read_b64_tr_b16): lane group g = lane>>4 reads pixels 8*(g>>1) + (i>>2) [+4], channels
+    // 16*(g&1) + 4*(i&3) .. +3 of the wave's 32-channel half
+    const int g = lane >> 4, i4 = lane & 15;
+    const int prow = grp * 64 + 8 * (g >> 1) + (i4 >> 2);
+    auto lds_off = [](int px, int ch) { return px * 128 + ((((ch >> 3) ^ (((px >> 1) & 1) << 2))) << 4) + (ch & 7) * 2; };
+    const int aA = C::NIN * C::INROW + lds_off(prow, wm * 32 + (g & 1) * 16 + 4 * (i4 & 3));
+    int aB[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) aB[kw] = lds_off(prow + kw, wn * 32 + (g & 1) * 16 + 4 * (i4 & 3));
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // ring slots: In row ih lives in slot (ih - r0 + 1) % 5, dOut row oh in slot (oh - r0) % 3
+    issue_in(r0 - 1, 0);
+    issue_in(r0, 1);
+    issue_in(r0 + 1, 2);
+    issue_out(r0, 0);
+    if (r0 + 1 < r1) {
+        issue_in(r0 + 2, 3);
+        issue_out(r0 + 1, 1);
+    }
+    int si = 0, so = 0;  // slots of In row r-1 and dOut row r
+    for (int r = r0; r < r1; ++r) {
+        if (r + 1 < r1) {  // the step group of row r+1 may stay in flight
+            if (my_cnt == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (my_cnt == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (r + 2 < r1) {
+            issue_in(r + 3, si + 4 >= 5 ? si - 1 : si + 4);
+            issue_out(r + 2, so + 2 >= 3 ? so - 1 : so + 2);
+        }
+        const int s1 = si + 1 >= 5 ? si - 4 : si + 1, s2 = si + 2 >= 5 ? si - 3 : si + 2;
+        const unsigned char* sa = w3sm + aA + so * C::OUTROW;
+        const unsigned char* sb0 = w3sm + si * C::INROW;
+        const unsigned char* sb1 = w3sm + s1 * C::INROW;
+        const unsigned char* sb2 = w3sm + s2 * C::INROW;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 a = tr_frag(sa + ks * 2048);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const bf16x8 b0 = tr_frag(sb0 + aB[kw] + ks * 2048);
+                const bf16x8 b1 = tr_frag(sb1 + aB[kw] + ks * 2048);
+                const bf16x8 b2 = tr_frag(sb2 + aB[kw] + ks * 2048);
+                acc[0 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[0 + kw], 0, 0, 0);
+                acc[3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[3 + kw], 0, 0, 0);
+                acc[6 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, acc[6 + kw], 0, 0, 0);
+            }
+        }
+        si = s1;
+        so = so + 1 >= 3 ? 0 : so + 1;
+    }
+    if (NG == 2) {  // sum the two pixel groups: 3 taps at a time through the (now idle) ring memory
+        float* red = reinterpret_cast<float*>(w3sm);
+        const int t256 = tid & 255;
+#pragma unroll
+        for (int tb = 0; tb < 9; tb += 3) {
+            __syncthreads();
+            if (grp == 1) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[(t * 16 + e) * 256 + t256] = acc[tb + t][e];
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[tb + t][e] += red[(t * 16 + e) * 256 + t256];
+            }
+        }
+        if (grp == 1) return;
+    }
+    const size_t wsize = (size_t)p.Cout * 9 * p.Cin;
+    float* dst = p.partial + (size_t)slice * wsize;
+    const int ci = ci0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            dst[((size_t)co * 9 + t) * p.Cin + ci] = acc[t][e];
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_s64(Wgrad3Params p) { wgrad3x3_body<1>(p); }
+__global__ __launch_bounds__(512, 1) void conv_wgrad3x3_s128(Wgrad3Params p) { wgrad3x3_body<2>(p); }
+
 // dw = sum over the pixel splits (fixed order: deterministic), written in the requested layout
 __global__ void conv_wgrad_reduce(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw, int cin_real,
                                   float* __restrict__ dw) {
@@ -646,11 +847,39 @@ static void wgrad_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW,
     *gz = (M + *m_per_split - 1) / *m_per_split;
 }
 
+// 3x3 / stride 1 / pad 1 with 64-multiples of channels -> the all-taps row-march kernel
+static bool wgrad3_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, int stride, int pad, int IH, int IW, Wgrad3Params* p) {
+    if (getenv("MGN_WGRAD_NO3X3")) return false;
+    if (KH != 3 || KW != 3 || stride != 1 || pad != 1 || IH != OH || IW != OW || Cin % 64 || Cout % 64) return false;
+    if ((size_t)N * OH * OW * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fffffffu) return false;  // 32-bit buffer offsets
+    p->N = N; p->H = OH; p->W = OW; p->Cin = Cin; p->Cout = Cout;
+    p->co_tiles = Cout / 64; p->ci_tiles = Cin / 64;
+    const char* eng = getenv("MGN_WGRAD3_NG");
+    p->ng = eng ? atoi(eng) : (OW > 64 ? 2 : 1);        // 128-pixel strips (8 waves) unless the image is narrower
+    if (p->ng != 1 && p->ng != 2) p->ng = 1;
+    p->strips = (OW + 64 * p->ng - 1) / (64 * p->ng);
+    const int tiles = p->co_tiles * p->ci_tiles;
+    const int resident = 256 * (2 / p->ng);               // blocks resident at once: one round of equal-work blocks
+    int want = (resident + tiles - 1) / tiles;
+    int chunks = want / (N * p->strips);
+    if (chunks > OH / 4) chunks = OH / 4;                 // >= 4 rows per block (2 rows of prologue)
+    if (chunks < 1) chunks = 1;
+    p->rows_per_chunk = (OH + chunks - 1) / chunks;
+    p->chunks = (OH + p->rows_per_chunk - 1) / p->rows_per_chunk;
+    p->nslices = N * p->strips * p->chunks;
+    return true;
+}
+
 int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, size_t* bytes) {
     if (!bytes || N < 1 || OH < 1 || OW < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1) return MGN_EINVAL;
     bool pack; int NT, MT, cit, cot; long mps, gz;
     wgrad_plan(N, OH, OW, Cin, Cout, KH, KW, &pack, &NT, &MT, &cit, &cot, &mps, &gz);
     *bytes = sizeof(float) * (size_t)gz * Cout * KH * KW * Cin;
+    Wgrad3Params p3;  // stride / pad are not known here: cover the 3x3 stride-1 plan too
+    if (wgrad3_plan(N, OH, OW, Cin, Cout, KH, KW, 1, 1, OH, OW, &p3)) {
+        const size_t b3 = sizeof(float) * (size_t)p3.nslices * Cout * 9 * Cin;
+        if (b3 > *bytes) *bytes = b3;
+    }
     return MGN_OK;
 }
 
@@ -663,9 +892,27 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.oihw = oihw_cin > 0; p.cin_real = oihw_cin > 0 ? oihw_cin : Cin;
     if (oihw_cin > Cin) return MGN_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t wsize = (size_t)Cout * KH * KW * Cin;
+    Wgrad3Params p3;
+    if (wgrad3_plan(N, OH, OW, Cin, Cout, KH, KW, stride, pad, IH, IW, &p3)) {
+        if (workspace_bytes < sizeof(float) * p3.nslices * wsize) return MGN_ENOSPC;
+        p3.dout = p.dout; p3.in = p.in; p3.partial = (float*)workspace;
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_s64), hipFuncAttributeMaxDynamicSharedMemorySize, W3<1>::LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_s128), hipFuncAttributeMaxDynamicSharedMemorySize, W3<2>::LDS);
+            attr3 = true;
+        }
+        const unsigned nblk = (unsigned)((p3.nslices + 7) / 8) * 8 * p3.co_tiles * p3.ci_tiles;
+        if (p3.ng == 2) hipLaunchKernelGGL(conv_wgrad3x3_s128, dim3(nblk), dim3(512), W3<2>::LDS, st, p3);
+        else hipLaunchKernelGGL(conv_wgrad3x3_s64, dim3(nblk), dim3(256), W3<1>::LDS, st, p3);
+        hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((wsize + 255) / 256)), dim3(256), 0, st, (const float*)workspace, p3.nslices,
+                           Cout, 9, Cin, p.oihw, p.cin_real, dw);
+        return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+    }
     bool pack; int NT, MT, co_tiles; long gz;
     wgrad_plan(N, OH, OW, Cin, Cout, KH, KW, &pack, &NT, &MT, &p.ci_tiles, &co_tiles, &p.m_per_split, &gz);
-    const size_t wsize = (size_t)Cout * KH * KW * Cin;
     if (workspace_bytes < sizeof(float) * gz * wsize) return MGN_ENOSPC;
     p.partial = (float*)workspace;
     const dim3 grid(co_tiles, (pack ? 1 : KH * KW) * p.ci_tiles, (unsigned)gz);
@@ -680,7 +927,6 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipStream_t st = (hipStream_t)stream;
     if (pack && MT == 1) hipLaunchKernelGGL((conv_wgrad<1, 2, true>), grid, dim3(256), lds, st, p);
     else if (pack) hipLaunchKernelGGL((conv_wgrad<2, 2, true>), grid, dim3(256), lds, st, p);
     else if (MT == 1 && NT == 1) hipLaunchKernelGGL((conv_wgrad<1, 1>), grid, dim3(256), lds, st, p);

@@ -16,7 +16,10 @@ CASES = [(2, 64, 128, 16, 24, 1, 1, 0, False, False),
          (2, 512, 256, 4, 6, 1, 1, 0, True, True),        # pose conv1: bias + ReLU
          (1, 256, 256, 8, 8, 3, 1, 1, True, True),
          (3, 32, 64, 5, 7, 3, 1, 1, False, False),
-         (2, 128, 1, 6, 10, 1, 1, 0, False, False)]
+         (2, 128, 1, 6, 10, 1, 1, 0, False, False),
+         (1, 64, 64, 70, 150, 3, 1, 1, False, False),     # all-taps wgrad: 3 strips with a ragged tail, several row chunks
+         (2, 64, 192, 5, 64, 3, 1, 1, False, False),      # all-taps wgrad: 3 co tiles, one exact strip
+         (9, 128, 64, 3, 7, 3, 1, 1, False, False)]       # all-taps wgrad: fewer rows than the ring depth
 
 
 @pytest.mark.parametrize("case", CASES)
