@@ -57,31 +57,58 @@ class GradReducer:
                 p.data = flat_p[o:o + p.numel()].view(p.shape)
         for p, o in zip(plist, offsets):
             p.grad = flat_g[o:o + p.numel()].view(p.shape)
-        b = dict(flat_g=flat_g, flat_p=flat_p, params=plist, offsets=offsets, pending=len(plist), n=len(plist))
+        b = dict(flat_g=flat_g, flat_p=flat_p, params=plist, offsets=offsets, pending=len(plist), n=len(plist), seen=set(), packed=True)
         self.buckets.append(b)
         for p in plist:
             self._bucket_of[p] = b
 
     def zero_grad(self):
+        """Gradients are not zeroed: `.grad` is dropped, so autograd hands over each freshly computed gradient without an
+        accumulate kernel per parameter; `_hook` packs a bucket's gradients into its flat buffer with one multi-tensor
+        copy when the bucket is complete (parameters that got no gradient are zero-filled in `finish`)."""
         for b in self.buckets:
-            b["flat_g"].zero_()
             b["pending"] = b["n"]
-            for p, o in zip(b["params"], b["offsets"]):  # restore the views if someone replaced .grad
-                if p.grad is None or p.grad.data_ptr() != b["flat_g"].data_ptr() + o * 4:
-                    p.grad = b["flat_g"][o:o + p.numel()].view(p.shape)
+            b["seen"] = set()
+            for p in b["params"]:
+                p.grad = None
+
+    def _view(self, b, i):
+        p, o = b["params"][i], b["offsets"][i]
+        return b["flat_g"][o:o + p.numel()].view(p.shape)
+
+    def _pack(self, b):
+        idx = [i for i, p in enumerate(b["params"]) if p.grad is not None]
+        views = [self._view(b, i) for i in idx]
+        if idx:
+            torch._foreach_copy_(views, [b["params"][i].grad for i in idx])
+        got = set(idx)
+        for i, p in enumerate(b["params"]):
+            v = views[idx.index(i)] if i in got else self._view(b, i)
+            if i not in got:
+                v.zero_()
+            p.grad = v
+        b["packed"] = True
 
     def _hook(self, p):
         b = self._bucket_of[p]
+        if id(p) in b["seen"]:   # second accumulation into the same parameter: already counted
+            return
+        b["seen"].add(id(p))
+        b["packed"] = False
         b["pending"] -= 1
-        if b["pending"] == 0 and self.world > 1:
-            self._handles.append(dist.all_reduce(b["flat_g"], group=self.group, async_op=True))
+        if b["pending"] == 0:
+            self._pack(b)
+            if self.world > 1:
+                self._handles.append(dist.all_reduce(b["flat_g"], group=self.group, async_op=True))
 
     def finish(self):
-        """Wait for the in-flight buckets, launch the ones whose parameters got no gradient this step, average."""
-        if self.world > 1:
-            for b in self.buckets:
-                if b["pending"] > 0:  # unused parameters this iteration: still reduce (zeros) to stay in lock step
+        """Pack / launch the buckets whose parameters did not all get a gradient this step, wait, average."""
+        for b in self.buckets:
+            if b["pending"] > 0:  # unused parameters this iteration: zero-filled, still reduced to stay in lock step
+                self._pack(b)
+                if self.world > 1:
                     self._handles.append(dist.all_reduce(b["flat_g"], group=self.group, async_op=True))
+        if self.world > 1:
             for h in self._handles:
                 h.wait()
             self._handles.clear()

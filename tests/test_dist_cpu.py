@@ -22,6 +22,9 @@ def _worker(rank, world, port, fn, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         q.put((rank, fn(rank, world)))
+    except Exception as e:  # report instead of leaving the parent blocked on the queue
+        import traceback
+        q.put((rank, "worker failed: " + "".join(traceback.format_exception(type(e), e, e.__traceback__))))
     finally:
         dist.destroy_process_group()
 
@@ -36,6 +39,9 @@ def _spawn(fn, world=2):
     out = dict(q.get() for _ in range(world))
     for p in procs:
         p.join(60)
+    for r, v in out.items():
+        assert v is True, (r, v)
+    for p in procs:
         assert p.exitcode == 0
     return out
 
@@ -77,6 +83,8 @@ def _reducer(rank, world):
 
     torch.manual_seed(1)
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1000))
+    import copy
+    ref = copy.deepcopy(net)             # same weights, no reducer: the per-rank local gradients
     params = list(net.parameters())
     red = GradReducer(params, bucket_bytes=4096)  # several buckets
     assert len(red.buckets) >= 3
@@ -84,12 +92,15 @@ def _reducer(rank, world):
     x = torch.randn(5, 8)
     red.zero_grad()
     net[:3](x).sum().backward()      # the last layer gets no gradient this step (unused-parameter path)
-    local = [p.grad.clone() for p in params]
+    ref[:3](x).sum().backward()
+    local = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in ref.parameters()]
     red.finish()
+    ok0 = all(p.grad.data_ptr() == b["flat_g"].data_ptr() + 4 * o          # .grad are views into the flat buckets again
+              for b in red.buckets for p, o in zip(b["params"], b["offsets"]))
     gathered = [[torch.zeros_like(g) for _ in range(world)] for g in local]
     for lst, g in zip(gathered, local):
         dist.all_gather(lst, g)
-    ok = all(torch.allclose(p.grad, sum(lst) / world, atol=1e-6) for p, lst in zip(params, gathered))
+    ok = ok0 and all(torch.allclose(p.grad, sum(lst) / world, atol=1e-6) for p, lst in zip(params, gathered))
     ok = ok and float(params[-1].grad.abs().max()) == 0.0
     # second step reuses the same flat buffers
     red.zero_grad()

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Which torch (non-HIP-library) ops are still in the training step: torch.profiler table by op with stacks."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from mgnet_amd import add_mgnet_config, get_cfg
+from mgnet_amd.data import synthetic_batch
+from mgnet_amd.engine import Trainer
+from mgnet_amd.registry import build_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B, H, W = 8, 1024, 2048
+dev = torch.device("cuda:0")
+cfg = get_cfg(); add_mgnet_config(cfg)
+cfg.merge_from_file(os.path.join(ROOT, "configs", "bench-c4-cityscapes-videosequence.yaml"))
+cfg.merge_from_list(["MODEL.DEVICE", str(dev), "SOLVER.IMS_PER_BATCH", B, "MODEL.SEM_SEG_HEAD.OHEM_N_MIN", min(524287, B * H * W // 4 - 1)])
+torch.manual_seed(0)
+model = build_model(cfg); trainer = Trainer(cfg, model)
+batch = synthetic_batch(B, H, W, dev, seed=1234)
+for _ in range(3):
+    trainer.run_step(batch)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    for _ in range(2):
+        trainer.run_step(batch)
+    torch.cuda.synchronize()
+print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=40, max_src_column_width=110))
