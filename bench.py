@@ -151,6 +151,7 @@ def full_step_bench(args, world, rank, dev):
     for k in range(args.steps):
         depth_loss.prof_events = ev.pairs[k]
         last = trainer.run_step(batch)
+    t_issue = time.perf_counter() - t0   # host time to issue the K steps (no sync inside a step): ~dt means launch-bound
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -180,7 +181,7 @@ def full_step_bench(args, world, rank, dev):
                                    f"reprojection + smoothness, uncertainty weighting, grad all-reduce, clip, Adam), "
                                    f"{B} frames/GPU of {H}x{W}",
                        "frames_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
-                       "parallelism": f"dp{world}", "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
+                       "parallelism": f"dp{world}", "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2), "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
                        "losses": {k: round(float(v.detach()), 5) for k, v in last.items()}},
             "roofline": {"bound": "hbm", "kernel": "reproj_march<true> (fused reprojection loss + photometric gradient)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -110,6 +110,11 @@ int mgn_reproj_loss_bwd(const mgn_reproj_cfg* cfg,
 int mgn_iabn_workspace_bytes(long M, int C, int dtype, size_t* bytes);
 int mgn_iabn_stats(const void* x, int dtype, long M, int C, float* stats /*[3][C]: count, mean, M2*/,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* single-rank training forward: statistics AND the coefficients of one process in ONE launch (= stats + combine with
+ * n_ranks = 1; coef[4][C] = scale, offset, mean, rstd; running statistics updated when non-null) */
+int mgn_iabn_train_coeffs(const void* x, int dtype, long M, int C, const float* weight, const float* bias, float eps,
+                          float momentum, float* running_mean, float* running_var, float* coef /*[4][C]*/,
+                          void* workspace, size_t workspace_bytes, void* stream);
 int mgn_iabn_combine(const float* gathered /*[n_ranks][3][C]*/, int n_ranks, int C, const float* weight, const float* bias,
                      float eps, float momentum, float* running_mean /*nullable*/, float* running_var,
                      float* scale, float* offset, float* saved /*[2][C]: mean, rstd*/, void* stream);

@@ -13,7 +13,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 
 # every symbol include/mgnet_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
-           "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
+           "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
            "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
@@ -53,6 +53,7 @@ def lib():
         cl, cf = ctypes.c_long, ctypes.c_float
         L.mgn_iabn_workspace_bytes.argtypes = [cl, ci, ci, ctypes.POINTER(sz)]
         L.mgn_iabn_stats.argtypes = [vp, ci, cl, ci, vp, vp, sz, vp]
+        L.mgn_iabn_train_coeffs.argtypes = [vp, ci, cl, ci, vp, vp, cf, cf, vp, vp, vp, vp, sz, vp]
         L.mgn_iabn_combine.argtypes = [vp, ci, ci, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp]
         L.mgn_iabn_eval_coeffs.argtypes = [ci, vp, vp, vp, vp, cf, vp, vp, vp]
         L.mgn_iabn_apply.argtypes = [vp, vp, ci, cl, ci, vp, vp, ci, cf, vp]
@@ -197,6 +198,17 @@ def iabn_stats(x2d_like, M, C):
     check(lib().mgn_iabn_stats(x2d_like.data_ptr(), _act_dtype(x2d_like), M, C, stats.data_ptr(), ws.data_ptr(),
                                ws.numel() * 4, _stream()), "mgn_iabn_stats")
     return stats
+
+
+def iabn_train_coeffs(x, M, C, weight, bias, eps, momentum, running_mean, running_var):
+    """single-rank training forward: batch statistics -> coef[4,C] = (scale, offset, mean, rstd) in one launch"""
+    out = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    ws = _iabn_ws(x.device)
+    check(lib().mgn_iabn_train_coeffs(x.data_ptr(), _act_dtype(x), M, C, weight.data_ptr(), bias.data_ptr(), eps, momentum,
+                                      None if running_mean is None else running_mean.data_ptr(),
+                                      None if running_var is None else running_var.data_ptr(), out.data_ptr(),
+                                      ws.data_ptr(), ws.numel() * 4, _stream()), "mgn_iabn_train_coeffs")
+    return out
 
 
 def iabn_combine(gathered, weight, bias, eps, momentum, running_mean, running_var):

@@ -28,17 +28,17 @@ constexpr int MAX_BLOCKS = 2048;
 template <typename T> struct Vec;
 template <> struct Vec<float> {
     static constexpr int N = 4;
-    using raw = float4;
-    __device__ static void load(const float* p, float (&v)[4]) {
-        const float4 r = *reinterpret_cast<const float4*>(p);
-        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
-    }
+    using Raw = float4;
+    __device__ static Raw load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static void unpack(const Raw& r, float (&v)[4]) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+    __device__ static void load(const float* p, float (&v)[4]) { unpack(load_raw(p), v); }
     __device__ static void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
 template <> struct Vec<__hip_bfloat16> {
     static constexpr int N = 8;
-    __device__ static void load(const __hip_bfloat16* p, float (&v)[8]) {
-        const uint4 r = *reinterpret_cast<const uint4*>(p);
+    using Raw = uint4;
+    __device__ static Raw load_raw(const __hip_bfloat16* p) { return *reinterpret_cast<const uint4*>(p); }
+    __device__ static void unpack(const Raw& r, float (&v)[8]) {
         const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -46,6 +46,7 @@ template <> struct Vec<__hip_bfloat16> {
             v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
         }
     }
+    __device__ static void load(const __hip_bfloat16* p, float (&v)[8]) { unpack(load_raw(p), v); }
     __device__ static uint32_t pack(float a, float b) {  // round-to-nearest-even bf16 x2
         auto rne = [](float f) -> uint32_t {
             uint32_t u = __float_as_uint(f);
@@ -62,20 +63,44 @@ template <> struct Vec<__hip_bfloat16> {
 };
 
 // ------------------------------------------------------------------------------------------------------
-// column sums of f(row) for two quantities.  partials: [gridDim.x][2][C]
+// column sums of two per-row quantities + finalize, in ONE launch.
+//   * every block accumulates its rows (4 independent 16-byte loads in flight per thread) and writes its partial
+//     sums [2][C] to the workspace;
+//   * the block that finishes last (device-scope ticket counter; release/acquire fences around it) sums the block
+//     partials in a fixed order -- deterministic whichever block that is -- and calls finalize(c, s1, s2) per channel.
+// workspace: partials [gridDim.x][2][C] | final sums [2][C] at float offset 2*C*MAX_STAT_BLOCKS
 // ------------------------------------------------------------------------------------------------------
-template <typename T, typename F>
-__device__ __forceinline__ void column_sums2(long M, int C, float* partials, F&& row_values) {
+constexpr int MAX_STAT_BLOCKS = 512;
+
+template <typename T, typename L, typename A, typename G>
+__device__ __forceinline__ void column_sums2(long M, int C, float* ws, unsigned* counter, L&& load_row, A&& add_row, G&& finalize) {
     constexpr int V = Vec<T>::N;
-    __shared__ float sh[TPB * 2 * 8];
+    __shared__ __attribute__((aligned(16))) float sh[TPB * 2 * 8];
+    __shared__ int is_last;
     const int tpr = C / V;            // threads per row
     const int rpb = TPB / tpr;        // rows per block pass
     const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
     float a[V], b[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) a[k] = b[k] = 0.f;
-    if (ty < rpb) {
-        for (long r = (long)blockIdx.x * rpb + ty; r < M; r += (long)gridDim.x * rpb) row_values(r, tx * V, a, b);
+    {
+        const long stride = (long)gridDim.x * rpb;
+        long r = (long)blockIdx.x * rpb + ty;
+        typename Vec<T>::Raw q0[2], q1[2], q2[2], q3[2];
+        for (; r + 3 * stride < M; r += 4 * stride) {
+            load_row(r, tx * V, q0);
+            load_row(r + stride, tx * V, q1);
+            load_row(r + 2 * stride, tx * V, q2);
+            load_row(r + 3 * stride, tx * V, q3);
+            add_row(q0, a, b);
+            add_row(q1, a, b);
+            add_row(q2, a, b);
+            add_row(q3, a, b);
+        }
+        for (; r < M; r += stride) {
+            load_row(r, tx * V, q0);
+            add_row(q0, a, b);
+        }
     }
     // reduce over ty
 #pragma unroll
@@ -84,70 +109,128 @@ __device__ __forceinline__ void column_sums2(long M, int C, float* partials, F&&
         sh[(ty * tpr + tx) * 2 * V + V + k] = b[k];
     }
     __syncthreads();
+    float* partials = ws;
+    // partials travel through device-coherent accesses (sc0 sc1: written through to / read from memory), so the
+    // finalizing block on another XCD sees them without any L2 write-back / invalidate
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int COHERENT = 17;  // cache policy sc0 | sc1
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (uint32_t)(sizeof(float) * 2 * (size_t)C * (MAX_STAT_BLOCKS + 1)), 0x00020000);
     if (ty == 0) {
+        float sa[V], sb[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            float sa = 0.f, sb = 0.f;
+            sa[k] = sb[k] = 0.f;
             for (int y = 0; y < rpb; ++y) {
-                sa += sh[(y * tpr + tx) * 2 * V + k];
-                sb += sh[(y * tpr + tx) * 2 * V + V + k];
+                sa[k] += sh[(y * tpr + tx) * 2 * V + k];
+                sb[k] += sh[(y * tpr + tx) * 2 * V + V + k];
             }
-            partials[((size_t)blockIdx.x * 2 + 0) * C + tx * V + k] = sa;
-            partials[((size_t)blockIdx.x * 2 + 1) * C + tx * V + k] = sb;
+        }
+#pragma unroll
+        for (int k = 0; k < V; k += 4) {
+            const f32x4 va = {sa[k], sa[k + 1], sa[k + 2], sa[k + 3]}, vb = {sb[k], sb[k + 1], sb[k + 2], sb[k + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, va), rs,
+                                                   (int)((((size_t)blockIdx.x * 2 + 0) * C + tx * V + k) * 4), 0, COHERENT);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, vb), rs,
+                                                   (int)((((size_t)blockIdx.x * 2 + 1) * C + tx * V + k) * 4), 0, COHERENT);
         }
     }
+    // ticket: the last block to arrive finalizes.  No agent-scope fences (a release would write back the whole L2, an
+    // acquire invalidate it): the partials are device-coherent accesses, ordered before the ticket by
+    // waiting for their completion (workgroup-scope release = s_waitcnt) and the barrier.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const int nblk = gridDim.x;
+    const int ncol4 = 2 * C / 4;                       // float4 columns of one partial row [2][C]
+    const int cols = ncol4 < TPB ? ncol4 : TPB;
+    const int slices = TPB / cols, sl = threadIdx.x / cols, cc = threadIdx.x % cols;
+    float* fin = ws + (size_t)2 * C * MAX_STAT_BLOCKS;
+    float4* sh4 = reinterpret_cast<float4*>(sh);
+    for (int base = 0; base < ncol4; base += cols) {
+        const int col = base + cc;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sl < slices && col < ncol4)
+#pragma unroll 8
+            for (int k = sl; k < nblk; k += slices) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((size_t)k * ncol4 + col) * 16), 0, COHERENT));
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        __syncthreads();
+        sh4[threadIdx.x] = acc;
+        __syncthreads();
+        if (sl == 0 && col < ncol4) {
+            float4 t = sh4[cc];
+            for (int k = 1; k < slices; ++k) {
+                const float4 v = sh4[k * cols + cc];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            reinterpret_cast<float4*>(fin)[col] = t;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += TPB) finalize(c, fin[c], fin[C + c]);
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
 }
 
-// forward statistics: sum (x - shift), sum (x - shift)^2 with shift = x[0, c]
+// forward statistics: sum (x - shift), sum (x - shift)^2 with shift = x[0, c]; the last block emits
+//   stats[3][C] = {count, mean, M2} of THIS rank, and -- single-rank training (coef != null) -- directly the
+//   scale/offset/mean/rstd of the apply + backward kernels and the running-statistics update (= iabn_combine with R=1)
+struct StatsOut {
+    float* stats;          // [3][C] or null
+    float* coef;           // [4][C] = scale, offset, mean, rstd, or null
+    const float* weight; const float* bias;
+    float* running_mean; float* running_var;
+    float eps, momentum;
+};
+
 template <typename T>
-__global__ __launch_bounds__(TPB) void iabn_stats_partial(const T* __restrict__ x, long M, int C, float* partials) {
+__global__ __launch_bounds__(TPB) void iabn_stats_kernel(const T* __restrict__ x, long M, int C, float* ws, unsigned* counter, StatsOut o) {
     constexpr int V = Vec<T>::N;
     float s[V];
     Vec<T>::load(x + (threadIdx.x % (C / V)) * V, s);
-    column_sums2<T>(M, C, partials, [&](long r, int c0, float (&a)[V], float (&b)[V]) {
-        float v[V];
-        Vec<T>::load(x + r * C + c0, v);
+    column_sums2<T>(M, C, ws, counter,
+        [&](long r, int c0, typename Vec<T>::Raw (&q)[2]) { q[0] = Vec<T>::load_raw(x + r * C + c0); },
+        [&](const typename Vec<T>::Raw (&q)[2], float (&a)[V], float (&b)[V]) {
+            float v[V];
+            Vec<T>::unpack(q[0], v);
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const float d = v[k] - s[k];
-            a[k] += d;
-            b[k] += d * d;
-        }
-    });
-}
-
-// sum the block partials [nblk][2][C] for 32 channels per block: 8 slices of blocks in parallel, then LDS (fixed order)
-__device__ __forceinline__ void reduce_partials(const float* partials, int nblk, int C, int c, int slice, float& s1, float& s2) {
-    __shared__ float r1[8][32], r2[8][32];
-    float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int k = slice; k < nblk; k += 8) {
-            a += partials[((size_t)k * 2 + 0) * C + c];
-            b += partials[((size_t)k * 2 + 1) * C + c];
-        }
-    r1[slice][threadIdx.x] = a;
-    r2[slice][threadIdx.x] = b;
-    __syncthreads();
-    s1 = s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
-}
-
-// stats[3][C] = {count, mean, M2} of THIS rank.  block (32, 8), grid C/32
-template <typename T>
-__global__ void iabn_stats_final(const T* __restrict__ x, const float* partials, int nblk, long M, int C, float* stats) {
-    const int c = blockIdx.x * 32 + threadIdx.x;
-    float s1, s2;
-    reduce_partials(partials, nblk, C, c, threadIdx.y, s1, s2);
-    if (c >= C || threadIdx.y != 0) return;
-    float sv[Vec<T>::N];
-    Vec<T>::load(x + (c / Vec<T>::N) * Vec<T>::N, sv);
-    const float shift = sv[c % Vec<T>::N];
-    const float n = (float)M;
-    const float md = s1 / n;
-    stats[c] = n;
-    stats[C + c] = shift + md;
-    stats[2 * C + c] = fmaxf(s2 - s1 * md, 0.f);  // sum (x-mean)^2
+            for (int k = 0; k < V; ++k) {
+                const float d = v[k] - s[k];
+                a[k] += d;
+                b[k] += d * d;
+            }
+        },
+        [&](int c, float s1, float s2) {
+            float sv[V];
+            Vec<T>::load(x + (c / V) * V, sv);
+            const float shift = sv[c % V];
+            const float n = (float)M;
+            const float md = s1 / n;
+            const float mean = shift + md, m2 = fmaxf(s2 - s1 * md, 0.f);  // sum (x-mean)^2
+            if (o.stats) {
+                o.stats[c] = n;
+                o.stats[C + c] = mean;
+                o.stats[2 * C + c] = m2;
+            }
+            if (o.coef) {
+                const float var = m2 / n;
+                const float rstd = rsqrtf(var + o.eps);
+                const float g = fabsf(o.weight[c]) + o.eps;
+                o.coef[c] = g * rstd;
+                o.coef[C + c] = o.bias[c] - mean * g * rstd;
+                o.coef[2 * C + c] = mean;
+                o.coef[3 * C + c] = rstd;
+                if (o.running_mean) {
+                    o.running_mean[c] = (1.f - o.momentum) * o.running_mean[c] + o.momentum * mean;
+                    o.running_var[c] = (1.f - o.momentum) * o.running_var[c] + o.momentum * var * (n / fmaxf(n - 1.f, 1.f));
+                }
+            }
+        });
 }
 
 // combine R ranks (Chan), update running stats, emit scale/offset/rstd for the apply + backward kernels.
@@ -190,6 +273,8 @@ __global__ void iabn_eval_coeffs(int C, const float* weight, const float* bias, 
     offset[c] = bias[c] - running_mean[c] * g;
 }
 
+// The grid stride (gridDim.x * TPB vectors) is a multiple of C/V, so a thread always meets the same V channels: their
+// coefficients are loaded once; two independent vectors are in flight per thread.
 template <typename T>
 __global__ __launch_bounds__(TPB) void iabn_apply(const T* __restrict__ x, T* __restrict__ y, long M, int C,
                                                   const float* __restrict__ scale, const float* __restrict__ offset,
@@ -197,54 +282,74 @@ __global__ __launch_bounds__(TPB) void iabn_apply(const T* __restrict__ x, T* __
     constexpr int V = Vec<T>::N;
     const long nvec = M * C / V;
     const int cv = C / V;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cv) * V;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    const int c0 = (int)(i0 % cv) * V;
+    float sc[V], of[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { sc[k] = scale[c0 + k]; of[k] = offset[c0 + k]; }
+    auto body = [&](const typename Vec<T>::Raw& q, long i) {
         float v[V];
-        Vec<T>::load(x + i * V, v);
+        Vec<T>::unpack(q, v);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            float z = fmaf(v[k], scale[c0 + k], offset[c0 + k]);
+            float z = fmaf(v[k], sc[k], of[k]);
             if (leaky) z = z > 0.f ? z : z * slope;
             v[k] = z;
         }
         Vec<T>::store(y + i * V, v);
+    };
+    long i = i0;
+    for (; i + stride < nvec; i += 2 * stride) {
+        const typename Vec<T>::Raw q0 = Vec<T>::load_raw(x + i * V), q1 = Vec<T>::load_raw(x + (i + stride) * V);
+        body(q0, i);
+        body(q1, i + stride);
     }
+    if (i < nvec) body(Vec<T>::load_raw(x + i * V), i);
 }
 
-// backward pass 1: per-channel sum dz and sum dz * x_hat, with z = act^-1(y), dz = dy * act'(z), x_hat = (z - beta)/gamma'
+// backward pass 1: per-channel sum dz and sum dz * x_hat, with z = act^-1(y), dz = dy * act'(z), x_hat = (z - beta)/gamma';
+// the last block writes sums[2][C] and the local parameter gradients
+//   d bias = sum dz ; d weight = sign(weight) * sum dz*x_hat  (gamma' = |weight| + eps)
 template <typename T>
-__global__ __launch_bounds__(TPB) void iabn_bwd_partial(const T* __restrict__ y, const T* __restrict__ dy, long M, int C,
-                                                        const float* __restrict__ weight, const float* __restrict__ bias,
-                                                        float eps, int leaky, float slope, float* partials) {
+__global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dy, long M, int C,
+                                                              const float* __restrict__ weight, const float* __restrict__ bias,
+                                                              float eps, int leaky, float slope, float* ws, unsigned* counter,
+                                                              float* sums, float* dwb) {
     constexpr int V = Vec<T>::N;
     const float inv_slope = 1.f / slope;
-    column_sums2<T>(M, C, partials, [&](long r, int c0, float (&a)[V], float (&b)[V]) {
-        float yv[V], gv[V];
-        Vec<T>::load(y + r * C + c0, yv);
-        Vec<T>::load(dy + r * C + c0, gv);
+    const int c0t = (threadIdx.x % (C / V)) * V;   // this thread's channels never change
+    float bk[V], igk[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            float z = yv[k], dz = gv[k];
-            if (leaky && z < 0.f) { z *= inv_slope; dz *= slope; }
-            const float xh = (z - bias[c0 + k]) / (fabsf(weight[c0 + k]) + eps);
-            a[k] += dz;
-            b[k] += dz * xh;
-        }
-    });
-}
-
-__global__ void iabn_bwd_final(const float* partials, int nblk, int C, const float* weight, float* sums, float* dwb) {
-    const int c = blockIdx.x * 32 + threadIdx.x;
-    float s1, s2;
-    reduce_partials(partials, nblk, C, c, threadIdx.y, s1, s2);
-    if (c >= C || threadIdx.y != 0) return;
-    sums[c] = s1;
-    sums[C + c] = s2;
-    if (dwb) {  // local parameter gradients: d bias = sum dz ; d weight = sign(weight) * sum dz*x_hat  (gamma' = |weight| + eps)
-        const float w = weight[c];
-        dwb[c] = s2 * (float)((w > 0.f) - (w < 0.f));
-        dwb[C + c] = s1;
+    for (int k = 0; k < V; ++k) {
+        bk[k] = bias[c0t + k];
+        igk[k] = 1.f / (fabsf(weight[c0t + k]) + eps);
     }
+    column_sums2<T>(M, C, ws, counter,
+        [&](long r, int c0, typename Vec<T>::Raw (&q)[2]) {
+            q[0] = Vec<T>::load_raw(y + r * C + c0);
+            q[1] = Vec<T>::load_raw(dy + r * C + c0);
+        },
+        [&](const typename Vec<T>::Raw (&q)[2], float (&a)[V], float (&b)[V]) {
+            float yv[V], gv[V];
+            Vec<T>::unpack(q[0], yv);
+            Vec<T>::unpack(q[1], gv);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float z = yv[k], dz = gv[k];
+                if (leaky && z < 0.f) { z *= inv_slope; dz *= slope; }
+                a[k] += dz;
+                b[k] += dz * ((z - bk[k]) * igk[k]);
+            }
+        },
+        [&](int c, float s1, float s2) {
+            sums[c] = s1;
+            sums[C + c] = s2;
+            if (dwb) {
+                const float w = weight[c];
+                dwb[c] = s2 * (float)((w > 0.f) - (w < 0.f));
+                dwb[C + c] = s1;
+            }
+        });
 }
 
 // backward pass 2: dx = gamma' * rstd * (dz - sum_dz/n - x_hat * sum_dzxh/n)     (sums are GLOBAL over ranks, n too)
@@ -258,22 +363,39 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_apply(const T* __restrict__ y, c
     const long nvec = M * C / V;
     const int cv = C / V;
     const float inv_slope = 1.f / slope;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cv) * V;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    const int c0 = (int)(i0 % cv) * V;   // fixed per thread (the stride is a multiple of C/V)
+    // dx = A * (dz - m1) - (z - beta) * B   with A = gamma' * rstd, m1 = sum_dz / n, B = rstd * sum_dzxh / n
+    float A[V], m1[V], Bc[V], bk[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int c = c0 + k;
+        const float g = fabsf(weight[c]) + eps, rstd = saved[C + c];
+        A[k] = g * rstd;
+        m1[k] = sums[c] * inv_n;
+        Bc[k] = rstd * sums[C + c] * inv_n;
+        bk[k] = bias[c];
+    }
+    auto body = [&](const typename Vec<T>::Raw& qy, const typename Vec<T>::Raw& qg, long i) {
         float yv[V], gv[V];
-        Vec<T>::load(y + i * V, yv);
-        Vec<T>::load(dy + i * V, gv);
+        Vec<T>::unpack(qy, yv);
+        Vec<T>::unpack(qg, gv);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const int c = c0 + k;
             float z = yv[k], dz = gv[k];
             if (leaky && z < 0.f) { z *= inv_slope; dz *= slope; }
-            const float g = fabsf(weight[c]) + eps;
-            const float xh = (z - bias[c]) / g;
-            gv[k] = g * saved[C + c] * (dz - sums[c] * inv_n - xh * sums[C + c] * inv_n);
+            gv[k] = A[k] * (dz - m1[k]) - (z - bk[k]) * Bc[k];
         }
         Vec<T>::store(dx + i * V, gv);
+    };
+    long i = i0;
+    for (; i + stride < nvec; i += 2 * stride) {
+        const typename Vec<T>::Raw y0 = Vec<T>::load_raw(y + i * V), g0 = Vec<T>::load_raw(dy + i * V);
+        const typename Vec<T>::Raw y1 = Vec<T>::load_raw(y + (i + stride) * V), g1 = Vec<T>::load_raw(dy + (i + stride) * V);
+        body(y0, g0, i);
+        body(y1, g1, i + stride);
     }
+    if (i < nvec) body(Vec<T>::load_raw(y + i * V), Vec<T>::load_raw(dy + i * V), i);
 }
 
 inline int grid_for(long nvec) {
@@ -291,8 +413,22 @@ inline int check_shape(long M, int C, int dtype) {
 inline int stat_blocks(long M, int C, int dtype) {
     const int V = dtype == 1 ? 8 : 4;
     const int rpb = TPB / (C / V);
-    long b = (M + (long)rpb * 8 - 1) / ((long)rpb * 8);  // >= 8 rows per thread before adding blocks
-    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+    long b = (M + (long)rpb * 64 - 1) / ((long)rpb * 64);  // >= 64 rows (16 four-deep iterations) per thread before adding blocks
+    return (int)(b < 1 ? 1 : (b > MAX_STAT_BLOCKS ? MAX_STAT_BLOCKS : b));
+}
+
+// Ticket counters of the single-launch reductions: a library-owned, zero-initialised pool per device; every launch
+// takes the next slot (concurrent launches on different streams never share one) and the kernel leaves it at zero.
+unsigned* next_counter() {
+    static unsigned* pool[64] = {};
+    static unsigned next[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pool[dev]) {
+        if (hipMalloc((void**)&pool[dev], 4096 * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(pool[dev], 0, 4096 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    }
+    return pool[dev] + (next[dev]++ & 4095);
 }
 
 }  // namespace
@@ -314,13 +450,27 @@ int mgn_iabn_stats(const void* x, int dtype, long M, int C, float* stats, void* 
     if (ws_bytes < sizeof(float) * 2 * (size_t)C * 1024) return MGN_ENOSPC;
     hipStream_t s = (hipStream_t)stream_;
     const int nb = stat_blocks(M, C, dtype);
-    if (dtype == 1) {
-        hipLaunchKernelGGL(iabn_stats_partial<__hip_bfloat16>, dim3(nb), dim3(TPB), 0, s, (const __hip_bfloat16*)x, M, C, (float*)ws);
-        hipLaunchKernelGGL(iabn_stats_final<__hip_bfloat16>, dim3((C + 31) / 32), dim3(32, 8), 0, s, (const __hip_bfloat16*)x, (const float*)ws, nb, M, C, stats);
-    } else {
-        hipLaunchKernelGGL(iabn_stats_partial<float>, dim3(nb), dim3(TPB), 0, s, (const float*)x, M, C, (float*)ws);
-        hipLaunchKernelGGL(iabn_stats_final<float>, dim3((C + 31) / 32), dim3(32, 8), 0, s, (const float*)x, (const float*)ws, nb, M, C, stats);
-    }
+    unsigned* ctr = next_counter();
+    if (!ctr) return MGN_ELAUNCH;
+    StatsOut o = {stats, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
+    if (dtype == 1) hipLaunchKernelGGL(iabn_stats_kernel<__hip_bfloat16>, dim3(nb), dim3(TPB), 0, s, (const __hip_bfloat16*)x, M, C, (float*)ws, ctr, o);
+    else hipLaunchKernelGGL(iabn_stats_kernel<float>, dim3(nb), dim3(TPB), 0, s, (const float*)x, M, C, (float*)ws, ctr, o);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_iabn_train_coeffs(const void* x, int dtype, long M, int C, const float* weight, const float* bias, float eps, float momentum,
+                          float* running_mean, float* running_var, float* coef, void* ws, size_t ws_bytes, void* stream_) {
+    int rc = check_shape(M, C, dtype);
+    if (rc != MGN_OK) return rc;
+    if (!x || !weight || !bias || !coef || !ws) return MGN_EINVAL;
+    if (ws_bytes < sizeof(float) * 2 * (size_t)C * 1024) return MGN_ENOSPC;
+    hipStream_t s = (hipStream_t)stream_;
+    const int nb = stat_blocks(M, C, dtype);
+    unsigned* ctr = next_counter();
+    if (!ctr) return MGN_ELAUNCH;
+    StatsOut o = {nullptr, coef, weight, bias, running_mean, running_var, eps, momentum};
+    if (dtype == 1) hipLaunchKernelGGL(iabn_stats_kernel<__hip_bfloat16>, dim3(nb), dim3(TPB), 0, s, (const __hip_bfloat16*)x, M, C, (float*)ws, ctr, o);
+    else hipLaunchKernelGGL(iabn_stats_kernel<float>, dim3(nb), dim3(TPB), 0, s, (const float*)x, M, C, (float*)ws, ctr, o);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -364,13 +514,14 @@ int mgn_iabn_bwd_reduce(const void* y, const void* dy, int dtype, long M, int C,
     if (ws_bytes < sizeof(float) * 2 * (size_t)C * 1024) return MGN_ENOSPC;
     hipStream_t s = (hipStream_t)stream_;
     const int nb = stat_blocks(M, C, dtype);
+    unsigned* ctr = next_counter();
+    if (!ctr) return MGN_ELAUNCH;
     if (dtype == 1)
-        hipLaunchKernelGGL(iabn_bwd_partial<__hip_bfloat16>, dim3(nb), dim3(TPB), 0, s, (const __hip_bfloat16*)y,
-                           (const __hip_bfloat16*)dy, M, C, weight, bias, eps, activation, slope, (float*)ws);
+        hipLaunchKernelGGL(iabn_bwd_reduce_kernel<__hip_bfloat16>, dim3(nb), dim3(TPB), 0, s, (const __hip_bfloat16*)y,
+                           (const __hip_bfloat16*)dy, M, C, weight, bias, eps, activation, slope, (float*)ws, ctr, sums, dwb);
     else
-        hipLaunchKernelGGL(iabn_bwd_partial<float>, dim3(nb), dim3(TPB), 0, s, (const float*)y, (const float*)dy, M, C, weight, bias,
-                           eps, activation, slope, (float*)ws);
-    hipLaunchKernelGGL(iabn_bwd_final, dim3((C + 31) / 32), dim3(32, 8), 0, s, (const float*)ws, nb, C, weight, sums, dwb);
+        hipLaunchKernelGGL(iabn_bwd_reduce_kernel<float>, dim3(nb), dim3(TPB), 0, s, (const float*)y, (const float*)dy, M, C, weight,
+                           bias, eps, activation, slope, (float*)ws, ctr, sums, dwb);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

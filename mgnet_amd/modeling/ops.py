@@ -50,13 +50,13 @@ class _IABNFn(torch.autograd.Function):
         w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
         world = dist.get_world_size(group) if _dist_active(group) else 1
         if training:
-            stats = _C.iabn_stats(xs, M, C)
             if world > 1:
+                stats = _C.iabn_stats(xs, M, C)
                 gathered = torch.empty((world, 3, C), dtype=torch.float32, device=x.device)
                 dist.all_gather(list(gathered.unbind(0)), stats, group=group)  # (list form: also available on gloo)
-            else:
-                gathered = stats.unsqueeze(0)
-            coef = _C.iabn_combine(gathered, w32, b32, eps, momentum, running_mean, running_var)
+                coef = _C.iabn_combine(gathered, w32, b32, eps, momentum, running_mean, running_var)
+            else:  # one process: statistics and coefficients in one launch
+                coef = _C.iabn_train_coeffs(xs, M, C, w32, b32, eps, momentum, running_mean, running_var)
             # every rank holds the same number of pixels (same per-GPU batch shape), as in the reference's DDP recipe;
             # the forward statistics themselves are combined with the true per-rank counts (Chan), this is only the
             # 1/n of the backward and avoids a host sync per layer
