@@ -373,6 +373,289 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// conv_igemm_big: the same LDS-DMA pipeline with a 256(M) x BN(N) block tile, BN = 64*NWN (128 or 256), 2 x NWN waves of
+// 128 x 64 each (4 x 2 MFMA tiles: 6 fragment reads per 8 MFMAs instead of 8, half the L2->LDS bytes per flop of the
+// 128 x 128 tile).  BK = 32, ring of three 16 KB + BN*64 B stages, two k-steps in flight across the raw barrier.
+// Used when the layer has enough 256-pixel tiles to fill the chip (host dispatch).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NWN>
+struct IgemmBig {
+    static constexpr int BMB = 256, BN = 64 * NWN, NW = 2 * NWN, THREADS = 64 * NW;
+    static constexpr int ATILE = BMB * 64, BTILE = BN * 64, STAGE = ATILE + BTILE, LDS = 3 * STAGE;
+    static constexpr int PA = (BMB / 16) / NW, PB = (BN / 16) / NW;   // 1-KB DMA pieces (16 rows x 64 B) per wave and stage
+};
+
+template <int NWN>
+__device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
+    using C = IgemmBig<NWN>;
+    constexpr int PA = C::PA, PB = C::PB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / NWN, wn = wave % NWN;
+    const int bm = blockIdx.x, bn = blockIdx.y;
+    const long M = (long)p.N * p.OH * p.OW;
+    const int lrow = lane >> 2, seg = lane & 3;   // row inside a 16-row piece, 16-byte slot
+
+    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * p.KH * p.KW * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, w_bytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+
+    // piece q of wave w covers tile rows (w + NW*q)*16 .. +16
+    int ihb[PA], iwb[PA], abase[PA], wbase[PB];
+    bool vm[PA];
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+        const int row = (wave + C::NW * q) * 16 + lrow;
+        const int sseg = seg ^ ((row >> 2) & 3);
+        const long m = (long)bm * C::BMB + row;
+        vm[q] = m < M;
+        const long mm = vm[q] ? m : 0;
+        const int n = (int)(mm / ((long)p.OH * p.OW));
+        const int rem = (int)(mm - (long)n * p.OH * p.OW);
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        ihb[q] = oh * p.stride - p.pad;
+        iwb[q] = ow * p.stride - p.pad;
+        abase[q] = (n * p.IH * p.IW * p.Cin + sseg * 8) * 2;
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int row = (wave + C::NW * q) * 16 + lrow;
+        const int sseg = seg ^ ((row >> 2) & 3);
+        const int co = bn * C::BN + row;
+        wbase[q] = co < p.Cout ? (co * p.KH * p.KW * p.Cin + sseg * 8) * 2 : OOB;
+    }
+    const int cpt = p.Cin / 32;
+    const int ksteps = p.KH * p.KW * cpt;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int kh = 0, kw = 0, cc = 0;
+    int avoff[PA], wtap = 0;
+    auto set_tap = [&]() {
+        wtap = (kh * p.KW + kw) * p.Cin * 2;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            int th = ihb[q] + kh, tw = iwb[q] + kw;
+            bool ok = vm[q];
+            if (p.up > 1) {
+                ok = ok && th >= 0 && tw >= 0 && (th % p.up == 0) && (tw % p.up == 0);
+                th /= p.up;
+                tw /= p.up;
+            }
+            ok = ok && th >= 0 && th < p.IH && tw >= 0 && tw < p.IW;
+            avoff[q] = ok ? abase[q] + (th * p.IW + tw) * p.Cin * 2 : OOB;
+        }
+    };
+    set_tap();
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue = [&](int buf) {
+        const int soff = cc * 64;
+        unsigned char* a0 = bsm + buf * C::STAGE;
+        unsigned char* b0 = a0 + C::ATILE;
+#pragma unroll
+        for (int q = 0; q < PA; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a0 + (wave + C::NW * q) * 1024), 16, avoff[q], soff, 0, 0);
+#pragma unroll
+        for (int q = 0; q < PB; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b0 + (wave + C::NW * q) * 1024), 16, wbase[q] == OOB ? OOB : wbase[q] + wtap, soff, 0, 0);
+        if (++cc == cpt) {
+            cc = 0;
+            if (++kw == p.KW) { kw = 0; ++kh; }
+            set_tap();
+        }
+    };
+
+    issue(0);
+    if (ksteps > 1) issue(1);
+    int buf = 0;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        if (ks + 1 < ksteps) {
+            if (PA + PB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (ks + 2 < ksteps) issue(buf == 0 ? 2 : buf - 1);  // (ks+2) % 3
+        const unsigned char* sA = bsm + buf * C::STAGE;
+        mma_tile<4, 2, 2, 64, true, true>(sA, sA + C::ATILE, wm, wn, lane, acc);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    const bool vec_ok = (p.Cout % 4) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = (long)bm * C::BMB + wm * 128 + i * 32 + (lane & 31);
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = bn * C::BN + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][q * 4 + e] + ((p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f);
+                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (vec_ok) {
+                    if (p.out_f32)
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * p.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + m * p.Cout + co) =
+                            make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= p.Cout) break;
+                        if (p.out_f32) reinterpret_cast<float*>(p.out)[m * p.Cout + co + e] = v[e];
+                        else reinterpret_cast<uint16_t*>(p.out)[m * p.Cout + co + e] = f2bf(v[e]);
+                    }
+                }
+            }
+    }
+}
+__global__ __launch_bounds__(256, 2) void conv_igemm_big128(ConvParams p) { igemm_big_body<2>(p); }
+__global__ __launch_bounds__(512, 1) void conv_igemm_big256(ConvParams p) { igemm_big_body<4>(p); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv3x3_c64: 3x3 / stride 1 / pad 1 convolution with 64 input channels (ResNet layer1 forward and data gradient, 16
+// launches per step), row march with the WEIGHTS IN REGISTERS.
+//
+// With only 64 output channels per tile the implicit-GEMM kernels are bound by staging the gathered A operand (every input
+// element is fetched 9 times, once per tap, and used 64 times).  Here a block owns a 128-pixel strip of one image and
+// marches down its rows: input rows live in an LDS ring ([pixel][64 ch], filled by LDS-DMA, zero padding from the
+// buffer bounds), a tap is an address offset into the ring (each input row is fetched from HBM once), and every wave
+// keeps its 32 output channels x 576 reduction elements of the weights in 144 VGPRs for the whole march, so the only
+// LDS traffic is one ds_read_b128 per MFMA.  8 waves = 4 pixel groups x 2 channel halves; 36 MFMAs per wave and row;
+// rows are prefetched two steps ahead (ring of 5), output rows are stored straight from the accumulators.
+// ---------------------------------------------------------------------------------------------------------------
+struct Conv64Params {
+    const uint16_t* in;    // [N, H, W, 64] bf16
+    const uint16_t* w;     // [Cout, 3, 3, 64] bf16
+    uint16_t* out;         // [N, H, W, Cout] bf16
+    int N, H, W, Cout;
+    int strips, chunks, rows_per_chunk, nslices, co_tiles;
+};
+constexpr int C64_INROW = 136 * 128, C64_LDS = 5 * C64_INROW;
+
+__global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char c64sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpx = wave >> 1, wco = wave & 1;
+    const int L = blockIdx.x, q = L >> 3;
+    const int slice = (q / p.co_tiles) * 8 + (L & 7), tile = q % p.co_tiles;
+    if (slice >= p.nslices) return;
+    int s = slice;
+    const int chunk = s % p.chunks; s /= p.chunks;
+    const int strip = s % p.strips, n = s / p.strips;
+    const int ow0 = strip * 128;
+    const int r0 = chunk * p.rows_per_chunk, r1 = r0 + p.rows_per_chunk < p.H ? r0 + p.rows_per_chunk : p.H;
+    const int co_w = tile * 64 + wco * 32;   // this wave's 32 output channels
+
+    // weights -> registers: fragment (tap, kk) = W[co_w + (lane & 31)][tap][kk*16 + 8*(lane>>5) .. +7]
+    bf16x8 wr[36];
+    {
+        const uint16_t* wp = p.w + ((size_t)(co_w + (lane & 31)) * 9) * 64 + 8 * (lane >> 5);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wr[t * 4 + kk] = *reinterpret_cast<const bf16x8*>(wp + t * 64 + kk * 16);
+    }
+
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, (uint32_t)((size_t)p.N * p.H * p.W * 64 * 2), 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // LDS-DMA plan: 17 one-KB pieces (8 pixels x 128 B) per input row; wave w issues pieces w, w+8, w+16
+    int voff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = wave + 8 * i;
+        const int px = 8 * j + (lane >> 3);
+        const int seg = (lane & 7) ^ ((px >> 1) & 7);
+        const int iw = ow0 - 1 + px;
+        voff[i] = (j < 17 && iw >= 0 && iw < p.W) ? (iw * 64 + seg * 8) * 2 : OOB;
+    }
+    auto issue_in = [&](int ih, int slot) {
+        const bool ok = ih >= 0 && ih < p.H;
+        const int soff = ok ? ((n * p.H + ih) * p.W) * 128 : 0;
+        unsigned char* base = c64sm + slot * C64_INROW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = wave + 8 * i;
+            if (j < 17) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(base + j * 1024), 16, ok ? voff[i] : OOB, soff, 0, 0);
+        }
+    };
+    const int my_cnt = wave == 0 ? 3 : 2;
+
+    // A-fragment (pixel) addresses for the three kw shifts: patch pixel = 32*wpx + (lane & 31) + kw
+    int abase[3], asw[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int px = 32 * wpx + (lane & 31) + kw;
+        abase[kw] = px * 128;
+        asw[kw] = (px >> 1) & 7;
+    }
+    const int hi = lane >> 5;
+
+    issue_in(r0 - 1, 0);
+    issue_in(r0, 1);
+    issue_in(r0 + 1, 2);
+    issue_in(r0 + 2, 3);
+    int si = 0;  // slot of input row r-1
+    const int opx = ow0 + 32 * wpx + (lane & 31);
+    const bool wstore = ow0 + 32 * wpx < p.W;   // wave-uniform: does this wave issue output stores at all
+    for (int r = r0; r < r1; ++r) {
+        // rows up to r+1 must have landed; the row issued last (r+2) and the previous step's 4 output stores may be in flight
+        if (r == r0 || !wstore) {
+            if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        issue_in(r + 3, si + 4 >= 5 ? si - 1 : si + 4);   // (always issued: rows past the chunk land in unused slots)
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int sl = si + kh >= 5 ? si + kh - 5 : si + kh;
+            const unsigned char* rowp = c64sm + sl * C64_INROW;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowp + abase[kw] + ((((kk * 2 + hi) ^ asw[kw])) << 4));
+                    const int idx = (kh * 3 + kw) * 4 + kk;
+                    if (idx & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], a, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], a, acc0, 0, 0, 0);
+                }
+            }
+        }
+        // D = W-rows x pixels: col = lane & 31 -> pixel, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel
+        if (opx < p.W) {
+            uint16_t* orow = p.out + ((size_t)(n * p.H + r) * p.W + opx) * p.Cout + co_w + 4 * hi;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float v0 = acc0[qd * 4 + 0] + acc1[qd * 4 + 0], v1 = acc0[qd * 4 + 1] + acc1[qd * 4 + 1];
+                const float v2 = acc0[qd * 4 + 2] + acc1[qd * 4 + 2], v3 = acc0[qd * 4 + 3] + acc1[qd * 4 + 3];
+                *reinterpret_cast<uint2*>(orow + 8 * qd) =
+                    make_uint2((uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16));
+            }
+        }
+        si = si + 1 >= 5 ? 0 : si + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------------
 struct WgradParams {
@@ -813,7 +1096,54 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
     if (pack) {
         if (Cout <= 64) hipLaunchKernelGGL((conv_igemm<1, 2, true>), dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm<2, 2, true>), dim3((unsigned)gx, (Cout + 127) / 128), dim3(256), 0, st, p);
+    } else if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 1 && Cin == 64 && Cout % 64 == 0 && IH == OH && IW == OW && !bias &&
+               !relu && !out_f32 && (size_t)N * OH * OW * (Cout > 64 ? Cout : 64) * 2 < 0x7fffffffu && !getenv("MGN_CONV_NOC64")) {
+        Conv64Params q;
+        q.in = p.in; q.w = p.w; q.out = (uint16_t*)out; q.N = N; q.H = OH; q.W = OW; q.Cout = Cout;
+        q.strips = (OW + 127) / 128; q.co_tiles = Cout / 64;
+        int chunks = (256 / q.co_tiles) / (N * q.strips);      // one 8-wave block per CU
+        if (chunks > OH / 4) chunks = OH / 4;
+        if (chunks < 1) chunks = 1;
+        q.rows_per_chunk = (OH + chunks - 1) / chunks;
+        q.chunks = (OH + q.rows_per_chunk - 1) / q.rows_per_chunk;
+        q.nslices = N * q.strips * q.chunks;
+        static bool cattr = false;
+        if (!cattr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+            cattr = true;
+        }
+        hipLaunchKernelGGL(conv3x3_c64, dim3((unsigned)((q.nslices + 7) / 8) * 8 * q.co_tiles), dim3(512), C64_LDS, st, q);
+        return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
     } else if (!getenv("MGN_CONV_NOGLDS")) {
+        // big tiles when there are enough of them to fill 256 CUs (BN = 256: one 8-wave block per CU; BN = 128: two)
+        const long gxb = (M + 255) / 256;
+        static bool battr = false;
+        if (!battr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_big128), hipFuncAttributeMaxDynamicSharedMemorySize, IgemmBig<2>::LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_big256), hipFuncAttributeMaxDynamicSharedMemorySize, IgemmBig<4>::LDS);
+            battr = true;
+        }
+        const char* ebig = getenv("MGN_CONV_BIG");   // "0" disables, "128"/"256" force a tile
+        const int fbig = ebig ? atoi(ebig) : -1;
+        if (fbig != 0 && Cout % 128 == 0) {
+            const bool can256 = Cout % 256 == 0;
+            const long blocks256 = gxb * (Cout / 256 > 0 ? Cout / 256 : 1), blocks128 = gxb * (Cout / 128);
+            int pick = 0;
+            if (fbig == 256 && can256) pick = 256;
+            else if (fbig == 128) pick = 128;
+            else if (fbig < 0) {
+                if (can256 && blocks256 >= 200) pick = 256;
+                // (BN = 128 measured slower than the 128 x 128 kernel on the 128-channel layers: only on request)
+            }
+            if (pick == 256) {
+                hipLaunchKernelGGL(conv_igemm_big256, dim3((unsigned)gxb, Cout / 256), dim3(512), IgemmBig<4>::LDS, st, p);
+                return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+            }
+            if (pick == 128) {
+                hipLaunchKernelGGL(conv_igemm_big128, dim3((unsigned)gxb, Cout / 128), dim3(256), IgemmBig<2>::LDS, st, p);
+                return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+            }
+        }
         if (Cout <= 64) hipLaunchKernelGGL((conv_igemm_glds<1>), dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm_glds<2>), dim3((unsigned)gx, (Cout + 127) / 128), dim3(256), 0, st, p);
     } else if (Cout <= 64) {

@@ -112,3 +112,31 @@ def test_prep_input_matches_reference_normalisation():
     assert float(out16[:, 9:].abs().max()) == 0.0
     out8 = _C.prep_input([frames[0].cuda()], mean, std, 8)
     assert torch.equal(out8[:, :3], out16[:, :3]) and float(out8[:, 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("big,case", [("256", (1, 64, 256, 19, 23, 3, 1, 1)), ("256", (2, 128, 512, 9, 14, 3, 2, 1)),
+                                      ("128", (1, 256, 128, 21, 17, 3, 1, 1)), ("128", (2, 64, 128, 16, 24, 1, 2, 0)),
+                                      ("256", (1, 256, 256, 8, 40, 1, 1, 0))])
+def test_big_tile_igemm(monkeypatch, big, case):
+    """conv_igemm_big (256 x 128|256 block tiles), forced through MGN_CONV_BIG on shapes with ragged pixel tails:
+    forward and data gradient (stride 2 exercises the `up` gather) against F.conv2d in fp64."""
+    from mgnet_amd.modeling import ops
+
+    monkeypatch.setenv("MGN_CONV_BIG", big)
+    N, Cin, Cout, H, W, k, s, p = case
+    torch.manual_seed(sum(case))
+    x0 = torch.randn(N, Cin, H, W).to(torch.bfloat16)
+    w0 = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    w_r = w0.to(torch.bfloat16).double().requires_grad_(True)
+    x_r = x0.double().requires_grad_(True)
+    y_r = F.conv2d(x_r, w_r, None, stride=s, padding=p)
+    g0 = torch.randn(*y_r.shape).to(torch.bfloat16)
+    (y_r * g0.double()).sum().backward()
+    x = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = w0.cuda().requires_grad_(True)
+    y = ops.conv2d(x, w, None, stride=s, padding=p)
+    (y.float() * g0.cuda().float()).sum().backward()
+
+    def rel(a, r):
+        return float((a.detach().float().cpu().double() - r).abs().max() / (r.abs().max() + 1e-12))
+    assert rel(y, y_r.detach()) < 1e-2 and rel(x.grad, x_r.grad) < 1e-2 and rel(w.grad, w_r.grad) < 2e-3
