@@ -1021,6 +1021,207 @@ __device__ __forceinline__ void wgrad3x3_body(const Wgrad3Params& p) {
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_s64(Wgrad3Params p) { wgrad3x3_body<1>(p); }
 __global__ __launch_bounds__(512, 1) void conv_wgrad3x3_s128(Wgrad3Params p) { wgrad3x3_body<2>(p); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// conv_wgrad_stem: weight gradient of the 7x7 / stride 2 / pad 3 stems on the channel-padded input (CP = 8 or 16), same
+// construction as conv_wgrad3x3: a block marches down a 128-output-pixel strip; the input rows (natural [pixel][CP]
+// order, 7 + 4 rows in a ring of 11, two new rows per step) and the dOut rows ([pixel][64], ring of 3) arrive by LDS-DMA,
+// fragments are gathered with ds_read_b64_tr_b16 (K = output pixels; the stride-2 gather is only a per-lane address).
+// dW columns of one kernel row kh are laid out as [8 kw slots][CP] (slot 7 is padding): a 16-column fragment block is
+// then 32 CONTIGUOUS input bytes for either CP, and a kernel row is 4 (CP=16) or 2 (CP=8) 32-column MFMA tiles.
+// 8 waves x 7 accumulator tiles: CP=16: 2 co halves x 4 groups of 7 of the 28 column tiles; CP=8: 2 co halves x 2 groups
+// of 7 of the 14 column tiles x 2 pixel halves (summed through LDS at the end).
+// ---------------------------------------------------------------------------------------------------------------
+struct WgradStemParams {
+    const uint16_t* dout;  // [N, OH, OW, Cout] bf16
+    const uint16_t* in;    // [N, IH, IW, CP] bf16
+    float* partial;        // [nslices][Cout][7][8*CP]
+    int N, IH, IW, OH, OW, Cout;
+    int strips, chunks, rows_per_chunk, nslices, co_tiles;
+};
+template <int CP>
+struct WS {
+    static constexpr int PIN = CP == 16 ? 9 : 5;      // 1-KB pieces per input row of the strip (262 pixels)
+    static constexpr int INROW = PIN * 1024, OUTROW = 128 * 128, POUT = 16;
+    static constexpr int NIN = 11, NOUT = 3, LDS = NIN * INROW + NOUT * OUTROW;
+    static constexpr int PXG = CP == 16 ? 1 : 2, TPK = CP == 16 ? 4 : 2;   // pixel groups, 32-column tiles per kernel row
+    static constexpr int KSW = 8 / PXG;               // 16-pixel k-steps per wave and row
+    static constexpr int PXB = CP * 2;                // bytes per input pixel
+};
+
+template <int CP>
+__device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
+    using C = WS<CP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wssm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1;
+    const int ngrp = CP == 16 ? wave >> 1 : (wave >> 1) & 1, pxg = CP == 16 ? 0 : wave >> 2;
+    const int L = blockIdx.x, q8 = L >> 3;
+    const int slice = (q8 / p.co_tiles) * 8 + (L & 7), tile = q8 % p.co_tiles;
+    if (slice >= p.nslices) return;
+    const int co0 = tile * 64;
+    int s = slice;
+    const int chunk = s % p.chunks; s /= p.chunks;
+    const int strip = s % p.strips, n = s / p.strips;
+    const int ow0 = strip * 128;
+    const int r0 = chunk * p.rows_per_chunk, r1 = r0 + p.rows_per_chunk < p.OH ? r0 + p.rows_per_chunk : p.OH;
+
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dout), 0, (uint32_t)((size_t)p.N * p.OH * p.OW * p.Cout * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, (uint32_t)((size_t)p.N * p.IH * p.IW * C::PXB), 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    // LDS-DMA plan.  Input row pieces j (1 KB = a contiguous run of the image row, starting at column 2*ow0 - 3) go to
+    // wave (j + rot) % 8 (rot = 0 / 4 for the two rows of a step); dOut pieces jj to wave jj % 8.
+    int vin[2], vout[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // input piece index for this wave is resolved at issue time (depends on rot); the lane part is fixed:
+        vin[i] = 0;
+        const int jj = wave + 8 * i;
+        const int px = 8 * jj + (lane >> 3);
+        const int seg = (lane & 7) ^ (((px >> 1) & 1) << 2);
+        const int ow = ow0 + px;
+        vout[i] = ow < p.OW ? (ow * p.Cout + co0 + seg * 8) * 2 : OOB;
+    }
+    (void)vin;
+    const int iw_base = 2 * ow0 - 3;
+    auto issue_in = [&](int ih, int slot, int rot) {
+        const bool ok = ih >= 0 && ih < p.IH;
+        const int soff = ok ? ((n * p.IH + ih) * p.IW) * C::PXB : 0;
+        unsigned char* base = wssm + slot * C::INROW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = ((wave - rot) & 7) + 8 * i;
+            if (j < C::PIN) {
+                const int boff = j * 1024 + lane * 16;
+                const int iw = iw_base + boff / C::PXB;
+                const int vo = (ok && iw >= 0 && iw < p.IW) ? iw_base * C::PXB + boff : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(base + j * 1024), 16, vo, soff, 0, 0);
+            }
+        }
+    };
+    auto issue_out = [&](int oh, int slot) {
+        const bool ok = oh < p.OH;
+        const int soff = ok ? ((n * p.OH + oh) * p.OW) * p.Cout * 2 : 0;
+        unsigned char* base = wssm + C::NIN * C::INROW + slot * C::OUTROW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lds_ptr)(base + (wave + 8 * i) * 1024), 16, ok ? vout[i] : OOB, soff, 0, 0);
+    };
+    int my_cnt = 2;  // pieces per step of this wave: 2 dOut + the input pieces of both rows
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (((wave - 0) & 7) + 8 * i < C::PIN) ++my_cnt;
+        if (((wave - 4) & 7) + 8 * i < C::PIN) ++my_cnt;
+    }
+
+    // fragment addresses.  A (dOut): pixel rows, co columns.  B (input): rows = output pixels -> input pixel 2*px (+kw
+    // through the column block), columns = 32-byte blocks of the kernel row.
+    const int g = lane >> 4, i4 = lane & 15;
+    const int prow = pxg * 64 + 8 * (g >> 1) + (i4 >> 2);
+    auto lds_off = [](int px, int ch) { return px * 128 + ((((ch >> 3) ^ (((px >> 1) & 1) << 2))) << 4) + (ch & 7) * 2; };
+    const int aA = C::NIN * C::INROW + lds_off(prow, wm * 32 + (g & 1) * 16 + 4 * (i4 & 3));
+    const int bB = 2 * prow * C::PXB + 32 * (g & 1) + 8 * (i4 & 3);
+    typedef __attribute__((address_space(3))) s16x4* lp;
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // ring slots: input row ih -> (ih - (2*r0 - 3)) % 11, dOut row oh -> (oh - r0) % 3
+    for (int k = 0; k < 7; ++k) issue_in(2 * r0 - 3 + k, k, (k & 1) * 4);
+    issue_out(r0, 0);
+    issue_in(2 * r0 + 4, 7, 0);
+    issue_in(2 * r0 + 5, 8, 4);
+    issue_out(r0 + 1, 1);
+    int s0 = 0, so = 0;  // slots of input row 2r-3 and dOut row r
+    for (int r = r0; r < r1; ++r) {
+        if (my_cnt == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (my_cnt == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (my_cnt == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {   // rows of step r+2 (always issued: out-of-range rows read as zeros into slots nobody uses)
+            const int sa = s0 + 9 >= 11 ? s0 - 2 : s0 + 9, sb = s0 + 10 >= 11 ? s0 - 1 : s0 + 10;
+            issue_in(2 * r + 6, sa, 0);
+            issue_in(2 * r + 7, sb, 4);
+            issue_out(r + 2, so + 2 >= 3 ? so - 1 : so + 2);
+        }
+        const unsigned char* sa_ = wssm + aA + so * C::OUTROW;
+#pragma unroll
+        for (int ks = 0; ks < C::KSW; ++ks) {
+            const bf16x8 a = tr_frag(sa_ + ks * 2048);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int t = ngrp * 7 + i, kh = t / C::TPK, qq = t % C::TPK;
+                const int sl = s0 + kh >= 11 ? s0 + kh - 11 : s0 + kh;
+                const unsigned char* bp = wssm + sl * C::INROW + bB + qq * 64 + ks * (32 * C::PXB);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bp));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bp + 8 * C::PXB));
+                const bf16x8 b = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+            }
+        }
+        s0 = s0 + 2 >= 11 ? s0 - 9 : s0 + 2;
+        so = so + 1 >= 3 ? 0 : so + 1;
+    }
+    if (C::PXG == 2) {  // sum the two pixel halves: 3 tiles at a time through the (now idle) ring memory
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* red = reinterpret_cast<float*>(wssm);
+        const int t256 = tid & 255;
+#pragma unroll
+        for (int tb = 0; tb < 7; tb += 3) {
+            __syncthreads();
+            if (pxg == 1) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (tb + t < 7)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) red[(t * 16 + e) * 256 + t256] = acc[tb + t][e];
+            }
+            __syncthreads();
+            if (pxg == 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (tb + t < 7)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[tb + t][e] += red[(t * 16 + e) * 256 + t256];
+            }
+        }
+        if (pxg == 1) return;
+    }
+    const size_t rowf = (size_t)7 * 8 * CP;                      // floats per output channel
+    float* dst = p.partial + (size_t)slice * p.Cout * rowf;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int t = ngrp * 7 + i, kh = t / C::TPK, qq = t % C::TPK;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            dst[(size_t)co * rowf + kh * 8 * CP + qq * 32 + (lane & 31)] = acc[i][e];
+        }
+    }
+}
+__global__ __launch_bounds__(512, 1) void conv_wgrad_stem16(WgradStemParams p) { wgrad_stem_body<16>(p); }
+__global__ __launch_bounds__(512, 1) void conv_wgrad_stem8(WgradStemParams p) { wgrad_stem_body<8>(p); }
+
+// dw[co][c][kh][kw] (torch layout, c < cin_real) = sum over the slices of partial[s][co][kh][kw*CP + c]
+__global__ void conv_wgrad_stem_reduce(const float* __restrict__ partial, int splits, int Cout, int CP, int cin_real, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = Cout * cin_real * 49;
+    if (i >= total) return;
+    const int kw = i % 7, kh = (i / 7) % 7, c = (i / 49) % cin_real, co = i / (49 * cin_real);
+    const size_t rowf = (size_t)56 * CP;
+    const float* src = partial + (size_t)co * rowf + kh * 8 * CP + kw * CP + c;
+    float sacc = 0.f;
+    for (int z = 0; z < splits; ++z) sacc += src[(size_t)z * Cout * rowf];
+    dw[i] = sacc;
+}
+
 // dw = sum over the pixel splits (fixed order: deterministic), written in the requested layout
 __global__ void conv_wgrad_reduce(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw, int cin_real,
                                   float* __restrict__ dw) {
@@ -1177,6 +1378,24 @@ static void wgrad_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW,
     *gz = (M + *m_per_split - 1) / *m_per_split;
 }
 
+// 7x7 / stride 2 / pad 3 on a channel-padded (8 | 16) input -> the stem row-march kernel
+static bool wgrad_stem_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, int stride, int pad, int IH, int IW, WgradStemParams* p) {
+    if (getenv("MGN_WGRAD_NOSTEM")) return false;
+    if (KH != 7 || KW != 7 || stride != 2 || pad != 3 || (Cin != 8 && Cin != 16) || Cout % 64) return false;
+    if (OH != (IH - 1) / 2 + 1 || OW != (IW - 1) / 2 + 1) return false;
+    if ((size_t)N * OH * OW * Cout * 2 >= 0x7fffffffu || (size_t)N * IH * IW * Cin * 2 >= 0x7fffffffu) return false;
+    p->N = N; p->IH = IH; p->IW = IW; p->OH = OH; p->OW = OW; p->Cout = Cout;
+    p->co_tiles = Cout / 64;
+    p->strips = (OW + 127) / 128;
+    int chunks = (256 / p->co_tiles) / (N * p->strips);   // one 8-wave block per CU
+    if (chunks > OH / 8) chunks = OH / 8;                 // >= 8 rows per block (prologue of 9 input rows)
+    if (chunks < 1) chunks = 1;
+    p->rows_per_chunk = (OH + chunks - 1) / chunks;
+    p->chunks = (OH + p->rows_per_chunk - 1) / p->rows_per_chunk;
+    p->nslices = N * p->strips * p->chunks;
+    return true;
+}
+
 // 3x3 / stride 1 / pad 1 with 64-multiples of channels -> the all-taps row-march kernel
 static bool wgrad3_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, int stride, int pad, int IH, int IW, Wgrad3Params* p) {
     if (getenv("MGN_WGRAD_NO3X3")) return false;
@@ -1205,6 +1424,11 @@ int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int
     bool pack; int NT, MT, cit, cot; long mps, gz;
     wgrad_plan(N, OH, OW, Cin, Cout, KH, KW, &pack, &NT, &MT, &cit, &cot, &mps, &gz);
     *bytes = sizeof(float) * (size_t)gz * Cout * KH * KW * Cin;
+    WgradStemParams ps;
+    if (wgrad_stem_plan(N, OH, OW, Cin, Cout, KH, KW, 2, 3, 2 * OH, 2 * OW, &ps)) {
+        const size_t b7 = sizeof(float) * (size_t)ps.nslices * Cout * 56 * Cin;
+        if (b7 > *bytes) *bytes = b7;
+    }
     Wgrad3Params p3;  // stride / pad are not known here: cover the 3x3 stride-1 plan too
     if (wgrad3_plan(N, OH, OW, Cin, Cout, KH, KW, 1, 1, OH, OW, &p3)) {
         const size_t b3 = sizeof(float) * (size_t)p3.nslices * Cout * 9 * Cin;
@@ -1224,6 +1448,24 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
     if (oihw_cin > Cin) return MGN_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const size_t wsize = (size_t)Cout * KH * KW * Cin;
+    WgradStemParams ps;
+    if (oihw_cin > 0 && wgrad_stem_plan(N, OH, OW, Cin, Cout, KH, KW, stride, pad, IH, IW, &ps)) {
+        if (workspace_bytes < sizeof(float) * (size_t)ps.nslices * Cout * 56 * Cin) return MGN_ENOSPC;
+        ps.dout = p.dout; ps.in = p.in; ps.partial = (float*)workspace;
+        static bool attrs = false;
+        if (!attrs) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_stem16), hipFuncAttributeMaxDynamicSharedMemorySize, WS<16>::LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_stem8), hipFuncAttributeMaxDynamicSharedMemorySize, WS<8>::LDS);
+            attrs = true;
+        }
+        const unsigned nblk = (unsigned)((ps.nslices + 7) / 8) * 8 * ps.co_tiles;
+        if (Cin == 16) hipLaunchKernelGGL(conv_wgrad_stem16, dim3(nblk), dim3(512), WS<16>::LDS, st, ps);
+        else hipLaunchKernelGGL(conv_wgrad_stem8, dim3(nblk), dim3(512), WS<8>::LDS, st, ps);
+        const int total = Cout * oihw_cin * 49;
+        hipLaunchKernelGGL(conv_wgrad_stem_reduce, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)workspace, ps.nslices, Cout, Cin,
+                           oihw_cin, dw);
+        return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+    }
     Wgrad3Params p3;
     if (wgrad3_plan(N, OH, OW, Cin, Cout, KH, KW, stride, pad, IH, IW, &p3)) {
         if (workspace_bytes < sizeof(float) * p3.nslices * wsize) return MGN_ENOSPC;
