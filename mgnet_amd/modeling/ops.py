@@ -256,7 +256,11 @@ class _NearestFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         from .. import _C
-        return _C.nearest_bwd(_cl(g), *ctx.hw), None, None
+        g = _cl(g)
+        if ctx.hw[0] == 1 and ctx.hw[1] == 1:  # broadcast of a pooled vector (GlobalContextModule): its adjoint is a column sum
+            N, C = g.shape[:2]
+            return _C.colsum(g, None, 1.0).to(g.dtype).view(N, C, 1, 1).contiguous(memory_format=torch.channels_last), None, None
+        return _C.nearest_bwd(g, *ctx.hw), None, None
 
 
 def upsample_nearest(x, size):
