@@ -39,6 +39,30 @@ struct ConvParams {
     int N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32;
 };
 
+// Parity class of the output pixels of an `up`-strided gather (data gradient of a stride-`up` conv).  Class (a, b) =
+// (oh % up, ow % up) only meets the taps kh = k0h + up*i, kw = k0w + up*i, k0 = (pad - a) mod up; up == 1: one class,
+// all taps.  pixel(): class-local pixel index -> linear output pixel.
+struct UpClass {
+    int a, b, OHc, OWc, k0h, k0w, nkh, nkw;
+    __device__ __forceinline__ UpClass(const ConvParams& p, int cz) {
+        a = cz / p.up; b = cz - a * p.up;
+        OHc = (p.OH - a + p.up - 1) / p.up; OWc = (p.OW - b + p.up - 1) / p.up;
+        if (OHc < 0) OHc = 0;
+        if (OWc < 0) OWc = 0;
+        const int ra = ((p.pad - a * p.stride) % p.up + p.up) % p.up, rb = ((p.pad - b * p.stride) % p.up + p.up) % p.up;
+        k0h = ra; k0w = rb;
+        nkh = k0h < p.KH ? (p.KH - k0h + p.up - 1) / p.up : 0;
+        nkw = k0w < p.KW ? (p.KW - k0w + p.up - 1) / p.up : 0;
+    }
+    __device__ __forceinline__ long pixel(const ConvParams& p, long mc) const {
+        if (p.up == 1) return mc;
+        const int n = (int)(mc / ((long)OHc * OWc));
+        const int rem = (int)(mc - (long)n * OHc * OWc);
+        const int ohc = rem / OWc, owc = rem - ohc * OWc;
+        return ((long)n * p.OH + a + ohc * p.up) * p.OW + b + owc * p.up;
+    }
+};
+
 __device__ __forceinline__ uint16_t f2bf(float f) {
     uint32_t u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
@@ -249,7 +273,11 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[3][2][TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int bm = blockIdx.x, bn = blockIdx.y;
-    const long M = (long)p.N * p.OH * p.OW;
+    // up > 1 (data gradient of a strided conv): blockIdx.z is the parity class (a, b) of the output pixels; only the
+    // taps kh = k0h + up*i meet a non-zero of the zero-upsampled gradient, so each class is a dense conv over its taps
+    const UpClass uc(p, blockIdx.z);
+    const long M = (long)p.N * uc.OHc * uc.OWc;
+    if ((long)bm * BM >= M) return;
     const int lrow = tid >> 2, seg = tid & 3;
 
     const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * p.KH * p.KW * p.Cin * 2);
@@ -266,17 +294,17 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
         const long m = (long)bm * BM + row;
         vm[r] = m < M;
         const long mm = vm[r] ? m : 0;
-        const int n = (int)(mm / ((long)p.OH * p.OW));
-        const int rem = (int)(mm - (long)n * p.OH * p.OW);
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        ihb[r] = oh * p.stride - p.pad;
-        iwb[r] = ow * p.stride - p.pad;
+        const int n = (int)(mm / ((long)uc.OHc * uc.OWc));
+        const int rem = (int)(mm - (long)n * uc.OHc * uc.OWc);
+        const int ohc = rem / uc.OWc, owc = rem - ohc * uc.OWc;
+        ihb[r] = (uc.a + ohc * p.up) * p.stride - p.pad;
+        iwb[r] = (uc.b + owc * p.up) * p.stride - p.pad;
         abase[r] = (n * p.IH * p.IW * p.Cin + sseg * 8) * 2;
         const int co = bn * BN + row;
         wbase[r] = (co < p.Cout && row < BN) ? (co * p.KH * p.KW * p.Cin + sseg * 8) * 2 : OOB;
     }
     const int cpt = p.Cin / BK;
-    const int ksteps = p.KH * p.KW * cpt;
+    const int ksteps = uc.nkh * uc.nkw * cpt;
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -286,20 +314,20 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    int kh = 0, kw = 0, cc = 0;
+    int khi = 0, kwi = 0, cc = 0;
     int avoff[2], wvoff[2];
     auto set_tap = [&]() {
+        const int kh = uc.k0h + khi * p.up, kw = uc.k0w + kwi * p.up;
         const int wtap = (kh * p.KW + kw) * p.Cin * 2;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             int th = ihb[r] + kh, tw = iwb[r] + kw;
-            bool ok = vm[r];
-            if (p.up > 1) {
-                ok = ok && th >= 0 && tw >= 0 && (th % p.up == 0) && (tw % p.up == 0);
+            bool ok = vm[r] && th >= 0 && tw >= 0;
+            if (p.up > 1) {  // divisible by construction of the class
                 th /= p.up;
                 tw /= p.up;
             }
-            ok = ok && th >= 0 && th < p.IH && tw >= 0 && tw < p.IW;
+            ok = ok && th < p.IH && tw < p.IW;
             avoff[r] = ok ? abase[r] + (th * p.IW + tw) * p.Cin * 2 : OOB;
             wvoff[r] = wbase[r] == OOB ? OOB : wbase[r] + wtap;
         }
@@ -316,12 +344,12 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
         if (NT == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b0 + 4096), 16, wvoff[1], soff, 0, 0);
         if (++cc == cpt) {
             cc = 0;
-            if (++kw == p.KW) { kw = 0; ++kh; }
+            if (++kwi == uc.nkw) { kwi = 0; ++khi; }
             set_tap();
         }
     };
 
-    issue(0);
+    if (ksteps > 0) issue(0);
     if (ksteps > 1) issue(1);
     int buf = 0;
     for (int ks = 0; ks < ksteps; ++ks) {
@@ -340,8 +368,9 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
     const bool vec_ok = (p.Cout % 4) == 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const long m = (long)bm * BM + wm * 64 + i * 32 + (lane & 31);
-        if (m >= M) continue;
+        const long mc = (long)bm * BM + wm * 64 + i * 32 + (lane & 31);
+        if (mc >= M) continue;
+        const long m = uc.pixel(p, mc);   // linear output pixel (n*OH + oh)*OW + ow
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -392,7 +421,9 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / NWN, wn = wave % NWN;
     const int bm = blockIdx.x, bn = blockIdx.y;
-    const long M = (long)p.N * p.OH * p.OW;
+    const UpClass uc(p, blockIdx.z);
+    const long M = (long)p.N * uc.OHc * uc.OWc;
+    if ((long)bm * C::BMB >= M) return;
     const int lrow = lane >> 2, seg = lane & 3;   // row inside a 16-row piece, 16-byte slot
 
     const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * p.KH * p.KW * p.Cin * 2);
@@ -410,11 +441,11 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
         const long m = (long)bm * C::BMB + row;
         vm[q] = m < M;
         const long mm = vm[q] ? m : 0;
-        const int n = (int)(mm / ((long)p.OH * p.OW));
-        const int rem = (int)(mm - (long)n * p.OH * p.OW);
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        ihb[q] = oh * p.stride - p.pad;
-        iwb[q] = ow * p.stride - p.pad;
+        const int n = (int)(mm / ((long)uc.OHc * uc.OWc));
+        const int rem = (int)(mm - (long)n * uc.OHc * uc.OWc);
+        const int ohc = rem / uc.OWc, owc = rem - ohc * uc.OWc;
+        ihb[q] = (uc.a + ohc * p.up) * p.stride - p.pad;
+        iwb[q] = (uc.b + owc * p.up) * p.stride - p.pad;
         abase[q] = (n * p.IH * p.IW * p.Cin + sseg * 8) * 2;
     }
 #pragma unroll
@@ -425,7 +456,7 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
         wbase[q] = co < p.Cout ? (co * p.KH * p.KW * p.Cin + sseg * 8) * 2 : OOB;
     }
     const int cpt = p.Cin / 32;
-    const int ksteps = p.KH * p.KW * cpt;
+    const int ksteps = uc.nkh * uc.nkw * cpt;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -435,20 +466,20 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    int kh = 0, kw = 0, cc = 0;
+    int khi = 0, kwi = 0, cc = 0;
     int avoff[PA], wtap = 0;
     auto set_tap = [&]() {
+        const int kh = uc.k0h + khi * p.up, kw = uc.k0w + kwi * p.up;
         wtap = (kh * p.KW + kw) * p.Cin * 2;
 #pragma unroll
         for (int q = 0; q < PA; ++q) {
             int th = ihb[q] + kh, tw = iwb[q] + kw;
-            bool ok = vm[q];
+            bool ok = vm[q] && th >= 0 && tw >= 0;
             if (p.up > 1) {
-                ok = ok && th >= 0 && tw >= 0 && (th % p.up == 0) && (tw % p.up == 0);
                 th /= p.up;
                 tw /= p.up;
             }
-            ok = ok && th >= 0 && th < p.IH && tw >= 0 && tw < p.IW;
+            ok = ok && th < p.IH && tw < p.IW;
             avoff[q] = ok ? abase[q] + (th * p.IW + tw) * p.Cin * 2 : OOB;
         }
     };
@@ -466,12 +497,12 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b0 + (wave + C::NW * q) * 1024), 16, wbase[q] == OOB ? OOB : wbase[q] + wtap, soff, 0, 0);
         if (++cc == cpt) {
             cc = 0;
-            if (++kw == p.KW) { kw = 0; ++kh; }
+            if (++kwi == uc.nkw) { kwi = 0; ++khi; }
             set_tap();
         }
     };
 
-    issue(0);
+    if (ksteps > 0) issue(0);
     if (ksteps > 1) issue(1);
     int buf = 0;
     for (int ks = 0; ks < ksteps; ++ks) {
@@ -491,8 +522,9 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
     const bool vec_ok = (p.Cout % 4) == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long m = (long)bm * C::BMB + wm * 128 + i * 32 + (lane & 31);
-        if (m >= M) continue;
+        const long mc = (long)bm * C::BMB + wm * 128 + i * 32 + (lane & 31);
+        if (mc >= M) continue;
+        const long m = uc.pixel(p, mc);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1316,8 +1348,12 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
         hipLaunchKernelGGL(conv3x3_c64, dim3((unsigned)((q.nslices + 7) / 8) * 8 * q.co_tiles), dim3(512), C64_LDS, st, q);
         return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
     } else if (!getenv("MGN_CONV_NOGLDS")) {
+        // up > 1: one grid slice per parity class, sized for the largest class
+        const long Mc = up > 1 ? (long)N * ((OH + up - 1) / up) * ((OW + up - 1) / up) : M;
+        const unsigned gz = (unsigned)(up * up);
+        const long gxc = (Mc + BM - 1) / BM;
         // big tiles when there are enough of them to fill 256 CUs (BN = 256: one 8-wave block per CU; BN = 128: two)
-        const long gxb = (M + 255) / 256;
+        const long gxb = (Mc + 255) / 256;
         static bool battr = false;
         if (!battr) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_big128), hipFuncAttributeMaxDynamicSharedMemorySize, IgemmBig<2>::LDS);
@@ -1328,7 +1364,7 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
         const int fbig = ebig ? atoi(ebig) : -1;
         if (fbig != 0 && Cout % 128 == 0) {
             const bool can256 = Cout % 256 == 0;
-            const long blocks256 = gxb * (Cout / 256 > 0 ? Cout / 256 : 1), blocks128 = gxb * (Cout / 128);
+            const long blocks256 = gxb * gz * (Cout / 256 > 0 ? Cout / 256 : 1);
             int pick = 0;
             if (fbig == 256 && can256) pick = 256;
             else if (fbig == 128) pick = 128;
@@ -1337,16 +1373,16 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
                 // (BN = 128 measured slower than the 128 x 128 kernel on the 128-channel layers: only on request)
             }
             if (pick == 256) {
-                hipLaunchKernelGGL(conv_igemm_big256, dim3((unsigned)gxb, Cout / 256), dim3(512), IgemmBig<4>::LDS, st, p);
+                hipLaunchKernelGGL(conv_igemm_big256, dim3((unsigned)gxb, Cout / 256, gz), dim3(512), IgemmBig<4>::LDS, st, p);
                 return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
             }
             if (pick == 128) {
-                hipLaunchKernelGGL(conv_igemm_big128, dim3((unsigned)gxb, Cout / 128), dim3(256), IgemmBig<2>::LDS, st, p);
+                hipLaunchKernelGGL(conv_igemm_big128, dim3((unsigned)gxb, Cout / 128, gz), dim3(256), IgemmBig<2>::LDS, st, p);
                 return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
             }
         }
-        if (Cout <= 64) hipLaunchKernelGGL((conv_igemm_glds<1>), dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_igemm_glds<2>), dim3((unsigned)gx, (Cout + 127) / 128), dim3(256), 0, st, p);
+        if (Cout <= 64) hipLaunchKernelGGL((conv_igemm_glds<1>), dim3((unsigned)gxc, (Cout + 63) / 64, gz), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_glds<2>), dim3((unsigned)gxc, (Cout + 127) / 128, gz), dim3(256), 0, st, p);
     } else if (Cout <= 64) {
         const dim3 grid((unsigned)gx, (Cout + 63) / 64);
         if (k64) hipLaunchKernelGGL((conv_igemm<1, 4>), grid, dim3(256), 0, st, p);
