@@ -15,7 +15,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -66,6 +66,7 @@ def lib():
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
         L.mgn_weight_layout.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.mgn_weight_layout_batch.argtypes = [vp, ci, cl, vp]
         L.mgn_upce_partials.argtypes = [ci, ci, ci]
         L.mgn_upce_fwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp, vp]
         L.mgn_upce_bwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
@@ -326,19 +327,93 @@ def conv_wgrad(dy, x, kh, kw, stride, pad, cin_real=None):
     return dw
 
 
-def weight_layout(w, mode, Cp=0):
-    """fp32 OIHW parameter -> bf16 kernel layout (0: OHWI, 1: flipped IHWO for the data gradient, 2: packed stem)"""
+def _layout_empty(w, mode, Cp):
     Cout, Cin, KH, KW = w.shape
     if mode == 0:
-        out = torch.empty((Cout, KH, KW, Cin), dtype=torch.bfloat16, device=w.device)
-    elif mode == 1:
-        out = torch.empty((Cin, KH, KW, Cout), dtype=torch.bfloat16, device=w.device)
-    else:
-        out = torch.empty((Cout, (KH * KW * Cp + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
+        return torch.empty((Cout, KH, KW, Cin), dtype=torch.bfloat16, device=w.device)
+    if mode == 1:
+        return torch.empty((Cin, KH, KW, Cout), dtype=torch.bfloat16, device=w.device)
+    return torch.empty((Cout, (KH * KW * Cp + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
+
+
+def weight_layout(w, mode, Cp=0):
+    """fp32 OIHW parameter -> bf16 kernel layout (0: OHWI, 1: flipped IHWO for the data gradient, 2: packed stem).
+    Parameters are served from `weight_cache` (all layouts refreshed by ONE launch after the optimizer step)."""
+    return weight_cache.get(w, mode, Cp)
+
+
+def _weight_layout_now(w, mode, Cp, out=None):
+    Cout, Cin, KH, KW = w.shape
+    out = _layout_empty(w, mode, Cp) if out is None else out
     wc = w.detach()
     wc = wc if (wc.dtype == torch.float32 and wc.is_contiguous()) else wc.float().contiguous()
     check(lib().mgn_weight_layout(wc.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, mode, Cp, _stream()), "mgn_weight_layout")
     return out
+
+
+class _WeightCache:
+    """bf16 kernel layouts of the conv parameters.  A layout is valid while the parameter's storage and version are
+    unchanged and no `refresh()` happened since; `refresh()` (called by FusedAdam.step, whose kernel updates the flat
+    parameter buffer behind torch's version counter) re-derives EVERY registered layout with one batched launch."""
+
+    def __init__(self):
+        self.entries = {}     # (id(param), mode, Cp) -> dict(ref, out, version, ptr)
+        self.table = None     # device table of the batched kernel (rebuilt when the entry set changed)
+        self.total_blocks = 0
+        self.dirty = True
+        self.off = bool(os.environ.get("MGN_NO_WCACHE"))   # A/B switch: convert per call
+
+    def get(self, w, mode, Cp=0):
+        import weakref
+        if self.off or not (isinstance(w, torch.nn.Parameter) and w.is_leaf and w.dtype == torch.float32 and w.is_contiguous()):
+            return _weight_layout_now(w, mode, Cp)   # temporaries (e.g. Cout-padded predictors): converted per call
+        key = (id(w), mode, Cp)
+        e = self.entries.get(key)
+        if e is not None and e["ref"]() is w and e["ptr"] == w.data_ptr() and e["version"] == w._version:
+            return e["out"]
+        out = _weight_layout_now(w, mode, Cp, None if e is None or e["ref"]() is not w else e["out"])
+        if e is None or e["ref"]() is not w or e["ptr"] != w.data_ptr():
+            self.dirty = True
+        self.entries[key] = dict(ref=weakref.ref(w), out=out, version=w._version, ptr=w.data_ptr(), mode=mode, Cp=Cp)
+        return out
+
+    def _rebuild(self):
+        rows, blocks = [], 0
+        dead = [k for k, e in self.entries.items() if e["ref"]() is None]
+        for k in dead:
+            del self.entries[k]
+        dev = None
+        for e in self.entries.values():
+            w = e["ref"]()
+            if dev is None:
+                dev = w.device
+            if w.device != dev:
+                continue
+            Cout, Cin, KH, KW = w.shape
+            n_out = e["out"].numel()
+            rows.append([w.data_ptr(), e["out"].data_ptr(), n_out, blocks, Cout, Cin, (KH << 32) | KW, (e["mode"] << 32) | e["Cp"]])
+            e["ptr"] = w.data_ptr()
+            blocks += (n_out + 255) // 256
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None
+        self.total_blocks, self.dirty = blocks, False
+
+    def refresh(self):
+        """re-derive every registered layout from the current parameter values (one launch)"""
+        if any(e["ref"]() is not None and e["ptr"] != e["ref"]().data_ptr() for e in self.entries.values()):
+            self.dirty = True
+        if self.dirty:
+            self._rebuild()
+        if self.table is None:
+            return
+        check(lib().mgn_weight_layout_batch(self.table.data_ptr(), self.table.shape[0], self.total_blocks, _stream()),
+              "mgn_weight_layout_batch")
+        for e in self.entries.values():
+            w = e["ref"]()
+            if w is not None:
+                e["version"] = w._version
+
+
+weight_cache = _WeightCache()
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -1296,6 +1296,42 @@ __global__ void weight_layout_kernel(const float* __restrict__ w, uint16_t* __re
     out[i] = f2bf(v);
 }
 
+// all conv weights of a model in ONE launch: table rows of 8 x int64 = {src fp32 OIHW, dst bf16, n_out, first block,
+// Cout, Cin, KH << 32 | KW, mode << 32 | Cp}; a block finds its row by binary search over the first-block column
+__global__ void weight_layout_batch_kernel(const long long* __restrict__ table, int n_entries) {
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(size_t)mid * 8 + 3] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* e = table + (size_t)lo * 8;
+    const float* w = reinterpret_cast<const float*>(e[0]);
+    uint16_t* out = reinterpret_cast<uint16_t*>(e[1]);
+    const long n_out = e[2];
+    const long i = ((long)blockIdx.x - e[3]) * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const int Cout = (int)e[4], Cin = (int)e[5], KH = (int)(e[6] >> 32), KW = (int)(e[6] & 0xffffffff);
+    const int mode = (int)(e[7] >> 32), Cp = (int)(e[7] & 0xffffffff);
+    float v = 0.f;
+    if (mode == 0) {
+        const int ci = (int)(i % Cin); long r = i / Cin;
+        const int kw = (int)(r % KW); r /= KW;
+        const int kh = (int)(r % KH); const int co = (int)(r / KH);
+        v = w[(((long)co * Cin + ci) * KH + kh) * KW + kw];
+    } else if (mode == 1) {
+        const int co = (int)(i % Cout); long r = i / Cout;
+        const int kw = (int)(r % KW); r /= KW;
+        const int kh = (int)(r % KH); const int ci = (int)(r / KH);
+        v = w[(((long)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+    } else {
+        const int Kpad = (KH * KW * Cp + 31) / 32 * 32;
+        const int k = (int)(i % Kpad), co = (int)(i / Kpad);
+        const int tap = k / Cp, c = k - tap * Cp;
+        if (tap < KH * KW && c < Cin) v = w[(((long)co * Cin + c) * KH + tap / KW) * KW + tap % KW];
+    }
+    out[i] = f2bf(v);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1307,6 +1343,12 @@ int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, in
     const long n = mode == 2 ? (long)Cout * Kpad : (long)Cout * Cin * KH * KW;
     hipLaunchKernelGGL(weight_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
                        (uint16_t*)out_bf16, Cout, Cin, KH, KW, mode, Cp, Kpad, n);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_weight_layout_batch(const void* table_dev, int n_entries, long total_blocks, void* stream) {
+    if (!table_dev || n_entries < 1 || total_blocks < 1 || total_blocks > 0x7fffffffL) return MGN_EINVAL;
+    hipLaunchKernelGGL(weight_layout_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)table_dev, n_entries);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

@@ -50,6 +50,8 @@ class FusedAdam(torch.optim.Optimizer):
         for k, b in enumerate(self.reducer.buckets):
             _C.adam_step(b["flat_p"], b["flat_g"], self._m[k], self._v[k], self._lr_dev[k], self._wd_dev[k],
                          g0["betas"][0], g0["betas"][1], g0["eps"], self._t, self._coef, grad_scale)
+        # the kernel rewrote the flat parameter buffers behind torch's version counters: re-derive the bf16 conv layouts
+        _C.weight_cache.refresh()
 
     def grad_norm(self):
         """total gradient norm of the last step (device scalar; no sync)"""

