@@ -154,14 +154,18 @@ int mgn_adam_step(float* p, const float* g, float* m, float* v, long n, const fl
  * in  : [N, IH, IW, Cin]  bf16 (channels-last);  w : [Cout, KH, KW, Cin] bf16;  out : [N, OH, OW, Cout] bf16 | fp32
  * mgn_conv_igemm: out[n,oh,ow,co] = bias[co] + sum_{kh,kw,ci} in[n, t(oh,kh), t(ow,kw), ci] * w[co,kh,kw,ci], optional ReLU,
  *   t(o,k) = o*stride + k - pad, and when up > 1 the tap only contributes where t is divisible by `up` (then t /= up):
- *   with (w flipped+transposed, stride=1, pad=K-1-pad, up=forward stride) this is the data gradient.
+ *   with (w flipped+transposed, stride=1, pad=K-1-pad, up=forward stride) this is the data gradient (computed per
+ *   output parity class over the taps that meet a non-zero, not over the zero-upsampled tensor).
  *   Cin must be a multiple of 32 (MGN_ENOTSUP otherwise: the 3/9-channel 7x7 stems).
  * mgn_conv_wgrad: dw[co,kh,kw,ci] = sum_{n,oh,ow} dout[n,oh,ow,co] * in[n, oh*stride+kh-pad, ow*stride+kw-pad, ci]
  *   (pixels are split over blocks; per-split partial tiles go to the workspace with plain stores and a second kernel
  *    sums them in a fixed order -- deterministic, no atomics; Cin, Cout multiples of 8)
  * ---------------------------------------------------------------------------------------------- */
 int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH,
-                   int OW, int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, void* stream);
+                   int OW, int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32,
+                   const void* residual /* bf16 [N,OH,OW,Cout] added before rounding (the gradient of a second branch of the
+                                           same tensor, e.g. the ResNet shortcut), or NULL */,
+                   void* stream);
 int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout,
                    int KH, int KW, int stride, int pad, int oihw_cin /* >0: dw is [Cout][oihw_cin][KH][KW] */,
                    void* workspace, size_t workspace_bytes, void* stream);

@@ -62,7 +62,7 @@ def lib():
         L.mgn_sqnorm.argtypes = [vp, cl, vp, ci, ctypes.POINTER(ci), vp]
         L.mgn_clip_coef.argtypes = [vp, ci, cf, cf, vp, vp]
         L.mgn_adam_step.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, ci, vp, cf, vp]
-        L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp]
+        L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp, vp]
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
         L.mgn_weight_layout.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
@@ -296,7 +296,7 @@ def prep_input(frames_u8, mean3, std3, Cp):
     return out
 
 
-def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=torch.bfloat16, khw=None):
+def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=torch.bfloat16, khw=None, residual=None):
     """x [N,Cin,IH,IW] channels_last bf16; w_ohwi [Cout,KH,KW,Cin] bf16 contiguous (or, for Cin 8/16, the packed
     [Cout, Kpad] layout with khw=(KH,KW)) -> out [N,Cout,OH,OW] channels_last"""
     N, Cin, IH, IW = x.shape
@@ -308,7 +308,8 @@ def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dt
     out = torch.empty((N, Cout, OH, OW), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
     check(lib().mgn_conv_igemm(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(),
                                N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, int(relu),
-                               int(out_dtype == torch.float32), _stream()), "mgn_conv_igemm")
+                               int(out_dtype == torch.float32), None if residual is None else residual.data_ptr(), _stream()),
+          "mgn_conv_igemm")
     return out
 
 

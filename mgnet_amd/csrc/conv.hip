@@ -36,6 +36,7 @@ struct ConvParams {
     const uint16_t* w;    // [Cout, KH, KW, Cin] bf16
     void* out;            // [N, OH, OW, Cout] bf16 or fp32
     const float* bias;    // [Cout] or null
+    const uint16_t* residual;  // [N, OH, OW, Cout] bf16 added to the result before rounding, or null
     int N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32;
 };
 
@@ -68,6 +69,37 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+
+// epilogue of the implicit-GEMM kernels: 4 consecutive output channels of one pixel (+ bias, + residual, ReLU)
+__device__ __forceinline__ void emit4(const ConvParams& p, long m, int co, float a0, float a1, float a2, float a3, bool vec_ok) {
+    float v[4] = {a0, a1, a2, a3};
+    if (p.residual && vec_ok) {  // fused accumulation of a second gradient branch (bf16, same layout as the output)
+        const uint2 r = *reinterpret_cast<const uint2*>(p.residual + m * p.Cout + co);
+        v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+        v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] += (p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+        if (p.residual && !vec_ok && co + e < p.Cout) v[e] += __uint_as_float((uint32_t)p.residual[m * p.Cout + co + e] << 16);
+        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (vec_ok) {
+        if (p.out_f32)
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * p.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + m * p.Cout + co) =
+                make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (co + e >= p.Cout) break;
+            if (p.out_f32) reinterpret_cast<float*>(p.out)[m * p.Cout + co + e] = v[e];
+            else reinterpret_cast<uint16_t*>(p.out)[m * p.Cout + co + e] = f2bf(v[e]);
+        }
+    }
+}
+
 
 // XOR swizzle of the 16-byte slot inside a 128-byte LDS row (found by exhaustive search: conflict-free for both the
 // 8-lane ds_write_b128 groups of the transposing loader and the 16-lane ds_read_b128 groups of the fragment reads)
@@ -235,26 +267,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
             for (int q = 0; q < 4; ++q) {
                 const int co = bn * BN + wn * 32 * NT + j * 32 + 8 * q + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][q * 4 + e] + ((p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f);
-                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (vec_ok) {
-                    if (p.out_f32)
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * p.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
-                    else
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + m * p.Cout + co) =
-                            make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co + e >= p.Cout) break;
-                        if (p.out_f32) reinterpret_cast<float*>(p.out)[m * p.Cout + co + e] = v[e];
-                        else reinterpret_cast<uint16_t*>(p.out)[m * p.Cout + co + e] = f2bf(v[e]);
-                    }
-                }
+                emit4(p, m, co, acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3], vec_ok);
             }
     }
 }
@@ -377,26 +390,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
             for (int q = 0; q < 4; ++q) {
                 const int co = bn * BN + wn * 32 * NT + j * 32 + 8 * q + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][q * 4 + e] + ((p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f);
-                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (vec_ok) {
-                    if (p.out_f32)
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * p.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
-                    else
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + m * p.Cout + co) =
-                            make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co + e >= p.Cout) break;
-                        if (p.out_f32) reinterpret_cast<float*>(p.out)[m * p.Cout + co + e] = v[e];
-                        else reinterpret_cast<uint16_t*>(p.out)[m * p.Cout + co + e] = f2bf(v[e]);
-                    }
-                }
+                emit4(p, m, co, acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3], vec_ok);
             }
     }
 }
@@ -531,26 +525,7 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
             for (int q = 0; q < 4; ++q) {
                 const int co = bn * C::BN + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][q * 4 + e] + ((p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f);
-                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (vec_ok) {
-                    if (p.out_f32)
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * p.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
-                    else
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + m * p.Cout + co) =
-                            make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co + e >= p.Cout) break;
-                        if (p.out_f32) reinterpret_cast<float*>(p.out)[m * p.Cout + co + e] = v[e];
-                        else reinterpret_cast<uint16_t*>(p.out)[m * p.Cout + co + e] = f2bf(v[e]);
-                    }
-                }
+                emit4(p, m, co, acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3], vec_ok);
             }
     }
 }
@@ -573,6 +548,7 @@ struct Conv64Params {
     const uint16_t* in;    // [N, H, W, 64] bf16
     const uint16_t* w;     // [Cout, 3, 3, 64] bf16
     uint16_t* out;         // [N, H, W, Cout] bf16
+    const uint16_t* residual;  // like ConvParams::residual
     int N, H, W, Cout;
     int strips, chunks, rows_per_chunk, nslices, co_tiles;
 };
@@ -677,8 +653,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
             uint16_t* orow = p.out + ((size_t)(n * p.H + r) * p.W + opx) * p.Cout + co_w + 4 * hi;
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                const float v0 = acc0[qd * 4 + 0] + acc1[qd * 4 + 0], v1 = acc0[qd * 4 + 1] + acc1[qd * 4 + 1];
-                const float v2 = acc0[qd * 4 + 2] + acc1[qd * 4 + 2], v3 = acc0[qd * 4 + 3] + acc1[qd * 4 + 3];
+                float v0 = acc0[qd * 4 + 0] + acc1[qd * 4 + 0], v1 = acc0[qd * 4 + 1] + acc1[qd * 4 + 1];
+                float v2 = acc0[qd * 4 + 2] + acc1[qd * 4 + 2], v3 = acc0[qd * 4 + 3] + acc1[qd * 4 + 3];
+                if (p.residual) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (orow - p.out) + 8 * qd);
+                    v0 += __uint_as_float(rr.x << 16); v1 += __uint_as_float(rr.x & 0xffff0000u);
+                    v2 += __uint_as_float(rr.y << 16); v3 += __uint_as_float(rr.y & 0xffff0000u);
+                }
                 *reinterpret_cast<uint2*>(orow + 8 * qd) =
                     make_uint2((uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16));
             }
@@ -1353,14 +1334,15 @@ int mgn_weight_layout_batch(const void* table_dev, int n_entries, long total_blo
 }
 
 int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
-                   int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, void* stream) {
+                   int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, const void* residual, void* stream) {
     if (!in || !w || !out || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || up < 1)
         return MGN_EINVAL;
     const bool pack = (Cin == 8 || Cin == 16);            // small-Cin stems: taps packed into the k-slab
     if (!pack && (Cin < 32 || Cin % 32 != 0)) return MGN_ENOTSUP;  // k-slab = 32 or 64 input channels of one tap
     if (pack && up != 1) return MGN_ENOTSUP;
     ConvParams p;
-    p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = out; p.bias = bias;
+    p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = out; p.bias = bias; p.residual = (const uint16_t*)residual;
+    if (residual && out_f32) return MGN_ENOTSUP;
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.up = up; p.relu = relu; p.out_f32 = out_f32;
     const long M = (long)N * OH * OW;
@@ -1374,7 +1356,7 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
     } else if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 1 && Cin == 64 && Cout % 64 == 0 && IH == OH && IW == OW && !bias &&
                !relu && !out_f32 && (size_t)N * OH * OW * (Cout > 64 ? Cout : 64) * 2 < 0x7fffffffu && !getenv("MGN_CONV_NOC64")) {
         Conv64Params q;
-        q.in = p.in; q.w = p.w; q.out = (uint16_t*)out; q.N = N; q.H = OH; q.W = OW; q.Cout = Cout;
+        q.in = p.in; q.w = p.w; q.out = (uint16_t*)out; q.residual = p.residual; q.N = N; q.H = OH; q.W = OW; q.Cout = Cout;
         q.strips = (OW + 127) / 128; q.co_tiles = Cout / 64;
         int chunks = (256 / q.co_tiles) / (N * q.strips);      // one 8-wave block per CU
         if (chunks > OH / 4) chunks = OH / 4;

@@ -52,13 +52,17 @@ class Conv2d(nn.Conv2d):
         self.norm = norm
         self.activation = activation
 
-    def forward(self, x):
-        x = ops.conv2d(x, self.weight, self.bias, self.stride, self.padding)
+    def forward(self, x, with_skip=False):
+        skip = None
+        if with_skip:   # also hand back the input for a second consumer (its gradient is fused into the conv's backward)
+            x, skip = ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, with_skip=True)
+        else:
+            x = ops.conv2d(x, self.weight, self.bias, self.stride, self.padding)
         if self.norm is not None:
             x = self.norm(x)
         if self.activation is not None:
             x = self.activation(x)
-        return x
+        return (x, skip) if with_skip else x
 
 
 class PlainConv2d(nn.Conv2d):

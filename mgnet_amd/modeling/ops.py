@@ -2,6 +2,8 @@
 kernel behind the C-ABI once it exists (marked [HIP]), otherwise a torch GPU op used as staging while the row is
 being ported (marked [torch-staging]; listed as not-yet-HIP in DESIGN.md section 7).  There is no CPU fallback and the
 oracle is never used here."""
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -130,7 +132,7 @@ class _ConvFn(torch.autograd.Function):
     gradient on the bf16 matrix cores.  Master weights stay fp32 OIHW; the kernel layouts are derived per call."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu):
+    def forward(ctx, x, weight, bias, stride, pad, relu, with_skip=False):
         from .. import _C
 
         N, Cin, IH, IW = x.shape   # Cin of the ACTIVATION (8/16 = channel-padded stem input)
@@ -145,10 +147,12 @@ class _ConvFn(torch.autograd.Function):
             out = _C.conv_igemm(xs, _C.weight_layout(weight, 0), (OH, OW), b, stride, pad, 1, relu)
         ctx.save_for_backward(xs, weight, out if relu else None)
         ctx.cfg = (stride, pad, relu, bias is not None)
+        if with_skip:   # second output: the input itself (autograd makes it an alias); its gradient comes back into backward
+            return out, x
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         from .. import _C
 
         xs, weight, out = ctx.saved_tensors
@@ -162,34 +166,43 @@ class _ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             assert Cx == Cin, "no data gradient for the channel-padded stem input"
-            dx = _C.conv_igemm(dy, _C.weight_layout(weight, 1), xs.shape[2:], None, 1, KH - 1 - pad, up=stride)
+            # the gradient of the skip branch is added in the kernel's epilogue instead of by a separate accumulate pass
+            res = None if dskip is None else dskip.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            dx = _C.conv_igemm(dy, _C.weight_layout(weight, 1), xs.shape[2:], None, 1, KH - 1 - pad, up=stride, residual=res)
         if ctx.needs_input_grad[1]:
             dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad, cin_real=Cin)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum((0, 2, 3))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=False):
     """Convolution in the activation dtype (bf16 under AMP) from fp32 master weights.
     bf16 CUDA activations with Cin % 32 == 0: [HIP] implicit GEMM (Cout is zero-padded to a multiple of 32 for the
-    few-class predictors).  Otherwise (fp32 activations, the 3/9-channel 7x7 stems, CPU tests): [torch-staging]."""
+    few-class predictors).  Otherwise (fp32 activations, the 3/9-channel 7x7 stems, CPU tests): [torch-staging].
+    with_skip: also return the input as a second output whose gradient is accumulated inside the data-gradient kernel
+    (ResNet shortcut: `out, skip = conv2d(x, ..., with_skip=True)` then use `skip` wherever `x` would be re-used)."""
     stride = stride[0] if isinstance(stride, (tuple, list)) else stride
     padding = padding[0] if isinstance(padding, (tuple, list)) else padding
     from .. import _C
     if _C.conv_supported(x, weight):
         Cout = weight.shape[0]
         if Cout % 32:
+            assert not with_skip
             padc = 32 - Cout % 32
             weight = torch.cat([weight, weight.new_zeros((padc,) + tuple(weight.shape[1:]))], 0)
             if bias is not None:
                 bias = torch.cat([bias, bias.new_zeros(padc)], 0)
             return _ConvFn.apply(x, weight, bias, stride, padding, relu)[:, :Cout]
-        return _ConvFn.apply(x, weight, bias, stride, padding, relu)
+        if with_skip and x.requires_grad and x.shape[1] == weight.shape[1] and not os.environ.get("MGN_NO_SKIPFUSE"):
+            return _ConvFn.apply(x, weight, bias, stride, padding, relu, True)
+        y = _ConvFn.apply(x, weight, bias, stride, padding, relu)
+        return (y, x) if with_skip else y
     w = weight.to(x.dtype)
     b = None if bias is None else bias.to(x.dtype)
     y = F.conv2d(x, w, b, stride=stride, padding=padding)
-    return torch.relu_(y) if relu else y
+    y = torch.relu_(y) if relu else y
+    return (y, x) if with_skip else y
 
 
 class _MaxPoolFn(torch.autograd.Function):

@@ -33,8 +33,9 @@ class BasicBlock(nn.Module):  # res_net.py:11-79
                 c2_msra_fill(layer)
 
     def forward(self, x):
-        out = self.conv2(self.conv1(x))
-        sc = x if self.shortcut is None else self.shortcut(x)
+        out, skip = self.conv1(x, with_skip=True)   # res_net.py:62-79; `skip` is x: the shortcut's gradient joins conv1's dgrad
+        out = self.conv2(out)
+        sc = skip if self.shortcut is None else self.shortcut(skip)
         return ops.add_relu(out, sc)
 
 

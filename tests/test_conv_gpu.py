@@ -166,3 +166,27 @@ def test_weight_layout_cache_batched_refresh():
     with torch.no_grad():
         ws[0].mul_(2.0)  # torch update: version bump -> served fresh without a refresh
     assert torch.equal(_C.weight_layout(ws[0], 0, 0), _C._weight_layout_now(ws[0], 0, 0))
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 12, 140, 3, 1, 1), (1, 64, 128, 17, 23, 3, 2, 1), (2, 128, 256, 9, 11, 3, 1, 1)])
+def test_conv_with_skip_fuses_the_second_gradient(case):
+    """`out, skip = conv2d(x, w, with_skip=True)`: the gradient arriving at `skip` is added inside the data-gradient kernel
+    (row-march 64-channel kernel, parity-class strided gradient, generic kernel)."""
+    from mgnet_amd.modeling import ops
+
+    N, Cin, Cout, H, W, k, s, p = case
+    torch.manual_seed(sum(case))
+    x0 = torch.randn(N, Cin, H, W).to(torch.bfloat16)
+    w0 = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    x_r = x0.double().requires_grad_(True)
+    w_r = w0.to(torch.bfloat16).double().requires_grad_(True)
+    y_r = F.conv2d(x_r, w_r, None, stride=s, padding=p)
+    g1 = torch.randn(*y_r.shape).to(torch.bfloat16)
+    g2 = torch.randn(N, Cin, H, W).to(torch.bfloat16)
+    ((y_r * g1.double()).sum() + (x_r * g2.double()).sum()).backward()
+    x = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = w0.cuda().requires_grad_(True)
+    y, skip = ops.conv2d(x, w, None, stride=s, padding=p, with_skip=True)
+    ((y.float() * g1.cuda().float()).sum() + (skip.float() * g2.cuda().float()).sum()).backward()
+    rel = float((x.grad.float().cpu().double() - x_r.grad).abs().max() / x_r.grad.abs().max())
+    assert rel < 1e-2, rel
