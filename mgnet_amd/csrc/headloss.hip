@@ -91,44 +91,61 @@ __device__ __forceinline__ float interp_logits(const uint16_t* __restrict__ lg, 
 // Phase 2 of the backward tile kernels, separable: rows first (sum over the tile's x with the horizontal bilinear weight
 // of every footprint column), then columns.  res: [TY*TX][KK] residuals in LDS; rowsum: [TY][MAXC][KK] scratch in LDS.
 constexpr int MAXC = 8, MAXR = 6;  // footprint bound of a 32x16 tile for scale >= 4 (checked on the host)
+constexpr int RP = TX + 1;         // pitch of a residual row in LDS: res[(k*TY + yy)*RP + xx] (conflict-free for the phase-1
+                                   // writes, lanes along xx, and for the row pass, lanes along yy and k)
+__device__ __forceinline__ int res_idx(int k, int yy, int xx) { return (k * TY + yy) * RP + xx; }
 
 template <int KK>
 __device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int Y0, int K, const float* res, float* rowsum,
                                              float* out, int out_stride) {
+    __shared__ float wxs[TX * MAXC], wys[TY * MAXR];   // bilinear weight of tile column xx (row yy) on footprint column cxi (row cyi)
     const int ly0 = min((int)(Y0 * g.ry), g.h - 1), lx0 = min((int)(X0 * g.rx), g.w - 1);
     const int Yl = min(Y0 + TY, g.H) - 1, Xl = min(X0 + TX, g.W) - 1;
     const int ly1 = min(min((int)(Yl * g.ry), g.h - 1) + 1, g.h - 1), lx1 = min(min((int)(Xl * g.rx), g.w - 1) + 1, g.w - 1);
     const int nr = min(ly1 - ly0 + 1, MAXR), nc = min(lx1 - lx0 + 1, MAXC);
     const int ny = Yl - Y0 + 1, nx = Xl - X0 + 1;
-    for (int o = threadIdx.x; o < ny * nc * KK; o += TPB) {
-        const int k = o % KK, cxi = (o / KK) % nc, yy = o / (KK * nc);
-        float acc = 0.f;
-        if (k < K) {
-            const int cx = lx0 + cxi;
-            for (int xx = 0; xx < nx; ++xx) {
-                const float sx = (X0 + xx) * g.rx;
-                const int x0 = min((int)sx, g.w - 1), x1 = min(x0 + 1, g.w - 1);
-                const float tx = sx - x0;
-                const float wx = (x0 == cx ? 1.f - tx : 0.f) + (x1 == cx ? tx : 0.f);
-                acc += wx * res[(yy * TX + xx) * KK + k];
-            }
+    for (int o = threadIdx.x; o < TX * MAXC; o += TPB) {
+        const int xx = o / MAXC, cxi = o % MAXC;
+        float wgt = 0.f;
+        if (xx < nx && cxi < nc) {
+            const float sx = (X0 + xx) * g.rx;
+            const int x0 = min((int)sx, g.w - 1), x1 = min(x0 + 1, g.w - 1), cx = lx0 + cxi;
+            const float tx = sx - x0;
+            wgt = (x0 == cx ? 1.f - tx : 0.f) + (x1 == cx ? tx : 0.f);
         }
-        rowsum[(yy * MAXC + cxi) * KK + k] = acc;
+        wxs[o] = wgt;
+    }
+    for (int o = threadIdx.x; o < TY * MAXR; o += TPB) {
+        const int yy = o / MAXR, cyi = o % MAXR;
+        float wgt = 0.f;
+        if (yy < ny && cyi < nr) {
+            const float sy = (Y0 + yy) * g.ry;
+            const int y0 = min((int)sy, g.h - 1), y1 = min(y0 + 1, g.h - 1), cy = ly0 + cyi;
+            const float ty = sy - y0;
+            wgt = (y0 == cy ? 1.f - ty : 0.f) + (y1 == cy ? ty : 0.f);
+        }
+        wys[o] = wgt;
+    }
+    __syncthreads();
+    // rows: rowsum[k][yy][cxi] = sum_xx wxs[xx][cxi] * res[k][yy][xx]      (lanes: yy fastest, then k)
+    for (int o = threadIdx.x; o < TY * KK * nc; o += TPB) {
+        const int yy = o % TY, k = (o / TY) % KK, cxi = o / (TY * KK);
+        float acc = 0.f;
+        if (k < K && yy < ny) {
+            const float* rr = res + res_idx(k, yy, 0);
+#pragma unroll 8
+            for (int xx = 0; xx < TX; ++xx) acc += wxs[xx * MAXC + cxi] * rr[xx];   // columns beyond nx carry weight 0
+        }
+        rowsum[(k * TY + yy) * MAXC + cxi] = acc;
     }
     __syncthreads();
     for (int o = threadIdx.x; o < nr * nc * KK; o += TPB) {
         const int k = o % KK, cxi = (o / KK) % nc, cyi = o / (KK * nc);
         if (k >= K) continue;
-        const int cy = ly0 + cyi;
         float acc = 0.f;
-        for (int yy = 0; yy < ny; ++yy) {
-            const float sy = (Y0 + yy) * g.ry;
-            const int y0 = min((int)sy, g.h - 1), y1 = min(y0 + 1, g.h - 1);
-            const float ty = sy - y0;
-            const float wy = (y0 == cy ? 1.f - ty : 0.f) + (y1 == cy ? ty : 0.f);
-            acc += wy * rowsum[(yy * MAXC + cxi) * KK + k];
-        }
-        if (acc != 0.f) atomicAdd(out + (((long)b * g.h + cy) * g.w + lx0 + cxi) * out_stride + k, acc);
+#pragma unroll
+        for (int yy = 0; yy < TY; ++yy) acc += wys[yy * MAXR + cyi] * rowsum[(k * TY + yy) * MAXC + cxi];
+        if (acc != 0.f) atomicAdd(out + (((long)b * g.h + ly0 + cyi) * g.w + lx0 + cxi) * out_stride + k, acc);
     }
 }
 
@@ -193,7 +210,7 @@ template <int K8>
 __global__ __launch_bounds__(TPB) void upce_bwd(const uint16_t* __restrict__ lg, UpGeom g, int K, int Kp, const long* __restrict__ labels,
                                                 const float* __restrict__ weights, int ignore, const float* __restrict__ ce_map,
                                                 const float* __restrict__ sel, const float* __restrict__ gout, float* dlg) {
-    extern __shared__ float res[];  // [TY*TX][K8*8] residuals g*(p_k - onehot)
+    extern __shared__ float res[];  // [K8*8][TY][RP] residuals g*(p_k - onehot)
     constexpr int KK = K8 * 8;
     const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY, b = blockIdx.z;
     const float tau = sel[0], tie_w = sel[1], scale = sel[2] * gout[0];
@@ -219,12 +236,12 @@ __global__ __launch_bounds__(TPB) void upce_bwd(const uint16_t* __restrict__ lg,
         for (int k = 0; k < KK; ++k) {
             float r = 0.f;
             if (gpx != 0.f && k < K) r = gpx * (__expf(z[k] - lse) - (k == (int)lab ? 1.f : 0.f));
-            res[t * KK + k] = r;
+            res[res_idx(k, t / TX, t % TX)] = r;
         }
     }
     __syncthreads();
     // ---- phase 2: separable bilinear adjoint of the tile into its low-res footprint
-    scatter_tile<KK>(g, b, X0, Y0, K, res, res + TX * TY * KK, dlg, Kp);
+    scatter_tile<KK>(g, b, X0, Y0, K, res, res + KK * TY * RP, dlg, Kp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -306,7 +323,7 @@ __global__ void sum4_kernel(const float* partials, int nblk, float* out) {
 
 // gout = {d/d loss_center, d/d loss_offset}; sums = output of sum4_kernel
 __global__ __launch_bounds__(TPB) void ins_bwd(InsMaps m, const float* __restrict__ sums, const float* __restrict__ gout, float* dco) {
-    __shared__ float res[TY * TX * 4 + TY * MAXC * 4];
+    __shared__ float res[4 * TY * RP + 4 * TY * MAXC];
     const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY, b = blockIdx.z;
     const UpGeom& g = m.gc;  // centre and offset maps share the geometry
     const float sc = sums[2] > 0.f ? gout[0] / sums[2] : 0.f, so = sums[3] > 0.f ? gout[1] / sums[3] : 0.f;
@@ -324,10 +341,10 @@ __global__ __launch_bounds__(TPB) void ins_bwd(InsMaps m, const float* __restric
             r1 = wo * (float)((d0 > 0.f) - (d0 < 0.f));
             r2 = wo * (float)((d1 > 0.f) - (d1 < 0.f));
         }
-        res[t * 4 + 0] = r0; res[t * 4 + 1] = r1; res[t * 4 + 2] = r2; res[t * 4 + 3] = 0.f;
+        res[res_idx(0, t / TX, t % TX)] = r0; res[res_idx(1, t / TX, t % TX)] = r1; res[res_idx(2, t / TX, t % TX)] = r2;
     }
     __syncthreads();
-    scatter_tile<4>(g, b, X0, Y0, 3, res, res + TX * TY * 4, dco, 4);
+    scatter_tile<4>(g, b, X0, Y0, 3, res, res + 4 * TY * RP, dco, 4);
 }
 
 // a 32x16 pixel tile must fall into at most MAXC x MAXR low-res cells
@@ -348,14 +365,14 @@ __global__ __launch_bounds__(TPB) void up1_fwd(const float* __restrict__ lr, UpG
 }
 
 __global__ __launch_bounds__(TPB) void up1_bwd(const float* __restrict__ dfull, UpGeom g, float* dlr) {
-    __shared__ float res[TY * TX + TY * MAXC];
+    __shared__ float res[TY * RP + TY * MAXC];
     const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY, b = blockIdx.z;
     for (int t = threadIdx.x; t < TX * TY; t += TPB) {
         const int X = X0 + (t % TX), Y = Y0 + (t / TX);
-        res[t] = (X < g.W && Y < g.H) ? dfull[((long)b * g.H + Y) * g.W + X] : 0.f;
+        res[res_idx(0, t / TX, t % TX)] = (X < g.W && Y < g.H) ? dfull[((long)b * g.H + Y) * g.W + X] : 0.f;
     }
     __syncthreads();
-    scatter_tile<1>(g, b, X0, Y0, 1, res, res + TX * TY, dlr, 1);
+    scatter_tile<1>(g, b, X0, Y0, 1, res, res + TY * RP, dlr, 1);
 }
 
 inline int geom_ok(int B, int h, int w, int H, int W) { return B >= 1 && h >= 2 && w >= 2 && H >= h && W >= w; }
@@ -403,7 +420,7 @@ int mgn_upce_bwd(const void* logits_bf16, long sb, long sh, long sw, int B, int 
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* lg = (const uint16_t*)logits_bf16;
     const int k8 = (K + 7) / 8;
-    const size_t lds = sizeof(float) * (TX * TY + TY * MAXC) * k8 * 8;
+    const size_t lds = sizeof(float) * (TY * RP + TY * MAXC) * k8 * 8;
     switch (k8) {
         case 1: hipLaunchKernelGGL(upce_bwd<1>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
         case 2: hipLaunchKernelGGL(upce_bwd<2>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
