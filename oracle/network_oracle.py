@@ -2,21 +2,23 @@
 
 TEST INFRASTRUCTURE ONLY (never imported by mgnet_amd/).
 
-Parity status: **module level PINNED, model assembly UNPINNED**.
-  * PINNED by tests/golden/net_*.npz (tests/test_network_golden.py): BasicBlock (stride 1/2), BasicStem, GlobalContextModule,
-    AttentionRefinementModule, FeatureFusionModule, MGNetDecoder, MGNetHead.  The fixtures are outputs of the REFERENCE's
-    own mgnet/modeling/layers.py and res_net.py, imported unmodified in the build container
-    (tests/golden/make_golden_network.py); the three third-party packages they import are absent from the image and from
-    /root/reference, so the generating harness supplies stand-ins for the names used and the fixtures pin the reference's
-    wiring (state-dict keys, hyper-parameters, order of operations, interpolation modes, concat order, residual/attention
-    arithmetic), not those packages' internals, which are restated from their published behaviour:
+Parity status: **PINNED against outputs of the reference's own code, with stand-ins for three absent third-party packages**.
+  * modules -- tests/golden/net_*.npz (tests/test_network_golden.py): BasicBlock (stride 1/2), BasicStem,
+    GlobalContextModule, AttentionRefinementModule, FeatureFusionModule, MGNetDecoder, MGNetHead;
+  * the full training step -- tests/golden/model_step.npz (tests/test_model_golden.py): MGNet.forward in training mode
+    (input normalisation, PoseCNN, both ResNet-18, the three decoders/heads, target assembly, OhemCE, centre/offset losses,
+    MultiViewPhotometricLoss, uncertainty weighting) -> loss dictionary, gradients of log_vars / pose_net.conv4.bias and the
+    gradient norm of every top-level submodule.
+  The fixtures are outputs of mgnet/modeling/{mg_net,layers,res_net,loss}.py + mgnet/geometry imported UNMODIFIED in the
+  build container (tests/golden/make_golden_network.py, make_golden_model.py).  detectron2, inplace_abn and fvcore are
+  absent from the image and from /root/reference, so those harnesses supply stand-ins for exactly the names the files
+  use; the fixtures therefore pin the reference's wiring and arithmetic (state-dict keys, hyper-parameters and their
+  config keys, order of operations, interpolation modes, concat order, loss weights, task order of the uncertainty
+  weighting), while the internals of the third-party pieces stay restated from their published behaviour:
       - detectron2.layers.Conv2d             = conv -> norm -> activation
       - inplace_abn.InPlaceABNSync (>=1.1.0)  = batch_norm with gamma := |weight| + eps, leaky_relu(0.01) or identity
-      - detectron2 ImageList.from_tensors     = zero-pad to a multiple of 32 and stack
-  * UNPINNED: the assembly of the full model and its loss dictionary (mgnet/modeling/mg_net.py needs detectron2's config,
-    registries, structures and event storage; the reference has no tests or golden vectors for it): `mgnet_losses` below is
-    a restatement read off mg_net.py:220-373 / :597-715 / :804-807.
-  * The loss functions that ARE importable (OhemCE/DeepLabCE, MultiViewPhotometricLoss) are pinned separately by
+      - detectron2 ResNet container / ImageList.from_tensors = stem -> res2..res5 / zero-pad to a multiple of 32 and stack
+  * The loss functions (OhemCE/DeepLabCE, MultiViewPhotometricLoss) are additionally pinned on their own by
     tests/golden/{ce_losses,reproj_*}.npz.
 """
 import numpy as np
