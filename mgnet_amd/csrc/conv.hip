@@ -602,15 +602,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
     };
     const int my_cnt = wave == 0 ? 3 : 2;
 
-    // A-fragment (pixel) addresses for the three kw shifts: patch pixel = 32*wpx + (lane & 31) + kw
-    int abase[3], asw[3];
+    // A-fragment byte offsets inside an input row for (kw, kk): patch pixel = 32*wpx + (lane & 31) + kw, 16-byte slot
+    // (2*kk + lane>>5) XOR-swizzled by the pixel
+    const int hi = lane >> 5;
+    int aoff[3][4];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
         const int px = 32 * wpx + (lane & 31) + kw;
-        abase[kw] = px * 128;
-        asw[kw] = (px >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) aoff[kw][kk] = px * 128 + ((((kk * 2 + hi) ^ ((px >> 1) & 7))) << 4);
     }
-    const int hi = lane >> 5;
 
     issue_in(r0 - 1, 0);
     issue_in(r0, 1);
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
             for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowp + abase[kw] + ((((kk * 2 + hi) ^ asw[kw])) << 4));
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowp + aoff[kw][kk]);
                     const int idx = (kh * 3 + kw) * 4 + kk;
                     if (idx & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], a, acc1, 0, 0, 0);
                     else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], a, acc0, 0, 0, 0);
