@@ -36,6 +36,7 @@ class MGNet(nn.Module):
                  amp_dtype=None, **unused_inference_kwargs):
         super().__init__()
         self.size_divisibility = size_divisibility
+        self._mean01, self._std01 = [float(x) / 255.0 for x in pixel_mean], [float(x) / 255.0 for x in pixel_std]  # host copies
         self.register_buffer("pixel_mean", torch.tensor([x / 255.0 for x in pixel_mean]).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor([x / 255.0 for x in pixel_std]).view(-1, 1, 1), False)
         self.backbone = backbone
@@ -74,9 +75,25 @@ class MGNet(nn.Module):
     # ---- batching helpers (mg_net.py:250-345) --------------------------------------------------------------
     def _stack(self, batched_inputs, key, scale=None):
         ts = [x[key].to(self.device) for x in batched_inputs]
-        if scale is not None:
-            ts = [t.float() / scale for t in ts]
-        return ImageList.from_tensors(ts, self.size_divisibility).tensor
+        t = ImageList.from_tensors(ts, self.size_divisibility).tensor
+        # `.float() / 255` (mg_net.py:250,320-335) once on the stacked batch instead of per frame: same values (the zero
+        # padding stays zero), 2 launches instead of 2 per frame
+        return t if scale is None else t.float() / scale
+
+    def _to_device_async(self, t):
+        """Small host tensor -> device without stalling the host: a copy from pageable memory is stream-ordered AND blocks
+        the host, i.e. it waits for every kernel queued so far (here: the whole forward pass).  Staged through two
+        alternating pinned buffers instead."""
+        if t.device == self.device or self.device.type != "cuda":
+            return t.to(self.device)
+        key = (tuple(t.shape), t.dtype)
+        st = self.__dict__.setdefault("_pinned", {})
+        if key not in st:
+            st[key] = [[torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(2)], 0]
+        bufs, turn = st[key]
+        st[key][1] = turn ^ 1
+        bufs[turn].copy_(t)
+        return bufs[turn].to(self.device, non_blocking=True)
 
     def _net_input(self, batched_inputs, key):
         x = (self._stack(batched_inputs, key, 255.0) - self.pixel_mean) / self.pixel_std
@@ -89,7 +106,7 @@ class MGNet(nn.Module):
         fused_prep = self.pixel_mean.is_cuda and self.amp_dtype == torch.bfloat16 and batched_inputs[0]["image"].dtype == torch.uint8
         if fused_prep:  # [HIP] uint8 frames -> normalised, channel-padded NHWC bf16 in one pass (csrc/prep.hip)
             from .. import _C
-            mean, std = self.pixel_mean.flatten().tolist(), self.pixel_std.flatten().tolist()
+            mean, std = self._mean01, self._std01   # (host constants: reading the device buffers would sync every step)
             frames = [self._stack(batched_inputs, "image")]
             inputs["image"] = _C.prep_input(frames, mean, std, 8)
             if self.training and self.with_depth:
@@ -128,7 +145,7 @@ class MGNet(nn.Module):
                 "image_orig": self._stack(batched_inputs, "image_orig", 255.0),  # NOT mean/std normalised (:320-335)
                 "image_prev_orig": self._stack(batched_inputs, "image_prev_orig", 255.0),
                 "image_next_orig": self._stack(batched_inputs, "image_next_orig", 255.0),
-                "camera_matrix": torch.stack([x["camera_matrix"] for x in batched_inputs], 0).to(self.device),
+                "camera_matrix": self._to_device_async(torch.stack([x["camera_matrix"] for x in batched_inputs], 0)),
                 "reprojection_mask": self._stack(batched_inputs, "reprojection_mask").unsqueeze(1),
             })
 
@@ -140,12 +157,21 @@ class MGNet(nn.Module):
             losses.update(self.depth_head.losses(outputs, targets))
 
         if self.with_uncertainty:  # mg_net.py:360-372 -- same scalar names, but no .item() host syncs inside forward
+            # evaluated for all tasks at once (a handful of launches instead of ~20 scalar kernels per task):
+            #   loss_k <- tau_k * exp(-log_vars[k]) * loss_k + 0.5 * log_vars[k],  tau = 1 for loss_sem_seg, else 0.5
             storage = get_event_storage()
-            for idx, (key, value) in enumerate(list(losses.items())):
-                storage.put_scalar(key + "_raw", value.detach())
-                tau = 1.0 if key == "loss_sem_seg" else 0.5
-                losses[key] = tau * torch.exp(-self.log_vars[idx]) * value + 0.5 * self.log_vars[idx]
-                storage.put_scalar(key + "_uncertainty", torch.exp(self.log_vars[idx].detach()))
+            keys = list(losses.keys())
+            raw = torch.stack([losses[k].float().reshape(()) for k in keys])
+            lv = self.log_vars[:len(keys)]
+            tau = torch.tensor([1.0 if k == "loss_sem_seg" else 0.5 for k in keys], dtype=raw.dtype).to(raw.device, non_blocking=True) \
+                if not hasattr(self, "_tau") or self._tau[0] != keys else self._tau[1]
+            self._tau = (keys, tau)
+            weighted = tau * torch.exp(-lv) * raw + 0.5 * lv
+            unc = torch.exp(lv.detach())
+            for idx, key in enumerate(keys):
+                storage.put_scalar(key + "_raw", raw[idx].detach())
+                storage.put_scalar(key + "_uncertainty", unc[idx])
+                losses[key] = weighted[idx]
         return losses
 
 

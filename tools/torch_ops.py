@@ -25,4 +25,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     for _ in range(2):
         trainer.run_step(batch)
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=40, max_src_column_width=110))
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.self_device_time_total > 0]
+rows.sort(key=lambda e: -e.self_device_time_total)
+for e in rows[:40]:
+    print(f"{e.self_device_time_total / 2e3:8.3f} ms/step  {e.count // 2:4d} calls  {e.key:28s} {str(e.input_shapes)[:150]}")
