@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
     constexpr int RPP = 256 / SEGS;       // rows covered per loader pass
     constexpr int NR = 128 / RPP;         // loader passes (rows per thread)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TILE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
     const int bm = blockIdx.x, bn = blockIdx.y;
     const long M = (long)p.N * p.OH * p.OW;
     const int lrow = tid / SEGS, seg = tid % SEGS;  // loader: rows lrow + r*RPP, 16-byte segment `seg` of the k-slab
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
     constexpr int BN = 64 * NT, BK = 32, PITCH = 64, TILE = 128 * PITCH;  // 8 KB per operand tile
     constexpr int LPT = 2 + NT;  // LDS-DMA instructions per thread and tile (2 A passes + NT B passes)
     __shared__ __attribute__((aligned(16))) unsigned char smem[3][2][TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
     const int bm = blockIdx.x, bn = blockIdx.y;
     // up > 1 (data gradient of a strided conv): blockIdx.z is the parity class (a, b) of the output pixels; only the
     // taps kh = k0h + up*i meet a non-zero of the zero-upsampled gradient, so each class is a dense conv over its taps
@@ -413,7 +413,7 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
     using C = IgemmBig<NWN>;
     constexpr int PA = C::PA, PB = C::PB;
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / NWN, wn = wave % NWN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / NWN, wn = wave % NWN;
     const int bm = blockIdx.x, bn = blockIdx.y;
     const UpClass uc(p, blockIdx.z);
     const long M = (long)p.N * uc.OHc * uc.OWc;
@@ -556,7 +556,7 @@ constexpr int C64_INROW = 136 * 128, C64_LDS = 5 * C64_INROW;
 
 __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char c64sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpx = wave >> 1, wco = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpx = wave >> 1, wco = wave & 1;
     const int L = blockIdx.x, q = L >> 3;
     const int slice = (q / p.co_tiles) * 8 + (L & 7), tile = q % p.co_tiles;
     if (slice >= p.nslices) return;
@@ -710,7 +710,7 @@ __device__ __forceinline__ void transpose8x8(const uint4 (&in)[8], uint4 (&out)[
 template <int MT, int NT, bool PACK = false>
 __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];  // [2 buffers][A | B][WTILE]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
     const int bco = blockIdx.x;
     const int tap_blk = PACK ? 0 : blockIdx.y / p.ci_tiles, bci = PACK ? blockIdx.y : blockIdx.y % p.ci_tiles;
     int kh = tap_blk / p.KW, kw = tap_blk % p.KW;
@@ -881,7 +881,7 @@ template <int NG>
 __device__ __forceinline__ void wgrad3x3_body(const Wgrad3Params& p) {
     using C = W3<NG>;
     extern __shared__ __attribute__((aligned(16))) unsigned char w3sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     const int tiles = p.co_tiles * p.ci_tiles;
     const int L = blockIdx.x, q = L >> 3;
     const int slice = (q / tiles) * 8 + (L & 7), tile = q % tiles;
