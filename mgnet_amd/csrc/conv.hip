@@ -1236,6 +1236,155 @@ __global__ void conv_wgrad_stem_reduce(const float* __restrict__ partial, int sp
     dw[i] = sacc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// conv_wgrad_tr: the per-tap weight-gradient tile kernel (1x1 convs, strided 3x3) without register staging: 32-pixel
+// slabs of dOut [pixel][64*MT co] and of the gathered input [pixel][64*NT ci] go HBM/L2 -> LDS by LDS-DMA into a ring of
+// three stages (counted vmcnt + raw barrier, like conv_igemm_glds); the K = pixel fragments are read with
+// ds_read_b64_tr_b16.  Replaces conv_wgrad's 8x8 register transposes (64 VALU + 8 ds_write_b128 per thread and slab).
+// 16-byte slot swizzle by pixel so that the 4 pixel rows of a transposing read fall into different bank quarters.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_tr(WgradParams p) {
+    constexpr int RA = 128 * MT, RB = 128 * NT;                 // bytes per pixel row of the A (dOut) / B (input) slab
+    constexpr int ATILE = 32 * RA, BTILE = 32 * RB, STAGE = ATILE + BTILE;
+    constexpr int PA = MT, PB = NT;                             // 1-KB pieces per wave and stage (4*MT resp. 4*NT per block)
+    __shared__ __attribute__((aligned(16))) unsigned char sm[3 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int bco = blockIdx.x;
+    const int tap = blockIdx.y / p.ci_tiles, bci = blockIdx.y % p.ci_tiles;
+    const int kh = tap / p.KW, kw = tap % p.KW;
+    const long M = (long)p.N * p.OH * p.OW;
+    const long m_begin = (long)blockIdx.z * p.m_per_split;
+    const long m_end = m_begin + p.m_per_split < M ? m_begin + p.m_per_split : M;
+    if (m_begin >= M) return;
+    const int ksteps = (int)((m_end - m_begin + 31) / 32);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dout), 0, (uint32_t)((size_t)M * p.Cout * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto swzA = [](int px) { return MT == 1 ? (((px >> 1) & 1) << 2) : ((px & 3) << 2); };
+    auto swzB = [](int px) { return NT == 1 ? (((px >> 1) & 1) << 2) : ((px & 3) << 2); };
+
+    // loader state: piece q of this wave covers slab pixels (wave + 4q) * (8/MT) .. for A, (8/NT) for B
+    constexpr int CA = 8 * MT, CB = 8 * NT;          // 16-byte chunks per pixel row
+    int a_px[PA], a_col[PA], b_px[PB], b_col[PB];
+    bool a_vc[PA], b_vc[PB];
+    int bn[PB], boh[PB], bow[PB];                     // (image, oh, ow) of the B loader's pixel of the CURRENT slab
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+        a_px[q] = (wave + 4 * q) * (64 / CA) + lane / CA;
+        const int ch = (lane % CA) ^ swzA(a_px[q]);
+        a_col[q] = (bco * 64 * MT + ch * 8) * 2;
+        a_vc[q] = bco * 64 * MT + ch * 8 < p.Cout;
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        b_px[q] = (wave + 4 * q) * (64 / CB) + lane / CB;
+        const int ch = (lane % CB) ^ swzB(b_px[q]);
+        b_col[q] = (bci * 64 * NT + ch * 8) * 2;
+        b_vc[q] = bci * 64 * NT + ch * 8 < p.Cin;
+        const long m = m_begin + b_px[q];
+        bn[q] = (int)(m / ((long)p.OH * p.OW));
+        const int rem = (int)(m - (long)bn[q] * p.OH * p.OW);
+        boh[q] = rem / p.OW;
+        bow[q] = rem - boh[q] * p.OW;
+    }
+    long mcur = m_begin;
+    auto issue = [&](int buf) {
+        unsigned char* a0 = sm + buf * STAGE;
+        unsigned char* b0 = a0 + ATILE;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const long m = mcur + a_px[q];
+            const int vo = (a_vc[q] && m < m_end) ? (int)(m * p.Cout * 2) + a_col[q] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a0 + (wave + 4 * q) * 1024), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int ih = boh[q] * p.stride - p.pad + kh, iw = bow[q] * p.stride - p.pad + kw;
+            const bool ok = b_vc[q] && mcur + b_px[q] < m_end && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+            const int vo = ok ? (((bn[q] * p.IH + ih) * p.IW + iw) * p.Cin) * 2 + b_col[q] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b0 + (wave + 4 * q) * 1024), 16, vo, 0, 0, 0);
+            bow[q] += 32;   // next slab
+            while (bow[q] >= p.OW) { bow[q] -= p.OW; if (++boh[q] == p.OH) { boh[q] = 0; ++bn[q]; } }
+        }
+        mcur += 32;
+    };
+
+    // fragment addresses: lane group g = lane>>4 reads pixels 8*(g>>1) + (i>>2) [+4], columns 16*(g&1) + 4*(i&3) of a 32-wide tile
+    const int g = lane >> 4, i4 = lane & 15;
+    const int prow = 8 * (g >> 1) + (i4 >> 2);
+    int fa[MT], fb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int col = wm * 32 * MT + i * 32 + (g & 1) * 16 + 4 * (i4 & 3);
+        fa[i] = prow * RA + (((col >> 3) ^ swzA(prow)) << 4) + (col & 7) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = wn * 32 * NT + j * 32 + (g & 1) * 16 + 4 * (i4 & 3);
+        fb[j] = ATILE + prow * RB + (((col >> 3) ^ swzB(prow)) << 4) + (col & 7) * 2;
+    }
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    auto frag = [&](const unsigned char* q, int row_bytes) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(q));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(q + 4 * row_bytes));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue(0);
+    if (ksteps > 1) issue(1);
+    int buf = 0;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        if (ks + 1 < ksteps) {
+            if (PA + PB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (PA + PB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (ks + 2 < ksteps) issue(buf == 0 ? 2 : buf - 1);
+        const unsigned char* st = sm + buf * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {   // the swizzle depends on pixel bits 0..1 (and 1): unchanged by +16 pixels
+            bf16x8 a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = frag(st + fa[i] + kk * 16 * RA, RA);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = frag(st + fb[j] + kk * 16 * RB, RB);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    const size_t wsize = (size_t)p.Cout * p.KH * p.KW * p.Cin;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ci = bci * 64 * NT + wn * 32 * NT + j * 32 + (lane & 31);
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = bco * 64 * MT + wm * 32 * MT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                p.partial[(size_t)blockIdx.z * wsize + (((size_t)co * p.KH * p.KW + tap) * p.Cin + ci)] = acc[i][j][e];
+            }
+    }
+}
+
 // dw = sum over the pixel splits (fixed order: deterministic), written in the requested layout
 __global__ void conv_wgrad_reduce(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw, int cin_real,
                                   float* __restrict__ dw) {
@@ -1560,8 +1709,17 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
+    const size_t M_total = (size_t)N * OH * OW;
+    // (measured: the transposing-read kernel wins on the strided 3x3 layers, 168->144 / 124->90 / 120->90 us; the 1x1 layers
+    //  are bound by their inputs and split partials either way and stay on conv_wgrad)
+    const bool use_tr = !pack && KH * KW > 1 && !getenv("MGN_WGRAD_NOTR") && M_total * (Cout > Cin ? Cout : Cin) * 2 < 0x7fffffffu &&
+                        (size_t)N * IH * IW * Cin * 2 < 0x7fffffffu;
     if (pack && MT == 1) hipLaunchKernelGGL((conv_wgrad<1, 2, true>), grid, dim3(256), lds, st, p);
     else if (pack) hipLaunchKernelGGL((conv_wgrad<2, 2, true>), grid, dim3(256), lds, st, p);
+    else if (use_tr && MT == 1 && NT == 1) hipLaunchKernelGGL((conv_wgrad_tr<1, 1>), grid, dim3(256), 0, st, p);
+    else if (use_tr && MT == 1) hipLaunchKernelGGL((conv_wgrad_tr<1, 2>), grid, dim3(256), 0, st, p);
+    else if (use_tr && NT == 1) hipLaunchKernelGGL((conv_wgrad_tr<2, 1>), grid, dim3(256), 0, st, p);
+    else if (use_tr) hipLaunchKernelGGL((conv_wgrad_tr<2, 2>), grid, dim3(256), 0, st, p);
     else if (MT == 1 && NT == 1) hipLaunchKernelGGL((conv_wgrad<1, 1>), grid, dim3(256), lds, st, p);
     else if (MT == 1) hipLaunchKernelGGL((conv_wgrad<1, 2>), grid, dim3(256), lds, st, p);
     else if (NT == 1) hipLaunchKernelGGL((conv_wgrad<2, 1>), grid, dim3(256), lds, st, p);
