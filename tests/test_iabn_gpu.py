@@ -67,3 +67,28 @@ def test_iabn_eval_mode_uses_running_stats():
     ref = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(x, rm, rv, w.abs() + 1e-5, b, False, 0.0, 1e-5), 0.01)
     y = ops.iabn(x.clone(memory_format=torch.channels_last), w, b, rm.clone(), rv.clone(), False, 0.01, 1e-5, "leaky_relu", 0.01)
     assert torch.allclose(y, ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 33, 47), (2, 256, 9, 5), (8, 128, 1, 1)])
+def test_multi_rank_kernel_path_equals_single_launch_path(shape):
+    """The kernels of the multi-rank forward (mgn_iabn_stats -> [all_gather] -> mgn_iabn_combine) give the same coefficients
+    and running statistics as the fused single-process entry point, also when the batch is split into two 'ranks' and
+    combined with Chan's formula."""
+    from mgnet_amd import _C
+
+    N, C, H, W = shape
+    torch.manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, device="cuda") * 2 + 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w, b = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    rm1, rv1 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    rm3, rv3 = rm1.clone(), rv1.clone()
+    M = N * H * W
+    fused = _C.iabn_train_coeffs(x, M, C, w, b, 1e-5, 0.01, rm1, rv1)
+    one = _C.iabn_combine(_C.iabn_stats(x, M, C).unsqueeze(0).contiguous(), w, b, 1e-5, 0.01, rm2, rv2)
+    assert torch.allclose(fused, one, rtol=1e-5, atol=1e-6) and torch.allclose(rm1, rm2, atol=1e-7) and torch.allclose(rv1, rv2, rtol=1e-6)
+    h = N // 2
+    xa, xb = x[:h].contiguous(memory_format=torch.channels_last), x[h:].contiguous(memory_format=torch.channels_last)
+    two = torch.stack([_C.iabn_stats(xa, h * H * W, C), _C.iabn_stats(xb, (N - h) * H * W, C)]).contiguous()
+    comb = _C.iabn_combine(two, w, b, 1e-5, 0.01, rm3, rv3)
+    assert torch.allclose(comb, fused, rtol=2e-4, atol=2e-5) and torch.allclose(rv3, rv1, rtol=2e-4, atol=1e-6)
