@@ -401,16 +401,16 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
 // 128 x 128 tile).  BK = 32, ring of three 16 KB + BN*64 B stages, two k-steps in flight across the raw barrier.
 // Used when the layer has enough 256-pixel tiles to fill the chip (host dispatch).
 // ---------------------------------------------------------------------------------------------------------------
-template <int NWN>
+template <int NWN, int NWM = 2>
 struct IgemmBig {
-    static constexpr int BMB = 256, BN = 64 * NWN, NW = 2 * NWN, THREADS = 64 * NW;
+    static constexpr int BMB = 128 * NWM, BN = 64 * NWN, NW = NWM * NWN, THREADS = 64 * NW;
     static constexpr int ATILE = BMB * 64, BTILE = BN * 64, STAGE = ATILE + BTILE, LDS = 3 * STAGE;
     static constexpr int PA = (BMB / 16) / NW, PB = (BN / 16) / NW;   // 1-KB DMA pieces (16 rows x 64 B) per wave and stage
 };
 
-template <int NWN>
+template <int NWN, int NWM = 2>
 __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
-    using C = IgemmBig<NWN>;
+    using C = IgemmBig<NWN, NWM>;
     constexpr int PA = C::PA, PB = C::PB;
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / NWN, wn = wave % NWN;
@@ -502,6 +502,7 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
     for (int ks = 0; ks < ksteps; ++ks) {
         if (ks + 1 < ksteps) {
             if (PA + PB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (PA + PB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -531,6 +532,7 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
 }
 __global__ __launch_bounds__(256, 2) void conv_igemm_big128(ConvParams p) { igemm_big_body<2>(p); }
 __global__ __launch_bounds__(512, 1) void conv_igemm_big256(ConvParams p) { igemm_big_body<4>(p); }
+__global__ __launch_bounds__(512, 1) void conv_igemm_big512x128(ConvParams p) { igemm_big_body<2, 4>(p); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // conv3x3_c64: 3x3 / stride 1 / pad 1 convolution with 64 input channels (ResNet layer1 forward and data gradient, 16
@@ -1548,6 +1550,18 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
             }
             if (pick == 256) {
                 hipLaunchKernelGGL(conv_igemm_big256, dim3((unsigned)gxb, Cout / 256, gz), dim3(512), IgemmBig<4>::LDS, st, p);
+                return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+            }
+            // 512 x 128 tile: measured slower than the 128 x 128 kernel on the 128-channel layers (130 vs 122 us) -- the small-N
+            // layers are bound by the 9x re-gathered A operand, not by the weight tile; only on request
+            if (pick == 0 && Cout == 128 && fbig == 512) {
+                static bool a512 = false;
+                constexpr int L512 = IgemmBig<2, 4>::LDS;
+                if (!a512) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_big512x128), hipFuncAttributeMaxDynamicSharedMemorySize, L512);
+                    a512 = true;
+                }
+                hipLaunchKernelGGL(conv_igemm_big512x128, dim3((unsigned)((Mc + 511) / 512), 1, gz), dim3(512), L512, st, p);
                 return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
             }
             if (pick == 128) {

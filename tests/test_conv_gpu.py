@@ -116,7 +116,8 @@ def test_prep_input_matches_reference_normalisation():
 
 @pytest.mark.parametrize("big,case", [("256", (1, 64, 256, 19, 23, 3, 1, 1)), ("256", (2, 128, 512, 9, 14, 3, 2, 1)),
                                       ("128", (1, 256, 128, 21, 17, 3, 1, 1)), ("128", (2, 64, 128, 16, 24, 1, 2, 0)),
-                                      ("256", (1, 256, 256, 8, 40, 1, 1, 0))])
+                                      ("256", (1, 256, 256, 8, 40, 1, 1, 0)), ("512", (1, 128, 128, 37, 29, 3, 1, 1)),
+                                      ("512", (2, 256, 128, 18, 14, 3, 2, 1))])
 def test_big_tile_igemm(monkeypatch, big, case):
     """conv_igemm_big (256 x 128|256 block tiles), forced through MGN_CONV_BIG on shapes with ragged pixel tails:
     forward and data gradient (stride 2 exercises the `up` gather) against F.conv2d in fp64."""
