@@ -36,6 +36,17 @@ def _dist_active(group):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
+def _gather_stats(stats, world, group):
+    """[world, 3, C] statistics of all ranks.  RCCL: one all_gather_into_tensor (no per-rank output list and its copies);
+    other backends (gloo in the CPU tests): the list form."""
+    gathered = torch.empty((world,) + tuple(stats.shape), dtype=stats.dtype, device=stats.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(gathered.view(-1), stats.contiguous().view(-1), group=group)
+    else:
+        dist.all_gather(list(gathered.unbind(0)), stats, group=group)
+    return gathered
+
+
 class _IABNFn(torch.autograd.Function):
     """[HIP] mgnet_amd/csrc/iabn.hip through the C-ABI.  In place: the output overwrites the input's storage (the
     producing conv does not need its output for its own backward) and the backward re-derives x_hat from y."""
@@ -54,8 +65,7 @@ class _IABNFn(torch.autograd.Function):
         if training:
             if world > 1:
                 stats = _C.iabn_stats(xs, M, C)
-                gathered = torch.empty((world, 3, C), dtype=torch.float32, device=x.device)
-                dist.all_gather(list(gathered.unbind(0)), stats, group=group)  # (list form: also available on gloo)
+                gathered = _gather_stats(stats, world, group)
                 coef = _C.iabn_combine(gathered, w32, b32, eps, momentum, running_mean, running_var)
             else:  # one process: statistics and coefficients in one launch
                 coef = _C.iabn_train_coeffs(xs, M, C, w32, b32, eps, momentum, running_mean, running_var)

@@ -102,3 +102,37 @@ def _train(rank, world):
 
 def test_two_rank_training_keeps_replicas_identical():
     assert all(_spawn(_train).values())
+
+
+def _nccl_gather(rank, world):
+    """RCCL code path of the statistics exchange (single rank: the transport is trivial, the call sequence is the real one)."""
+    from mgnet_amd.modeling import ops
+
+    stats = torch.arange(3 * 64, dtype=torch.float32, device="cuda").view(3, 64)
+    g = ops._gather_stats(stats, world, dist.group.WORLD)
+    sums = torch.ones(2, 64, device="cuda")
+    dist.all_reduce(sums)
+    torch.cuda.synchronize()
+    return bool(g.shape == (world, 3, 64) and torch.equal(g[rank], stats) and float(sums.sum()) == 128.0 * world)
+
+
+def _worker_nccl(rank, world, port, fn, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        q.put((rank, fn(rank, world)))
+    except Exception as e:  # report instead of leaving the parent blocked
+        q.put((rank, "worker failed: " + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_single_rank_statistics_exchange():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_worker_nccl, args=(0, 1, _free_port(), _nccl_gather, q))
+    p.start()
+    rank, ok = q.get()
+    p.join(120)
+    assert ok is True, ok
