@@ -118,6 +118,30 @@ def cpu_baseline(H, W, state_dict=None, cfg=None):
             "sample": f"1 frame {H}x{W}, reprojection loss fwd+bwd, oracle/reproj_oracle.c fp32 OpenMP, {dt:.1f} s"}
 
 
+def conv_roofline(dev, B):
+    """Second roofline object (informative): the convolution kernel that takes the largest share of the step -- the 3x3
+    256->256 head/refine layers at 1/8 resolution (conv_igemm_big256) -- timed live with events on the launch stream."""
+    from mgnet_amd import _C
+    x = torch.randn(B, 256, 128, 256, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(256, 256, 3, 3, device=dev) * 0.02)
+    wl = _C.weight_layout(w, 0)
+    for _ in range(3):
+        _C.conv_igemm(x, wl, (128, 256), None, 1, 1)
+    n = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        _C.conv_igemm(x, wl, (128, 256), None, 1, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * B * 128 * 256 * 256 * 256 * 9
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_igemm_big256 (3x3, 256->256 channels, 8x128x256 pixels; 43 launches/step of this kernel)",
+            "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+            "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
+
+
 def full_step_bench(args, world, rank, dev):
     """The benchmark: one full MGNet training step (SURVEY 3.1 hot loop) per per-GPU batch of synthetic frames."""
     from mgnet_amd import add_mgnet_config, get_cfg
@@ -188,6 +212,7 @@ def full_step_bench(args, world, rank, dev):
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": FWD_BYTES_PER_PX * npx, "avg_launch_ms": round(kern_ms, 4)},
         }
+        line["roofline_mfma"] = conv_roofline(dev, B)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(H, W, model.state_dict(), cfg)
         print(json.dumps(line), flush=True)
