@@ -78,7 +78,8 @@ class MGNet(nn.Module):
         t = ImageList.from_tensors(ts, self.size_divisibility).tensor
         # `.float() / 255` (mg_net.py:250,320-335) once on the stacked batch instead of per frame: same values (the zero
         # padding stays zero), 2 launches instead of 2 per frame
-        return t if scale is None else t.float() / scale
+        # (true division of the uint8 batch promotes to fp32 inside ONE kernel: same values as .float() / scale)
+        return t if scale is None else (t / scale if not t.is_floating_point() else t.float() / scale)
 
     def _to_device_async(self, t):
         """Small host tensor -> device without stalling the host: a copy from pageable memory is stream-ordered AND blocks
