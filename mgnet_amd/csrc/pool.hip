@@ -55,43 +55,69 @@ __global__ __launch_bounds__(256) void maxpool_fwd(const uint16_t* __restrict__ 
     *reinterpret_cast<uint2*>(idx + op) = a;
 }
 
-// one thread: 8 channels of one INPUT pixel
+// one thread: 8 channels of a 2x2 INPUT patch (rows 2i, 2i+1; columns 2j, 2j+1).  The patch is covered by the four windows
+// (i | i+1, j | j+1): pixel (2i+a, 2j+b) lies in window oh = i at tap row a+1 and, when a = 1, in window i+1 at tap row 0
+// (columns alike), so 4 (dy, argmax) loads serve 4 pixels instead of 4 loads per pixel.
 __global__ __launch_bounds__(256) void maxpool_bwd(const uint16_t* __restrict__ dy, const uint8_t* __restrict__ idx, uint16_t* __restrict__ dx,
                                                    int N, int IH, int IW, int C, int OH, int OW) {
-    const int cv = C / 8;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)N * IH * IW * cv) return;
-    const int c8 = (int)(i % cv);
-    long r = i / cv;
-    const int iw = (int)(r % IW); r /= IW;
-    const int ih = (int)(r % IH);
-    const int n = (int)(r / IH);
-    float acc[8];
+    const int cv = C / 8, PH = (IH + 1) / 2, PW = (IW + 1) / 2;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)N * PH * PW * cv) return;
+    const int c8 = (int)(t % cv);
+    long r = t / cv;
+    const int j = (int)(r % PW); r /= PW;
+    const int i = (int)(r % PH);
+    const int n = (int)(r / PH);
+    float acc[2][2][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    // windows (oh, ow) with oh*2-1+kh == ih  =>  oh in {(ih+1)/2, (ih+1)/2 - 1 ...}: at most 2 per axis
-    for (int oh = (ih + 1 - 2 + 1) / 2 < 0 ? 0 : (ih) / 2; oh <= (ih + 1) / 2 && oh < OH; ++oh) {
-        const int kh = ih - (oh * 2 - 1);
-        if (kh < 0 || kh > 2) continue;
-        for (int ow = iw / 2; ow <= (iw + 1) / 2 && ow < OW; ++ow) {
-            const int kw = iw - (ow * 2 - 1);
-            if (kw < 0 || kw > 2) continue;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[a][b][k] = 0.f;
+#pragma unroll
+    for (int wo = 0; wo < 2; ++wo) {
+        const int oh = i + wo;
+        if (oh >= OH) continue;
+#pragma unroll
+        for (int wx = 0; wx < 2; ++wx) {
+            const int ow = j + wx;
+            if (ow >= OW) continue;
             const long op = (((long)n * OH + oh) * OW + ow) * C + c8 * 8;
             const uint4 g = *reinterpret_cast<const uint4*>(dy + op);
-            const uint2 a = *reinterpret_cast<const uint2*>(idx + op);
+            const uint2 am = *reinterpret_cast<const uint2*>(idx + op);
             const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
-            const uint32_t aw[2] = {a.x, a.y};
-            const int tap = kh * 3 + kw;
+            const uint32_t aw[2] = {am.x, am.y};
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if ((int)((aw[k >> 2] >> ((k & 3) * 8)) & 0xff) == tap) acc[k] += bf2f((uint16_t)(gw[k >> 1] >> ((k & 1) * 16)));
+            for (int k = 0; k < 8; ++k) {
+                const int tap = (int)((aw[k >> 2] >> ((k & 3) * 8)) & 0xff);
+                const float v = bf2f((uint16_t)(gw[k >> 1] >> ((k & 1) * 16)));
+                const int kh = tap / 3, kw = tap - kh * 3;
+                // window (oh, ow) tap (kh, kw) is input pixel (2*oh - 1 + kh, 2*ow - 1 + kw) = patch offset (a, b):
+                const int a = 2 * wo - 1 + kh, b = 2 * wx - 1 + kw;   // relative to (2i, 2j)
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb)
+                        if (a == aa && b == bb) acc[aa][bb][k] += v;
+            }
         }
     }
     auto f2bf = [](float f) -> uint32_t { uint32_t u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
-    uint4 o;
-    o.x = f2bf(acc[0]) | (f2bf(acc[1]) << 16); o.y = f2bf(acc[2]) | (f2bf(acc[3]) << 16);
-    o.z = f2bf(acc[4]) | (f2bf(acc[5]) << 16); o.w = f2bf(acc[6]) | (f2bf(acc[7]) << 16);
-    *reinterpret_cast<uint4*>(dx + (((long)n * IH + ih) * IW + iw) * C + c8 * 8) = o;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int ih = 2 * i + a;
+        if (ih >= IH) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int iw = 2 * j + b;
+            if (iw >= IW) continue;
+            uint4 o;
+            o.x = f2bf(acc[a][b][0]) | (f2bf(acc[a][b][1]) << 16); o.y = f2bf(acc[a][b][2]) | (f2bf(acc[a][b][3]) << 16);
+            o.z = f2bf(acc[a][b][4]) | (f2bf(acc[a][b][5]) << 16); o.w = f2bf(acc[a][b][6]) | (f2bf(acc[a][b][7]) << 16);
+            *reinterpret_cast<uint4*>(dx + (((long)n * IH + ih) * IW + iw) * C + c8 * 8) = o;
+        }
+    }
 }
 
 }  // namespace
@@ -110,7 +136,7 @@ int mgn_maxpool3x3s2_fwd(const void* x_bf16, void* y_bf16, uint8_t* argmax, int 
 int mgn_maxpool3x3s2_bwd(const void* dy_bf16, const uint8_t* argmax, void* dx_bf16, int N, int IH, int IW, int C, void* stream) {
     if (!dy_bf16 || !dx_bf16 || !argmax || N < 1 || IH < 1 || IW < 1 || C < 8 || C % 8) return MGN_EINVAL;
     const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
-    const long n = (long)N * IH * IW * (C / 8);
+    const long n = (long)N * ((IH + 1) / 2) * ((IW + 1) / 2) * (C / 8);
     hipLaunchKernelGGL(maxpool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy_bf16, argmax,
                        (uint16_t*)dx_bf16, N, IH, IW, C, OH, OW);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
