@@ -72,7 +72,7 @@ template <> struct Vec<__hip_bfloat16> {
 // ------------------------------------------------------------------------------------------------------
 constexpr int MAX_STAT_BLOCKS = 512;
 
-template <typename T, typename L, typename A, typename G>
+template <typename T, bool DEEP, typename L, typename A, typename G>
 __device__ __forceinline__ void column_sums2(long M, int C, float* ws, unsigned* counter, L&& load_row, A&& add_row, G&& finalize) {
     constexpr int V = Vec<T>::N;
     __shared__ __attribute__((aligned(16))) float sh[TPB * 2 * 8];
@@ -86,7 +86,25 @@ __device__ __forceinline__ void column_sums2(long M, int C, float* ws, unsigned*
     {
         const long stride = (long)gridDim.x * rpb;
         long r = (long)blockIdx.x * rpb + ty;
-        typename Vec<T>::Raw q0[2], q1[2], q2[2], q3[2];
+        typename Vec<T>::Raw q0[2], q1[2], q2[2], q3[2], q4[2], q5[2], q6[2], q7[2];
+        for (; DEEP && r + 7 * stride < M; r += 8 * stride) {   // 8 independent rows in flight (single-tensor reductions)
+            load_row(r, tx * V, q0);
+            load_row(r + stride, tx * V, q1);
+            load_row(r + 2 * stride, tx * V, q2);
+            load_row(r + 3 * stride, tx * V, q3);
+            load_row(r + 4 * stride, tx * V, q4);
+            load_row(r + 5 * stride, tx * V, q5);
+            load_row(r + 6 * stride, tx * V, q6);
+            load_row(r + 7 * stride, tx * V, q7);
+            add_row(q0, a, b);
+            add_row(q1, a, b);
+            add_row(q2, a, b);
+            add_row(q3, a, b);
+            add_row(q4, a, b);
+            add_row(q5, a, b);
+            add_row(q6, a, b);
+            add_row(q7, a, b);
+        }
         for (; r + 3 * stride < M; r += 4 * stride) {
             load_row(r, tx * V, q0);
             load_row(r + stride, tx * V, q1);
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(TPB) void iabn_stats_kernel(const T* __restrict__ x
     constexpr int V = Vec<T>::N;
     float s[V];
     Vec<T>::load(x + (threadIdx.x % (C / V)) * V, s);
-    column_sums2<T>(M, C, ws, counter,
+    column_sums2<T, true>(M, C, ws, counter,
         [&](long r, int c0, typename Vec<T>::Raw (&q)[2]) { q[0] = Vec<T>::load_raw(x + r * C + c0); },
         [&](const typename Vec<T>::Raw (&q)[2], float (&a)[V], float (&b)[V]) {
             float v[V];
@@ -324,7 +342,7 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restric
         bk[k] = bias[c0t + k];
         igk[k] = 1.f / (fabsf(weight[c0t + k]) + eps);
     }
-    column_sums2<T>(M, C, ws, counter,
+    column_sums2<T, false>(M, C, ws, counter,
         [&](long r, int c0, typename Vec<T>::Raw (&q)[2]) {
             q[0] = Vec<T>::load_raw(y + r * C + c0);
             q[1] = Vec<T>::load_raw(dy + r * C + c0);
