@@ -201,6 +201,13 @@ int mgn_upce_fwd(const void* logits_bf16, long sb, long sh, long sw, int B, int 
 int mgn_upce_bwd(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K, int Kp,
                  const long* labels, const float* weights, int ignore, const float* ce_map, const float* sel3,
                  const float* gout, float* dlogits, void* stream);
+/* OhemCE / DeepLabCE selection on the device (replaces the full torch.sort of loss.py:67-81 and its host-side branch):
+ * from the per-pixel loss map and sums3 of mgn_upce_fwd -> sel3 = {tau, tie_weight, scale} for mgn_upce_bwd and the loss.
+ * count(ce > thr) > n_sel: mean of {ce > thr}; otherwise (or force_topk: DeepLabCE hard-pixel mining) the mean of the n_sel
+ * largest values, found by a radix select (no sort, no host synchronisation). */
+int mgn_ohem_select_workspace_bytes(long n, size_t* bytes);
+int mgn_ohem_select(const float* ce_map, long n, const float* sums3, float thr, long n_sel, int force_topk, float* sel3,
+                    float* loss, void* workspace, size_t workspace_bytes, void* stream);
 int mgn_ins_loss_fwd(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh,
                      long osw, int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot,
                      const float* ow, float oscale, float* partials, float* out4, void* stream);

@@ -16,7 +16,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
            "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
-           "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
+           "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
            "mgn_nearest_bwd", "mgn_concat2", "mgn_split2"]
@@ -70,6 +70,8 @@ def lib():
         L.mgn_upce_partials.argtypes = [ci, ci, ci]
         L.mgn_upce_fwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp, vp]
         L.mgn_upce_bwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
+        L.mgn_ohem_select_workspace_bytes.argtypes = [cl, ctypes.POINTER(sz)]
+        L.mgn_ohem_select.argtypes = [vp, cl, vp, cf, cl, ci, vp, vp, vp, sz, vp]
         L.mgn_ins_loss_fwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp]
         L.mgn_ins_loss_bwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
         L.mgn_upsample1_fwd.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
@@ -442,6 +444,18 @@ def upce_fwd(lr, labels, weights, H, W, ignore, thr):
                              None if weights is None else weights.data_ptr(), ignore, thr, ce.data_ptr(), partials.data_ptr(),
                              sums.data_ptr(), _stream()), "mgn_upce_fwd")
     return ce, sums
+
+
+def ohem_select(ce, sums, thr, n_sel, force_topk):
+    """device-side OHEM / top-k selection -> (sel3, loss) without a host synchronisation"""
+    n = ce.numel()
+    nb = ctypes.c_size_t(0)
+    check(lib().mgn_ohem_select_workspace_bytes(n, ctypes.byref(nb)), "mgn_ohem_select_workspace_bytes")
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=ce.device)
+    out = torch.empty(4, dtype=torch.float32, device=ce.device)
+    check(lib().mgn_ohem_select(ce.data_ptr(), n, sums.data_ptr(), float(thr), int(n_sel), int(force_topk), out.data_ptr(),
+                                out[3:].data_ptr(), ws.data_ptr(), nb.value, _stream()), "mgn_ohem_select")
+    return out[:3], out[3]
 
 
 def upce_bwd(lr, labels, weights, H, W, ignore, ce, sel3, gout, Kp):

@@ -375,6 +375,104 @@ __global__ __launch_bounds__(TPB) void up1_bwd(const float* __restrict__ dfull, 
     scatter_tile<1>(g, b, X0, Y0, 1, res, res + TY * RP, dlr, 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// OHEM / top-k selection entirely on the device (loss.py:67-81 without the full sort AND without the host round trip of
+// `if pixel_losses[n_min] > thresh`): result-identical selection
+//     count(ce > thr) > n_sel  ->  mean of {ce > thr}                       sel = {thr, 0, 1/count}
+//     otherwise               ->  mean of the n_sel largest values         sel = {v_k, (n_sel - n_gt)/n_eq, 1/n_sel}
+// v_k (the n_sel-th largest value) by a 4-pass radix select over the fp32 bit patterns of the loss map (ce >= 0, so the
+// unsigned order is the float order); every pass leaves at once when the threshold branch is taken (the common case),
+// so the selection costs a few microseconds of launch latency there.
+// state: u32 {use_thr, prefix, k_remaining, pad}; hist: u32 [256]
+// ---------------------------------------------------------------------------------------------------------------
+struct OhemState { unsigned use_thr, prefix, k, pad; };
+
+__global__ void ohem_init(const float* sums3, long n, long n_sel, int force_topk, OhemState* st, unsigned* hist) {
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        st->use_thr = (!force_topk && (double)sums3[0] > (double)n_sel) ? 1u : 0u;
+        st->prefix = 0;
+        st->k = (unsigned)(n_sel < 1 ? 1 : (n_sel > n ? n : n_sel));
+    }
+}
+
+// histogram of byte `pass` (3 = most significant) of the values whose higher bytes equal the prefix found so far
+__global__ __launch_bounds__(TPB) void ohem_hist(const float* __restrict__ ce, long n, int pass, const OhemState* st, unsigned* hist) {
+    if (st->use_thr) return;
+    __shared__ unsigned h[256];
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned prefix = st->prefix;
+    const int hs = 8 * (pass + 1);
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+        const unsigned b = __float_as_uint(fmaxf(ce[i], 0.f));   // (a rounding-negative loss must not sort above the positives)
+        if (pass == 3 || (b >> hs) == prefix) atomicAdd(&h[(b >> (8 * pass)) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// walk the bins from the top: the bin where the cumulative count reaches k holds the k-th largest value
+__global__ void ohem_pick(OhemState* st, unsigned* hist) {
+    if (threadIdx.x == 0 && !st->use_thr) {
+        unsigned k = st->k, b = 255;
+        for (;; --b) {
+            const unsigned c = hist[b];
+            if (c >= k || b == 0) break;
+            k -= c;
+        }
+        st->k = k;
+        st->prefix = (st->prefix << 8) | b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+}
+
+// per-block partials {count(ce > v_k), count(ce == v_k), sum(ce | ce > v_k)} (fixed-order reduction in ohem_final)
+__global__ __launch_bounds__(TPB) void ohem_tail(const float* __restrict__ ce, long n, const OhemState* st, float* partials) {
+    if (st->use_thr) return;
+    __shared__ float red[3][TPB / 64];
+    const float vk = __uint_as_float(st->prefix);
+    float ngt = 0.f, neq = 0.f, sgt = 0.f;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+        const float v = fmaxf(ce[i], 0.f);
+        if (v > vk) { ngt += 1.f; sgt += v; } else if (v == vk) neq += 1.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ngt += __shfl_xor(ngt, o); neq += __shfl_xor(neq, o); sgt += __shfl_xor(sgt, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ngt; red[1][threadIdx.x >> 6] = neq; red[2][threadIdx.x >> 6] = sgt; }
+    __syncthreads();
+    if (threadIdx.x < 3) partials[(size_t)blockIdx.x * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void ohem_final(const float* sums3, float thr, long n_sel, const OhemState* st, const float* partials, int nblk, float* sel3, float* loss) {
+    __shared__ double sh[3][TPB];
+    double a[3] = {0, 0, 0};
+    if (!st->use_thr)
+        for (int i = threadIdx.x; i < nblk; i += TPB)
+            for (int k = 0; k < 3; ++k) a[k] += (double)partials[(size_t)i * 3 + k];
+    for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] = a[k];
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (st->use_thr) {
+            sel3[0] = thr; sel3[1] = 0.f; sel3[2] = 1.f / sums3[0];
+            loss[0] = sums3[1] / sums3[0];
+        } else {
+            const double vk = (double)__uint_as_float(st->prefix), ngt = sh[0][0], neq = sh[1][0], sgt = sh[2][0];
+            const double take = (double)n_sel - ngt;                     // how many of the values equal to v_k are selected
+            sel3[0] = (float)vk;
+            sel3[1] = neq > 0 ? (float)(take / neq) : 0.f;
+            sel3[2] = (float)(1.0 / (double)n_sel);
+            loss[0] = (float)((sgt + take * vk) / (double)n_sel);
+        }
+    }
+}
+
 inline int geom_ok(int B, int h, int w, int H, int W) { return B >= 1 && h >= 2 && w >= 2 && H >= h && W >= w; }
 
 inline UpGeom make_geom(int B, int h, int w, int H, int W, long sb, long sh, long sw) {
@@ -427,6 +525,31 @@ int mgn_upce_bwd(const void* logits_bf16, long sb, long sh, long sw, int B, int 
         case 3: hipLaunchKernelGGL(upce_bwd<3>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
         default: hipLaunchKernelGGL(upce_bwd<4>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
     }
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_ohem_select_workspace_bytes(long n, size_t* bytes) {
+    if (!bytes || n < 1) return MGN_EINVAL;
+    *bytes = sizeof(OhemState) + 256 * sizeof(unsigned) + sizeof(float) * 3 * 1024;
+    return MGN_OK;
+}
+
+int mgn_ohem_select(const float* ce_map, long n, const float* sums3, float thr, long n_sel, int force_topk, float* sel3, float* loss,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ce_map || !sums3 || !sel3 || !loss || !workspace || n < 1 || n_sel < 1) return MGN_EINVAL;
+    if (workspace_bytes < sizeof(OhemState) + 256 * sizeof(unsigned) + sizeof(float) * 3 * 1024) return MGN_ENOSPC;
+    hipStream_t s = (hipStream_t)stream;
+    OhemState* st = (OhemState*)workspace;
+    unsigned* hist = (unsigned*)(st + 1);
+    float* partials = (float*)(hist + 256);
+    const int nblk = (int)(n / (TPB * 16) < 1 ? 1 : (n / (TPB * 16) > 1024 ? 1024 : n / (TPB * 16)));
+    hipLaunchKernelGGL(ohem_init, dim3(1), dim3(256), 0, s, sums3, n, n_sel, force_topk, st, hist);
+    for (int pass = 3; pass >= 0; --pass) {
+        hipLaunchKernelGGL(ohem_hist, dim3(nblk), dim3(TPB), 0, s, ce_map, n, pass, (const OhemState*)st, hist);
+        hipLaunchKernelGGL(ohem_pick, dim3(1), dim3(256), 0, s, st, hist);
+    }
+    hipLaunchKernelGGL(ohem_tail, dim3(nblk), dim3(TPB), 0, s, ce_map, n, (const OhemState*)st, partials);
+    hipLaunchKernelGGL(ohem_final, dim3(1), dim3(TPB), 0, s, sums3, thr, n_sel, (const OhemState*)st, (const float*)partials, nblk, sel3, loss);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

@@ -428,19 +428,10 @@ class _UpCEFn(torch.autograd.Function):
         n_px = ce.numel()
         if mode == "mean":          # DeepLabCE(top_k=1.0): mean over ALL pixels (ignored ones count with loss 0)
             loss = sums[2] / n_px
-            sel = torch.stack([sums.new_tensor(-1.0), sums.new_tensor(0.0), sums.new_tensor(1.0 / n_px)])
+            sel = torch.cat([sums.new_full((1,), -1.0), sums.new_zeros(1), sums.new_full((1,), 1.0 / n_px)])  # (device fills: no H2D)
         else:
-            use_thr = mode == "ohem" and int(sums[0]) > n_sel   # one host sync, as in the reference (loss.py:76)
-            if use_thr:
-                loss = sums[1] / sums[0]
-                sel = torch.stack([sums.new_tensor(thr), sums.new_tensor(0.0), 1.0 / sums[0]])
-            else:                   # mean of the n_sel largest: [torch-staging] torch.topk for the n_sel-th value
-                flat = ce.view(-1)
-                vals = torch.topk(flat, n_sel)[0]
-                vk = vals[-1]
-                n_gt, n_eq = (flat > vk).sum(), (flat == vk).sum()
-                loss = vals.mean()
-                sel = torch.stack([vk, (n_sel - n_gt).float() / n_eq.float(), sums.new_tensor(1.0 / n_sel)])
+            # threshold vs top-n_sel branch (loss.py:76) decided ON THE DEVICE: no host sync, no sort, no torch.topk
+            sel, loss = _C.ohem_select(ce, sums, thr, n_sel, mode != "ohem")
         ctx.save_for_backward(lr, labels, weights, ce, sel.float().contiguous())
         ctx.cfg = (H, W, ignore)
         return loss
