@@ -116,7 +116,14 @@ def _dev_f32(t, name):
     return t
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's CURRENT stream of the current device (honours torch.cuda.stream(...) contexts).  The raw
+    getter avoids building a torch.cuda.Stream object on each of the ~900 launches of a step."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
