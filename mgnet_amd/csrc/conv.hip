@@ -554,7 +554,8 @@ struct Conv64Params {
     int N, H, W, Cout;
     int strips, chunks, rows_per_chunk, nslices, co_tiles;
 };
-constexpr int C64_INROW = 136 * 128, C64_LDS = 5 * C64_INROW;
+constexpr int C64_NR = 8;   // ring of input rows: r-1 .. r+2 in use by the two output rows of a step, r+3 .. r+6 in flight
+constexpr int C64_INROW = 136 * 128, C64_LDS = C64_NR * C64_INROW;
 
 __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char c64sm[];
@@ -615,59 +616,65 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
         for (int kk = 0; kk < 4; ++kk) aoff[kw][kk] = px * 128 + ((((kk * 2 + hi) ^ ((px >> 1) & 7))) << 4);
     }
 
-    issue_in(r0 - 1, 0);
-    issue_in(r0, 1);
-    issue_in(r0 + 1, 2);
-    issue_in(r0 + 2, 3);
+    // TWO output rows per step (72 MFMAs per wave between barriers; the weight registers serve both rows)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) issue_in(r0 - 1 + k, k);   // rows r0-1 .. r0+4: the first step's four rows + one step ahead
     int si = 0;  // slot of input row r-1
     const int opx = ow0 + 32 * wpx + (lane & 31);
     const bool wstore = ow0 + 32 * wpx < p.W;   // wave-uniform: does this wave issue output stores at all
-    for (int r = r0; r < r1; ++r) {
-        // rows up to r+1 must have landed; the row issued last (r+2) and the previous step's 4 output stores may be in flight
+    auto slot = [](int x) { return x >= C64_NR ? x - C64_NR : x; };
+    for (int r = r0; r < r1; r += 2) {
+        // rows up to r+2 must have landed; the two rows issued last (r+3, r+4) and the previous step's 8 output stores may be in flight
         if (r == r0 || !wstore) {
-            if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
-            if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        issue_in(r + 3, si + 4 >= 5 ? si - 1 : si + 4);   // (always issued: rows past the chunk land in unused slots)
-        f32x16 acc0, acc1;
+        issue_in(r + 5, slot(si + 6));   // (always issued: rows past the chunk land in unused slots)
+        issue_in(r + 6, slot(si + 7));
+        f32x16 acc0, acc1;   // output rows r and r+1
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int sl = si + kh >= 5 ? si + kh - 5 : si + kh;
-            const unsigned char* rowp = c64sm + sl * C64_INROW;
+            const unsigned char* rowa = c64sm + slot(si + kh) * C64_INROW;
+            const unsigned char* rowb = c64sm + slot(si + kh + 1) * C64_INROW;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowp + aoff[kw][kk]);
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowa + aoff[kw][kk]);
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(rowb + aoff[kw][kk]);
                     const int idx = (kh * 3 + kw) * 4 + kk;
-                    if (idx & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], a, acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], a, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], a, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], b, acc1, 0, 0, 0);
                 }
             }
         }
         // D = W-rows x pixels: col = lane & 31 -> pixel, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel
         if (opx < p.W) {
-            uint16_t* orow = p.out + ((size_t)(n * p.H + r) * p.W + opx) * p.Cout + co_w + 4 * hi;
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                float v0 = acc0[qd * 4 + 0] + acc1[qd * 4 + 0], v1 = acc0[qd * 4 + 1] + acc1[qd * 4 + 1];
-                float v2 = acc0[qd * 4 + 2] + acc1[qd * 4 + 2], v3 = acc0[qd * 4 + 3] + acc1[qd * 4 + 3];
-                if (p.residual) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (orow - p.out) + 8 * qd);
-                    v0 += __uint_as_float(rr.x << 16); v1 += __uint_as_float(rr.x & 0xffff0000u);
-                    v2 += __uint_as_float(rr.y << 16); v3 += __uint_as_float(rr.y & 0xffff0000u);
+            for (int rr2 = 0; rr2 < 2; ++rr2) {
+                if (r + rr2 >= r1) break;   // wave-uniform (odd number of rows: the last step has one row)
+                uint16_t* orow = p.out + ((size_t)(n * p.H + r + rr2) * p.W + opx) * p.Cout + co_w + 4 * hi;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    float v0 = rr2 ? acc1[qd * 4 + 0] : acc0[qd * 4 + 0], v1 = rr2 ? acc1[qd * 4 + 1] : acc0[qd * 4 + 1];
+                    float v2 = rr2 ? acc1[qd * 4 + 2] : acc0[qd * 4 + 2], v3 = rr2 ? acc1[qd * 4 + 3] : acc0[qd * 4 + 3];
+                    if (p.residual) {
+                        const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (orow - p.out) + 8 * qd);
+                        v0 += __uint_as_float(rr.x << 16); v1 += __uint_as_float(rr.x & 0xffff0000u);
+                        v2 += __uint_as_float(rr.y << 16); v3 += __uint_as_float(rr.y & 0xffff0000u);
+                    }
+                    *reinterpret_cast<uint2*>(orow + 8 * qd) =
+                        make_uint2((uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16));
                 }
-                *reinterpret_cast<uint2*>(orow + 8 * qd) =
-                    make_uint2((uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16));
             }
         }
-        si = si + 1 >= 5 ? 0 : si + 1;
+        si = slot(si + 2);
     }
 }
 
