@@ -564,8 +564,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
     const int slice = (q / p.co_tiles) * 8 + (L & 7), tile = q % p.co_tiles;
     if (slice >= p.nslices) return;
     int s = slice;
-    const int chunk = s % p.chunks; s /= p.chunks;
-    const int strip = s % p.strips, n = s / p.strips;
+    // strips fastest: blocks launched together walk the strips of the SAME image rows, so the rows stream from DRAM whole
+    const int strip = s % p.strips; s /= p.strips;
+    const int chunk = s % p.chunks, n = s / p.chunks;
     const int ow0 = strip * 128;
     const int r0 = chunk * p.rows_per_chunk, r1 = r0 + p.rows_per_chunk < p.H ? r0 + p.rows_per_chunk : p.H;
     const int co_w = tile * 64 + wco * 32;   // this wave's 32 output channels
@@ -897,8 +898,9 @@ __device__ __forceinline__ void wgrad3x3_body(const Wgrad3Params& p) {
     if (slice >= p.nslices) return;
     const int co0 = (tile / p.ci_tiles) * 64, ci0 = (tile % p.ci_tiles) * 64;
     int s = slice;
-    const int chunk = s % p.chunks; s /= p.chunks;
-    const int strip = s % p.strips, n = s / p.strips;
+    // strips fastest: blocks launched together walk the strips of the SAME image rows, so the rows stream from DRAM whole
+    const int strip = s % p.strips; s /= p.strips;
+    const int chunk = s % p.chunks, n = s / p.chunks;
     const int ow0 = strip * C::SW;
     const int r0 = chunk * p.rows_per_chunk, r1 = r0 + p.rows_per_chunk < p.H ? r0 + p.rows_per_chunk : p.H;
 
@@ -1084,8 +1086,9 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
     if (slice >= p.nslices) return;
     const int co0 = tile * 64;
     int s = slice;
-    const int chunk = s % p.chunks; s /= p.chunks;
-    const int strip = s % p.strips, n = s / p.strips;
+    // strips fastest: blocks launched together walk the strips of the SAME image rows, so the rows stream from DRAM whole
+    const int strip = s % p.strips; s /= p.strips;
+    const int chunk = s % p.chunks, n = s / p.chunks;
     const int ow0 = strip * 128;
     const int r0 = chunk * p.rows_per_chunk, r1 = r0 + p.rows_per_chunk < p.OH ? r0 + p.rows_per_chunk : p.OH;
 
