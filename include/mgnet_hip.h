@@ -232,12 +232,29 @@ int mgn_maxpool3x3s2_fwd(const void* x_bf16, void* y_bf16, uint8_t* argmax, int 
 int mgn_maxpool3x3s2_bwd(const void* dy_bf16, const uint8_t* argmax, void* dx_bf16, int N, int IH, int IW, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Channel-attention vectors (mgnet/modeling/layers.py:248-267 AttentionRefinementModule.channel_attention,
+ * :297-322 FeatureFusionModule.channel_attention): a 1x1 conv on the pooled [N, K] vectors (+ InPlaceABNSync over the N
+ * samples of ONE process, + activation) as one launch.  fp32; W is the conv's fp32 master weight [C][K] (= [C,K,1,1]).
+ * act: 0 none, 1 ReLU, 2 sigmoid.  bn_weight == NULL: no norm.  Training keeps xhat [N][C] and rstd [C] for the backward.
+ * N <= 64, N*K*4 <= 96 KB.  One block per 16 output channels; the input gradient is summed over the blocks in a fixed order.
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_vec_linear_fwd(const float* in, const float* W, int N, int K, int C, int act, const float* bn_weight,
+                       const float* bn_bias, float* running_mean, float* running_var, int training, float momentum,
+                       float eps, float* out, float* xhat, float* rstd, void* stream);
+int mgn_vec_linear_bwd_workspace_bytes(int N, int K, int C, size_t* bytes);
+int mgn_vec_linear_bwd(const float* dout, const float* out, const float* in, const float* W, int N, int K, int C, int act,
+                       const float* bn_weight, const float* xhat, const float* rstd, float eps, float din_scale /* din is
+                       multiplied by it (1/HW of the pool) */, float* dW, float* din, float* dbn_weight, float* dbn_bias,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Element-wise / broadcast / pooling glue of the blocks, channels-last bf16 [N, H*W, C], C % 8 == 0
  *   mgn_add_relu_fwd / mgn_relu_mask_bwd : res_net.py:77-78 (out + shortcut, relu_)
  *   mgn_colsum                          : out[n,c] = scale * sum_r x[n,r,c] (* x2[n,r,c]); layers.py:170-184 global
  *                                         average pool (scale = 1/HW) and the d/d attention reduction; deterministic
  *   mgn_bcast_rows                      : dx[n,r,c] = g[n,c] * scale (adjoint of the pool)
  *   mgn_scale_channels                  : y = x * s[n,c] (mode 0, layers.py:262-267) | x * (1 + s[n,c]) (mode 1, :315-322)
+ *                                         [+ add[n,c]]
  *   mgn_nearest_fwd / _bwd              : F.interpolate(mode="nearest") (layers.py:90, :217) and its adjoint
  *   mgn_concat2 / mgn_split2            : torch.cat([a, b], dim=1) (layers.py:316) and the split of its gradient
  * ---------------------------------------------------------------------------------------------- */
@@ -246,7 +263,8 @@ int mgn_relu_mask_bwd(const void* dy, const void* y, void* dx, long n_elems, voi
 int mgn_colsum(const void* x, const void* x2 /*nullable*/, int N, long HW, int C, float scale, float* out, float* workspace,
                size_t workspace_bytes /* >= N*64*C*4 */, void* stream);
 int mgn_bcast_rows(const float* g, int N, long HW, int C, float scale, void* dx, void* stream);
-int mgn_scale_channels(const void* x, const float* s, int N, long HW, int C, int mode, void* y, void* stream);
+int mgn_scale_channels(const void* x, const float* s, int N, long HW, int C, int mode, const float* add /* nullable:
+                       y += add[n,c] (the pooled branch of the attention backward) */, void* y, void* stream);
 int mgn_nearest_fwd(const void* x, int N, int h, int w, int H, int W, int C, void* y, void* stream);
 int mgn_nearest_bwd(const void* dy, int N, int h, int w, int H, int W, int C, void* dx, void* stream);
 int mgn_concat2(const void* a, const void* b, long rows, int Ca, int Cb, void* y, void* stream);

@@ -19,7 +19,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
-           "mgn_nearest_bwd", "mgn_concat2", "mgn_split2"]
+           "mgn_nearest_bwd", "mgn_concat2", "mgn_split2", "mgn_vec_linear_fwd", "mgn_vec_linear_bwd_workspace_bytes", "mgn_vec_linear_bwd"]
 
 
 class ReprojCfg(ctypes.Structure):
@@ -82,7 +82,10 @@ def lib():
         L.mgn_relu_mask_bwd.argtypes = [vp, vp, vp, cl, vp]
         L.mgn_colsum.argtypes = [vp, vp, ci, cl, ci, cf, vp, vp, sz, vp]
         L.mgn_bcast_rows.argtypes = [vp, ci, cl, ci, cf, vp, vp]
-        L.mgn_scale_channels.argtypes = [vp, vp, ci, cl, ci, ci, vp, vp]
+        L.mgn_scale_channels.argtypes = [vp, vp, ci, cl, ci, ci, vp, vp, vp]
+        L.mgn_vec_linear_fwd.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp]
+        L.mgn_vec_linear_bwd_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(sz)]
+        L.mgn_vec_linear_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, sz, vp]
         L.mgn_nearest_fwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_nearest_bwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_concat2.argtypes = [vp, vp, cl, ci, ci, vp, vp]
@@ -567,11 +570,56 @@ def bcast_rows(g, shape, scale):
     return dx
 
 
-def scale_channels(x, s, mode):
+def scale_channels(x, s, mode, add=None):
     N, C, H, W = x.shape
     y = _cl_like(x)
-    check(lib().mgn_scale_channels(x.data_ptr(), s.data_ptr(), N, H * W, C, mode, y.data_ptr(), _stream()), "mgn_scale_channels")
+    check(lib().mgn_scale_channels(x.data_ptr(), s.data_ptr(), N, H * W, C, mode, None if add is None else add.data_ptr(), y.data_ptr(),
+                                   _stream()), "mgn_scale_channels")
     return y
+
+
+_ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2}
+
+
+def vec_linear_fwd(v, w, act, bn=None):
+    """v [N,K] fp32, w [C,K(,1,1)] fp32 -> act(bn(v @ w.T)).  bn = (weight, bias, running_mean, running_var, training, momentum, eps)
+    -> (out [N,C], xhat | None, rstd | None)"""
+    N, K = v.shape
+    C = w.shape[0]
+    out = torch.empty((N, C), dtype=torch.float32, device=v.device)
+    xhat = rstd = None
+    if bn is not None:
+        bw, bb, rm, rv, training, momentum, eps = bn
+        if training:
+            xhat, rstd = torch.empty_like(out), torch.empty(C, dtype=torch.float32, device=v.device)
+        check(lib().mgn_vec_linear_fwd(v.data_ptr(), w.data_ptr(), N, K, C, _ACT[act], bw.data_ptr(), bb.data_ptr(),
+                                       None if rm is None else rm.data_ptr(), None if rv is None else rv.data_ptr(), int(training),
+                                       momentum, eps, out.data_ptr(), None if xhat is None else xhat.data_ptr(),
+                                       None if rstd is None else rstd.data_ptr(), _stream()), "mgn_vec_linear_fwd")
+    else:
+        check(lib().mgn_vec_linear_fwd(v.data_ptr(), w.data_ptr(), N, K, C, _ACT[act], None, None, None, None, 0, 0.0, 0.0,
+                                       out.data_ptr(), None, None, _stream()), "mgn_vec_linear_fwd")
+    return out, xhat, rstd
+
+
+def vec_linear_bwd(dout, out, v, w, act, bn_weight=None, xhat=None, rstd=None, eps=0.0, dv_scale=1.0):
+    """-> (dW like w, dv [N,K] * dv_scale, d bn weight, d bn bias)"""
+    N, K = v.shape
+    C = w.shape[0]
+    dW = torch.empty_like(w)
+    dv = torch.empty_like(v)
+    dbw = dbb = None
+    if bn_weight is not None:
+        dbw, dbb = torch.empty_like(bn_weight), torch.empty_like(bn_weight)
+    nb = ctypes.c_size_t(0)
+    check(lib().mgn_vec_linear_bwd_workspace_bytes(N, K, C, ctypes.byref(nb)), "mgn_vec_linear_bwd_workspace_bytes")
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=v.device)
+    check(lib().mgn_vec_linear_bwd(dout.data_ptr(), out.data_ptr(), v.data_ptr(), w.data_ptr(), N, K, C, _ACT[act],
+                                   None if bn_weight is None else bn_weight.data_ptr(), None if xhat is None else xhat.data_ptr(),
+                                   None if rstd is None else rstd.data_ptr(), eps, dv_scale, dW.data_ptr(), dv.data_ptr(),
+                                   None if dbw is None else dbw.data_ptr(), None if dbb is None else dbb.data_ptr(), ws.data_ptr(),
+                                   nb.value, _stream()), "mgn_vec_linear_bwd")
+    return dW, dv, dbw, dbb
 
 
 def nearest_fwd(x, H, W):

@@ -116,7 +116,7 @@ class AttentionRefinementModule(nn.Module):  # layers.py:221-267
 
     def forward(self, x):
         fm = self.conv(x)
-        return ops.scale_channels(fm, self.channel_attention(fm))
+        return ops.channel_attention(fm, self.channel_attention, "arm")
 
 
 class FeatureFusionModule(nn.Module):  # layers.py:270-322
@@ -135,7 +135,7 @@ class FeatureFusionModule(nn.Module):  # layers.py:270-322
 
     def forward(self, fsp, fcp):
         fm = self.conv(ops.concat_channels(fsp, fcp))
-        return ops.scale_channels(fm, self.channel_attention(fm), residual=True)
+        return ops.channel_attention(fm, self.channel_attention, "ffm", residual=True)
 
 
 class MGNetDecoder(nn.Module):  # layers.py:22-94

@@ -347,6 +347,68 @@ def scale_channels(x, s, residual=False):
     return x + x * s if residual else x * s
 
 
+class _ChannelAttentionFn(torch.autograd.Function):
+    """[HIP] y = x * s (ARM, layers.py:262-267) or x + x * s (FFM, :315-322) with s = attention(global_avg_pool(x)), the
+    whole attention branch in a handful of launches (csrc/attention.hip) and ONE autograd node: the pooled branch's
+    gradient is added inside the scale kernel of the backward (no broadcast tensor, no accumulate pass).
+      kind "arm": s = sigmoid(IABN_identity(W p))        params: W, bn_weight, bn_bias (+ running stats buffers)
+      kind "ffm": s = sigmoid(W2 relu(W1 p))             params: W1, W2"""
+
+    @staticmethod
+    def forward(ctx, x, kind, residual, w1, p2, p3, running_mean, running_var, training, momentum, eps):
+        from .. import _C
+        N, C, H, W = x.shape
+        pooled = _C.colsum(x, None, 1.0 / (H * W))
+        w1c = w1.detach().reshape(w1.shape[0], -1)
+        if kind == "arm":
+            s, xhat, rstd = _C.vec_linear_fwd(pooled, w1c, "sigmoid", (p2.detach(), p3.detach(), running_mean, running_var, training, momentum, eps))
+            ctx.save_for_backward(x, pooled, s, w1c, p2.detach(), xhat, rstd)
+        else:
+            w2c = p2.detach().reshape(p2.shape[0], -1)
+            h, _, _ = _C.vec_linear_fwd(pooled, w1c, "relu")
+            s, _, _ = _C.vec_linear_fwd(h, w2c, "sigmoid")
+            ctx.save_for_backward(x, pooled, s, w1c, w2c, h)
+        ctx.cfg = (kind, residual, eps, tuple(w1.shape), None if p2 is None else tuple(p2.shape))
+        return _C.scale_channels(x, s, 1 if residual else 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+        kind, residual, eps, w1s, p2s = ctx.cfg
+        g = _cl(g)
+        if kind == "arm":
+            x, pooled, s, w1c, bnw, xhat, rstd = ctx.saved_tensors
+            ds = _C.colsum(g, x, 1.0)
+            dW1, dpool, dbw, dbb = _C.vec_linear_bwd(ds, s, pooled, w1c, "sigmoid", bnw, xhat, rstd, eps, dv_scale=1.0 / (x.shape[2] * x.shape[3]))
+            d2, d3 = dbw, dbb
+        else:
+            x, pooled, s, w1c, w2c, h = ctx.saved_tensors
+            ds = _C.colsum(g, x, 1.0)
+            dW2, dh, _, _ = _C.vec_linear_bwd(ds, s, h, w2c, "sigmoid")
+            dW1, dpool, _, _ = _C.vec_linear_bwd(dh, h, pooled, w1c, "relu", dv_scale=1.0 / (x.shape[2] * x.shape[3]))
+            d2, d3 = dW2.view(p2s), None
+        N, C, H, W = x.shape
+        dx = _C.scale_channels(g, s, 1 if residual else 0, add=dpool)   # dpool already carries the pool's 1/(H*W)
+        return dx, None, None, dW1.view(w1s), d2, d3, None, None, None, None, None
+
+
+def channel_attention(x, attention, kind, residual=False):
+    """x * s / x + x * s with s = `attention`(x), an nn.Sequential(FastGlobalAvgPool2d, Conv2d(+norm | +ReLU), [conv], Sigmoid)
+    of the reference's decoder modules.  bf16 CUDA, one process: [HIP] fused path; otherwise the module itself."""
+    from .. import _C
+    conv = attention[1]
+    fused = _C.elt_supported(x) and x.shape[0] <= 64 and conv.bias is None and not os.environ.get("MGN_NO_ATTN_FUSE")
+    if kind == "arm":
+        bn = conv.norm
+        fused = fused and not _dist_active(bn.group) and (bn.training or not torch.is_grad_enabled())
+        if fused:
+            return _ChannelAttentionFn.apply(x, "arm", residual, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                             bn.training, bn.momentum, bn.eps)
+    elif fused and attention[2].bias is None:
+        return _ChannelAttentionFn.apply(x, "ffm", residual, conv.weight, attention[2].weight, None, None, None, True, 0.0, 0.0)
+    return scale_channels(x, attention(x), residual=residual)
+
+
 class _CatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -13,6 +13,19 @@ def main(db, out=None):
     lines = [f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}"]
     for n, k, s, a, mn, mx in rows:
         lines.append(f"{n[:70]:70s} {k:6d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
+    # GPU idle time between consecutive kernels over the last 60 % of the trace (steady state: no model set-up)
+    ks = c.execute("select start, end from kernels order by start").fetchall()
+    if len(ks) > 100:
+        ks = ks[int(len(ks) * 0.4):]
+        span = ks[-1][1] - ks[0][0]
+        busy, last_end, gaps = 0, ks[0][0], 0
+        for st, en in ks:
+            if st > last_end:
+                gaps += st - last_end
+            busy += en - st
+            last_end = max(last_end, en)
+        lines.append(f"steady-state window: span {span/1e6:.2f} ms, kernel time {busy/1e6:.2f} ms, idle between kernels {gaps/1e6:.2f} ms "
+                     f"({100*gaps/span:.1f} %), {len(ks)} launches, mean gap {gaps/len(ks)/1e3:.2f} us")
     txt = "\n".join(lines)
     print(txt)
     if out:
