@@ -172,10 +172,11 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
 int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, size_t* bytes);
 /* fp32 OIHW master weights -> bf16 kernel layout. mode 0: [Cout][KH][KW][Cin]; 1: [Cin][KH][KW][Cout] with flipped taps
  * (data gradient); 2: packed-tap stem layout [Cout][ceil(KH*KW*Cp/32)*32] for a Cp-channel (8|16) padded input */
-int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp, void* stream);
+int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp,
+                      int cout_pad /* > Cout: output channels zero-padded to cout_pad in the layout (few-class predictors) */, void* stream);
 /* every conv weight of a model in one launch (after the optimizer step): table_dev = n_entries rows of 8 x int64 on the
- * device {src fp32 OIHW pointer, dst bf16 pointer, n_out elements, first block (prefix sum of ceil(n_out/256)), Cout, Cin,
- * KH << 32 | KW, mode << 32 | Cp}, rows sorted by first block; total_blocks = sum of ceil(n_out/256). */
+ * device {src fp32 OIHW pointer, dst bf16 pointer, n_out elements, first block (prefix sum of ceil(n_out/256)), Cout | cout_pad << 32,
+ * Cin, KH << 32 | KW, mode << 32 | Cp}, rows sorted by first block; total_blocks = sum of ceil(n_out/256). */
 int mgn_weight_layout_batch(const void* table_dev, int n_entries, long total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -65,7 +65,7 @@ def lib():
         L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp, vp]
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
-        L.mgn_weight_layout.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.mgn_weight_layout.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
         L.mgn_weight_layout_batch.argtypes = [vp, ci, cl, vp]
         L.mgn_upce_partials.argtypes = [ci, ci, ci]
         L.mgn_upce_fwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp, vp]
@@ -340,8 +340,9 @@ def conv_wgrad(dy, x, kh, kw, stride, pad, cin_real=None):
     return dw
 
 
-def _layout_empty(w, mode, Cp):
+def _layout_empty(w, mode, Cp, cout_pad=0):
     Cout, Cin, KH, KW = w.shape
+    Cout = max(Cout, cout_pad)
     if mode == 0:
         return torch.empty((Cout, KH, KW, Cin), dtype=torch.bfloat16, device=w.device)
     if mode == 1:
@@ -349,18 +350,19 @@ def _layout_empty(w, mode, Cp):
     return torch.empty((Cout, (KH * KW * Cp + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
 
 
-def weight_layout(w, mode, Cp=0):
-    """fp32 OIHW parameter -> bf16 kernel layout (0: OHWI, 1: flipped IHWO for the data gradient, 2: packed stem).
-    Parameters are served from `weight_cache` (all layouts refreshed by ONE launch after the optimizer step)."""
-    return weight_cache.get(w, mode, Cp)
+def weight_layout(w, mode, Cp=0, cout_pad=0):
+    """fp32 OIHW parameter -> bf16 kernel layout (0: OHWI, 1: flipped IHWO for the data gradient, 2: packed stem), output
+    channels zero-padded to `cout_pad`.  Parameters are served from `weight_cache` (all layouts refreshed by ONE launch
+    after the optimizer step)."""
+    return weight_cache.get(w, mode, Cp, cout_pad)
 
 
-def _weight_layout_now(w, mode, Cp, out=None):
+def _weight_layout_now(w, mode, Cp, out=None, cout_pad=0):
     Cout, Cin, KH, KW = w.shape
-    out = _layout_empty(w, mode, Cp) if out is None else out
+    out = _layout_empty(w, mode, Cp, cout_pad) if out is None else out
     wc = w.detach()
     wc = wc if (wc.dtype == torch.float32 and wc.is_contiguous()) else wc.float().contiguous()
-    check(lib().mgn_weight_layout(wc.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, mode, Cp, _stream()), "mgn_weight_layout")
+    check(lib().mgn_weight_layout(wc.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, mode, Cp, cout_pad, _stream()), "mgn_weight_layout")
     return out
 
 
@@ -376,18 +378,18 @@ class _WeightCache:
         self.dirty = True
         self.off = bool(os.environ.get("MGN_NO_WCACHE"))   # A/B switch: convert per call
 
-    def get(self, w, mode, Cp=0):
+    def get(self, w, mode, Cp=0, cout_pad=0):
         import weakref
         if self.off or not (isinstance(w, torch.nn.Parameter) and w.is_leaf and w.dtype == torch.float32 and w.is_contiguous()):
-            return _weight_layout_now(w, mode, Cp)   # temporaries (e.g. Cout-padded predictors): converted per call
-        key = (id(w), mode, Cp)
+            return _weight_layout_now(w, mode, Cp, None, cout_pad)   # temporaries: converted per call
+        key = (id(w), mode, Cp, cout_pad)
         e = self.entries.get(key)
         if e is not None and e["ref"]() is w and e["ptr"] == w.data_ptr() and e["version"] == w._version:
             return e["out"]
-        out = _weight_layout_now(w, mode, Cp, None if e is None or e["ref"]() is not w else e["out"])
+        out = _weight_layout_now(w, mode, Cp, None if e is None or e["ref"]() is not w else e["out"], cout_pad)
         if e is None or e["ref"]() is not w or e["ptr"] != w.data_ptr():
             self.dirty = True
-        self.entries[key] = dict(ref=weakref.ref(w), out=out, version=w._version, ptr=w.data_ptr(), mode=mode, Cp=Cp)
+        self.entries[key] = dict(ref=weakref.ref(w), out=out, version=w._version, ptr=w.data_ptr(), mode=mode, Cp=Cp, cout_pad=cout_pad)
         return out
 
     def _rebuild(self):
@@ -404,7 +406,8 @@ class _WeightCache:
                 continue
             Cout, Cin, KH, KW = w.shape
             n_out = e["out"].numel()
-            rows.append([w.data_ptr(), e["out"].data_ptr(), n_out, blocks, Cout, Cin, (KH << 32) | KW, (e["mode"] << 32) | e["Cp"]])
+            rows.append([w.data_ptr(), e["out"].data_ptr(), n_out, blocks, Cout | (e["cout_pad"] << 32), Cin, (KH << 32) | KW,
+                         (e["mode"] << 32) | e["Cp"]])
             e["ptr"] = w.data_ptr()
             blocks += (n_out + 255) // 256
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None

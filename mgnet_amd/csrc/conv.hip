@@ -1416,31 +1416,35 @@ __global__ void conv_wgrad_reduce(const float* __restrict__ partial, int splits,
 //   mode 0: [Cout][KH][KW][Cin]                      (forward)
 //   mode 1: [Cin][KH][KW][Cout], taps flipped        (data gradient: w'[ci][kh][kw][co] = w[co][ci][KH-1-kh][KW-1-kw])
 //   mode 2: [Cout][Kpad], k = tap*Cp + c, zero padded (packed-tap stems; Cp = padded input channels)
-__global__ void weight_layout_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin, int KH, int KW,
-                                     int mode, int Cp, int Kpad, long n_out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_out) return;
-    float v = 0.f;
+// element i of the bf16 layout (CoutP >= Cout: output channels zero-padded to CoutP, e.g. the few-class predictors to 32)
+__device__ __forceinline__ float layout_value(const float* __restrict__ w, long i, int Cout, int CoutP, int Cin, int KH, int KW, int mode, int Cp) {
     if (mode == 0) {
         const int ci = (int)(i % Cin); long r = i / Cin;
         const int kw = (int)(r % KW); r /= KW;
         const int kh = (int)(r % KH); const int co = (int)(r / KH);
-        v = w[(((long)co * Cin + ci) * KH + kh) * KW + kw];
-    } else if (mode == 1) {
-        const int co = (int)(i % Cout); long r = i / Cout;
+        return co < Cout ? w[(((long)co * Cin + ci) * KH + kh) * KW + kw] : 0.f;
+    }
+    if (mode == 1) {
+        const int co = (int)(i % CoutP); long r = i / CoutP;
         const int kw = (int)(r % KW); r /= KW;
         const int kh = (int)(r % KH); const int ci = (int)(r / KH);
-        v = w[(((long)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
-    } else {
-        const int k = (int)(i % Kpad), co = (int)(i / Kpad);
-        const int tap = k / Cp, c = k - tap * Cp;
-        if (tap < KH * KW && c < Cin) v = w[(((long)co * Cin + c) * KH + tap / KW) * KW + tap % KW];
+        return co < Cout ? w[(((long)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)] : 0.f;
     }
-    out[i] = f2bf(v);
+    const int Kpad = (KH * KW * Cp + 31) / 32 * 32;
+    const int k = (int)(i % Kpad), co = (int)(i / Kpad);
+    const int tap = k / Cp, c = k - tap * Cp;
+    return (co < Cout && tap < KH * KW && c < Cin) ? w[(((long)co * Cin + c) * KH + tap / KW) * KW + tap % KW] : 0.f;
+}
+
+__global__ void weight_layout_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int CoutP, int Cin, int KH, int KW,
+                                     int mode, int Cp, long n_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    out[i] = f2bf(layout_value(w, i, Cout, CoutP, Cin, KH, KW, mode, Cp));
 }
 
 // all conv weights of a model in ONE launch: table rows of 8 x int64 = {src fp32 OIHW, dst bf16, n_out, first block,
-// Cout, Cin, KH << 32 | KW, mode << 32 | Cp}; a block finds its row by binary search over the first-block column
+// Cout | CoutPad << 32, Cin, KH << 32 | KW, mode << 32 | Cp}; a block finds its row by binary search over the first-block column
 __global__ void weight_layout_batch_kernel(const long long* __restrict__ table, int n_entries) {
     int lo = 0, hi = n_entries - 1;
     while (lo < hi) {
@@ -1453,39 +1457,23 @@ __global__ void weight_layout_batch_kernel(const long long* __restrict__ table, 
     const long n_out = e[2];
     const long i = ((long)blockIdx.x - e[3]) * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
-    const int Cout = (int)e[4], Cin = (int)e[5], KH = (int)(e[6] >> 32), KW = (int)(e[6] & 0xffffffff);
+    const int Cout = (int)(e[4] & 0xffffffff), CoutP = (int)(e[4] >> 32), Cin = (int)e[5], KH = (int)(e[6] >> 32), KW = (int)(e[6] & 0xffffffff);
     const int mode = (int)(e[7] >> 32), Cp = (int)(e[7] & 0xffffffff);
-    float v = 0.f;
-    if (mode == 0) {
-        const int ci = (int)(i % Cin); long r = i / Cin;
-        const int kw = (int)(r % KW); r /= KW;
-        const int kh = (int)(r % KH); const int co = (int)(r / KH);
-        v = w[(((long)co * Cin + ci) * KH + kh) * KW + kw];
-    } else if (mode == 1) {
-        const int co = (int)(i % Cout); long r = i / Cout;
-        const int kw = (int)(r % KW); r /= KW;
-        const int kh = (int)(r % KH); const int ci = (int)(r / KH);
-        v = w[(((long)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
-    } else {
-        const int Kpad = (KH * KW * Cp + 31) / 32 * 32;
-        const int k = (int)(i % Kpad), co = (int)(i / Kpad);
-        const int tap = k / Cp, c = k - tap * Cp;
-        if (tap < KH * KW && c < Cin) v = w[(((long)co * Cin + c) * KH + tap / KW) * KW + tap % KW];
-    }
-    out[i] = f2bf(v);
+    out[i] = f2bf(layout_value(w, i, Cout, CoutP > Cout ? CoutP : Cout, Cin, KH, KW, mode, Cp));
 }
 
 }  // namespace
 
 extern "C" {
 
-int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp, void* stream) {
+int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp, int cout_pad, void* stream) {
     if (!w_oihw || !out_bf16 || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || mode < 0 || mode > 2) return MGN_EINVAL;
-    const int Kpad = mode == 2 ? (KH * KW * Cp + 31) / 32 * 32 : 0;
     if (mode == 2 && (Cp < Cin || (Cp != 8 && Cp != 16))) return MGN_EINVAL;
-    const long n = mode == 2 ? (long)Cout * Kpad : (long)Cout * Cin * KH * KW;
+    const int CoutP = cout_pad > Cout ? cout_pad : Cout;
+    const int Kpad = mode == 2 ? (KH * KW * Cp + 31) / 32 * 32 : 0;
+    const long n = mode == 2 ? (long)CoutP * Kpad : (long)CoutP * Cin * KH * KW;
     hipLaunchKernelGGL(weight_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                       (uint16_t*)out_bf16, Cout, Cin, KH, KW, mode, Cp, Kpad, n);
+                       (uint16_t*)out_bf16, Cout, CoutP, Cin, KH, KW, mode, Cp, n);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

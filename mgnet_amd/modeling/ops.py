@@ -142,7 +142,7 @@ class _ConvFn(torch.autograd.Function):
     gradient on the bf16 matrix cores.  Master weights stay fp32 OIHW; the kernel layouts are derived per call."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, with_skip=False):
+    def forward(ctx, x, weight, bias, stride, pad, relu, with_skip=False, cout_pad=0):
         from .. import _C
 
         N, Cin, IH, IW = x.shape   # Cin of the ACTIVATION (8/16 = channel-padded stem input)
@@ -154,9 +154,13 @@ class _ConvFn(torch.autograd.Function):
         if packed:  # stem on a channel-padded input: k = tap*Cin + c, row padded to a multiple of 32
             out = _C.conv_igemm(xs, _C.weight_layout(weight, 2, Cin), (OH, OW), b, stride, pad, 1, relu, khw=(KH, KW))
         else:
-            out = _C.conv_igemm(xs, _C.weight_layout(weight, 0), (OH, OW), b, stride, pad, 1, relu)
+            if cout_pad and b is not None:
+                b = torch.cat([b, b.new_zeros(cout_pad - Cout)])
+            out = _C.conv_igemm(xs, _C.weight_layout(weight, 0, 0, cout_pad), (OH, OW), b, stride, pad, 1, relu)
         ctx.save_for_backward(xs, weight, out if relu else None)
-        ctx.cfg = (stride, pad, relu, bias is not None)
+        ctx.cfg = (stride, pad, relu, bias is not None, cout_pad)
+        if cout_pad:    # few-class predictors: the kernels work on 32-padded output channels, the caller sees the real ones
+            return out[:, :Cout]
         if with_skip:   # second output: the input itself (autograd makes it an alias); its gradient comes back into backward
             return out, x
         return out
@@ -166,10 +170,14 @@ class _ConvFn(torch.autograd.Function):
         from .. import _C
 
         xs, weight, out = ctx.saved_tensors
-        stride, pad, relu, has_bias = ctx.cfg
+        stride, pad, relu, has_bias, cout_pad = ctx.cfg
         Cout, Cin, KH, KW = weight.shape
         Cx = xs.shape[1]
         dy = dy.to(torch.bfloat16)
+        if cout_pad:    # zero gradient for the padding channels
+            dyp = torch.zeros((dy.shape[0], cout_pad) + tuple(dy.shape[2:]), dtype=dy.dtype, device=dy.device).contiguous(memory_format=torch.channels_last)
+            dyp[:, :Cout] = dy
+            dy = dyp
         if relu:
             dy = dy * (out > 0)
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -178,12 +186,12 @@ class _ConvFn(torch.autograd.Function):
             assert Cx == Cin, "no data gradient for the channel-padded stem input"
             # the gradient of the skip branch is added in the kernel's epilogue instead of by a separate accumulate pass
             res = None if dskip is None else dskip.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            dx = _C.conv_igemm(dy, _C.weight_layout(weight, 1), xs.shape[2:], None, 1, KH - 1 - pad, up=stride, residual=res)
+            dx = _C.conv_igemm(dy, _C.weight_layout(weight, 1, 0, cout_pad), xs.shape[2:], None, 1, KH - 1 - pad, up=stride, residual=res)
         if ctx.needs_input_grad[1]:
-            dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad, cin_real=Cin)
+            dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad, cin_real=Cin)[:Cout]
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum((0, 2, 3))
-        return dx, dw, db, None, None, None, None
+            db = dy.float().sum((0, 2, 3))[:Cout]
+        return dx, dw, db, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=False):
@@ -199,11 +207,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=Fals
         Cout = weight.shape[0]
         if Cout % 32:
             assert not with_skip
-            padc = 32 - Cout % 32
-            weight = torch.cat([weight, weight.new_zeros((padc,) + tuple(weight.shape[1:]))], 0)
-            if bias is not None:
-                bias = torch.cat([bias, bias.new_zeros(padc)], 0)
-            return _ConvFn.apply(x, weight, bias, stride, padding, relu)[:, :Cout]
+            return _ConvFn.apply(x, weight, bias, stride, padding, relu, False, (Cout + 31) // 32 * 32)
         if with_skip and x.requires_grad and x.shape[1] == weight.shape[1] and not os.environ.get("MGN_NO_SKIPFUSE"):
             return _ConvFn.apply(x, weight, bias, stride, padding, relu, True)
         y = _ConvFn.apply(x, weight, bias, stride, padding, relu)
