@@ -407,13 +407,17 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_apply(const T* __restrict__ y, c
         Vec<T>::store(dx + i * V, gv);
     };
     long i = i0;
-    for (; i + stride < nvec; i += 2 * stride) {
+    for (; i + 3 * stride < nvec; i += 4 * stride) {   // 8 independent 16-byte loads in flight per thread
         const typename Vec<T>::Raw y0 = Vec<T>::load_raw(y + i * V), g0 = Vec<T>::load_raw(dy + i * V);
         const typename Vec<T>::Raw y1 = Vec<T>::load_raw(y + (i + stride) * V), g1 = Vec<T>::load_raw(dy + (i + stride) * V);
+        const typename Vec<T>::Raw y2 = Vec<T>::load_raw(y + (i + 2 * stride) * V), g2 = Vec<T>::load_raw(dy + (i + 2 * stride) * V);
+        const typename Vec<T>::Raw y3 = Vec<T>::load_raw(y + (i + 3 * stride) * V), g3 = Vec<T>::load_raw(dy + (i + 3 * stride) * V);
         body(y0, g0, i);
         body(y1, g1, i + stride);
+        body(y2, g2, i + 2 * stride);
+        body(y3, g3, i + 3 * stride);
     }
-    if (i < nvec) body(Vec<T>::load_raw(y + i * V), Vec<T>::load_raw(dy + i * V), i);
+    for (; i < nvec; i += stride) body(Vec<T>::load_raw(y + i * V), Vec<T>::load_raw(dy + i * V), i);
 }
 
 inline int grid_for(long nvec) {
