@@ -72,9 +72,14 @@ template <> struct Vec<__hip_bfloat16> {
 // ------------------------------------------------------------------------------------------------------
 constexpr int MAX_STAT_BLOCKS = 512;
 
+// Channels are processed in slabs of SC (blockIdx.y): wide layers then have enough blocks to fill the chip and their
+// finalize runs on one block PER SLAB in parallel.  C below = channels of the slab, ch0 = first channel of the slab.
 template <typename T, bool DEEP, typename L, typename A, typename G>
-__device__ __forceinline__ void column_sums2(long M, int C, float* ws, unsigned* counter, L&& load_row, A&& add_row, G&& finalize) {
+__device__ __forceinline__ void column_sums2(long M, int C, float* ws_all, unsigned* counter_all, L&& load_row, A&& add_row, G&& finalize) {
     constexpr int V = Vec<T>::N;
+    const int ch0 = blockIdx.y * C;
+    float* ws = ws_all + (size_t)blockIdx.y * 2 * C * (MAX_STAT_BLOCKS + 1);
+    unsigned* counter = counter_all + blockIdx.y;
     __shared__ __attribute__((aligned(16))) float sh[TPB * 2 * 8];
     __shared__ int is_last;
     const int tpr = C / V;            // threads per row
@@ -88,14 +93,14 @@ __device__ __forceinline__ void column_sums2(long M, int C, float* ws, unsigned*
         long r = (long)blockIdx.x * rpb + ty;
         typename Vec<T>::Raw q0[2], q1[2], q2[2], q3[2], q4[2], q5[2], q6[2], q7[2];
         for (; DEEP && r + 7 * stride < M; r += 8 * stride) {   // 8 independent rows in flight (single-tensor reductions)
-            load_row(r, tx * V, q0);
-            load_row(r + stride, tx * V, q1);
-            load_row(r + 2 * stride, tx * V, q2);
-            load_row(r + 3 * stride, tx * V, q3);
-            load_row(r + 4 * stride, tx * V, q4);
-            load_row(r + 5 * stride, tx * V, q5);
-            load_row(r + 6 * stride, tx * V, q6);
-            load_row(r + 7 * stride, tx * V, q7);
+            load_row(r, ch0 + tx * V, q0);
+            load_row(r + stride, ch0 + tx * V, q1);
+            load_row(r + 2 * stride, ch0 + tx * V, q2);
+            load_row(r + 3 * stride, ch0 + tx * V, q3);
+            load_row(r + 4 * stride, ch0 + tx * V, q4);
+            load_row(r + 5 * stride, ch0 + tx * V, q5);
+            load_row(r + 6 * stride, ch0 + tx * V, q6);
+            load_row(r + 7 * stride, ch0 + tx * V, q7);
             add_row(q0, a, b);
             add_row(q1, a, b);
             add_row(q2, a, b);
@@ -106,17 +111,17 @@ __device__ __forceinline__ void column_sums2(long M, int C, float* ws, unsigned*
             add_row(q7, a, b);
         }
         for (; r + 3 * stride < M; r += 4 * stride) {
-            load_row(r, tx * V, q0);
-            load_row(r + stride, tx * V, q1);
-            load_row(r + 2 * stride, tx * V, q2);
-            load_row(r + 3 * stride, tx * V, q3);
+            load_row(r, ch0 + tx * V, q0);
+            load_row(r + stride, ch0 + tx * V, q1);
+            load_row(r + 2 * stride, ch0 + tx * V, q2);
+            load_row(r + 3 * stride, ch0 + tx * V, q3);
             add_row(q0, a, b);
             add_row(q1, a, b);
             add_row(q2, a, b);
             add_row(q3, a, b);
         }
         for (; r < M; r += stride) {
-            load_row(r, tx * V, q0);
+            load_row(r, ch0 + tx * V, q0);
             add_row(q0, a, b);
         }
     }
@@ -173,7 +178,7 @@ __device__ __forceinline__ void column_sums2(long M, int C, float* ws, unsigned*
         const int col = base + cc;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (sl < slices && col < ncol4)
-#pragma unroll 8
+#pragma unroll 16   // these device-coherent loads come from memory (~2 us each): the tail is their round trips / loads in flight
             for (int k = sl; k < nblk; k += slices) {
                 const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((size_t)k * ncol4 + col) * 16), 0, COHERENT));
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
@@ -191,7 +196,7 @@ __device__ __forceinline__ void column_sums2(long M, int C, float* ws, unsigned*
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += TPB) finalize(c, fin[c], fin[C + c]);
+    for (int c = threadIdx.x; c < C; c += TPB) finalize(ch0 + c, fin[c], fin[C + c]);
     if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
 }
 
@@ -207,11 +212,11 @@ struct StatsOut {
 };
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void iabn_stats_kernel(const T* __restrict__ x, long M, int C, float* ws, unsigned* counter, StatsOut o) {
+__global__ __launch_bounds__(TPB) void iabn_stats_kernel(const T* __restrict__ x, long M, int C, int SC, float* ws, unsigned* counter, StatsOut o) {
     constexpr int V = Vec<T>::N;
     float s[V];
-    Vec<T>::load(x + (threadIdx.x % (C / V)) * V, s);
-    column_sums2<T, true>(M, C, ws, counter,
+    Vec<T>::load(x + blockIdx.y * SC + (threadIdx.x % (SC / V)) * V, s);   // shift = first row of this thread's channels
+    column_sums2<T, true>(M, SC, ws, counter,
         [&](long r, int c0, typename Vec<T>::Raw (&q)[2]) { q[0] = Vec<T>::load_raw(x + r * C + c0); },
         [&](const typename Vec<T>::Raw (&q)[2], float (&a)[V], float (&b)[V]) {
             float v[V];
@@ -331,18 +336,18 @@ __global__ __launch_bounds__(TPB) void iabn_apply(const T* __restrict__ x, T* __
 template <typename T>
 __global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dy, long M, int C,
                                                               const float* __restrict__ weight, const float* __restrict__ bias,
-                                                              float eps, int leaky, float slope, float* ws, unsigned* counter,
+                                                              float eps, int leaky, float slope, int SC, float* ws, unsigned* counter,
                                                               float* sums, float* dwb) {
     constexpr int V = Vec<T>::N;
     const float inv_slope = 1.f / slope;
-    const int c0t = (threadIdx.x % (C / V)) * V;   // this thread's channels never change
+    const int c0t = blockIdx.y * SC + (threadIdx.x % (SC / V)) * V;   // this thread's channels never change
     float bk[V], igk[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         bk[k] = bias[c0t + k];
         igk[k] = 1.f / (fabsf(weight[c0t + k]) + eps);
     }
-    column_sums2<T, false>(M, C, ws, counter,
+    column_sums2<T, false>(M, SC, ws, counter,
         [&](long r, int c0, typename Vec<T>::Raw (&q)[2]) {
             q[0] = Vec<T>::load_raw(y + r * C + c0);
             q[1] = Vec<T>::load_raw(dy + r * C + c0);
@@ -432,10 +437,13 @@ inline int check_shape(long M, int C, int dtype) {
     return MGN_OK;
 }
 
-inline int stat_blocks(long M, int C, int dtype) {
+// channel slab of the reduction kernels: wide layers (few rows) get a block grid of (row blocks) x (C / 128)
+inline int slab_channels(int C) { return (C > 128 && C % 128 == 0) ? 128 : C; }
+
+inline int stat_blocks(long M, int SC, int dtype) {
     const int V = dtype == 1 ? 8 : 4;
-    const int rpb = TPB / (C / V);
-    long b = (M + (long)rpb * 64 - 1) / ((long)rpb * 64);  // >= 64 rows (16 four-deep iterations) per thread before adding blocks
+    const int rpb = TPB / (SC / V);
+    long b = (M + (long)rpb * 16 - 1) / ((long)rpb * 16);  // >= 16 rows (two 8-deep iterations) per thread before adding blocks
     return (int)(b < 1 ? 1 : (b > MAX_STAT_BLOCKS ? MAX_STAT_BLOCKS : b));
 }
 
@@ -450,7 +458,9 @@ unsigned* next_counter() {
         if (hipMalloc((void**)&pool[dev], 4096 * sizeof(unsigned)) != hipSuccess) return nullptr;
         if (hipMemset(pool[dev], 0, 4096 * sizeof(unsigned)) != hipSuccess) return nullptr;
     }
-    return pool[dev] + (next[dev]++ & 4095);
+    const unsigned slot = (next[dev] & 255u) * 16u;   // 16 consecutive counters per launch (one per channel slab)
+    ++next[dev];
+    return pool[dev] + slot;
 }
 
 }  // namespace
@@ -471,12 +481,12 @@ int mgn_iabn_stats(const void* x, int dtype, long M, int C, float* stats, void* 
     if (!x || !stats || !ws) return MGN_EINVAL;
     if (ws_bytes < sizeof(float) * 2 * (size_t)C * 1024) return MGN_ENOSPC;
     hipStream_t s = (hipStream_t)stream_;
-    const int nb = stat_blocks(M, C, dtype);
+    const int SC = slab_channels(C), nb = stat_blocks(M, SC, dtype);
     unsigned* ctr = next_counter();
-    if (!ctr) return MGN_ELAUNCH;
+    if (!ctr || C / SC > 16) return MGN_ELAUNCH;
     StatsOut o = {stats, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
-    if (dtype == 1) hipLaunchKernelGGL(iabn_stats_kernel<__hip_bfloat16>, dim3(nb), dim3(TPB), 0, s, (const __hip_bfloat16*)x, M, C, (float*)ws, ctr, o);
-    else hipLaunchKernelGGL(iabn_stats_kernel<float>, dim3(nb), dim3(TPB), 0, s, (const float*)x, M, C, (float*)ws, ctr, o);
+    if (dtype == 1) hipLaunchKernelGGL(iabn_stats_kernel<__hip_bfloat16>, dim3(nb, C / SC), dim3(TPB), 0, s, (const __hip_bfloat16*)x, M, C, SC, (float*)ws, ctr, o);
+    else hipLaunchKernelGGL(iabn_stats_kernel<float>, dim3(nb, C / SC), dim3(TPB), 0, s, (const float*)x, M, C, SC, (float*)ws, ctr, o);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -487,12 +497,12 @@ int mgn_iabn_train_coeffs(const void* x, int dtype, long M, int C, const float* 
     if (!x || !weight || !bias || !coef || !ws) return MGN_EINVAL;
     if (ws_bytes < sizeof(float) * 2 * (size_t)C * 1024) return MGN_ENOSPC;
     hipStream_t s = (hipStream_t)stream_;
-    const int nb = stat_blocks(M, C, dtype);
+    const int SC = slab_channels(C), nb = stat_blocks(M, SC, dtype);
     unsigned* ctr = next_counter();
-    if (!ctr) return MGN_ELAUNCH;
+    if (!ctr || C / SC > 16) return MGN_ELAUNCH;
     StatsOut o = {nullptr, coef, weight, bias, running_mean, running_var, eps, momentum};
-    if (dtype == 1) hipLaunchKernelGGL(iabn_stats_kernel<__hip_bfloat16>, dim3(nb), dim3(TPB), 0, s, (const __hip_bfloat16*)x, M, C, (float*)ws, ctr, o);
-    else hipLaunchKernelGGL(iabn_stats_kernel<float>, dim3(nb), dim3(TPB), 0, s, (const float*)x, M, C, (float*)ws, ctr, o);
+    if (dtype == 1) hipLaunchKernelGGL(iabn_stats_kernel<__hip_bfloat16>, dim3(nb, C / SC), dim3(TPB), 0, s, (const __hip_bfloat16*)x, M, C, SC, (float*)ws, ctr, o);
+    else hipLaunchKernelGGL(iabn_stats_kernel<float>, dim3(nb, C / SC), dim3(TPB), 0, s, (const float*)x, M, C, SC, (float*)ws, ctr, o);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -535,15 +545,15 @@ int mgn_iabn_bwd_reduce(const void* y, const void* dy, int dtype, long M, int C,
     if (!y || !dy || !weight || !bias || !sums || !ws) return MGN_EINVAL;
     if (ws_bytes < sizeof(float) * 2 * (size_t)C * 1024) return MGN_ENOSPC;
     hipStream_t s = (hipStream_t)stream_;
-    const int nb = stat_blocks(M, C, dtype);
+    const int SC = slab_channels(C), nb = stat_blocks(M, SC, dtype);
     unsigned* ctr = next_counter();
-    if (!ctr) return MGN_ELAUNCH;
+    if (!ctr || C / SC > 16) return MGN_ELAUNCH;
     if (dtype == 1)
-        hipLaunchKernelGGL(iabn_bwd_reduce_kernel<__hip_bfloat16>, dim3(nb), dim3(TPB), 0, s, (const __hip_bfloat16*)y,
-                           (const __hip_bfloat16*)dy, M, C, weight, bias, eps, activation, slope, (float*)ws, ctr, sums, dwb);
+        hipLaunchKernelGGL(iabn_bwd_reduce_kernel<__hip_bfloat16>, dim3(nb, C / SC), dim3(TPB), 0, s, (const __hip_bfloat16*)y,
+                           (const __hip_bfloat16*)dy, M, C, weight, bias, eps, activation, slope, SC, (float*)ws, ctr, sums, dwb);
     else
-        hipLaunchKernelGGL(iabn_bwd_reduce_kernel<float>, dim3(nb), dim3(TPB), 0, s, (const float*)y, (const float*)dy, M, C, weight,
-                           bias, eps, activation, slope, (float*)ws, ctr, sums, dwb);
+        hipLaunchKernelGGL(iabn_bwd_reduce_kernel<float>, dim3(nb, C / SC), dim3(TPB), 0, s, (const float*)y, (const float*)dy, M, C, weight,
+                           bias, eps, activation, slope, SC, (float*)ws, ctr, sums, dwb);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
