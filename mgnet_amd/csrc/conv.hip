@@ -630,8 +630,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
             if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
-            if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            // (allowance = the 2 rows issued last step + its output stores: 4 sixteen-byte stores, or 0 counted on the residual
+            //  path, whose 8-byte accesses must then simply be complete: a smaller allowance only waits for more)
+            if (p.residual) {
+                if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         issue_in(r + 5, slot(si + 6));   // (always issued: rows past the chunk land in unused slots)
@@ -655,23 +660,42 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
                 }
             }
         }
-        // D = W-rows x pixels: col = lane & 31 -> pixel, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel
+        // D = W-rows x pixels: col = lane & 31 -> pixel, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel.
+        // v_permlane32_swap exchanges the 4-channel groups between lane l and lane l+32 so that every lane owns 8 CONSECUTIVE
+        // channels of its pixel: 16-byte stores, half as many store instructions (pack8x2 below).
         if (opx < p.W) {
 #pragma unroll
             for (int rr2 = 0; rr2 < 2; ++rr2) {
                 if (r + rr2 >= r1) break;   // wave-uniform (odd number of rows: the last step has one row)
-                uint16_t* orow = p.out + ((size_t)(n * p.H + r + rr2) * p.W + opx) * p.Cout + co_w + 4 * hi;
+                uint16_t* opix = p.out + ((size_t)(n * p.H + r + rr2) * p.W + opx) * p.Cout + co_w;
+                if (p.residual) {
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    float v0 = rr2 ? acc1[qd * 4 + 0] : acc0[qd * 4 + 0], v1 = rr2 ? acc1[qd * 4 + 1] : acc0[qd * 4 + 1];
-                    float v2 = rr2 ? acc1[qd * 4 + 2] : acc0[qd * 4 + 2], v3 = rr2 ? acc1[qd * 4 + 3] : acc0[qd * 4 + 3];
-                    if (p.residual) {
-                        const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (orow - p.out) + 8 * qd);
+                    for (int qd = 0; qd < 4; ++qd) {
+                        uint16_t* orow = opix + 4 * hi + 8 * qd;
+                        float v0 = rr2 ? acc1[qd * 4 + 0] : acc0[qd * 4 + 0], v1 = rr2 ? acc1[qd * 4 + 1] : acc0[qd * 4 + 1];
+                        float v2 = rr2 ? acc1[qd * 4 + 2] : acc0[qd * 4 + 2], v3 = rr2 ? acc1[qd * 4 + 3] : acc0[qd * 4 + 3];
+                        const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (orow - p.out));
                         v0 += __uint_as_float(rr.x << 16); v1 += __uint_as_float(rr.x & 0xffff0000u);
                         v2 += __uint_as_float(rr.y << 16); v3 += __uint_as_float(rr.y & 0xffff0000u);
+                        *reinterpret_cast<uint2*>(orow) =
+                            make_uint2((uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16));
                     }
-                    *reinterpret_cast<uint2*>(orow + 8 * qd) =
-                        make_uint2((uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16));
+                } else {
+#pragma unroll
+                    for (int qp = 0; qp < 2; ++qp) {   // channel groups (qd = 2qp, 2qp+1) -> channels 16*qp + 8*hi .. +7
+                        uint32_t pk[2][2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int qd = 2 * qp + u;
+                            const float v0 = rr2 ? acc1[qd * 4 + 0] : acc0[qd * 4 + 0], v1 = rr2 ? acc1[qd * 4 + 1] : acc0[qd * 4 + 1];
+                            const float v2 = rr2 ? acc1[qd * 4 + 2] : acc0[qd * 4 + 2], v3 = rr2 ? acc1[qd * 4 + 3] : acc0[qd * 4 + 3];
+                            pk[u][0] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+                            pk[u][1] = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+                        }
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                        *reinterpret_cast<uint4*>(opix + 16 * qp + 8 * hi) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    }
                 }
             }
         }
