@@ -227,6 +227,49 @@ int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const
 int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
                    const float* pixel_std3, void* out_bf16, int Cp, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Panoptic training targets on the device (the producer of the hot path's target maps)
+ *   replaces mgnet/data/target_generator.py:54-158  PanopticDeepLabTargetGenerator.__call__,
+ *   the `rgb2id` decode before it (mgnet/data/dataset_mapper.py:178) and the per-class part of the
+ *   reprojection mask (dataset_mapper.py:214-216).
+ * Inputs
+ *   panoptic   : pan_rgb == 0: int32 [B,H,W] segment ids;  pan_rgb == 1: uint8 [B,H,W,3] label image as read from the
+ *                PNG (id = R + 256 G + 65536 B)
+ *   seg_ids    : int32 [B, max_segments], the ids of segments_info, ASCENDING and unique per image (host sorts)
+ *   seg_attr   : int32 [B, max_segments] in the same order: category_id (0..255) | iscrowd << 8 | is_thing << 9
+ *   seg_count  : int32 [B] number of valid table rows per image (<= max_segments <= MGN_TARGETS_MAX_SEGMENTS)
+ *   gauss      : fp32 [(6 sigma + 3)^2], the Gaussian patch of target_generator.py:45-50 rounded to fp32
+ * Outputs (dtypes and shapes of the reference's dict entries, stacked over the batch)
+ *   sem_seg int64 [B,H,W]; center fp32 [B,H,W]; offset fp32 [B,2,H,W] (dy, dx); sem_seg_weights fp32 [B,H,W];
+ *   center_weights, offset_weights fp32 [B,1,H,W]; reprojection_mask uint8 [B,H,W] (optional, NULL = skip):
+ *   0 where sem_seg is one of the classes in depth_ignore_mask; center_points fp64 [B,max_segments,2] (optional; (cy,cx)
+ *   per table row, NaN where the row has no centre); seg_area int64 [B,max_segments] (optional)
+ * Integer statistics + a gather formulation of the heat map: results do not depend on the launch shape.
+ * Algorithmic HBM bytes: 2 reads of the labels + one write of every map = 41 B/px (int32 labels, with mask).
+ * ---------------------------------------------------------------------------------------------- */
+#define MGN_TARGETS_MAX_SEGMENTS 1024
+typedef struct {
+    int B, H, W;
+    int pan_rgb;                  /* 0: int32 ids, 1: uint8 RGB label image                                           */
+    int ignore_label;             /* sem_seg value of pixels outside every segment (0..255)                           */
+    int sigma;                    /* Gaussian sigma (INPUT.GAUSSIAN_SIGMA, config.py:51), 1..64                        */
+    int first_thing_id;           /* thing_ids[0]: sem_seg < first_thing_id gets center weight 1 (:146)               */
+    int ignore_stuff_in_offset;
+    int small_instance_area;
+    int small_instance_weight;
+    int ignore_crowd_in_semantic;
+    int legacy_promotion;         /* 1: offsets = f32(center) - f32(coord) (NumPy < 2 value-based casting, the only
+                                     NumPy the reference's np.bool runs on); 0: f32(center64 - coord) (NEP 50)         */
+    int max_segments;             /* row stride of the segment tables                                                 */
+    uint32_t depth_ignore_mask[8];/* bit c set: class c is excluded from the photometric loss                         */
+} mgn_targets_cfg;
+
+int mgn_panoptic_targets_workspace_bytes(const mgn_targets_cfg* cfg, size_t* bytes);
+int mgn_panoptic_targets(const mgn_targets_cfg* cfg, const void* panoptic, const int32_t* seg_ids, const int32_t* seg_attr,
+                         const int32_t* seg_count, const float* gauss, int64_t* sem_seg, float* center, float* offset,
+                         float* sem_seg_weights, float* center_weights, float* offset_weights, uint8_t* reprojection_mask,
+                         double* center_points, int64_t* seg_area, void* workspace, size_t workspace_bytes, void* stream);
+
 /* 3x3 / stride 2 / pad 1 max pooling of the ResNet stems (res_net.py:109) on channels-last bf16 [N,IH,IW,C] (C % 8 == 0);
  * argmax: 1 byte per output element (winning tap 0..8); backward is a deterministic gather. */
 int mgn_maxpool3x3s2_fwd(const void* x_bf16, void* y_bf16, uint8_t* argmax, int N, int IH, int IW, int C, void* stream);

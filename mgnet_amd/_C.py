@@ -19,7 +19,16 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
-           "mgn_nearest_bwd", "mgn_concat2", "mgn_split2", "mgn_vec_linear_fwd", "mgn_vec_linear_bwd_workspace_bytes", "mgn_vec_linear_bwd"]
+           "mgn_nearest_bwd", "mgn_concat2", "mgn_split2", "mgn_vec_linear_fwd", "mgn_vec_linear_bwd_workspace_bytes", "mgn_vec_linear_bwd",
+           "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets"]
+TARGETS_MAX_SEGMENTS = 1024   # MGN_TARGETS_MAX_SEGMENTS
+
+
+class TargetsCfg(ctypes.Structure):   # mgn_targets_cfg
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "H", "W", "pan_rgb", "ignore_label", "sigma", "first_thing_id",
+                                            "ignore_stuff_in_offset", "small_instance_area", "small_instance_weight",
+                                            "ignore_crowd_in_semantic", "legacy_promotion", "max_segments")] + \
+               [("depth_ignore_mask", ctypes.c_uint32 * 8)]
 
 
 class ReprojCfg(ctypes.Structure):
@@ -91,6 +100,8 @@ def lib():
         L.mgn_concat2.argtypes = [vp, vp, cl, ci, ci, vp, vp]
         L.mgn_split2.argtypes = [vp, cl, ci, ci, vp, vp, vp]
         L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
+        L.mgn_panoptic_targets_workspace_bytes.argtypes = [ctypes.POINTER(TargetsCfg), ctypes.POINTER(sz)]
+        L.mgn_panoptic_targets.argtypes = [ctypes.POINTER(TargetsCfg)] + [vp] * 15 + [sz, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
         _lib = L
@@ -305,6 +316,43 @@ def prep_input(frames_u8, mean3, std3, Cp):
     m = (ctypes.c_float * 3)(*[float(v) for v in mean3])
     sd = (ctypes.c_float * 3)(*[float(v) for v in std3])
     check(lib().mgn_prep_input(ptrs, len(frames_u8), B, H, W, m, sd, out.data_ptr(), Cp, _stream()), "mgn_prep_input")
+    return out
+
+
+def panoptic_targets(cfg, panoptic, seg_ids, seg_attr, seg_count, gauss, want_mask=False, want_points=False):
+    """Device-side PanopticDeepLabTargetGenerator (csrc/targets.hip).  cfg: TargetsCfg; panoptic int32 [B,H,W] or uint8
+    [B,H,W,3]; seg_* int32 device tables; gauss fp32 device patch.  Returns the dict of batched target maps."""
+    B, H, W = cfg.B, cfg.H, cfg.W
+    dev = panoptic.device
+    assert panoptic.is_cuda and panoptic.is_contiguous()
+    assert tuple(panoptic.shape) == ((B, H, W, 3) if cfg.pan_rgb else (B, H, W))
+    assert panoptic.dtype == (torch.uint8 if cfg.pan_rgb else torch.int32)
+    for t in (seg_ids, seg_attr):
+        assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == (B, cfg.max_segments)
+    assert seg_count.is_cuda and seg_count.dtype == torch.int32 and seg_count.numel() == B
+    assert gauss.is_cuda and gauss.dtype == torch.float32 and gauss.numel() == (6 * cfg.sigma + 3) ** 2
+    nbytes = ctypes.c_size_t()
+    check(lib().mgn_panoptic_targets_workspace_bytes(ctypes.byref(cfg), ctypes.byref(nbytes)), "mgn_panoptic_targets_workspace_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    out = dict(sem_seg=torch.empty((B, H, W), dtype=torch.int64, device=dev),
+               center=torch.empty((B, H, W), dtype=torch.float32, device=dev),
+               offset=torch.empty((B, 2, H, W), dtype=torch.float32, device=dev),
+               sem_seg_weights=torch.empty((B, H, W), dtype=torch.float32, device=dev),
+               center_weights=torch.empty((B, 1, H, W), dtype=torch.float32, device=dev),
+               offset_weights=torch.empty((B, 1, H, W), dtype=torch.float32, device=dev))
+    mask = torch.empty((B, H, W), dtype=torch.bool, device=dev) if want_mask else None
+    pts = torch.empty((B, cfg.max_segments, 2), dtype=torch.float64, device=dev) if want_points else None
+    area = torch.empty((B, cfg.max_segments), dtype=torch.int64, device=dev) if want_points else None
+    opt = lambda t: None if t is None else t.data_ptr()
+    check(lib().mgn_panoptic_targets(ctypes.byref(cfg), panoptic.data_ptr(), seg_ids.data_ptr(), seg_attr.data_ptr(),
+                                     seg_count.data_ptr(), gauss.data_ptr(), out["sem_seg"].data_ptr(), out["center"].data_ptr(),
+                                     out["offset"].data_ptr(), out["sem_seg_weights"].data_ptr(), out["center_weights"].data_ptr(),
+                                     out["offset_weights"].data_ptr(), opt(mask), opt(pts), opt(area), ws.data_ptr(), ws.numel(),
+                                     _stream()), "mgn_panoptic_targets")
+    if want_mask:
+        out["reprojection_mask"] = mask
+    if want_points:
+        out["center_points"], out["seg_area"] = pts, area
     return out
 
 

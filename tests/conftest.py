@@ -47,3 +47,30 @@ def _build_oracle():
     import oracle
 
     oracle.build()
+
+
+# ---- panoptic target fixtures (tests/golden/targets_*.npz, outputs of the reference's target_generator.py) -------------
+import glob  # noqa: E402
+
+TARGET_GOLD = sorted(glob.glob(os.path.join(GOLDEN, "targets_*.npz")))
+
+
+def load_target_case(path):
+    """-> (npz, label image, segments_info, generator kwargs)"""
+    z = np.load(path)
+    kw = {str(k): int(v) for k, v in zip(z["gen_keys"], z["gen_vals"])}
+    for k in ("ignore_stuff_in_offset", "ignore_crowd_in_semantic"):
+        if k in kw:
+            kw[k] = bool(kw[k])
+    kw["thing_ids"] = [int(t) for t in z["thing_ids"]]
+    segs = [dict(id=int(r[0]), category_id=int(r[1]), iscrowd=int(r[2])) for r in z["segments"]]
+    return z, z["panoptic"], segs, kw
+
+
+def golden_script(name):
+    """Import tests/golden/<name>.py by path (for its synthetic-input builders)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(GOLDEN, name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
