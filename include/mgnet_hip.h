@@ -270,6 +270,58 @@ int mgn_panoptic_targets(const mgn_targets_cfg* cfg, const void* panoptic, const
                          float* sem_seg_weights, float* center_weights, float* offset_weights, uint8_t* reprojection_mask,
                          double* center_points, int64_t* seg_area, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Panoptic fusion of the inference path (the consumer of the hot path's head outputs)
+ *   replaces mgnet/postprocessing/panoptic_post_proc.py:9-147  get_panoptic_prediction
+ *   (+ _group_instances_and_fuse_logits), one image per call like the reference (mg_net.py:375).
+ * Inputs  : sem_seg int64 [H,W] (argmax labels), center_heatmap fp32 [H,W], offsets fp32 [2,H,W] (dy, dx); not modified
+ *           (the reference adds the pixel grid into `offsets` and scatters into `sem_seg` in place).
+ * Outputs : panoptic int64 [H,W]; info int32[2] = { centres that survived the NMS, 1 if that exceeded
+ *           MGN_PANOPTIC_MAX_CENTERS (the list is cut there; the reference's own 65535 sentinel breaks at the same point) }
+ * Centre order = row-major (torch.nonzero), nearest centre = first minimum of the fp32 L2 distance, class vote = first
+ * maximum: the instance ids equal the reference's.  No host synchronisation.
+ * ---------------------------------------------------------------------------------------------- */
+#define MGN_PANOPTIC_MAX_CENTERS 65534
+typedef struct {
+    int H, W;
+    int num_thing_classes;   /* len(thing ids)                                              */
+    int last_stuff_id;       /* max contiguous stuff id; sem_seg > last_stuff_id = thing     */
+    int label_divisor;       /* panoptic id = class * label_divisor + instance               */
+    int stuff_area;          /* MODEL.POST_PROCESSING.STUFF_AREA (config.py:122)             */
+    int void_label;          /* -1 (mg_net.py:166)                                           */
+    float threshold;         /* CENTER_THRESHOLD (config.py:123)                             */
+    int nms_kernel;          /* NMS_KERNEL (config.py:124), odd                              */
+} mgn_panoptic_cfg;
+
+int mgn_panoptic_post_workspace_bytes(const mgn_panoptic_cfg* cfg, size_t* bytes);
+int mgn_panoptic_post(const mgn_panoptic_cfg* cfg, const int64_t* sem_seg, const float* center_heatmap, const float* offsets,
+                      int64_t* panoptic, int32_t* info, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Depth post-processing with DGC metric rescaling
+ *   replaces mgnet/postprocessing/depth_post_proc.py:11-185  get_depth_prediction (+ _get_scale_recovery,
+ *   _get_surface_normal with nei = 1, _get_ground_mask with 5 degrees) and Camera.reconstruct (geometry/camera.py:107-141).
+ * depth fp32 [H,W] (H, W >= 3); panoptic int64 [H,W] or NULL (has_panoptic = 0: the ground mask comes from the surface
+ * normals); depth_out fp32 [H,W]; xyz fp32 [3,H,W] (camera-frame points, required when use_dgc_scaling); scale: device
+ * fp32[1] = real_camera_height / median ground height (NaN when no pixel is ground; 1 without DGC).
+ * The median is torch.median's (the lower middle element), found by a 4-pass radix select, not a sort.
+ * ---------------------------------------------------------------------------------------------- */
+#define MGN_DEPTH_MAX_FILTER_IDS 16
+typedef struct {
+    int H, W;
+    int use_dgc_scaling;          /* MODEL.POST_PROCESSING.USE_DGC_SCALING (config.py:126)                   */
+    int has_panoptic;
+    float fx, fy, cx, cy;         /* camera_matrix[0,0], [1,1], [0,2], [1,2]                                 */
+    float real_camera_height;
+    int n_filter;                 /* number of valid filter_ids                                              */
+    int64_t road_class_id;        /* panoptic id of the road class (trainId * label_divisor, mg_net.py:173-180) */
+    int64_t filter_ids[MGN_DEPTH_MAX_FILTER_IDS]; /* panoptic ids whose depth is set to 0 / points to NaN (:62-68) */
+} mgn_depth_post_cfg;
+
+int mgn_depth_post_workspace_bytes(const mgn_depth_post_cfg* cfg, size_t* bytes);
+int mgn_depth_post(const mgn_depth_post_cfg* cfg, const float* depth, const int64_t* panoptic, float* depth_out, float* xyz,
+                   float* scale, void* workspace, size_t workspace_bytes, void* stream);
+
 /* 3x3 / stride 2 / pad 1 max pooling of the ResNet stems (res_net.py:109) on channels-last bf16 [N,IH,IW,C] (C % 8 == 0);
  * argmax: 1 byte per output element (winning tap 0..8); backward is a deterministic gather. */
 int mgn_maxpool3x3s2_fwd(const void* x_bf16, void* y_bf16, uint8_t* argmax, int N, int IH, int IW, int C, void* stream);

@@ -20,7 +20,22 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
            "mgn_nearest_bwd", "mgn_concat2", "mgn_split2", "mgn_vec_linear_fwd", "mgn_vec_linear_bwd_workspace_bytes", "mgn_vec_linear_bwd",
-           "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets"]
+           "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
+           "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_depth_post_workspace_bytes", "mgn_depth_post"]
+DEPTH_MAX_FILTER_IDS = 16
+
+
+class DepthPostCfg(ctypes.Structure):   # mgn_depth_post_cfg
+    _fields_ = [("H", ctypes.c_int), ("W", ctypes.c_int), ("use_dgc_scaling", ctypes.c_int), ("has_panoptic", ctypes.c_int),
+                ("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float), ("cy", ctypes.c_float),
+                ("real_camera_height", ctypes.c_float), ("n_filter", ctypes.c_int), ("road_class_id", ctypes.c_int64),
+                ("filter_ids", ctypes.c_int64 * 16)]
+PANOPTIC_MAX_CENTERS = 65534   # MGN_PANOPTIC_MAX_CENTERS
+
+
+class PanopticCfg(ctypes.Structure):   # mgn_panoptic_cfg
+    _fields_ = [(n, ctypes.c_int) for n in ("H", "W", "num_thing_classes", "last_stuff_id", "label_divisor", "stuff_area",
+                                            "void_label")] + [("threshold", ctypes.c_float), ("nms_kernel", ctypes.c_int)]
 TARGETS_MAX_SEGMENTS = 1024   # MGN_TARGETS_MAX_SEGMENTS
 
 
@@ -100,6 +115,10 @@ def lib():
         L.mgn_concat2.argtypes = [vp, vp, cl, ci, ci, vp, vp]
         L.mgn_split2.argtypes = [vp, cl, ci, ci, vp, vp, vp]
         L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
+        L.mgn_depth_post_workspace_bytes.argtypes = [ctypes.POINTER(DepthPostCfg), ctypes.POINTER(sz)]
+        L.mgn_depth_post.argtypes = [ctypes.POINTER(DepthPostCfg), vp, vp, vp, vp, vp, vp, sz, vp]
+        L.mgn_panoptic_post_workspace_bytes.argtypes = [ctypes.POINTER(PanopticCfg), ctypes.POINTER(sz)]
+        L.mgn_panoptic_post.argtypes = [ctypes.POINTER(PanopticCfg), vp, vp, vp, vp, vp, vp, sz, vp]
         L.mgn_panoptic_targets_workspace_bytes.argtypes = [ctypes.POINTER(TargetsCfg), ctypes.POINTER(sz)]
         L.mgn_panoptic_targets.argtypes = [ctypes.POINTER(TargetsCfg)] + [vp] * 15 + [sz, vp]
         for n in SYMBOLS[4:]:
@@ -317,6 +336,41 @@ def prep_input(frames_u8, mean3, std3, Cp):
     sd = (ctypes.c_float * 3)(*[float(v) for v in std3])
     check(lib().mgn_prep_input(ptrs, len(frames_u8), B, H, W, m, sd, out.data_ptr(), Cp, _stream()), "mgn_prep_input")
     return out
+
+
+def panoptic_post(cfg, sem_seg, center, offsets):
+    """mgn_panoptic_post: sem_seg int64 [H,W], center f32 [H,W], offsets f32 [2,H,W] (CUDA, contiguous) ->
+    (panoptic int64 [H,W], info int32[2] on the device)."""
+    H, W = cfg.H, cfg.W
+    assert sem_seg.is_cuda and sem_seg.dtype == torch.int64 and sem_seg.is_contiguous() and tuple(sem_seg.shape) == (H, W)
+    assert center.dtype == torch.float32 and center.is_contiguous() and tuple(center.shape) == (H, W)
+    assert offsets.dtype == torch.float32 and offsets.is_contiguous() and tuple(offsets.shape) == (2, H, W)
+    nbytes = ctypes.c_size_t()
+    check(lib().mgn_panoptic_post_workspace_bytes(ctypes.byref(cfg), ctypes.byref(nbytes)), "mgn_panoptic_post_workspace_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=sem_seg.device)
+    pan = torch.empty((H, W), dtype=torch.int64, device=sem_seg.device)
+    info = torch.empty(2, dtype=torch.int32, device=sem_seg.device)
+    check(lib().mgn_panoptic_post(ctypes.byref(cfg), sem_seg.data_ptr(), center.data_ptr(), offsets.data_ptr(), pan.data_ptr(),
+                                  info.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "mgn_panoptic_post")
+    return pan, info
+
+
+def depth_post(cfg, depth, panoptic=None):
+    """mgn_depth_post: depth f32 [H,W] (+ panoptic int64 [H,W]) -> (depth [H,W], xyz [3,H,W] or None, scale f32[1])."""
+    H, W = cfg.H, cfg.W
+    assert depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous() and tuple(depth.shape) == (H, W)
+    if panoptic is not None:
+        assert panoptic.dtype == torch.int64 and panoptic.is_contiguous() and tuple(panoptic.shape) == (H, W)
+    nbytes = ctypes.c_size_t()
+    check(lib().mgn_depth_post_workspace_bytes(ctypes.byref(cfg), ctypes.byref(nbytes)), "mgn_depth_post_workspace_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=depth.device)
+    out = torch.empty_like(depth)
+    xyz = torch.empty((3, H, W), dtype=torch.float32, device=depth.device) if cfg.use_dgc_scaling else None
+    scale = torch.empty(1, dtype=torch.float32, device=depth.device)
+    check(lib().mgn_depth_post(ctypes.byref(cfg), depth.data_ptr(), None if panoptic is None else panoptic.data_ptr(),
+                               out.data_ptr(), None if xyz is None else xyz.data_ptr(), scale.data_ptr(), ws.data_ptr(),
+                               ws.numel(), _stream()), "mgn_depth_post")
+    return out, xyz, scale
 
 
 def panoptic_targets(cfg, panoptic, seg_ids, seg_attr, seg_count, gauss, want_mask=False, want_points=False):

@@ -12,8 +12,10 @@ _THINGS = ["person", "rider", "car", "truck", "bus", "train", "motorcycle", "bic
 def _make(names_stuff):
     cats = [{"name": n, "trainId": i, "isthing": 0} for i, n in enumerate(names_stuff)]
     cats += [{"name": n, "trainId": len(names_stuff) + i, "isthing": 1} for i, n in enumerate(_THINGS)]
+    # cityscapes_scene_seg.py:228-235: things and stuff in SEPARATE maps (keys there are the raw dataset ids; only the
+    # contiguous train ids -- the values -- are used by the model: mg_net.py:150-180)
     things = {c["trainId"]: c["trainId"] for c in cats if c["isthing"]}
-    stuff = {c["trainId"]: c["trainId"] for c in cats}
+    stuff = {c["trainId"]: c["trainId"] for c in cats if not c["isthing"]}
     return SimpleNamespace(categories=cats, thing_dataset_id_to_contiguous_id=things,
                            stuff_dataset_id_to_contiguous_id=stuff, label_divisor=1000, ignore_label=255,
                            stuff_classes=[c["name"] for c in cats], thing_classes=list(_THINGS))

@@ -1,7 +1,8 @@
 """MGNet meta-architecture and its three heads -- host-side mirror of mgnet/modeling/mg_net.py for the TRAINING
 path (mg_net.py:220-373) with the same registries, `@configurable`/`from_config` protocol, attribute names
-(=> state-dict keys) and loss dict keys.  The inference branch (mg_net.py:375-520: post-processing, multi-scale flip)
-is outside the hot path: eval mode returns the raw head outputs."""
+(=> state-dict keys) and loss dict keys, and for single-scale INFERENCE (mg_net.py:375-425): per-image
+`sem_seg_postprocess`, panoptic fusion and DGC depth rescaling through mgnet_amd.postprocessing (HIP).  Multi-scale flip
+inference (mg_net.py:427-520, row f4) is not built."""
 from typing import Dict, List
 
 import torch
@@ -33,7 +34,8 @@ class MGNet(nn.Module):
     @configurable
     def __init__(self, *, size_divisibility, pixel_mean, pixel_std, backbone, global_context, sem_seg_head,
                  ins_embed_head, depth_head, pose_net, with_panoptic, with_depth, with_uncertainty, msc_flip_eval=False,
-                 amp_dtype=None, **unused_inference_kwargs):
+                 amp_dtype=None, predict_instances=False, panoptic_post_proc_func=None, depth_post_proc_func=None,
+                 **unused_inference_kwargs):
         super().__init__()
         self.size_divisibility = size_divisibility
         self._mean01, self._std01 = [float(x) / 255.0 for x in pixel_mean], [float(x) / 255.0 for x in pixel_std]  # host copies
@@ -48,6 +50,8 @@ class MGNet(nn.Module):
         if with_uncertainty:  # mg_net.py:104-107
             self.register_parameter("log_vars", nn.Parameter(torch.zeros(5), requires_grad=True))
         self.msc_flip_eval = msc_flip_eval
+        self.predict_instances = predict_instances
+        self.panoptic_post_proc_func, self.depth_post_proc_func = panoptic_post_proc_func, depth_post_proc_func
         self.amp_dtype = amp_dtype  # activation dtype of the conv trunk (None = fp32); SOLVER.AMP.ENABLED -> bf16
 
     @classmethod
@@ -61,12 +65,31 @@ class MGNet(nn.Module):
             sem, ins = build_sem_seg_head(cfg, shapes), build_ins_embed_head(cfg, shapes)
         if cfg.WITH_DEPTH:
             dep, pose = build_depth_head(cfg, shapes), PoseCNN(cfg)
-        MetadataCatalog.get(cfg.DATASETS.TRAIN[0] if len(cfg.DATASETS.TRAIN) else "cityscapes")  # mg_net.py:147
+        meta = MetadataCatalog.get(cfg.DATASETS.TRAIN[0] if len(cfg.DATASETS.TRAIN) else "cityscapes")  # mg_net.py:147
+        pan_fn = dep_fn = None
+        if cfg.WITH_PANOPTIC:   # mg_net.py:155-170
+            from ..postprocessing import get_panoptic_prediction
+            pp = cfg.MODEL.POST_PROCESSING
+            pan_kw = dict(num_thing_classes=len(meta.thing_dataset_id_to_contiguous_id.values()),
+                          last_stuff_id=max(meta.stuff_dataset_id_to_contiguous_id.values()), label_divisor=meta.label_divisor,
+                          stuff_area=pp.STUFF_AREA, void_label=-1, threshold=pp.CENTER_THRESHOLD, nms_kernel=pp.NMS_KERNEL)
+
+            def pan_fn(sem_seg, center_heatmap, offsets):
+                return get_panoptic_prediction(sem_seg, center_heatmap, offsets, **pan_kw)
+        if cfg.WITH_DEPTH:      # mg_net.py:172-192
+            from ..postprocessing import get_depth_prediction
+            road = next((c["trainId"] * meta.label_divisor for c in meta.categories if c["name"] == "road"), None)
+            ignore = [c["trainId"] * meta.label_divisor for c in meta.categories if c["name"] in cfg.INPUT.IGNORED_CATEGORIES_IN_DEPTH]
+            dep_kw = dict(use_dgc_scaling=cfg.MODEL.POST_PROCESSING.USE_DGC_SCALING, road_class_id=road, depth_filter_class_ids=ignore)
+
+            def dep_fn(**kw):
+                return get_depth_prediction(**kw, **dep_kw)
         return dict(size_divisibility=cfg.MODEL.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN,
                     pixel_std=cfg.MODEL.PIXEL_STD, backbone=backbone, global_context=gcm, sem_seg_head=sem,
                     ins_embed_head=ins, depth_head=dep, pose_net=pose, with_panoptic=cfg.WITH_PANOPTIC,
                     with_depth=cfg.WITH_DEPTH, with_uncertainty=cfg.WITH_UNCERTAINTY, msc_flip_eval=cfg.TEST.MSC_FLIP_EVAL,
-                    amp_dtype=torch.bfloat16 if cfg.SOLVER.AMP.ENABLED else None)
+                    amp_dtype=torch.bfloat16 if cfg.SOLVER.AMP.ENABLED else None, predict_instances=cfg.TEST.EVAL_INSTANCE,
+                    panoptic_post_proc_func=pan_fn, depth_post_proc_func=dep_fn)
 
     @property
     def device(self):
@@ -130,7 +153,7 @@ class MGNet(nn.Module):
         if self.with_depth:
             outputs["depth"] = self.depth_head(features)
         if not self.training:
-            return outputs  # raw head outputs; post-processing (mg_net.py:375-425) is row f2
+            return self._inference(batched_inputs, outputs)
 
         if self.with_panoptic:
             targets.update({
@@ -174,6 +197,48 @@ class MGNet(nn.Module):
                 storage.put_scalar(key + "_uncertainty", unc[idx])
                 losses[key] = weighted[idx]
         return losses
+
+
+def sem_seg_postprocess(result, img_size, output_height, output_width):
+    """detectron2.modeling.postprocessing.sem_seg_postprocess (recalled): crop the padding away, resize [C,h,w] logits to
+    the requested output resolution (bilinear, align_corners=False)."""
+    result = result[:, :img_size[0], :img_size[1]]
+    if tuple(result.shape[-2:]) == (output_height, output_width):
+        return result   # (interpolating to the same size with align_corners=False is the identity)
+    return torch.nn.functional.interpolate(result[None].float(), size=(output_height, output_width), mode="bilinear",
+                                           align_corners=False)[0]
+
+
+def _inference(self, batched_inputs, outputs):
+    """mg_net.py:375-425: per image (the post-processing is not batched in the reference either)."""
+    if self.predict_instances:
+        raise NotImplementedError("TEST.EVAL_INSTANCE (instance_post_proc.py, detectron2 Instances/BitMasks) is not built")
+    results = []
+    for idx, inp in enumerate(batched_inputs):
+        size = tuple(inp["image"].shape[-2:])
+        height, width = inp.get("height", size[0]), inp.get("width", size[1])
+        if self.with_panoptic:
+            r = sem_seg_postprocess(outputs["sem_seg"][idx], size, height, width)
+            c = sem_seg_postprocess(outputs["center"][idx], size, height, width)
+            o = sem_seg_postprocess(outputs["offset"][idx], size, height, width)
+            pan = self.panoptic_post_proc_func(sem_seg=r.argmax(dim=0, keepdim=True), center_heatmap=c, offsets=o)
+            results.append({"sem_seg": r, "panoptic_seg": (pan, None)})
+        if self.with_depth:
+            d = sem_seg_postprocess(outputs["depth"][idx], size, height, width)
+            first = batched_inputs[0]   # sic: mg_net.py:409-414 read the camera of the FIRST input
+            depth, xyz = self.depth_post_proc_func(
+                depth_logits=d.unsqueeze(0),
+                camera_matrix=first["camera_matrix"].unsqueeze(0) if "camera_matrix" in first else None,
+                real_camera_height=first["camera_height"] if "camera_height" in first else None,
+                panoptic_seg=results[-1]["panoptic_seg"][0] if self.with_panoptic else None)
+            if self.with_panoptic:
+                results[-1]["depth"] = (depth, xyz)
+            else:
+                results.append({"depth": (depth, xyz)})
+    return results
+
+
+MGNet._inference = _inference
 
 
 @SEM_SEG_HEADS_REGISTRY.register()
