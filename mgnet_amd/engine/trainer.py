@@ -25,6 +25,19 @@ class Trainer:
         self.scheduler = build_lr_scheduler(cfg, self.optimizer)
         self.storage = EventStorage()
         self.iter = 0
+        from ..checkpoint import Checkpointer
+        self.checkpointer = Checkpointer(model, getattr(cfg, "OUTPUT_DIR", "") or "", optimizer=self.optimizer, scheduler=self.scheduler)
+
+    def resume_or_load(self, resume=True):
+        """detectron2 DefaultTrainer.resume_or_load (tools/train_net.py:234): MODEL.WEIGHTS, or the last checkpoint of
+        OUTPUT_DIR (then training continues after its iteration)."""
+        extra = self.checkpointer.resume_or_load(self.cfg.MODEL.WEIGHTS, resume=resume)
+        if resume and self.checkpointer.has_checkpoint():
+            self.iter = int(extra.get("iteration", -1)) + 1
+        return extra
+
+    def save(self, name=None):
+        return self.checkpointer.save(name or f"model_{self.iter - 1:07d}", iteration=self.iter - 1)
 
     def run_step(self, batched_inputs):
         self.model.train()

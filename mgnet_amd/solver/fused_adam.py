@@ -53,6 +53,44 @@ class FusedAdam(torch.optim.Optimizer):
         # the kernel rewrote the flat parameter buffers behind torch's version counters: re-derive the bf16 conv layouts
         _C.weight_cache.refresh()
 
+    # ---- torch.optim.Adam-compatible (de)serialisation: the reference's `.pth` "optimizer" entry ---------------------
+    def _slices(self):
+        """param -> (bucket index, offset) in the flat moment buffers"""
+        return {p: (k, o) for k, b in enumerate(self.reducer.buckets) for p, o in zip(b["params"], b["offsets"])}
+
+    def state_dict(self):
+        sd = super().state_dict()   # param_groups with integer ids in group order
+        where, state, idx = self._slices(), {}, 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                k, o = where[p]
+                if self._t:
+                    state[idx] = {"step": torch.tensor(float(self._t)),
+                                  "exp_avg": self._m[k][o:o + p.numel()].view(p.shape).clone(),
+                                  "exp_avg_sq": self._v[k][o:o + p.numel()].view(p.shape).clone()}
+                idx += 1
+        sd["state"] = state
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        where, idx, steps = self._slices(), 0, set()
+        assert len(sd["param_groups"]) == len(self.param_groups), "optimizer state has a different number of parameter groups"
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            for key, val in sg.items():
+                if key != "params":
+                    g[key] = val
+            for p in g["params"]:
+                st = sd["state"].get(idx, sd["state"].get(str(idx)))
+                if st is not None:
+                    k, o = where[p]
+                    self._m[k][o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+                    self._v[k][o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(int(float(st["step"])))
+                idx += 1
+        assert len(steps) <= 1, "per-parameter step counts differ: not a full-model Adam state"
+        self._t = steps.pop() if steps else 0
+
     def grad_norm(self):
         """total gradient norm of the last step (device scalar; no sync)"""
         return self._coef[1]
