@@ -1,8 +1,8 @@
 """MGNet meta-architecture and its three heads -- host-side mirror of mgnet/modeling/mg_net.py for the TRAINING
 path (mg_net.py:220-373) with the same registries, `@configurable`/`from_config` protocol, attribute names
 (=> state-dict keys) and loss dict keys, and for single-scale INFERENCE (mg_net.py:375-425): per-image
-`sem_seg_postprocess`, panoptic fusion and DGC depth rescaling through mgnet_amd.postprocessing (HIP).  Multi-scale flip
-inference (mg_net.py:427-520, row f4) is not built."""
+`sem_seg_postprocess`, panoptic fusion and DGC depth rescaling through mgnet_amd.postprocessing (HIP), and multi-scale +
+flip inference (mg_net.py:427-520, row f4: `TEST.MSC_FLIP_EVAL`)."""
 from typing import Dict, List
 
 import torch
@@ -143,8 +143,9 @@ class MGNet(nn.Module):
                 inputs["image_next"] = self._net_input(batched_inputs, "image_next")
                 outputs["poses"] = self.pose_net(torch.cat(list(inputs.values()), 1))  # mg_net.py:264
 
-        if self.msc_flip_eval and not self.training:
-            raise NotImplementedError("multi-scale flip inference (mg_net.py:427-520) is outside the training hot path")
+        if self.msc_flip_eval and not self.training:   # mg_net.py:267-268
+            norm = (self._stack(batched_inputs, "image", 255.0) - self.pixel_mean) / self.pixel_std
+            return self._inference(batched_inputs, self.forward_multi_scale_flip(norm))
         features = self.backbone(inputs["image"])
         features["global_context"] = self.global_context(features[self.bb_features[-1]])
         if self.with_panoptic:
@@ -197,6 +198,57 @@ class MGNet(nn.Module):
                 storage.put_scalar(key + "_uncertainty", unc[idx])
                 losses[key] = weighted[idx]
         return losses
+
+
+def _as_net_input(self, x):
+    """fp32 NCHW normalised frames -> what the backbone's stem consumes: under bf16 on the GPU the channels are zero-padded
+    to 8 (the packed-tap stem kernel's layout, like csrc/prep.hip produces), channels-last."""
+    if self.amp_dtype is not None:
+        if x.is_cuda and self.amp_dtype == torch.bfloat16:
+            x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 8 - x.shape[1]))
+        x = x.to(self.amp_dtype)
+    return x.contiguous(memory_format=torch.channels_last) if x.is_cuda else x.contiguous()
+
+
+def forward_multi_scale_flip(self, norm_images, scales=None, flip=True):
+    """mg_net.py:427-520: average the raw predictions over rescaled (bilinear, align_corners=True) and horizontally
+    flipped copies of the normalised frames; softmax probabilities for sem_seg, offsets rescaled by stride / scale and
+    their x component negated for the flipped pass."""
+    import torch.nn.functional as F
+    scales = [0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0] if scales is None else scales
+    n_flip = 2 if flip else 1
+    up = lambda t, stride, scale: F.interpolate(t.float(), scale_factor=stride / scale, mode="bilinear", align_corners=True)
+    avg = {"sem_seg": None, "center": None, "offset": None, "depth": None}
+
+    def add(key, v):
+        avg[key] = v if avg[key] is None else avg[key] + v
+    for scale in scales:
+        x = F.interpolate(norm_images, scale_factor=scale, mode="bilinear", align_corners=True)
+        for f in range(n_flip):
+            if f:
+                x = torch.flip(x, dims=(3,))
+            features = self.backbone(self._as_net_input(x))
+            features["global_context"] = self.global_context(features[self.bb_features[-1]])
+            if self.with_panoptic:
+                r = torch.softmax(up(self.sem_seg_head.layers(features), self.sem_seg_head.common_stride, scale), 1)
+                center, offset = self.ins_embed_head.layers(features)
+                c = up(center, self.ins_embed_head.common_stride, scale)
+                o = up(offset, self.ins_embed_head.common_stride, scale) * self.ins_embed_head.common_stride / scale
+                if f:
+                    r, c, o = torch.flip(r, dims=(3,)), torch.flip(c, dims=(3,)), torch.flip(o, dims=(3,))
+                    o[:, 1, :, :] *= -1
+                add("sem_seg", r)
+                add("center", c)
+                add("offset", o)
+            if self.with_depth:
+                d = 1.0 / up(self.depth_head.layers(features)[0], self.depth_head.common_stride, scale).clamp(min=1e-6)
+                add("depth", torch.flip(d, dims=(3,)) if f else d)
+    n = n_flip * len(scales)
+    return {k: (v / n if v is not None else None) for k, v in avg.items()}
+
+
+MGNet._as_net_input = _as_net_input
+MGNet.forward_multi_scale_flip = forward_multi_scale_flip
 
 
 def sem_seg_postprocess(result, img_size, output_height, output_width):
