@@ -1,0 +1,37 @@
+"""GPU: the other BASELINE.json configurations through the HIP path against the CPU oracle -- C3 (KITTI-shaped 192x640
+frames, depth + reprojection) and C2 (panoptic only, WITH_DEPTH False), bf16 like the benchmark.  Small batches so that the
+oracle finishes in seconds; these shapes exercise narrow feature maps (6x20 at stride 32) and the panoptic-only graph."""
+import pytest
+import torch
+from test_network_cpu import small_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,with_panoptic,with_depth,H,W", [("C3-kitti-192x640", True, True, 192, 640),
+                                                               ("C3-depth-only", False, True, 192, 640),
+                                                               ("C2-panoptic-only", True, False, 256, 512)])
+def test_config_shapes_match_oracle(name, with_panoptic, with_depth, H, W):
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.engine import Trainer
+    from oracle import network_oracle as NO
+
+    cfg, m = small_model(with_depth=with_depth, with_panoptic=with_panoptic, seed=4)
+    m.train()
+    batch = synthetic_batch(2, H, W, "cpu", seed=6, with_panoptic=with_panoptic, with_depth=with_depth)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ref = NO.mgnet_losses(sd, batch, pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD, ohem_n_min=1500,
+                          with_panoptic=with_panoptic, with_depth=with_depth)
+    m = m.cuda()
+    m.amp_dtype = torch.bfloat16
+    dev_batch = [{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in x.items()} for x in batch]
+    got = m(dev_batch)
+    want_keys = (["loss_sem_seg", "loss_center", "loss_offset"] if with_panoptic else []) + \
+                (["loss_photometric", "loss_smoothness"] if with_depth else [])
+    assert list(got) == want_keys == list(ref)
+    for k in ref:
+        assert float(got[k].detach()) == pytest.approx(float(ref[k]), rel=4e-2, abs=2e-4), (name, k)
+    # and a few optimizer steps run (fused Adam on the flat buckets) with finite, decreasing total loss
+    tr = Trainer(cfg, m)
+    tot = [float(sum(v.detach() for v in tr.run_step(dev_batch).values())) for _ in range(6)]
+    assert all(t == t and abs(t) < 1e6 for t in tot) and tot[-1] < tot[0], tot
