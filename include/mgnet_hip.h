@@ -322,6 +322,16 @@ int mgn_depth_post_workspace_bytes(const mgn_depth_post_cfg* cfg, size_t* bytes)
 int mgn_depth_post(const mgn_depth_post_cfg* cfg, const float* depth, const int64_t* panoptic, float* depth_out, float* xyz,
                    float* scale, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Depth metrics of one frame -- replaces the arithmetic of mgnet/evaluation/depth_evaluation.py:70-112
+ * (DepthEvaluator.process): mask = min_depth < label < max_depth inside rows [crop_y0, crop_y1) x columns [crop_x0, crop_x1)
+ * (the Eigen crop, or the whole frame), optional median scaling (np.median of both maps: two radix selects each), clamp,
+ * then out9 (device fp64) = { abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, scale ratio, number of masked pixels }.
+ * prediction, label: fp32 [H,W].  fp64 accumulation in a fixed order. */
+int mgn_depth_metrics_workspace_bytes(int H, int W, size_t* bytes);
+int mgn_depth_metrics(const float* prediction, const float* label, int H, int W, float min_depth, float max_depth,
+                      int use_gt_scale, int crop_y0, int crop_y1, int crop_x0, int crop_x1, double* out9, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* 3x3 / stride 2 / pad 1 max pooling of the ResNet stems (res_net.py:109) on channels-last bf16 [N,IH,IW,C] (C % 8 == 0);
  * argmax: 1 byte per output element (winning tap 0..8); backward is a deterministic gather. */
 int mgn_maxpool3x3s2_fwd(const void* x_bf16, void* y_bf16, uint8_t* argmax, int N, int IH, int IW, int C, void* stream);

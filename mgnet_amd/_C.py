@@ -21,7 +21,8 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
            "mgn_nearest_bwd", "mgn_concat2", "mgn_split2", "mgn_vec_linear_fwd", "mgn_vec_linear_bwd_workspace_bytes", "mgn_vec_linear_bwd",
            "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
-           "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_depth_post_workspace_bytes", "mgn_depth_post"]
+           "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
+           "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics"]
 DEPTH_MAX_FILTER_IDS = 16
 
 
@@ -115,6 +116,8 @@ def lib():
         L.mgn_concat2.argtypes = [vp, vp, cl, ci, ci, vp, vp]
         L.mgn_split2.argtypes = [vp, cl, ci, ci, vp, vp, vp]
         L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
+        L.mgn_depth_metrics_workspace_bytes.argtypes = [ci, ci, ctypes.POINTER(sz)]
+        L.mgn_depth_metrics.argtypes = [vp, vp, ci, ci, cf, cf, ci, ci, ci, ci, ci, vp, vp, sz, vp]
         L.mgn_depth_post_workspace_bytes.argtypes = [ctypes.POINTER(DepthPostCfg), ctypes.POINTER(sz)]
         L.mgn_depth_post.argtypes = [ctypes.POINTER(DepthPostCfg), vp, vp, vp, vp, vp, vp, sz, vp]
         L.mgn_panoptic_post_workspace_bytes.argtypes = [ctypes.POINTER(PanopticCfg), ctypes.POINTER(sz)]
@@ -353,6 +356,21 @@ def panoptic_post(cfg, sem_seg, center, offsets):
     check(lib().mgn_panoptic_post(ctypes.byref(cfg), sem_seg.data_ptr(), center.data_ptr(), offsets.data_ptr(), pan.data_ptr(),
                                   info.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "mgn_panoptic_post")
     return pan, info
+
+
+def depth_metrics(pred, label, min_depth, max_depth, use_gt_scale, crop):
+    """mgn_depth_metrics: pred, label f32 [H,W] (CUDA) -> device f64[9] (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, ratio, n)"""
+    H, W = label.shape
+    assert pred.is_cuda and pred.dtype == torch.float32 and pred.is_contiguous() and tuple(pred.shape) == (H, W)
+    assert label.is_cuda and label.dtype == torch.float32 and label.is_contiguous()
+    nbytes = ctypes.c_size_t()
+    check(lib().mgn_depth_metrics_workspace_bytes(H, W, ctypes.byref(nbytes)), "mgn_depth_metrics_workspace_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=pred.device)
+    out = torch.empty(9, dtype=torch.float64, device=pred.device)
+    check(lib().mgn_depth_metrics(pred.data_ptr(), label.data_ptr(), H, W, float(min_depth), float(max_depth), int(use_gt_scale),
+                                  int(crop[0]), int(crop[1]), int(crop[2]), int(crop[3]), out.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), _stream()), "mgn_depth_metrics")
+    return out
 
 
 def depth_post(cfg, depth, panoptic=None):

@@ -487,6 +487,118 @@ bool dcfg_ok(const mgn_depth_post_cfg* c) {
     return c && c->H >= 3 && c->W >= 3 && (long)c->H * c->W < (1L << 31) && c->n_filter >= 0 && c->n_filter <= MGN_DEPTH_MAX_FILTER_IDS;
 }
 
+// =====================================================================================================================
+// Depth metrics (mgnet/evaluation/depth_evaluation.py:48-112, DepthEvaluator.process for one frame)
+//   dm_keys    mask = min < label < max (and the Eigen crop); ordered keys of label / prediction for the median scaling
+//   dp_hist / dm_pick  radix selects of the two middle elements of each (np.median averages them)
+//   dm_reduce  per masked pixel: scaled + clamped prediction, the seven error terms, fp64 block partials
+//   dm_final   fixed-order sum of the partials -> means, sqrt
+struct DMParams {
+    const float* pred; const float* label;
+    int H, W, y0, y1, x0, x1;      // crop window (whole frame when the Eigen crop is off)
+    float min_depth, max_depth;
+    int use_gt_scale;
+    unsigned* keys_l; unsigned* keys_p; unsigned* hist; unsigned* state;   // state: [0] n, [1] prefix, [2] k
+    float* med;                    // [4]: label lower/upper middle, prediction lower/upper middle
+    double* partials;              // [nblk][8]
+    double* out;                   // [9]
+    int nblk;
+};
+
+__device__ __forceinline__ unsigned ord_key(float f) {   // order-preserving for all finite floats
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_ord(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__device__ __forceinline__ bool dm_mask(const DMParams& p, long i, float l) {
+    const int y = (int)(i / p.W), x = (int)(i - (long)y * p.W);
+    return l > p.min_depth && l < p.max_depth && y >= p.y0 && y < p.y1 && x >= p.x0 && x < p.x1;
+}
+
+__global__ __launch_bounds__(256) void dm_keys(DMParams p) {
+    __shared__ unsigned wcnt[4];
+    const long hw = (long)p.H * p.W;
+    unsigned mine = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+        const float l = p.label[i];
+        const bool m = dm_mask(p, i, l);
+        p.keys_l[i] = m ? ord_key(l) : 0xffffffffu;
+        p.keys_p[i] = m ? ord_key(p.pred[i]) : 0xffffffffu;
+        mine += (unsigned)__popcll(__ballot(m));
+    }
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned t = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]; if (t) atomicAdd(&p.state[0], t); }
+}
+
+__global__ void dm_begin(DMParams p, int upper) {   // k of the lower / upper middle element
+    if (threadIdx.x < 256) p.hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { const unsigned n = p.state[0]; p.state[1] = 0; p.state[2] = n ? (upper ? n / 2 : (n - 1) / 2) : 0; }
+}
+
+__global__ void dm_store(DMParams p, int slot) {
+    if (threadIdx.x == 0) p.med[slot] = p.state[0] ? key_ord(p.state[1]) : __int_as_float(0x7fc00000);
+}
+
+__global__ __launch_bounds__(256) void dm_reduce(DMParams p) {
+    __shared__ double red[8][4];
+    const long hw = (long)p.H * p.W;
+    float ratio = 1.0f;
+    if (p.use_gt_scale) {   // np.median = mean of the two middle elements, in float32 (:88-90)
+        const float ml = (p.med[0] + p.med[1]) * 0.5f, mp = (p.med[2] + p.med[3]) * 0.5f;
+        ratio = ml / mp;
+    }
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+        const float l = p.label[i];
+        if (!dm_mask(p, i, l)) continue;
+        float q = p.pred[i];
+        if (p.use_gt_scale) q = __fmul_rn(q, ratio);
+        q = q < p.min_depth ? p.min_depth : q;   // (:92-93)
+        q = q > p.max_depth ? p.max_depth : q;
+        const float th = fmaxf(l / q, q / l);
+        const float d = l - q, d2 = d * d, dl = logf(l) - logf(q);
+        a[0] += (double)(fabsf(d) / l);            // abs rel
+        a[1] += (double)(d2 / l);                  // sq rel
+        a[2] += (double)d2;                        // rmse^2
+        a[3] += (double)(dl * dl);                 // rmse log^2
+        a[4] += th < 1.25f ? 1.0 : 0.0;
+        a[5] += th < (float)(1.25 * 1.25) ? 1.0 : 0.0;
+        a[6] += th < (float)(1.25 * 1.25 * 1.25) ? 1.0 : 0.0;
+        a[7] += 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double v = a[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) p.partials[(long)blockIdx.x * 8 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void dm_final(DMParams p) {
+    if (threadIdx.x >= 8) return;
+    double s = 0;
+    for (int b = 0; b < p.nblk; ++b) s += p.partials[(long)b * 8 + threadIdx.x];
+    __shared__ double tot[8];
+    tot[threadIdx.x] = s;
+    __syncthreads();
+    const double n = tot[7];
+    if (threadIdx.x < 7) {
+        double m = s / n;
+        if (threadIdx.x == 2 || threadIdx.x == 3) m = sqrt(m);
+        p.out[threadIdx.x] = m;
+    } else {
+        p.out[8] = n;
+        float ratio = 1.0f;
+        if (p.use_gt_scale) ratio = ((p.med[0] + p.med[1]) * 0.5f) / ((p.med[2] + p.med[3]) * 0.5f);
+        p.out[7] = (double)ratio;
+    }
+}
+
 }  // namespace
 
 extern "C" int mgn_panoptic_post_workspace_bytes(const mgn_panoptic_cfg* cfg, size_t* bytes) {
@@ -552,5 +664,55 @@ extern "C" int mgn_depth_post(const mgn_depth_post_cfg* cfg, const float* depth,
         }
     }
     hipLaunchKernelGGL(dp_apply, grid, blk, 0, st, p);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+static const int DM_BLOCKS = 1024;
+
+extern "C" int mgn_depth_metrics_workspace_bytes(int H, int W, size_t* bytes) {
+    if (H < 1 || W < 1 || (long)H * W >= (1L << 31) || !bytes) return MGN_EINVAL;
+    *bytes = 2 * align16((size_t)H * W * 4) + 1024 + 16 + 16 + (size_t)DM_BLOCKS * 8 * sizeof(double);
+    return MGN_OK;
+}
+
+extern "C" int mgn_depth_metrics(const float* prediction, const float* label, int H, int W, float min_depth, float max_depth,
+                                 int use_gt_scale, int crop_y0, int crop_y1, int crop_x0, int crop_x1, double* out9,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    size_t need = 0;
+    if (mgn_depth_metrics_workspace_bytes(H, W, &need) != MGN_OK || !prediction || !label || !out9 || !workspace) return MGN_EINVAL;
+    if (workspace_bytes < need) return MGN_ENOSPC;
+    const size_t hw = (size_t)H * W;
+    char* w = (char*)workspace;
+    DMParams p;
+    p.pred = prediction; p.label = label; p.H = H; p.W = W; p.y0 = crop_y0; p.y1 = crop_y1; p.x0 = crop_x0; p.x1 = crop_x1;
+    p.min_depth = min_depth; p.max_depth = max_depth; p.use_gt_scale = use_gt_scale;
+    p.keys_l = (unsigned*)w; w += align16(hw * 4);
+    p.keys_p = (unsigned*)w; w += align16(hw * 4);
+    p.hist = (unsigned*)w; w += 1024;
+    p.state = (unsigned*)w; w += 16;
+    p.med = (float*)w; w += 16;
+    p.partials = (double*)w;
+    p.out = out9;
+    const unsigned nb = (unsigned)((hw + 256 * 16 - 1) / (256 * 16));
+    p.nblk = (int)(nb < (unsigned)DM_BLOCKS ? nb : (unsigned)DM_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 blk(256), grid(p.nblk);
+    if (use_gt_scale) {
+        if (hipMemsetAsync(p.state, 0, 16, st) != hipSuccess) return MGN_ELAUNCH;
+        hipLaunchKernelGGL(dm_keys, grid, blk, 0, st, p);
+        DPParams d;   // the select kernels of the depth post-processing, pointed at each key array in turn
+        d.c.H = H; d.c.W = W; d.hist = p.hist; d.state = p.state;
+        for (int slot = 0; slot < 4; ++slot) {
+            d.keys = slot < 2 ? p.keys_l : p.keys_p;
+            hipLaunchKernelGGL(dm_begin, dim3(1), blk, 0, st, p, slot & 1);
+            for (int pass = 3; pass >= 0; --pass) {
+                hipLaunchKernelGGL(dp_hist, grid, blk, 0, st, d, pass);
+                hipLaunchKernelGGL(dp_pick, dim3(1), blk, 0, st, d);
+            }
+            hipLaunchKernelGGL(dm_store, dim3(1), dim3(64), 0, st, p, slot);
+        }
+    }
+    hipLaunchKernelGGL(dm_reduce, grid, blk, 0, st, p);
+    hipLaunchKernelGGL(dm_final, dim3(1), dim3(64), 0, st, p);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
