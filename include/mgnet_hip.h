@@ -227,6 +227,18 @@ int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const
 int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
                    const float* pixel_std3, void* out_bf16, int Cp, void* stream);
 
+/* The stem's activated batch norm folded into the pooling (BasicStem, res_net.py:82-110: conv -> InPlaceABNSync -> max_pool):
+ * forward pools y = act(scale * x + offset) evaluated on the fly (bf16-rounded like mgn_iabn_apply stores it; the
+ * normalised map is never written), backward = mgn_iabn_bwd_reduce on (pooled, d pooled) for the channel sums, then
+ * mgn_abn_maxpool_bwd: gather of d y per 2x2 input patch + the norm's dx formula with z recomputed from the saved conv
+ * output x.  scale/offset/rstd: rows 0, 1, 3 of the coefficient block of mgn_iabn_train_coeffs / mgn_iabn_combine;
+ * sums: [2,C] of mgn_iabn_bwd_reduce (all-reduced over ranks by the caller); total_count = pixels of x over all ranks. */
+int mgn_abn_maxpool_fwd(const void* x_bf16, const float* scale, const float* offset, int activation, float slope, void* y_bf16,
+                        uint8_t* argmax, int N, int IH, int IW, int C, void* stream);
+int mgn_abn_maxpool_bwd(const void* x_bf16, const void* dpool_bf16, const uint8_t* argmax, void* dx_bf16, const float* scale,
+                        const float* offset, const float* weight, const float* bias, const float* rstd, const float* sums,
+                        float total_count, float eps, int activation, float slope, int N, int IH, int IW, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Panoptic training targets on the device (the producer of the hot path's target maps)
  *   replaces mgnet/data/target_generator.py:54-158  PanopticDeepLabTargetGenerator.__call__,

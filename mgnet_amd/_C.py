@@ -22,7 +22,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_nearest_bwd", "mgn_concat2", "mgn_split2", "mgn_vec_linear_fwd", "mgn_vec_linear_bwd_workspace_bytes", "mgn_vec_linear_bwd",
            "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
            "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
-           "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics"]
+           "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd"]
 DEPTH_MAX_FILTER_IDS = 16
 
 
@@ -116,6 +116,8 @@ def lib():
         L.mgn_concat2.argtypes = [vp, vp, cl, ci, ci, vp, vp]
         L.mgn_split2.argtypes = [vp, cl, ci, ci, vp, vp, vp]
         L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
+        L.mgn_abn_maxpool_fwd.argtypes = [vp, vp, vp, ci, cf, vp, vp, ci, ci, ci, ci, vp]
+        L.mgn_abn_maxpool_bwd.argtypes = [vp] * 10 + [cf, cf, ci, cf, ci, ci, ci, ci, vp]
         L.mgn_depth_metrics_workspace_bytes.argtypes = [ci, ci, ctypes.POINTER(sz)]
         L.mgn_depth_metrics.argtypes = [vp, vp, ci, ci, cf, cf, ci, ci, ci, ci, ci, vp, vp, sz, vp]
         L.mgn_depth_post_workspace_bytes.argtypes = [ctypes.POINTER(DepthPostCfg), ctypes.POINTER(sz)]
@@ -643,6 +645,26 @@ def maxpool_fwd(x):
     arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
     check(lib().mgn_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), arg.data_ptr(), N, IH, IW, C, _stream()), "mgn_maxpool3x3s2_fwd")
     return y, arg
+
+
+def abn_maxpool_fwd(x, scale, offset, activation, slope):
+    """x [N,C,IH,IW] bf16 channels_last (conv output, left untouched) -> max_pool3x3s2(act(scale*x+offset)), argmax"""
+    N, C, IH, IW = x.shape
+    OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
+    y = torch.empty((N, C, OH, OW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
+    check(lib().mgn_abn_maxpool_fwd(x.data_ptr(), scale.data_ptr(), offset.data_ptr(), activation, slope, y.data_ptr(),
+                                    arg.data_ptr(), N, IH, IW, C, _stream()), "mgn_abn_maxpool_fwd")
+    return y, arg
+
+
+def abn_maxpool_bwd(x, dpool, arg, coef, weight, bias, sums, total_count, eps, activation, slope):
+    N, C, IH, IW = x.shape
+    dx = torch.empty_like(x)
+    check(lib().mgn_abn_maxpool_bwd(x.data_ptr(), dpool.data_ptr(), arg.data_ptr(), dx.data_ptr(), coef[0].data_ptr(),
+                                    coef[1].data_ptr(), weight.data_ptr(), bias.data_ptr(), coef[3].data_ptr(), sums.data_ptr(),
+                                    float(total_count), eps, activation, slope, N, IH, IW, C, _stream()), "mgn_abn_maxpool_bwd")
+    return dx
 
 
 def maxpool_bwd(dy, arg, in_shape):

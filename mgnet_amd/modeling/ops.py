@@ -102,6 +102,60 @@ class _IABNFn(torch.autograd.Function):
         return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None
 
 
+class _AbnPoolFn(torch.autograd.Function):
+    """[HIP] csrc/pool.hip abn_maxpool_*: InPlaceABNSync + 3x3/s2 max pooling of the ResNet stems without materialising
+    the normalised map (the conv output is kept instead; see the header of pool.hip for the traffic accounting)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, activation, slope, group):
+        from .. import _C
+
+        N, C, H, W = x.shape
+        M = N * H * W
+        act = {"identity": 0, "leaky_relu": 1}[activation]
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        world = dist.get_world_size(group) if _dist_active(group) else 1
+        if training:   # statistics exactly as _IABNFn
+            if world > 1:
+                coef = _C.iabn_combine(_gather_stats(_C.iabn_stats(x, M, C), world, group), w32, b32, eps, momentum,
+                                       running_mean, running_var)
+            else:
+                coef = _C.iabn_train_coeffs(x, M, C, w32, b32, eps, momentum, running_mean, running_var)
+        else:
+            coef = _C.iabn_eval_coeffs(w32, b32, running_mean, running_var, eps)
+        y, arg = _C.abn_maxpool_fwd(x, coef[0], coef[1], act, slope)
+        ctx.save_for_backward(x, y, arg, w32, b32, coef)
+        ctx.cfg = (M, C, eps, act, slope, group, world, training, float(M) * world, weight.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _C
+
+        x, y, arg, w32, b32, coef = ctx.saved_tensors
+        M, C, eps, act, slope, group, world, training, total, wdtype = ctx.cfg
+        if not training:
+            raise NotImplementedError("backward through eval-mode InPlaceABNSync is not on the training path")
+        dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        # d y is zero away from the arg-max positions and y there is the pooled value: the channel sums over the full map
+        # equal the sums over the pooled tensors
+        sums, d_weight, d_bias = _C.iabn_bwd_reduce(y, dy, y.numel() // C, C, w32, b32, eps, act, slope)
+        if world > 1:
+            dist.all_reduce(sums, group=group)
+        dx = _C.abn_maxpool_bwd(x, dy, arg, coef, w32, b32, sums, total, eps, act, slope)
+        return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None
+
+
+def abn_max_pool(x, norm):
+    """`max_pool_3x3_s2(norm(x))` for an InPlaceABNSync `norm` (BasicStem); fused on the GPU path."""
+    from .. import _C
+    if (x.is_cuda and x.dtype == torch.bfloat16 and _C.elt_supported(x) and not os.environ.get("MGN_NO_STEMFUSE")
+            and norm.activation in ("identity", "leaky_relu")):
+        return _AbnPoolFn.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.training, norm.momentum,
+                                norm.eps, norm.activation, norm.activation_param, norm.group)
+    return max_pool_3x3_s2(norm(x))
+
+
 def iabn(x, weight, bias, running_mean, running_var, training, momentum, eps, activation, slope, group=None):
     """Fused batch-norm + activation with cross-rank statistics.  CUDA tensors: [HIP]; CPU tensors (host-logic tests
     only): torch restatement below."""

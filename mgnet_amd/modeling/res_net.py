@@ -47,7 +47,8 @@ class BasicStem(nn.Module):  # res_net.py:82-110
         c2_msra_fill(self.conv1)
 
     def forward(self, x):
-        return ops.max_pool_3x3_s2(self.conv1(x))
+        c = self.conv1   # conv -> InPlaceABNSync(leaky) -> max pool; norm + pooling run as one fused op on the GPU
+        return ops.abn_max_pool(ops.conv2d(x, c.weight, c.bias, c.stride, c.padding), c.norm)
 
 
 class ResNet(nn.Module):

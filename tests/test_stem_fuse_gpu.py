@@ -1,0 +1,63 @@
+"""GPU: InPlaceABNSync + max pooling of the ResNet stem as one fused op (csrc/pool.hip abn_maxpool_*) against the separate
+in-place norm + pooling kernels: the forward is bit-identical, the gradients agree to bf16 round-off."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def run(fused, seed, shape, activation):
+    from mgnet_amd.modeling import ops
+    from mgnet_amd.modeling.layers import InPlaceABNSync
+    if fused:
+        os.environ.pop("MGN_NO_STEMFUSE", None)
+    else:
+        os.environ["MGN_NO_STEMFUSE"] = "1"
+    try:
+        torch.manual_seed(seed)
+        N, C, H, W = shape
+        x = (torch.randn(N, C, H, W, device="cuda") * 1.7 + 0.4).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        norm = InPlaceABNSync(C, momentum=0.01, activation=activation).cuda().train()
+        with torch.no_grad():
+            norm.weight.uniform_(0.5, 1.5)
+            norm.weight[::3] *= -1      # |gamma| + eps parametrisation
+            norm.bias.uniform_(-0.3, 0.3)
+        y = ops.abn_max_pool(x * 1.0, norm)   # (x * 1.0: the unfused norm works in place on its input)
+        g = torch.randn_like(y)
+        y.backward(g)
+        return y.detach().float(), x.grad.float(), norm.weight.grad.clone(), norm.bias.grad.clone(), norm.running_mean.clone(), norm.running_var.clone()
+    finally:
+        os.environ.pop("MGN_NO_STEMFUSE", None)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 96), (1, 64, 37, 53), (2, 16, 30, 44)])
+@pytest.mark.parametrize("activation", ["leaky_relu", "identity"])
+def test_fused_equals_separate(shape, activation):
+    a = run(True, 3, shape, activation)
+    b = run(False, 3, shape, activation)
+    assert torch.equal(a[0], b[0]), "pooled forward must be bit-identical"
+    assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])          # running statistics
+    scale = float(b[1].abs().max())
+    assert float((a[1] - b[1]).abs().max()) <= 2e-2 * scale             # dx (bf16 storage of d y / y in the separate path)
+    for k in (2, 3):
+        assert torch.allclose(a[k], b[k], rtol=2e-2, atol=2e-2 * float(b[k].abs().max())), k
+
+
+def test_stem_module_uses_the_fused_op():
+    from mgnet_amd.modeling import ops
+    from mgnet_amd.modeling.res_net import BasicStem
+    calls = []
+    orig = ops._AbnPoolFn.apply
+    ops._AbnPoolFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        stem = BasicStem(3, 64).cuda().train()
+        x = torch.zeros(1, 8, 64, 64, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x[:, :3] = torch.randn(1, 3, 64, 64, device="cuda").to(torch.bfloat16)
+        y = stem(x)
+        y.float().sum().backward()
+    finally:
+        ops._AbnPoolFn.apply = orig
+    assert calls == [1] and tuple(y.shape) == (1, 64, 16, 16) and stem.conv1.weight.grad is not None
