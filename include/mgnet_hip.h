@@ -130,6 +130,16 @@ int mgn_iabn_bwd_apply(const void* y, const void* dy, void* dx /*may alias dy*/,
                        const float* weight, const float* bias, const float* saved, const float* sums,
                        float total_count, float eps, int activation, float slope, void* stream);
 
+/* "from x" forms of the two backward passes: `x` is the norm's INPUT (the producing conv's output, kept instead of the
+ * normalised map) and z = scale * x + offset is recomputed (scale/offset: rows 0, 1 of the coefficient block).  Used by
+ * the fused norm + add + ReLU tail of the residual blocks (mgn_abn_add_relu_fwd). */
+int mgn_iabn_bwd_reduce_x(const void* x, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
+                          const float* scale, const float* offset, float eps, int activation, float slope, float* sums, float* dwb,
+                          void* ws, size_t ws_bytes, void* stream);
+int mgn_iabn_bwd_apply_x(const void* x, const void* dy, void* dx, int dtype, long M, int C, const float* weight, const float* bias,
+                         const float* scale, const float* offset, const float* saved, const float* sums, float total_count, float eps,
+                         int activation, float slope, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Full-model gradient clipping + Adam over flat fp32 buckets
  *   replaces tools/train_net.py:108-154: torch.optim.Adam wrapped in FullModelGradientClippingOptimizer
@@ -377,6 +387,10 @@ int mgn_vec_linear_bwd(const float* dout, const float* out, const float* in, con
  *   mgn_concat2 / mgn_split2            : torch.cat([a, b], dim=1) (layers.py:316) and the split of its gradient
  * ---------------------------------------------------------------------------------------------- */
 int mgn_add_relu_fwd(const void* a, const void* b, void* y, long n_elems, void* stream);
+/* BasicBlock tail (res_net.py:62-79) with the second InPlaceABNSync(identity) folded in:
+ * y = relu(bf16(scale[c] * x + offset[c]) + shortcut), x [M,C] bf16 = conv2 output (kept for the backward), C % 8 == 0. */
+int mgn_abn_add_relu_fwd(const void* x, const float* scale, const float* offset, const void* shortcut, void* y, long M, int C,
+                         void* stream);
 int mgn_relu_mask_bwd(const void* dy, const void* y, void* dx, long n_elems, void* stream);
 int mgn_colsum(const void* x, const void* x2 /*nullable*/, int N, long HW, int C, float scale, float* out, float* workspace,
                size_t workspace_bytes /* >= N*64*C*4 */, void* stream);

@@ -22,7 +22,8 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_nearest_bwd", "mgn_concat2", "mgn_split2", "mgn_vec_linear_fwd", "mgn_vec_linear_bwd_workspace_bytes", "mgn_vec_linear_bwd",
            "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
            "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
-           "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd"]
+           "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd",
+           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd"]
 DEPTH_MAX_FILTER_IDS = 16
 
 
@@ -116,6 +117,9 @@ def lib():
         L.mgn_concat2.argtypes = [vp, vp, cl, ci, ci, vp, vp]
         L.mgn_split2.argtypes = [vp, cl, ci, ci, vp, vp, vp]
         L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
+        L.mgn_iabn_bwd_reduce_x.argtypes = [vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, ci, cf, vp, vp, vp, sz, vp]
+        L.mgn_iabn_bwd_apply_x.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp]
+        L.mgn_abn_add_relu_fwd.argtypes = [vp, vp, vp, vp, vp, cl, ci, vp]
         L.mgn_abn_maxpool_fwd.argtypes = [vp, vp, vp, ci, cf, vp, vp, ci, ci, ci, ci, vp]
         L.mgn_abn_maxpool_bwd.argtypes = [vp] * 10 + [cf, cf, ci, cf, ci, ci, ci, ci, vp]
         L.mgn_depth_metrics_workspace_bytes.argtypes = [ci, ci, ctypes.POINTER(sz)]
@@ -290,6 +294,30 @@ def iabn_bwd_reduce(y, dy, M, C, weight, bias, eps, activation, slope):
                                     eps, activation, slope, out.data_ptr(), out[2].data_ptr(), ws.data_ptr(), ws.numel() * 4,
                                     _stream()), "mgn_iabn_bwd_reduce")
     return out[:2], out[2], out[3]
+
+
+def iabn_bwd_reduce_x(x, dy, M, C, weight, bias, coef, eps, activation, slope):
+    """like iabn_bwd_reduce, from the norm's input x (z = coef[0] * x + coef[1] recomputed)"""
+    out = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    ws = _iabn_ws(x.device)
+    check(lib().mgn_iabn_bwd_reduce_x(x.data_ptr(), dy.data_ptr(), _act_dtype(x), M, C, weight.data_ptr(), bias.data_ptr(),
+                                      coef[0].data_ptr(), coef[1].data_ptr(), eps, activation, slope, out.data_ptr(),
+                                      out[2].data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()), "mgn_iabn_bwd_reduce_x")
+    return out[:2], out[2], out[3]
+
+
+def iabn_bwd_apply_x(x, dy, dx, M, C, weight, bias, coef, sums, total_count, eps, activation, slope):
+    check(lib().mgn_iabn_bwd_apply_x(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), _act_dtype(x), M, C, weight.data_ptr(),
+                                     bias.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2:].data_ptr(), sums.data_ptr(),
+                                     float(total_count), eps, activation, slope, _stream()), "mgn_iabn_bwd_apply_x")
+
+
+def abn_add_relu_fwd(x, coef, shortcut):
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    check(lib().mgn_abn_add_relu_fwd(x.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), shortcut.data_ptr(), y.data_ptr(),
+                                     N * H * W, C, _stream()), "mgn_abn_add_relu_fwd")
+    return y
 
 
 def iabn_bwd_apply(y, dy, dx, M, C, weight, bias, saved, sums, total_count, eps, activation, slope):

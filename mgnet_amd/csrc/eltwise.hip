@@ -52,6 +52,28 @@ __global__ __launch_bounds__(TPB) void add_relu_fwd(const uint4* __restrict__ a,
         y[i] = pack8(va);
     }
 }
+// residual-block tail with the second norm folded in: y = relu(bf16(scale[c] * x + offset[c]) + b)  -- the value the separate
+// in-place norm + add_relu_fwd produce, without writing the normalised map (x, the conv output, is kept for the backward)
+__global__ __launch_bounds__(TPB) void abn_add_relu_fwd(const uint4* __restrict__ x, const float* __restrict__ scale,
+                                                        const float* __restrict__ offset, const uint4* __restrict__ b, uint4* __restrict__ y,
+                                                        long nvec, int cv) {
+    const long i0 = (long)blockIdx.x * TPB + threadIdx.x, stride = (long)gridDim.x * TPB;   // stride % cv == 0 (host)
+    const int c0 = (int)(i0 % cv) * 8;
+    float sc[8], of[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; of[k] = offset[c0 + k]; }
+    for (long i = i0; i < nvec; i += stride) {
+        float va[8], vb[8];
+        unpack8(x[i], va);
+        unpack8(b[i], vb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) va[k] = fmaf(va[k], sc[k], of[k]);
+        unpack8(pack8(va), va);   // the bf16 rounding of the stored normalised value
+#pragma unroll
+        for (int k = 0; k < 8; ++k) va[k] = fmaxf(va[k] + vb[k], 0.f);
+        y[i] = pack8(va);
+    }
+}
 // dx = dy where y > 0 (the same tensor is the gradient of both summands)
 __global__ __launch_bounds__(TPB) void relu_mask_bwd(const uint4* __restrict__ dy, const uint4* __restrict__ y, uint4* __restrict__ dx, long nvec) {
     for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
@@ -226,6 +248,15 @@ extern "C" {
 int mgn_add_relu_fwd(const void* a, const void* b, void* y, long n_elems, void* stream) {
     if (!a || !b || !y || n_elems < 8 || n_elems % 8) return MGN_EINVAL;
     hipLaunchKernelGGL(add_relu_fwd, dim3(blocks_for(n_elems / 8)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b, (uint4*)y, n_elems / 8);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int mgn_abn_add_relu_fwd(const void* x, const float* scale, const float* offset, const void* b, void* y, long M, int C, void* stream) {
+    if (!x || !scale || !offset || !b || !y || M < 1 || !c_ok(C)) return MGN_EINVAL;
+    const long nvec = M * C / 8;
+    const int cv = C / 8;
+    // c_ok guarantees TPB % cv == 0: with any block count the grid stride stays a multiple of cv (fixed channels per thread)
+    hipLaunchKernelGGL(abn_add_relu_fwd, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)x, scale, offset, (const uint4*)b,
+                       (uint4*)y, nvec, cv);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 int mgn_relu_mask_bwd(const void* dy, const void* y, void* dx, long n_elems, void* stream) {

@@ -337,15 +337,20 @@ template <typename T>
 __global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dy, long M, int C,
                                                               const float* __restrict__ weight, const float* __restrict__ bias,
                                                               float eps, int leaky, float slope, int SC, float* ws, unsigned* counter,
-                                                              float* sums, float* dwb) {
+                                                              float* sums, float* dwb, const float* __restrict__ psc = nullptr,
+                                                              const float* __restrict__ pof = nullptr) {
+    // psc/pof != null ("from x"): `y` holds the norm's INPUT x and z = psc * x + pof is recomputed instead of inverted from
+    // the activated output (used where the normalised map is not kept: fused norm + add + ReLU of the residual blocks)
     constexpr int V = Vec<T>::N;
-    const float inv_slope = 1.f / slope;
+    const float inv_slope = psc ? 1.f : 1.f / slope;
     const int c0t = blockIdx.y * SC + (threadIdx.x % (SC / V)) * V;   // this thread's channels never change
-    float bk[V], igk[V];
+    float bk[V], igk[V], sck[V], ofk[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         bk[k] = bias[c0t + k];
         igk[k] = 1.f / (fabsf(weight[c0t + k]) + eps);
+        sck[k] = psc ? psc[c0t + k] : 1.f;
+        ofk[k] = psc ? pof[c0t + k] : 0.f;
     }
     column_sums2<T, false>(M, SC, ws, counter,
         [&](long r, int c0, typename Vec<T>::Raw (&q)[2]) {
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restric
             Vec<T>::unpack(q[1], gv);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                float z = yv[k], dz = gv[k];
+                float z = psc ? fmaf(yv[k], sck[k], ofk[k]) : yv[k], dz = gv[k];
                 if (leaky && z < 0.f) { z *= inv_slope; dz *= slope; }
                 a[k] += dz;
                 b[k] += dz * ((z - bk[k]) * igk[k]);
@@ -381,15 +386,16 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_apply(const T* __restrict__ y, c
                                                       long M, int C, const float* __restrict__ weight,
                                                       const float* __restrict__ bias, const float* __restrict__ saved,
                                                       const float* __restrict__ sums, float inv_n, float eps, int leaky,
-                                                      float slope) {
+                                                      float slope, const float* __restrict__ psc = nullptr,
+                                                      const float* __restrict__ pof = nullptr) {
     constexpr int V = Vec<T>::N;
     const long nvec = M * C / V;
     const int cv = C / V;
-    const float inv_slope = 1.f / slope;
+    const float inv_slope = psc ? 1.f : 1.f / slope;   // "from x" (see iabn_bwd_reduce_kernel): z comes from the affine map
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
     const int c0 = (int)(i0 % cv) * V;   // fixed per thread (the stride is a multiple of C/V)
     // dx = A * (dz - m1) - (z - beta) * B   with A = gamma' * rstd, m1 = sum_dz / n, B = rstd * sum_dzxh / n
-    float A[V], m1[V], Bc[V], bk[V];
+    float A[V], m1[V], Bc[V], bk[V], sck[V], ofk[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const int c = c0 + k;
@@ -398,6 +404,8 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_apply(const T* __restrict__ y, c
         m1[k] = sums[c] * inv_n;
         Bc[k] = rstd * sums[C + c] * inv_n;
         bk[k] = bias[c];
+        sck[k] = psc ? psc[c] : 1.f;
+        ofk[k] = psc ? pof[c] : 0.f;
     }
     auto body = [&](const typename Vec<T>::Raw& qy, const typename Vec<T>::Raw& qg, long i) {
         float yv[V], gv[V];
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_apply(const T* __restrict__ y, c
         Vec<T>::unpack(qg, gv);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            float z = yv[k], dz = gv[k];
+            float z = psc ? fmaf(yv[k], sck[k], ofk[k]) : yv[k], dz = gv[k];
             if (leaky && z < 0.f) { z *= inv_slope; dz *= slope; }
             gv[k] = A[k] * (dz - m1[k]) - (z - bk[k]) * Bc[k];
         }
@@ -540,9 +548,16 @@ int mgn_iabn_apply(const void* x, void* y, int dtype, long M, int C, const float
 
 int mgn_iabn_bwd_reduce(const void* y, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
                         float eps, int activation, float slope, float* sums, float* dwb, void* ws, size_t ws_bytes, void* stream_) {
+    return mgn_iabn_bwd_reduce_x(y, dy, dtype, M, C, weight, bias, nullptr, nullptr, eps, activation, slope, sums, dwb, ws, ws_bytes,
+                                 stream_);
+}
+
+int mgn_iabn_bwd_reduce_x(const void* y, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
+                          const float* scale, const float* offset, float eps, int activation, float slope, float* sums, float* dwb,
+                          void* ws, size_t ws_bytes, void* stream_) {
     int rc = check_shape(M, C, dtype);
     if (rc != MGN_OK) return rc;
-    if (!y || !dy || !weight || !bias || !sums || !ws) return MGN_EINVAL;
+    if (!y || !dy || !weight || !bias || !sums || !ws || ((scale == nullptr) != (offset == nullptr))) return MGN_EINVAL;
     if (ws_bytes < sizeof(float) * 2 * (size_t)C * 1024) return MGN_ENOSPC;
     hipStream_t s = (hipStream_t)stream_;
     const int SC = slab_channels(C), nb = stat_blocks(M, SC, dtype);
@@ -550,27 +565,36 @@ int mgn_iabn_bwd_reduce(const void* y, const void* dy, int dtype, long M, int C,
     if (!ctr || C / SC > 16) return MGN_ELAUNCH;
     if (dtype == 1)
         hipLaunchKernelGGL(iabn_bwd_reduce_kernel<__hip_bfloat16>, dim3(nb, C / SC), dim3(TPB), 0, s, (const __hip_bfloat16*)y,
-                           (const __hip_bfloat16*)dy, M, C, weight, bias, eps, activation, slope, SC, (float*)ws, ctr, sums, dwb);
+                           (const __hip_bfloat16*)dy, M, C, weight, bias, eps, activation, slope, SC, (float*)ws, ctr, sums, dwb, scale,
+                           offset);
     else
         hipLaunchKernelGGL(iabn_bwd_reduce_kernel<float>, dim3(nb, C / SC), dim3(TPB), 0, s, (const float*)y, (const float*)dy, M, C, weight,
-                           bias, eps, activation, slope, SC, (float*)ws, ctr, sums, dwb);
+                           bias, eps, activation, slope, SC, (float*)ws, ctr, sums, dwb, scale, offset);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
 int mgn_iabn_bwd_apply(const void* y, const void* dy, void* dx, int dtype, long M, int C, const float* weight, const float* bias,
                        const float* saved, const float* sums, float total_count, float eps, int activation, float slope,
                        void* stream_) {
+    return mgn_iabn_bwd_apply_x(y, dy, dx, dtype, M, C, weight, bias, nullptr, nullptr, saved, sums, total_count, eps, activation, slope,
+                                stream_);
+}
+
+int mgn_iabn_bwd_apply_x(const void* y, const void* dy, void* dx, int dtype, long M, int C, const float* weight, const float* bias,
+                         const float* scale, const float* offset, const float* saved, const float* sums, float total_count, float eps,
+                         int activation, float slope, void* stream_) {
     int rc = check_shape(M, C, dtype);
     if (rc != MGN_OK) return rc;
     if (!y || !dy || !dx || !weight || !bias || !saved || !sums || !(total_count > 0.f)) return MGN_EINVAL;
+    if ((scale == nullptr) != (offset == nullptr)) return MGN_EINVAL;
     hipStream_t s = (hipStream_t)stream_;
     if (dtype == 1)
         hipLaunchKernelGGL(iabn_bwd_apply<__hip_bfloat16>, dim3(grid_for(M * C / 8)), dim3(TPB), 0, s, (const __hip_bfloat16*)y,
                            (const __hip_bfloat16*)dy, (__hip_bfloat16*)dx, M, C, weight, bias, saved, sums, 1.f / total_count, eps,
-                           activation, slope);
+                           activation, slope, scale, offset);
     else
         hipLaunchKernelGGL(iabn_bwd_apply<float>, dim3(grid_for(M * C / 4)), dim3(TPB), 0, s, (const float*)y, (const float*)dy,
-                           (float*)dx, M, C, weight, bias, saved, sums, 1.f / total_count, eps, activation, slope);
+                           (float*)dx, M, C, weight, bias, saved, sums, 1.f / total_count, eps, activation, slope, scale, offset);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

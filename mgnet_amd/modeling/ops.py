@@ -146,6 +146,58 @@ class _AbnPoolFn(torch.autograd.Function):
         return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None
 
 
+class _AbnAddReluFn(torch.autograd.Function):
+    """[HIP] BasicBlock tail: relu(InPlaceABNSync_identity(x) + shortcut) in one pass over x; the normalised map is not
+    written (x, the conv output, is kept and the norm's backward recomputes z = scale * x + offset)."""
+
+    @staticmethod
+    def forward(ctx, x, shortcut, weight, bias, running_mean, running_var, training, momentum, eps, group):
+        from .. import _C
+
+        N, C, H, W = x.shape
+        M = N * H * W
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        world = dist.get_world_size(group) if _dist_active(group) else 1
+        if training:
+            if world > 1:
+                coef = _C.iabn_combine(_gather_stats(_C.iabn_stats(x, M, C), world, group), w32, b32, eps, momentum,
+                                       running_mean, running_var)
+            else:
+                coef = _C.iabn_train_coeffs(x, M, C, w32, b32, eps, momentum, running_mean, running_var)
+        else:
+            coef = _C.iabn_eval_coeffs(w32, b32, running_mean, running_var, eps)
+        y = _C.abn_add_relu_fwd(x, coef, shortcut)
+        ctx.save_for_backward(x, y, w32, b32, coef)
+        ctx.cfg = (M, C, eps, group, world, training, float(M) * world, weight.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+
+        x, y, w32, b32, coef = ctx.saved_tensors
+        M, C, eps, group, world, training, total, wdtype = ctx.cfg
+        if not training:
+            raise NotImplementedError("backward through eval-mode InPlaceABNSync is not on the training path")
+        dm = _C.relu_mask_bwd(_cl(g), y)   # gradient of both summands
+        sums, d_weight, d_bias = _C.iabn_bwd_reduce_x(x, dm, M, C, w32, b32, coef, eps, 0, 0.01)
+        if world > 1:
+            dist.all_reduce(sums, group=group)
+        dx = torch.empty_like(x)
+        _C.iabn_bwd_apply_x(x, dm, dx, M, C, w32, b32, coef, sums, total, eps, 0, 0.01)
+        return dx, dm, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None
+
+
+def abn_add_relu(x, norm, shortcut):
+    """`relu_(norm(x) + shortcut)` for an identity-activation InPlaceABNSync (res_net.py:62-79); fused on the GPU path."""
+    from .. import _C
+    if (_C.elt_supported(x) and _C.elt_supported(shortcut) and x.shape == shortcut.shape and norm.activation == "identity"
+            and not os.environ.get("MGN_NO_TAILFUSE")):
+        return _AbnAddReluFn.apply(x, shortcut, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.training,
+                                   norm.momentum, norm.eps, norm.group)
+    return add_relu(norm(x), shortcut)
+
+
 def abn_max_pool(x, norm):
     """`max_pool_3x3_s2(norm(x))` for an InPlaceABNSync `norm` (BasicStem); fused on the GPU path."""
     from .. import _C

@@ -34,9 +34,9 @@ class BasicBlock(nn.Module):  # res_net.py:11-79
 
     def forward(self, x):
         out, skip = self.conv1(x, with_skip=True)   # res_net.py:62-79; `skip` is x: the shortcut's gradient joins conv1's dgrad
-        out = self.conv2(out)
         sc = skip if self.shortcut is None else self.shortcut(skip)
-        return ops.add_relu(out, sc)
+        c2 = self.conv2   # conv -> InPlaceABNSync(identity) -> + shortcut -> ReLU; norm, add and ReLU run as one fused op on the GPU
+        return ops.abn_add_relu(ops.conv2d(out, c2.weight, c2.bias, c2.stride, c2.padding), c2.norm, sc)
 
 
 class BasicStem(nn.Module):  # res_net.py:82-110

@@ -61,3 +61,37 @@ def test_stem_module_uses_the_fused_op():
     finally:
         ops._AbnPoolFn.apply = orig
     assert calls == [1] and tuple(y.shape) == (1, 64, 16, 16) and stem.conv1.weight.grad is not None
+
+
+# ---- BasicBlock tail: InPlaceABNSync(identity) + shortcut add + ReLU as one op --------------------------------------------
+def run_block(fused, cin, cout, stride, seed=5):
+    from mgnet_amd.modeling.res_net import BasicBlock
+    if fused:
+        os.environ.pop("MGN_NO_TAILFUSE", None)
+    else:
+        os.environ["MGN_NO_TAILFUSE"] = "1"
+    try:
+        torch.manual_seed(seed)
+        blk = BasicBlock(cin, cout, stride=stride).cuda().train()
+        with torch.no_grad():
+            for m in blk.modules():
+                if type(m).__name__ == "InPlaceABNSync":
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.3, 0.3)
+        x = torch.randn(2, cin, 32, 48, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = blk(x)
+        y.backward(torch.randn_like(y))
+        grads = {n: p.grad.float().clone() for n, p in blk.named_parameters()}
+        return y.detach().float(), x.grad.float(), grads, blk.conv2.norm.running_var.clone()
+    finally:
+        os.environ.pop("MGN_NO_TAILFUSE", None)
+
+
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 2), (128, 128, 1)])
+def test_block_tail_fused_equals_separate(cin, cout, stride):
+    a, b = run_block(True, cin, cout, stride), run_block(False, cin, cout, stride)
+    assert torch.equal(a[0], b[0]), "block output must be bit-identical"
+    assert torch.equal(a[3], b[3])
+    assert float((a[1] - b[1]).abs().max()) <= 3e-2 * float(b[1].abs().max())
+    for n in b[2]:
+        assert torch.allclose(a[2][n], b[2][n], rtol=3e-2, atol=3e-2 * float(b[2][n].abs().max())), n
