@@ -333,24 +333,25 @@ __global__ __launch_bounds__(TPB) void iabn_apply(const T* __restrict__ x, T* __
 // backward pass 1: per-channel sum dz and sum dz * x_hat, with z = act^-1(y), dz = dy * act'(z), x_hat = (z - beta)/gamma';
 // the last block writes sums[2][C] and the local parameter gradients
 //   d bias = sum dz ; d weight = sign(weight) * sum dz*x_hat  (gamma' = |weight| + eps)
-template <typename T>
+template <typename T, bool FROMX = false>
 __global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dy, long M, int C,
                                                               const float* __restrict__ weight, const float* __restrict__ bias,
                                                               float eps, int leaky, float slope, int SC, float* ws, unsigned* counter,
                                                               float* sums, float* dwb, const float* __restrict__ psc = nullptr,
                                                               const float* __restrict__ pof = nullptr) {
-    // psc/pof != null ("from x"): `y` holds the norm's INPUT x and z = psc * x + pof is recomputed instead of inverted from
-    // the activated output (used where the normalised map is not kept: fused norm + add + ReLU of the residual blocks)
+    // FROMX: `y` holds the norm's INPUT x and z = psc * x + pof is recomputed instead of inverted from the activated output
+    // (used where the normalised map is not kept: fused norm + add + ReLU of the residual blocks).  Compile-time: a run-time
+    // test inside the streaming loop cost the ordinary path 30 %.
     constexpr int V = Vec<T>::N;
-    const float inv_slope = psc ? 1.f : 1.f / slope;
+    const float inv_slope = FROMX ? 1.f : 1.f / slope;
     const int c0t = blockIdx.y * SC + (threadIdx.x % (SC / V)) * V;   // this thread's channels never change
     float bk[V], igk[V], sck[V], ofk[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         bk[k] = bias[c0t + k];
         igk[k] = 1.f / (fabsf(weight[c0t + k]) + eps);
-        sck[k] = psc ? psc[c0t + k] : 1.f;
-        ofk[k] = psc ? pof[c0t + k] : 0.f;
+        sck[k] = FROMX ? psc[c0t + k] : 1.f;
+        ofk[k] = FROMX ? pof[c0t + k] : 0.f;
     }
     column_sums2<T, false>(M, SC, ws, counter,
         [&](long r, int c0, typename Vec<T>::Raw (&q)[2]) {
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restric
             Vec<T>::unpack(q[1], gv);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                float z = psc ? fmaf(yv[k], sck[k], ofk[k]) : yv[k], dz = gv[k];
+                float z = FROMX ? fmaf(yv[k], sck[k], ofk[k]) : yv[k], dz = gv[k];
                 if (leaky && z < 0.f) { z *= inv_slope; dz *= slope; }
                 a[k] += dz;
                 b[k] += dz * ((z - bk[k]) * igk[k]);
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restric
 }
 
 // backward pass 2: dx = gamma' * rstd * (dz - sum_dz/n - x_hat * sum_dzxh/n)     (sums are GLOBAL over ranks, n too)
-template <typename T>
+template <typename T, bool FROMX = false>
 __global__ __launch_bounds__(TPB) void iabn_bwd_apply(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx,
                                                       long M, int C, const float* __restrict__ weight,
                                                       const float* __restrict__ bias, const float* __restrict__ saved,
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_apply(const T* __restrict__ y, c
     constexpr int V = Vec<T>::N;
     const long nvec = M * C / V;
     const int cv = C / V;
-    const float inv_slope = psc ? 1.f : 1.f / slope;   // "from x" (see iabn_bwd_reduce_kernel): z comes from the affine map
+    const float inv_slope = FROMX ? 1.f : 1.f / slope;   // "from x" (see iabn_bwd_reduce_kernel): z comes from the affine map
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
     const int c0 = (int)(i0 % cv) * V;   // fixed per thread (the stride is a multiple of C/V)
     // dx = A * (dz - m1) - (z - beta) * B   with A = gamma' * rstd, m1 = sum_dz / n, B = rstd * sum_dzxh / n
@@ -404,8 +405,8 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_apply(const T* __restrict__ y, c
         m1[k] = sums[c] * inv_n;
         Bc[k] = rstd * sums[C + c] * inv_n;
         bk[k] = bias[c];
-        sck[k] = psc ? psc[c] : 1.f;
-        ofk[k] = psc ? pof[c] : 0.f;
+        sck[k] = FROMX ? psc[c] : 1.f;
+        ofk[k] = FROMX ? pof[c] : 0.f;
     }
     auto body = [&](const typename Vec<T>::Raw& qy, const typename Vec<T>::Raw& qg, long i) {
         float yv[V], gv[V];
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_apply(const T* __restrict__ y, c
         Vec<T>::unpack(qg, gv);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            float z = psc ? fmaf(yv[k], sck[k], ofk[k]) : yv[k], dz = gv[k];
+            float z = FROMX ? fmaf(yv[k], sck[k], ofk[k]) : yv[k], dz = gv[k];
             if (leaky && z < 0.f) { z *= inv_slope; dz *= slope; }
             gv[k] = A[k] * (dz - m1[k]) - (z - bk[k]) * Bc[k];
         }
@@ -563,13 +564,12 @@ int mgn_iabn_bwd_reduce_x(const void* y, const void* dy, int dtype, long M, int 
     const int SC = slab_channels(C), nb = stat_blocks(M, SC, dtype);
     unsigned* ctr = next_counter();
     if (!ctr || C / SC > 16) return MGN_ELAUNCH;
-    if (dtype == 1)
-        hipLaunchKernelGGL(iabn_bwd_reduce_kernel<__hip_bfloat16>, dim3(nb, C / SC), dim3(TPB), 0, s, (const __hip_bfloat16*)y,
-                           (const __hip_bfloat16*)dy, M, C, weight, bias, eps, activation, slope, SC, (float*)ws, ctr, sums, dwb, scale,
-                           offset);
-    else
-        hipLaunchKernelGGL(iabn_bwd_reduce_kernel<float>, dim3(nb, C / SC), dim3(TPB), 0, s, (const float*)y, (const float*)dy, M, C, weight,
-                           bias, eps, activation, slope, SC, (float*)ws, ctr, sums, dwb, scale, offset);
+    const dim3 grid(nb, C / SC);
+#define MGN_LAUNCH_REDUCE(T, CT, FX) hipLaunchKernelGGL((iabn_bwd_reduce_kernel<T, FX>), grid, dim3(TPB), 0, s, (const CT*)y, (const CT*)dy, M, \
+        C, weight, bias, eps, activation, slope, SC, (float*)ws, ctr, sums, dwb, scale, offset)
+    if (dtype == 1) { if (scale) MGN_LAUNCH_REDUCE(__hip_bfloat16, __hip_bfloat16, true); else MGN_LAUNCH_REDUCE(__hip_bfloat16, __hip_bfloat16, false); }
+    else { if (scale) MGN_LAUNCH_REDUCE(float, float, true); else MGN_LAUNCH_REDUCE(float, float, false); }
+#undef MGN_LAUNCH_REDUCE
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -588,13 +588,11 @@ int mgn_iabn_bwd_apply_x(const void* y, const void* dy, void* dx, int dtype, lon
     if (!y || !dy || !dx || !weight || !bias || !saved || !sums || !(total_count > 0.f)) return MGN_EINVAL;
     if ((scale == nullptr) != (offset == nullptr)) return MGN_EINVAL;
     hipStream_t s = (hipStream_t)stream_;
-    if (dtype == 1)
-        hipLaunchKernelGGL(iabn_bwd_apply<__hip_bfloat16>, dim3(grid_for(M * C / 8)), dim3(TPB), 0, s, (const __hip_bfloat16*)y,
-                           (const __hip_bfloat16*)dy, (__hip_bfloat16*)dx, M, C, weight, bias, saved, sums, 1.f / total_count, eps,
-                           activation, slope, scale, offset);
-    else
-        hipLaunchKernelGGL(iabn_bwd_apply<float>, dim3(grid_for(M * C / 4)), dim3(TPB), 0, s, (const float*)y, (const float*)dy,
-                           (float*)dx, M, C, weight, bias, saved, sums, 1.f / total_count, eps, activation, slope, scale, offset);
+#define MGN_LAUNCH_APPLY(T, V, FX) hipLaunchKernelGGL((iabn_bwd_apply<T, FX>), dim3(grid_for(M * C / V)), dim3(TPB), 0, s, (const T*)y, \
+        (const T*)dy, (T*)dx, M, C, weight, bias, saved, sums, 1.f / total_count, eps, activation, slope, scale, offset)
+    if (dtype == 1) { if (scale) MGN_LAUNCH_APPLY(__hip_bfloat16, 8, true); else MGN_LAUNCH_APPLY(__hip_bfloat16, 8, false); }
+    else { if (scale) MGN_LAUNCH_APPLY(float, 4, true); else MGN_LAUNCH_APPLY(float, 4, false); }
+#undef MGN_LAUNCH_APPLY
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
