@@ -136,6 +136,35 @@ def lib():
     return _lib
 
 
+class PinnedStager:
+    """Host -> device copies of small per-step tensors without stalling the host: a copy from pageable memory is
+    stream-ordered AND blocks the host until every kernel queued before it has run.  Staged through a ring of pinned
+    buffers; each buffer carries an event recorded after its copy was queued, and is only rewritten once that event has
+    completed (the host runs ahead of the GPU, so without it a buffer could be overwritten before its copy executes --
+    the wait only ever blocks when the host is a full ring ahead, which is the back-pressure one wants anyway)."""
+
+    def __init__(self, depth=3):
+        self.depth, self.rings = depth, {}
+
+    def stage(self, src, device, slot=None):
+        """`slot`: one ring per call site (two sites staging equal shapes in the same step must not share buffers)"""
+        key = (slot, tuple(src.shape), src.dtype, str(device))
+        ring = self.rings.get(key)
+        if ring is None:
+            ring = self.rings[key] = dict(bufs=[torch.empty(src.shape, dtype=src.dtype).pin_memory() for _ in range(self.depth)],
+                                          evs=[None] * self.depth, turn=0)
+        i = ring["turn"]
+        ring["turn"] = (i + 1) % self.depth
+        if ring["evs"][i] is not None:
+            ring["evs"][i].synchronize()
+        ring["bufs"][i].copy_(src)
+        out = ring["bufs"][i].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring["evs"][i] = ev
+        return out
+
+
 def check(rc, what):
     if rc != 0:
         err = _ERR.get(rc, str(rc))

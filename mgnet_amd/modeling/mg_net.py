@@ -104,20 +104,15 @@ class MGNet(nn.Module):
         # (true division of the uint8 batch promotes to fp32 inside ONE kernel: same values as .float() / scale)
         return t if scale is None else (t / scale if not t.is_floating_point() else t.float() / scale)
 
-    def _to_device_async(self, t):
-        """Small host tensor -> device without stalling the host: a copy from pageable memory is stream-ordered AND blocks
-        the host, i.e. it waits for every kernel queued so far (here: the whole forward pass).  Staged through two
-        alternating pinned buffers instead."""
+    def _to_device_async(self, t, slot=None):
+        """Small host tensor -> device without stalling the host (see _C.PinnedStager)."""
         if t.device == self.device or self.device.type != "cuda":
             return t.to(self.device)
-        key = (tuple(t.shape), t.dtype)
-        st = self.__dict__.setdefault("_pinned", {})
-        if key not in st:
-            st[key] = [[torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(2)], 0]
-        bufs, turn = st[key]
-        st[key][1] = turn ^ 1
-        bufs[turn].copy_(t)
-        return bufs[turn].to(self.device, non_blocking=True)
+        from .. import _C
+        st = self.__dict__.get("_stager")
+        if st is None:
+            st = self.__dict__["_stager"] = _C.PinnedStager()
+        return st.stage(t, self.device, slot)
 
     def _net_input(self, batched_inputs, key):
         x = (self._stack(batched_inputs, key, 255.0) - self.pixel_mean) / self.pixel_std
@@ -170,7 +165,7 @@ class MGNet(nn.Module):
                 "image_orig": self._stack(batched_inputs, "image_orig", 255.0),  # NOT mean/std normalised (:320-335)
                 "image_prev_orig": self._stack(batched_inputs, "image_prev_orig", 255.0),
                 "image_next_orig": self._stack(batched_inputs, "image_next_orig", 255.0),
-                "camera_matrix": self._to_device_async(torch.stack([x["camera_matrix"] for x in batched_inputs], 0)),
+                "camera_matrix": self._to_device_async(torch.stack([x["camera_matrix"] for x in batched_inputs], 0), "camera_matrix"),
                 "reprojection_mask": self._stack(batched_inputs, "reprojection_mask").unsqueeze(1),
             })
 

@@ -19,7 +19,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._v = [torch.zeros_like(b["flat_g"]) for b in reducer.buckets]
         self._lr_dev = [torch.zeros(b["flat_g"].numel() // self.chunk, device=dev) for b in reducer.buckets]
         self._wd_dev = [torch.zeros(b["flat_g"].numel() // self.chunk, device=dev) for b in reducer.buckets]
-        self._host = [[torch.zeros(2, t.numel(), pin_memory=True) for _ in range(2)] for t in self._lr_dev]
+        self._stager = _C.PinnedStager()
         self._partials = torch.zeros(1024 * len(reducer.buckets), device=dev)
         self._coef = torch.zeros(2, device=dev)
         self._group_of = {p: g for g in self.param_groups for p in g["params"]}
@@ -30,11 +30,8 @@ class FusedAdam(torch.optim.Optimizer):
         for k, b in enumerate(self.reducer.buckets):
             lr = np.repeat(np.array([self._group_of[p]["lr"] for p in b["params"]], np.float32), self._reps[k])
             wd = np.repeat(np.array([self._group_of[p]["weight_decay"] or 0.0 for p in b["params"]], np.float32), self._reps[k])
-            host = self._host[k][self._t % 2]
-            host[0].copy_(torch.from_numpy(lr))
-            host[1].copy_(torch.from_numpy(wd))
-            self._lr_dev[k].copy_(host[0], non_blocking=True)
-            self._wd_dev[k].copy_(host[1], non_blocking=True)
+            tab = self._stager.stage(torch.from_numpy(np.stack([lr, wd])), self._lr_dev[k].device, slot=k)   # (event-guarded pinned ring)
+            self._lr_dev[k], self._wd_dev[k] = tab[0], tab[1]
 
     @torch.no_grad()
     def step(self, closure=None):

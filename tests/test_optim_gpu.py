@@ -40,3 +40,41 @@ def test_fused_adam_matches_torch(max_norm):
             g["lr"] *= 0.9
     for p, q in zip(ref_p, my_p):
         assert torch.allclose(p, q, rtol=2e-5, atol=1e-7), float((p - q).abs().max())
+
+
+def test_per_step_tables_survive_a_host_that_runs_ahead():
+    """The LR / weight-decay tables go to the device through pinned staging buffers while the host is not synchronised with
+    the GPU: with the queue kept busy, six steps with a halving LR are issued before the first one executes.  (A staging
+    buffer rewritten before its copy ran would apply a later step's LR to an earlier step.)"""
+    from mgnet_amd import _C
+    from mgnet_amd.engine import GradReducer
+    from mgnet_amd.solver.fused_adam import FusedAdam
+
+    torch.manual_seed(1)
+    ref_p = [torch.nn.Parameter(torch.randn(300, 300, device="cuda")), torch.nn.Parameter(torch.randn(77, device="cuda"))]
+    my_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    grads = [[torch.randn_like(p) for p in ref_p] for _ in range(6)]
+    ref_opt = torch.optim.Adam([dict(params=[p], lr=1e-2) for p in ref_p], 1e-2)
+    red = GradReducer(my_p, bucket_bytes=1 << 20, align=_C.optim_chunk(), flatten_params=True, average=False)
+    my_opt = FusedAdam([dict(params=[p], lr=1e-2) for p in my_p], 1e-2, red)
+    for step in range(6):
+        for p, g in zip(ref_p, grads[step]):
+            p.grad = g.clone()
+        ref_opt.step()
+        for g in ref_opt.param_groups:
+            g["lr"] *= 0.5
+    torch.cuda.synchronize()
+    busy = torch.randn(8192, 8192, device="cuda")
+    for _ in range(40):   # ~0.3 s of queued work
+        busy = (busy @ busy) * 1e-4
+    for step in range(6):
+        my_opt.zero_grad()
+        for q, g in zip(my_p, grads[step]):
+            q.grad = g.clone()
+        red.finish()
+        my_opt.step()
+        for g in my_opt.param_groups:
+            g["lr"] *= 0.5
+    torch.cuda.synchronize()
+    for p, q in zip(ref_p, my_p):
+        assert torch.allclose(p, q, rtol=2e-5, atol=1e-6), float((p - q).abs().max())
