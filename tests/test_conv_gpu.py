@@ -19,12 +19,23 @@ CASES = [(2, 64, 128, 16, 24, 1, 1, 0, False, False),
          (2, 128, 1, 6, 10, 1, 1, 0, False, False),
          (1, 64, 64, 70, 150, 3, 1, 1, False, False),     # all-taps wgrad: 3 strips with a ragged tail, several row chunks
          (2, 64, 192, 5, 64, 3, 1, 1, False, False),      # all-taps wgrad: 3 co tiles, one exact strip
-         (9, 128, 64, 3, 7, 3, 1, 1, False, False)]       # all-taps wgrad: fewer rows than the ring depth
+         (9, 128, 64, 3, 7, 3, 1, 1, False, False),       # all-taps wgrad: fewer rows than the ring depth
+         # streaming 1x1 kernel (conv1x1_stream): every instantiation, ragged last tile, stride 2, several tiles per block
+         (2, 256, 256, 16, 24, 1, 1, 0, False, False),
+         (1, 256, 512, 9, 13, 1, 1, 0, False, False),     # two channel halves (grid.y = 2), 117 pixels
+         (1, 256, 512, 18, 27, 1, 2, 0, False, False),    # stride 2, odd width
+         (1, 128, 256, 17, 23, 1, 2, 0, False, False),
+         (2, 512, 256, 6, 10, 1, 1, 0, False, False),
+         (2, 512, 128, 5, 9, 1, 1, 0, False, False),
+         (2, 256, 32, 11, 15, 1, 1, 0, False, False),
+         (4, 256, 256, 128, 200, 1, 1, 0, False, False),  # 800 tiles on 256 persistent blocks: the double-buffered pipeline
+         (2, 64, 128, 130, 258, 1, 2, 0, False, False)]   # stride 2 with several tiles per block
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_conv_fwd_dgrad_wgrad(case):
+def test_conv_fwd_dgrad_wgrad(case, monkeypatch):
     from mgnet_amd.modeling import ops
+    monkeypatch.setenv("MGN_CONV_FORCE1X1", "1")   # small shapes would otherwise stay on the generic kernel
 
     N, Cin, Cout, H, W, k, s, p, has_bias, relu = case
     torch.manual_seed(sum(case[:8]))
