@@ -1436,16 +1436,43 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_stem16(WgradStemParams p) {
 __global__ __launch_bounds__(512, 1) void conv_wgrad_stem8(WgradStemParams p) { wgrad_stem_body<8>(p); }
 
 // dw[co][c][kh][kw] (torch layout, c < cin_real) = sum over the slices of partial[s][co][kh][kw*CP + c]
-__global__ void conv_wgrad_stem_reduce(const float* __restrict__ partial, int splits, int Cout, int CP, int cin_real, float* __restrict__ dw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = Cout * cin_real * 49;
-    if (i >= total) return;
-    const int kw = i % 7, kh = (i / 7) % 7, c = (i / 49) % cin_real, co = i / (49 * cin_real);
+// block = one (co, kh) row of 8*CP floats: 32 lanes x 16 bytes along the row times 8 groups along the slices, combined in a
+// fixed order through LDS (16-byte coalesced loads; the first version read 4 bytes per thread with a CP*4-byte stride)
+__global__ __launch_bounds__(256) void conv_wgrad_stem_reduce(const float* __restrict__ partial, int splits, int Cout, int CP, int cin_real,
+                                                              float* __restrict__ dw) {
+    __shared__ float4 sc[8][32];
+    const int co = blockIdx.x / 7, kh = blockIdx.x % 7, el = threadIdx.x & 31, g = threadIdx.x >> 5;
     const size_t rowf = (size_t)56 * CP;
-    const float* src = partial + (size_t)co * rowf + kh * 8 * CP + kw * CP + c;
-    float sacc = 0.f;
-    for (int z = 0; z < splits; ++z) sacc += src[(size_t)z * Cout * rowf];
-    dw[i] = sacc;
+    const int nv = 8 * CP / 4;   // float4 per row (32 or 16)
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (el < nv) {
+        const float* q = partial + (size_t)co * rowf + (size_t)kh * 8 * CP + el * 4;
+        const size_t zs = (size_t)Cout * rowf;
+        int z = g;
+        for (; z + 8 < splits; z += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(q + z * zs), c = *reinterpret_cast<const float4*>(q + (z + 8) * zs);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += c.x; s1.y += c.y; s1.z += c.z; s1.w += c.w;
+        }
+        if (z < splits) {
+            const float4 a = *reinterpret_cast<const float4*>(q + z * zs);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+        s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
+    }
+    sc[g][el] = s0;
+    __syncthreads();
+    if (g == 0 && el < nv) {
+        float4 r = sc[0][el];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { r.x += sc[k][el].x; r.y += sc[k][el].y; r.z += sc[k][el].z; r.w += sc[k][el].w; }
+        const float v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = el * 4 + k, kw = e / CP, c = e - kw * CP;   // row position = kw * CP + c
+            if (kw < 7 && c < cin_real) dw[(((size_t)co * cin_real + c) * 7 + kh) * 7 + kw] = v[k];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1940,8 +1967,7 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
         const unsigned nblk = (unsigned)((ps.nslices + 7) / 8) * 8 * ps.co_tiles;
         if (Cin == 16) hipLaunchKernelGGL(conv_wgrad_stem16, dim3(nblk), dim3(512), WS<16>::LDS, st, ps);
         else hipLaunchKernelGGL(conv_wgrad_stem8, dim3(nblk), dim3(512), WS<8>::LDS, st, ps);
-        const int total = Cout * oihw_cin * 49;
-        hipLaunchKernelGGL(conv_wgrad_stem_reduce, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)workspace, ps.nslices, Cout, Cin,
+        hipLaunchKernelGGL(conv_wgrad_stem_reduce, dim3((unsigned)Cout * 7), dim3(256), 0, st, (const float*)workspace, ps.nslices, Cout, Cin,
                            oihw_cin, dw);
         return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
     }
