@@ -1625,61 +1625,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgradParams p) {
 }
 
 // dw = sum over the pixel splits (fixed order: deterministic), written in the requested layout.
-// One block per output channel: 64 lanes x 16 bytes along the (tap, ci) axis times 4 groups along the splits (group g sums the
-// splits z = g, g+4, ... with two independent accumulators; the groups are combined in a fixed order through LDS), so that a
-// block streams its 4-590 KB of partials with ~8 sixteen-byte loads in flight per thread.  For the OIHW master layout the
-// channel's [tap][ci] block is transposed in LDS and written as ONE contiguous run of cin_real * taps floats (the first
-// version had a thread per element: 4-byte loads, 36-byte-strided 4-byte stores -- 0.6 TB/s, 1.6 ms per training step).
+// Block = 64 lanes x 16 bytes along one output channel's (tap, ci) axis times 4 groups along the splits (group g sums the
+// splits z = g, g+4, ... with two independent accumulators; the groups are combined in a fixed order through LDS): ~8
+// sixteen-byte loads in flight per thread and Cout * ceil(taps*Cin/256) blocks.  (The first version had a thread per element:
+// 4-byte loads in a dependent chain -- 0.6 TB/s, 1.6 ms per training step.)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw,
                                                          int cin_real, float* __restrict__ dw) {
-    extern __shared__ float wr_sh[];          // [per] transposed result (OIHW only) + [4][64] float4 scratch
+    __shared__ float4 scratch[4][64];
     const int per = taps * Cin, co = blockIdx.x, el = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long wsize = (long)Cout * per;
-    float4* scratch = reinterpret_cast<float4*>(wr_sh + (oihw ? per : 0));
-    const float* base = partial + (long)co * per;
-    for (int e0 = 0; e0 < per / 4; e0 += 64) {
-        const int e4 = e0 + el;
-        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-        if (e4 < per / 4) {
-            const float* q = base + (long)e4 * 4;
-            int z = g;
-            for (; z + 4 < splits; z += 8) {
-                const float4 a = *reinterpret_cast<const float4*>(q + (long)z * wsize);
-                const float4 c = *reinterpret_cast<const float4*>(q + (long)(z + 4) * wsize);
-                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-                s1.x += c.x; s1.y += c.y; s1.z += c.z; s1.w += c.w;
-            }
-            if (z < splits) {
-                const float4 a = *reinterpret_cast<const float4*>(q + (long)z * wsize);
-                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-            }
-            s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
+    const int e4 = blockIdx.y * 64 + el;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (e4 < per / 4) {
+        const float* q = partial + (long)co * per + (long)e4 * 4;
+        int z = g;
+        for (; z + 4 < splits; z += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(q + (long)z * wsize);
+            const float4 c = *reinterpret_cast<const float4*>(q + (long)(z + 4) * wsize);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += c.x; s1.y += c.y; s1.z += c.z; s1.w += c.w;
         }
-        scratch[g * 64 + el] = s0;
-        __syncthreads();
-        if (g == 0 && e4 < per / 4) {
-            const float4 a = scratch[el], b2 = scratch[64 + el], c = scratch[128 + el], d = scratch[192 + el];
-            float4 r;
-            r.x = (a.x + b2.x) + (c.x + d.x); r.y = (a.y + b2.y) + (c.y + d.y);
-            r.z = (a.z + b2.z) + (c.z + d.z); r.w = (a.w + b2.w) + (c.w + d.w);
-            if (!oihw) *reinterpret_cast<float4*>(dw + (long)co * per + (long)e4 * 4) = r;
-            else {
-                const int e = e4 * 4, tap = e / Cin, ci = e - tap * Cin;   // 4 consecutive input channels of one tap (Cin % 4 == 0)
-                const float v[4] = {r.x, r.y, r.z, r.w};
+        if (z < splits) {
+            const float4 a = *reinterpret_cast<const float4*>(q + (long)z * wsize);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+        s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
+    }
+    scratch[g][el] = s0;
+    __syncthreads();
+    if (g != 0 || e4 >= per / 4) return;
+    const float4 a = scratch[0][el], b2 = scratch[1][el], c = scratch[2][el], d = scratch[3][el];
+    float4 r;
+    r.x = (a.x + b2.x) + (c.x + d.x); r.y = (a.y + b2.y) + (c.y + d.y);
+    r.z = (a.z + b2.z) + (c.z + d.z); r.w = (a.w + b2.w) + (c.w + d.w);
+    if (!oihw) { *reinterpret_cast<float4*>(dw + (long)co * per + (long)e4 * 4) = r; return; }
+    const int e = e4 * 4, tap = e / Cin, ci = e - tap * Cin;   // 4 consecutive input channels of one tap (Cin % 4 == 0)
+    const float v[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (ci + k < cin_real) wr_sh[(ci + k) * taps + tap] = v[k];
-            }
-        }
-        __syncthreads();
-    }
-    if (oihw) {
-        const int n = cin_real * taps;
-        float* dst = dw + (long)co * n;
-        for (int j = threadIdx.x; j < n; j += 256) dst[j] = wr_sh[j];
-    }
+    for (int k = 0; k < 4; ++k)
+        if (ci + k < cin_real) dw[((long)co * cin_real + ci + k) * taps + tap] = v[k];
 }
-static inline size_t wgrad_reduce_lds(int taps, int Cin, int oihw) { return (size_t)(oihw ? taps * Cin : 0) * 4 + 4 * 64 * 16; }
+static inline dim3 wgrad_reduce_grid(int Cout, int taps, int Cin) { return dim3((unsigned)Cout, (unsigned)((taps * Cin / 4 + 63) / 64)); }
 
 // fp32 OIHW master weights -> bf16 kernel layouts, one launch per conv
 //   mode 0: [Cout][KH][KW][Cin]                      (forward)
@@ -1984,8 +1970,8 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
         const unsigned nblk = (unsigned)((p3.nslices + 7) / 8) * 8 * p3.co_tiles * p3.ci_tiles;
         if (p3.ng == 2) hipLaunchKernelGGL(conv_wgrad3x3_s128, dim3(nblk), dim3(512), W3<2>::LDS, st, p3);
         else hipLaunchKernelGGL(conv_wgrad3x3_s64, dim3(nblk), dim3(256), W3<1>::LDS, st, p3);
-        hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)Cout), dim3(256), wgrad_reduce_lds(9, Cin, p.oihw), st, (const float*)workspace,
-                           p3.nslices, Cout, 9, Cin, p.oihw, p.cin_real, dw);
+        hipLaunchKernelGGL(conv_wgrad_reduce, wgrad_reduce_grid(Cout, 9, Cin), dim3(256), 0, st, (const float*)workspace, p3.nslices, Cout, 9,
+                           Cin, p.oihw, p.cin_real, dw);
         return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
     }
     bool pack; int NT, MT, co_tiles; long gz;
@@ -2019,8 +2005,8 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
     else if (MT == 1) hipLaunchKernelGGL((conv_wgrad<1, 2>), grid, dim3(256), lds, st, p);
     else if (NT == 1) hipLaunchKernelGGL((conv_wgrad<2, 1>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((conv_wgrad<2, 2>), grid, dim3(256), lds, st, p);
-    hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)Cout), dim3(256), wgrad_reduce_lds(KH * KW, Cin, p.oihw), st, (const float*)workspace,
-                       (int)gz, Cout, KH * KW, Cin, p.oihw, p.cin_real, dw);
+    hipLaunchKernelGGL(conv_wgrad_reduce, wgrad_reduce_grid(Cout, KH * KW, Cin), dim3(256), 0, st, (const float*)workspace, (int)gz, Cout,
+                       KH * KW, Cin, p.oihw, p.cin_real, dw);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
