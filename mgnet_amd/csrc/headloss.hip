@@ -186,19 +186,42 @@ __global__ __launch_bounds__(TPB) void upce_fwd(const uint16_t* __restrict__ lg,
     }
 }
 
-// out[0]=n_hard, out[1]=sum_hard, out[2]=sum_all  (fp64 accumulation, fixed order)
-__global__ void sum3_kernel(const float* partials, int nblk, float* out) {
-    __shared__ double sh[3][TPB];
-    double a[3] = {0, 0, 0};
-    for (int i = threadIdx.x; i < nblk; i += TPB)
-        for (int k = 0; k < 3; ++k) a[k] += (double)partials[(size_t)i * 3 + k];
-    for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] = a[k];
+// Final sums over the per-block partials [nblk][NK] (65536 blocks at 8 x 1024 x 2048): ONE block of 1024 threads, four
+// independent fp64 accumulator sets per thread so that the loads overlap (the 256-thread dependent-chain version took 72 us),
+// then a fixed-order LDS tree.  Result in sh[k][0].
+constexpr int SUMT = 1024;
+template <int NK>
+__device__ __forceinline__ void block_sums(const float* __restrict__ partials, int nblk, double (*sh)[SUMT]) {
+    double a[4][NK];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a[u][k] = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3 * SUMT < nblk; i += 4 * SUMT) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) a[u][k] += (double)partials[(size_t)(i + u * SUMT) * NK + k];
+    }
+    for (; i < nblk; i += SUMT)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a[0][k] += (double)partials[(size_t)i * NK + k];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) sh[k][threadIdx.x] = (a[0][k] + a[1][k]) + (a[2][k] + a[3][k]);
     __syncthreads();
-    for (int o = TPB / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o)
-            for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+    for (int o = SUMT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
         __syncthreads();
     }
+}
+
+// out[0]=n_hard, out[1]=sum_hard, out[2]=sum_all  (fp64 accumulation, fixed order)
+__global__ __launch_bounds__(SUMT) void sum3_kernel(const float* partials, int nblk, float* out) {
+    __shared__ double sh[3][SUMT];
+    block_sums<3>(partials, nblk, sh);
     if (threadIdx.x < 3) out[threadIdx.x] = (float)sh[threadIdx.x][0];
 }
 
@@ -300,18 +323,9 @@ __global__ __launch_bounds__(TPB) void ins_fwd(InsMaps m, float* partials) {
     }
 }
 
-__global__ void sum4_kernel(const float* partials, int nblk, float* out) {
-    __shared__ double sh[4][TPB];
-    double a[4] = {0, 0, 0, 0};
-    for (int i = threadIdx.x; i < nblk; i += TPB)
-        for (int k = 0; k < 4; ++k) a[k] += (double)partials[(size_t)i * 4 + k];
-    for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = a[k];
-    __syncthreads();
-    for (int o = TPB / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o)
-            for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
-        __syncthreads();
-    }
+__global__ __launch_bounds__(SUMT) void sum4_kernel(const float* partials, int nblk, float* out) {
+    __shared__ double sh[4][SUMT];
+    block_sums<4>(partials, nblk, sh);
     // out = {loss_center (sum/wsum or 0), loss_offset, wsum_c, wsum_o}   (mg_net.py:697-715)
     if (threadIdx.x == 0) {
         out[0] = sh[1][0] > 0 ? (float)(sh[0][0] / sh[1][0]) : 0.f;
@@ -503,7 +517,7 @@ int mgn_upce_fwd(const void* logits_bf16, long sb, long sh, long sw, int B, int 
         case 3: hipLaunchKernelGGL(upce_fwd<3>, grid, dim3(TPB), 0, s, lg, g, K, labels, weights, ignore, thr, ce_map, partials); break;
         default: hipLaunchKernelGGL(upce_fwd<4>, grid, dim3(TPB), 0, s, lg, g, K, labels, weights, ignore, thr, ce_map, partials); break;
     }
-    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(TPB), 0, s, partials, (int)(grid.x * grid.y * grid.z), sums3);
+    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(SUMT), 0, s, partials, (int)(grid.x * grid.y * grid.z), sums3);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -564,7 +578,7 @@ int mgn_ins_loss_fwd(const float* center_lr, long csb, long csh, long csw, const
     m.ct = ct; m.cw = cw; m.ot = ot; m.ow = ow; m.oscale = oscale;
     const dim3 grid((W + 63) / 64, (H + 3) / 4, B);
     hipLaunchKernelGGL(ins_fwd, grid, dim3(TPB), 0, (hipStream_t)stream, m, partials);
-    hipLaunchKernelGGL(sum4_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)stream, partials, (int)(grid.x * grid.y * grid.z), out4);
+    hipLaunchKernelGGL(sum4_kernel, dim3(1), dim3(SUMT), 0, (hipStream_t)stream, partials, (int)(grid.x * grid.y * grid.z), out4);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
