@@ -38,7 +38,17 @@ struct ConvParams {
     const float* bias;    // [Cout] or null
     const uint16_t* residual;  // [N, OH, OW, Cout] bf16 added to the result before rounding, or null
     int N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32;
+    int xcd_bands;        // 1: remap blockIdx.x so that every XCD works on one contiguous band of pixel tiles (see xcd_tile)
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8, observed; MI355X_MICROARCH.md) and every XCD has its
+// own 4 MB L2.  With tile = blockIdx.x each L2 ends up loading (nearly) the whole input: vertically adjacent tiles share
+// their 3x3 halo rows but sit on different XCDs.  Remapped, XCD k owns the contiguous band of tiles
+// [start_k, start_k + cnt_k): the rows a band needs are fetched into ONE L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_tile(int b, int nb) {
+    const int k = b & 7, j = b >> 3, q = nb >> 3, r = nb & 7;
+    return k * q + (k < r ? k : r) + j;
+}
 
 // Parity class of the output pixels of an `up`-strided gather (data gradient of a stride-`up` conv).  Class (a, b) =
 // (oh % up, ow % up) only meets the taps kh = k0h + up*i, kw = k0w + up*i, k0 = (pad - a) mod up; up == 1: one class,
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
     constexpr int LPT = 2 + NT;  // LDS-DMA instructions per thread and tile (2 A passes + NT B passes)
     __shared__ __attribute__((aligned(16))) unsigned char smem[3][2][TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
-    const int bm = blockIdx.x, bn = blockIdx.y;
+    const int bm = p.xcd_bands ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x, bn = blockIdx.y;
     // up > 1 (data gradient of a strided conv): blockIdx.z is the parity class (a, b) of the output pixels; only the
     // taps kh = k0h + up*i meet a non-zero of the zero-upsampled gradient, so each class is a dense conv over its taps
     const UpClass uc(p, blockIdx.z);
@@ -590,7 +600,7 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
     constexpr int PA = C::PA, PB = C::PB;
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / NWN, wn = wave % NWN;
-    const int bm = blockIdx.x, bn = blockIdx.y;
+    const int bm = p.xcd_bands ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x, bn = blockIdx.y;
     const UpClass uc(p, blockIdx.z);
     const long M = (long)p.N * uc.OHc * uc.OWc;
     if ((long)bm * C::BMB >= M) return;
@@ -1749,7 +1759,11 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
     p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = out; p.bias = bias; p.residual = (const uint16_t*)residual;
     if (residual && out_f32) return MGN_ENOTSUP;
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
-    p.stride = stride; p.pad = pad; p.up = up; p.relu = relu; p.out_f32 = out_f32;
+    p.stride = stride; p.pad = pad; p.up = up; p.relu = relu; p.out_f32 = out_f32; p.xcd_bands = 0;
+    // block -> XCD is (linear block id) % 8: the x-only remap is a per-XCD banding when the x extent is a multiple of 8 or the
+    // grid is one-dimensional
+    const bool no_xcd = getenv("MGN_CONV_NOXCD") != nullptr;
+    auto xcd_ok = [&](long gxx, long gyz) { return (!no_xcd && gxx >= 16 && (gxx % 8 == 0 || gyz == 1)) ? 1 : 0; };
     const long M = (long)N * OH * OW;
     const long gx = (M + BM - 1) / BM;
     if (gx > 0x7fffffffL) return MGN_EINVAL;
@@ -1817,6 +1831,7 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
                 // (BN = 128 measured slower than the 128 x 128 kernel on the 128-channel layers: only on request)
             }
             if (pick == 256) {
+                p.xcd_bands = xcd_ok(gxb, (long)(Cout / 256) * gz);
                 hipLaunchKernelGGL(conv_igemm_big256, dim3((unsigned)gxb, Cout / 256, gz), dim3(512), IgemmBig<4>::LDS, st, p);
                 return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
             }
@@ -1833,10 +1848,12 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
                 return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
             }
             if (pick == 128) {
+                p.xcd_bands = xcd_ok(gxb, (long)(Cout / 128) * gz);
                 hipLaunchKernelGGL(conv_igemm_big128, dim3((unsigned)gxb, Cout / 128, gz), dim3(256), IgemmBig<2>::LDS, st, p);
                 return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
             }
         }
+        p.xcd_bands = xcd_ok(gxc, (long)(Cout <= 64 ? (Cout + 63) / 64 : (Cout + 127) / 128) * gz);
         if (Cout <= 64) hipLaunchKernelGGL((conv_igemm_glds<1>), dim3((unsigned)gxc, (Cout + 63) / 64, gz), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm_glds<2>), dim3((unsigned)gxc, (Cout + 127) / 128, gz), dim3(256), 0, st, p);
     } else if (Cout <= 64) {
