@@ -237,6 +237,11 @@ int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const
 int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
                    const float* pixel_std3, void* out_bf16, int Cp, void* stream);
 
+/* uint8 frames -> fp32 `x / divisor` stacked into one batch tensor -- replaces the `.float() / 255` of the un-jittered frames
+ * of the photometric loss and their stacking (mg_net.py:320-335).  frames_u8: HOST array of n_frames (<= 16) device pointers
+ * (16-byte aligned) to n_per_frame bytes each (n_per_frame % 16 == 0); out: [n_frames, n_per_frame] fp32.  IEEE division. */
+int mgn_u8_frames_to_f32(const void* const* frames_u8, int n_frames, long n_per_frame, float divisor, float* out, void* stream);
+
 /* The stem's activated batch norm folded into the pooling (BasicStem, res_net.py:82-110: conv -> InPlaceABNSync -> max_pool):
  * forward pools y = act(scale * x + offset) evaluated on the fly (bf16-rounded like mgn_iabn_apply stores it; the
  * normalised map is never written), backward = mgn_iabn_bwd_reduce on (pooled, d pooled) for the channel sums, then

@@ -23,7 +23,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
            "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
            "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd",
-           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd"]
+           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32"]
 DEPTH_MAX_FILTER_IDS = 16
 
 
@@ -117,6 +117,7 @@ def lib():
         L.mgn_concat2.argtypes = [vp, vp, cl, ci, ci, vp, vp]
         L.mgn_split2.argtypes = [vp, cl, ci, ci, vp, vp, vp]
         L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
+        L.mgn_u8_frames_to_f32.argtypes = [vp, ci, cl, cf, vp, vp]
         L.mgn_iabn_bwd_reduce_x.argtypes = [vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, ci, cf, vp, vp, vp, sz, vp]
         L.mgn_iabn_bwd_apply_x.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp]
         L.mgn_abn_add_relu_fwd.argtypes = [vp, vp, vp, vp, vp, cl, ci, vp]
@@ -386,6 +387,19 @@ def adam_step(p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, step, coef, gra
 def conv_supported(x, weight):
     """Cin % 32 == 0, or a channel-padded stem input (Cin 8/16 holding the weight's 3/9 real channels)"""
     return x.is_cuda and x.dtype == torch.bfloat16 and (weight.shape[1] % 32 == 0 or (x.shape[1] in (8, 16) and weight.shape[1] <= x.shape[1]))
+
+
+def u8_frames_to_f32(frames, divisor):
+    """list of equal-shape uint8 CUDA tensors -> stacked fp32 batch `frame / divisor` (one launch), or None if unsupported"""
+    f0 = frames[0]
+    n = f0.numel()
+    if (len(frames) > 16 or n % 16 or any(t.dtype != torch.uint8 or not t.is_cuda or t.shape != f0.shape or not t.is_contiguous()
+                                          or t.data_ptr() % 16 for t in frames)):
+        return None
+    out = torch.empty((len(frames),) + tuple(f0.shape), dtype=torch.float32, device=f0.device)
+    ptrs = (ctypes.c_void_p * len(frames))(*[t.data_ptr() for t in frames])
+    check(lib().mgn_u8_frames_to_f32(ptrs, len(frames), n, float(divisor), out.data_ptr(), _stream()), "mgn_u8_frames_to_f32")
+    return out
 
 
 def prep_input(frames_u8, mean3, std3, Cp):

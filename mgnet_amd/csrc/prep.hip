@@ -43,7 +43,38 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
     if (p.Cp == 16) dst[1] = make_uint4(v[8] | (v[9] << 16), v[10] | (v[11] << 16), v[12] | (v[13] << 16), v[14] | (v[15] << 16));
 }
 
+// uint8 frames -> fp32 in [0,1] (x.float() / 255, mg_net.py:320-335: the un-jittered frames of the photometric loss), stacked
+// into one batch tensor: replaces torch.stack + a type-promoting division (two passes, the second at 2.4 TB/s)
+struct U8Frames { const uint8_t* f[16]; };
+__global__ __launch_bounds__(256) void u8_frames_to_f32(U8Frames fr, long n16, float divisor, float* __restrict__ out) {
+    const uint8_t* src = fr.f[blockIdx.y];
+    float4* dst = reinterpret_cast<float4*>(out) + (long)blockIdx.y * n16 * 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)   // IEEE division: bit-identical to torch's true division
+            dst[i * 4 + k] = make_float4(__fdiv_rn((float)(w[k] & 255u), divisor), __fdiv_rn((float)((w[k] >> 8) & 255u), divisor),
+                                         __fdiv_rn((float)((w[k] >> 16) & 255u), divisor), __fdiv_rn((float)(w[k] >> 24), divisor));
+    }
+}
+
 }  // namespace
+
+extern "C" int mgn_u8_frames_to_f32(const void* const* frames_u8, int n_frames, long n_per_frame, float divisor, float* out,
+                                    void* stream) {
+    if (!frames_u8 || n_frames < 1 || n_frames > 16 || n_per_frame < 16 || n_per_frame % 16 || !(divisor != 0.f) || !out) return MGN_EINVAL;
+    U8Frames fr;
+    for (int i = 0; i < 16; ++i) {
+        fr.f[i] = i < n_frames ? (const uint8_t*)frames_u8[i] : nullptr;
+        if (i < n_frames && (!fr.f[i] || ((uintptr_t)fr.f[i] & 15))) return MGN_EINVAL;
+    }
+    const long n16 = n_per_frame / 16;
+    long bx = (n16 + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(u8_frames_to_f32, dim3((unsigned)bx, (unsigned)n_frames), dim3(256), 0, (hipStream_t)stream, fr, n16, divisor, out);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
 
 extern "C" int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
                               const float* pixel_std3, void* out_bf16, int Cp, void* stream) {

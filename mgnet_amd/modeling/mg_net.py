@@ -98,6 +98,13 @@ class MGNet(nn.Module):
     # ---- batching helpers (mg_net.py:250-345) --------------------------------------------------------------
     def _stack(self, batched_inputs, key, scale=None):
         ts = [x[key].to(self.device) for x in batched_inputs]
+        d = self.size_divisibility
+        if (scale is not None and ts[0].is_cuda and ts[0].dtype == torch.uint8
+                and (d <= 1 or (ts[0].shape[-2] % d == 0 and ts[0].shape[-1] % d == 0))):
+            from .. import _C
+            out = _C.u8_frames_to_f32(ts, scale)   # [HIP] stack + `/ 255` in one pass (no padding needed)
+            if out is not None:
+                return out
         t = ImageList.from_tensors(ts, self.size_divisibility).tensor
         # `.float() / 255` (mg_net.py:250,320-335) once on the stacked batch instead of per frame: same values (the zero
         # padding stays zero), 2 launches instead of 2 per frame

@@ -74,3 +74,25 @@ def test_concat_channels():
     (yr * g.float()).sum().backward()
     y = ops.concat_channels(a, b); (y.float() * g.cuda().float()).sum().backward()
     assert torch.equal(y.float().cpu(), yr.detach()) and torch.equal(a.grad.float().cpu(), ar.grad) and torch.equal(b.grad.float().cpu(), br.grad)
+
+
+def test_u8_frames_to_f32_is_exactly_float_div_255():
+    """mgn_u8_frames_to_f32 (stack + `.float() / 255` of the un-jittered frames, mg_net.py:320-335): bit-identical values"""
+    import torch
+    from mgnet_amd import _C
+    torch.manual_seed(0)
+    frames = [torch.randint(0, 256, (3, 64, 96), dtype=torch.uint8, device="cuda") for _ in range(5)]
+    frames[1][0, 0, :16] = torch.arange(240, 256, dtype=torch.uint8, device="cuda")
+    out = _C.u8_frames_to_f32(frames, 255.0)
+    assert out is not None and tuple(out.shape) == (5, 3, 64, 96)
+    # IEEE division like the reference's CPU path / numpy (torch's GPU kernel multiplies by the reciprocal of a scalar divisor,
+    # which differs by one ulp for some byte values)
+    import numpy as np
+    want = torch.stack(frames).cpu().numpy().astype(np.float32) / np.float32(255.0)
+    assert np.array_equal(out.cpu().numpy(), want)
+    allv = torch.arange(256, dtype=torch.uint8, device="cuda")   # every byte value
+    assert np.array_equal(_C.u8_frames_to_f32([allv], 255.0)[0].cpu().numpy(), np.arange(256, dtype=np.float32) / np.float32(255.0))
+    assert torch.allclose(out, torch.stack(frames).float() / 255.0, rtol=2e-7, atol=0)
+    # unsupported layouts fall back (None): not a multiple of 16 bytes, non-contiguous
+    assert _C.u8_frames_to_f32([torch.zeros(3, 5, 7, dtype=torch.uint8, device="cuda")], 255.0) is None
+    assert _C.u8_frames_to_f32([frames[0].transpose(1, 2)], 255.0) is None
