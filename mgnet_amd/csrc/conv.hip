@@ -289,7 +289,10 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvParams p) {
 // (wave base + lane*16), which is exactly the unpadded [row][64 B] tile; the XOR swizzle is therefore applied to the
 // SOURCE segment each lane fetches.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NT>
+// PACK (the 7x7 stems, Cin = 8 | 16 channel-padded inputs): k = tap * Cin + c, weights [Cout][Kpad]; every 16-byte DMA segment
+// of a k-step belongs to its own tap (Cin = 8: four taps per 32-wide step; Cin = 16: two), so the per-lane gather address is
+// recomputed per step from the segment's tap -- the same ring / MFMA code otherwise.
+template <int NT, bool PACK = false>
 __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
     constexpr int BN = 64 * NT, BK = 32, PITCH = 64, TILE = 128 * PITCH;  // 8 KB per operand tile
     constexpr int LPT = 2 + NT;  // LDS-DMA instructions per thread and tile (2 A passes + NT B passes)
@@ -303,17 +306,21 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
     if ((long)bm * BM >= M) return;
     const int lrow = tid >> 2, seg = tid & 3;
 
-    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * p.KH * p.KW * p.Cin * 2);
+    const int kpad = PACK ? (p.KH * p.KW * p.Cin + 31) / 32 * 32 : p.KH * p.KW * p.Cin;   // weight row length
+    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * kpad * 2);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, w_bytes, 0x00020000);
     constexpr int OOB = (int)0x80000000;
 
-    int ihb[2], iwb[2], abase[2], wbase[2];
+    int ihb[2], iwb[2], abase[2], wbase[2], ptap[2], pcoff[2];
     bool vm[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int row = lrow + r * 64;
         const int sseg = seg ^ ((row >> 2) & 3);  // source segment that lands in LDS slot `seg` of this row
+        // PACK: tap of this segment inside a k-step and its byte offset inside the tap's channels
+        ptap[r] = p.Cin == 8 ? sseg : (sseg >> 1);
+        pcoff[r] = p.Cin == 8 ? 0 : (sseg & 1) * 16;
         const long m = (long)bm * BM + row;
         vm[r] = m < M;
         const long mm = vm[r] ? m : 0;
@@ -322,12 +329,13 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
         const int ohc = rem / uc.OWc, owc = rem - ohc * uc.OWc;
         ihb[r] = (uc.a + ohc * p.up) * p.stride - p.pad;
         iwb[r] = (uc.b + owc * p.up) * p.stride - p.pad;
-        abase[r] = (n * p.IH * p.IW * p.Cin + sseg * 8) * 2;
+        abase[r] = PACK ? n * p.IH * p.IW * p.Cin * 2 : (n * p.IH * p.IW * p.Cin + sseg * 8) * 2;
         const int co = bn * BN + row;
-        wbase[r] = (co < p.Cout && row < BN) ? (co * p.KH * p.KW * p.Cin + sseg * 8) * 2 : OOB;
+        wbase[r] = (co < p.Cout && row < BN) ? (co * kpad + sseg * 8) * 2 : OOB;
     }
-    const int cpt = p.Cin / BK;
-    const int ksteps = uc.nkh * uc.nkw * cpt;
+    const int cpt = PACK ? 1 : p.Cin / BK;
+    const int ksteps = PACK ? kpad / BK : uc.nkh * uc.nkw * cpt;
+    const int tps = PACK ? BK / p.Cin : 1, ntaps = p.KH * p.KW;   // taps per k-step (PACK)
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -340,6 +348,18 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
     int khi = 0, kwi = 0, cc = 0;
     int avoff[2], wvoff[2];
     auto set_tap = [&]() {
+        if (PACK) {   // cc = k-step: segment's tap = cc * tps + ptap
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int tap = cc * tps + ptap[r];
+                const int kh = tap / p.KW, kw = tap - kh * p.KW;
+                const int th = ihb[r] + kh, tw = iwb[r] + kw;
+                const bool ok = vm[r] && tap < ntaps && th >= 0 && tw >= 0 && th < p.IH && tw < p.IW;
+                avoff[r] = ok ? abase[r] + (th * p.IW + tw) * p.Cin * 2 + pcoff[r] : OOB;
+                wvoff[r] = wbase[r];
+            }
+            return;
+        }
         const int kh = uc.k0h + khi * p.up, kw = uc.k0w + kwi * p.up;
         const int wtap = (kh * p.KW + kw) * p.Cin * 2;
 #pragma unroll
@@ -361,10 +381,11 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
         const int soff = cc * BK * 2;
         unsigned char* a0 = &smem[buf][0][wave * 1024];
         unsigned char* b0 = &smem[buf][1][wave * 1024];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)a0, 16, avoff[0], soff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a0 + 4096), 16, avoff[1], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)a0, 16, avoff[0], PACK ? 0 : soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a0 + 4096), 16, avoff[1], PACK ? 0 : soff, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)b0, 16, wvoff[0], soff, 0, 0);
         if (NT == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b0 + 4096), 16, wvoff[1], soff, 0, 0);
+        if (PACK) { ++cc; set_tap(); return; }
         if (++cc == cpt) {
             cc = 0;
             if (++kwi == uc.nkw) { kwi = 0; ++khi; }
@@ -1783,6 +1804,13 @@ int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, 
         else if (Cin == 128 && Cout % 256 == 0) rc1 = launch_conv1x1<128, 2, 4>(conv1x1_s_128_2_4, q, st);
         else if (Cin == 512 && Cout % 128 == 0) rc1 = launch_conv1x1<512, 1, 4>(conv1x1_s_512_1_4, q, st);
         if (rc1 <= 0) return rc1;
+    }
+    if (pack && !getenv("MGN_CONV_NOPACKDMA") && stride >= 1 && up == 1 && (size_t)N * IH * IW * Cin * 2 < 0x7fffffffu) {
+        // the stems on the LDS-DMA kernel (per-lane tap gather); grid like the generic LDS-DMA launch
+        p.xcd_bands = xcd_ok(gx, (long)(Cout <= 64 ? (Cout + 63) / 64 : (Cout + 127) / 128));
+        if (Cout <= 64) hipLaunchKernelGGL((conv_igemm_glds<1, true>), dim3((unsigned)gx, (Cout + 63) / 64, 1), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_glds<2, true>), dim3((unsigned)gx, (Cout + 127) / 128, 1), dim3(256), 0, st, p);
+        return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
     }
     if (pack) {
         if (Cout <= 64) hipLaunchKernelGGL((conv_igemm<1, 2, true>), dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, st, p);
