@@ -598,11 +598,12 @@ class _WeightCache:
             if w.device != dev:
                 continue
             Cout, Cin, KH, KW = w.shape
-            n_out = e["out"].numel()
-            rows.append([w.data_ptr(), e["out"].data_ptr(), n_out, blocks, Cout | (e["cout_pad"] << 32), Cin, (KH << 32) | KW,
+            # work items of the batched kernel: (co, ci) pairs for the plain layouts, output elements for the packed stems
+            n_items = e["out"].numel() if e["mode"] == 2 else max(Cout, e["cout_pad"]) * Cin
+            rows.append([w.data_ptr(), e["out"].data_ptr(), n_items, blocks, Cout | (e["cout_pad"] << 32), Cin, (KH << 32) | KW,
                          (e["mode"] << 32) | e["Cp"]])
             e["ptr"] = w.data_ptr()
-            blocks += (n_out + 255) // 256
+            blocks += (n_items + 255) // 256
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None
         self.total_blocks, self.dirty = blocks, False
 

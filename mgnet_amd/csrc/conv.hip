@@ -1729,8 +1729,12 @@ __global__ void weight_layout_kernel(const float* __restrict__ w, uint16_t* __re
     out[i] = f2bf(layout_value(w, i, Cout, CoutP, Cin, KH, KW, mode, Cp));
 }
 
-// all conv weights of a model in ONE launch: table rows of 8 x int64 = {src fp32 OIHW, dst bf16, n_out, first block,
-// Cout | CoutPad << 32, Cin, KH << 32 | KW, mode << 32 | Cp}; a block finds its row by binary search over the first-block column
+// all conv weights of a model in ONE launch: table rows of 8 x int64 = {src fp32 OIHW, dst bf16, n_items, first block,
+// Cout | CoutPad << 32, Cin, KH << 32 | KW, mode << 32 | Cp}; a block finds its row by binary search over the first-block column.
+// Modes 0 / 1: an item is a (co, ci) PAIR -- the thread reads the pair's KH*KW taps (contiguous in OIHW) once and writes one
+// element per tap, with the pair index ordered so that consecutive threads write consecutive elements (mode 0: ci fastest,
+// mode 1: co fastest).  A thread per OUTPUT element re-read every source line once per tap (9x for the 3x3 layers).
+// Mode 2 (packed stems): an item is an output element.
 __global__ void weight_layout_batch_kernel(const long long* __restrict__ table, int n_entries) {
     int lo = 0, hi = n_entries - 1;
     while (lo < hi) {
@@ -1743,9 +1747,21 @@ __global__ void weight_layout_batch_kernel(const long long* __restrict__ table, 
     const long n_out = e[2];
     const long i = ((long)blockIdx.x - e[3]) * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
-    const int Cout = (int)(e[4] & 0xffffffff), CoutP = (int)(e[4] >> 32), Cin = (int)e[5], KH = (int)(e[6] >> 32), KW = (int)(e[6] & 0xffffffff);
+    const int Cout = (int)(e[4] & 0xffffffff), CoutPr = (int)(e[4] >> 32), Cin = (int)e[5], KH = (int)(e[6] >> 32), KW = (int)(e[6] & 0xffffffff);
     const int mode = (int)(e[7] >> 32), Cp = (int)(e[7] & 0xffffffff);
-    out[i] = f2bf(layout_value(w, i, Cout, CoutP > Cout ? CoutP : Cout, Cin, KH, KW, mode, Cp));
+    const int CoutP = CoutPr > Cout ? CoutPr : Cout;
+    if (mode == 2) { out[i] = f2bf(layout_value(w, i, Cout, CoutP, Cin, KH, KW, mode, Cp)); return; }
+    const int taps = KH * KW;
+    int co, ci;
+    if (mode == 0) { co = (int)(i / Cin); ci = (int)(i - (long)co * Cin); }
+    else { ci = (int)(i / CoutP); co = (int)(i - (long)ci * CoutP); }
+    const float* src = w + ((long)co * Cin + ci) * taps;
+    const bool real = co < Cout;
+    for (int t = 0; t < taps; ++t) {
+        const uint16_t v = real ? f2bf(src[t]) : (uint16_t)0;
+        if (mode == 0) out[((long)co * taps + t) * Cin + ci] = v;                 // [Cout][KH][KW][Cin]
+        else out[((long)ci * taps + (taps - 1 - t)) * CoutP + co] = v;            // [Cin][KH][KW][Cout], taps flipped
+    }
 }
 
 }  // namespace
