@@ -92,23 +92,30 @@ __device__ __forceinline__ void column_sums2(long M, int C, float* ws_all, unsig
         const long stride = (long)gridDim.x * rpb;
         long r = (long)blockIdx.x * rpb + ty;
         typename Vec<T>::Raw q0[2], q1[2], q2[2], q3[2], q4[2], q5[2], q6[2], q7[2];
-        for (; DEEP && r + 7 * stride < M; r += 8 * stride) {   // 8 independent rows in flight (single-tensor reductions)
-            load_row(r, ch0 + tx * V, q0);
-            load_row(r + stride, ch0 + tx * V, q1);
-            load_row(r + 2 * stride, ch0 + tx * V, q2);
-            load_row(r + 3 * stride, ch0 + tx * V, q3);
-            load_row(r + 4 * stride, ch0 + tx * V, q4);
-            load_row(r + 5 * stride, ch0 + tx * V, q5);
-            load_row(r + 6 * stride, ch0 + tx * V, q6);
-            load_row(r + 7 * stride, ch0 + tx * V, q7);
-            add_row(q0, a, b);
-            add_row(q1, a, b);
-            add_row(q2, a, b);
-            add_row(q3, a, b);
-            add_row(q4, a, b);
-            add_row(q5, a, b);
-            add_row(q6, a, b);
-            add_row(q7, a, b);
+        if (DEEP && r + 7 * stride < M) {
+            // 8 independent rows in flight (single-tensor reductions), software-pipelined: the next group of 8 loads is issued
+            // BEFORE the current group is reduced, so that a block with only a few groups per thread (the 30-130 MB layers)
+            // does not drain its memory pipeline between groups
+            typename Vec<T>::Raw p0[2], p1[2], p2[2], p3[2], p4[2], p5[2], p6[2], p7[2];
+#define MGN_LOAD8(Q, R) load_row(R, ch0 + tx * V, Q##0); load_row(R + stride, ch0 + tx * V, Q##1); load_row(R + 2 * stride, ch0 + tx * V, Q##2); \
+            load_row(R + 3 * stride, ch0 + tx * V, Q##3); load_row(R + 4 * stride, ch0 + tx * V, Q##4); load_row(R + 5 * stride, ch0 + tx * V, Q##5); \
+            load_row(R + 6 * stride, ch0 + tx * V, Q##6); load_row(R + 7 * stride, ch0 + tx * V, Q##7)
+#define MGN_ADD8(Q) add_row(Q##0, a, b); add_row(Q##1, a, b); add_row(Q##2, a, b); add_row(Q##3, a, b); add_row(Q##4, a, b); \
+            add_row(Q##5, a, b); add_row(Q##6, a, b); add_row(Q##7, a, b)
+            MGN_LOAD8(q, r);
+            r += 8 * stride;
+            for (;;) {
+                if (!(r + 7 * stride < M)) { MGN_ADD8(q); break; }
+                MGN_LOAD8(p, r);
+                r += 8 * stride;
+                MGN_ADD8(q);
+                if (!(r + 7 * stride < M)) { MGN_ADD8(p); break; }
+                MGN_LOAD8(q, r);
+                r += 8 * stride;
+                MGN_ADD8(p);
+            }
+#undef MGN_LOAD8
+#undef MGN_ADD8
         }
         for (; r + 3 * stride < M; r += 4 * stride) {
             load_row(r, ch0 + tx * V, q0);
