@@ -217,6 +217,7 @@ def full_step_bench(args, world, rank, dev):
             line["cpu_baseline"] = cpu_baseline(H, W, model.state_dict(), cfg)
         print(json.dumps(line), flush=True)
     if world > 1:
+        torch.distributed.barrier()   # rank 0 may still be timing the informative conv roofline: leave together
         torch.distributed.destroy_process_group()
 
 
