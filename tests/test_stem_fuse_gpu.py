@@ -95,3 +95,37 @@ def test_block_tail_fused_equals_separate(cin, cout, stride):
     assert float((a[1] - b[1]).abs().max()) <= 3e-2 * float(b[1].abs().max())
     for n in b[2]:
         assert torch.allclose(a[2][n], b[2][n], rtol=3e-2, atol=3e-2 * float(b[2][n].abs().max())), n
+
+
+# ---- BASELINE sizes: the same equalities on the tensors of the benchmark step (8 frames of 1024 x 2048) -------------------
+def test_full_size_stem_and_block_tail():
+    a = run(True, 9, (8, 64, 512, 1024), "leaky_relu")
+    b = run(False, 9, (8, 64, 512, 1024), "leaky_relu")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+    assert float((a[1] - b[1]).abs().max()) <= 2e-2 * float(b[1].abs().max())
+    for k in (2, 3):   # d gamma / d beta: 4.2e6 pixels per channel summed in fp32 partials
+        assert torch.allclose(a[k], b[k], rtol=2e-2, atol=2e-2 * float(b[k].abs().max())), k
+    del a, b
+    torch.cuda.empty_cache()
+
+    from mgnet_amd.modeling import ops
+    from mgnet_amd.modeling.layers import InPlaceABNSync
+
+    def tail(fused):
+        if fused:
+            os.environ.pop("MGN_NO_TAILFUSE", None)
+        else:
+            os.environ["MGN_NO_TAILFUSE"] = "1"
+        try:
+            torch.manual_seed(4)
+            x = torch.randn(8, 64, 256, 512, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            sc = torch.randn(8, 64, 256, 512, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            norm = InPlaceABNSync(64, momentum=0.01, activation="identity").cuda().train()
+            y = ops.abn_add_relu(x * 1.0, norm, sc)
+            y.backward(torch.ones_like(y))
+            return y.detach(), x.grad.float(), sc.grad.float()
+        finally:
+            os.environ.pop("MGN_NO_TAILFUSE", None)
+    f, u = tail(True), tail(False)
+    assert torch.equal(f[0], u[0]) and torch.equal(f[2], u[2])
+    assert float((f[1] - u[1]).abs().max()) <= 3e-2 * float(u[1].abs().max())
