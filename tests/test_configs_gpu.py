@@ -35,3 +35,33 @@ def test_config_shapes_match_oracle(name, with_panoptic, with_depth, H, W):
     tr = Trainer(cfg, m)
     tot = [float(sum(v.detach() for v in tr.run_step(dev_batch).values())) for _ in range(6)]
     assert all(t == t and abs(t) < 1e6 for t in tot) and tot[-1] < tot[0], tot
+
+
+def test_full_size_step_properties():
+    """BASELINE C4 frame size (1024 x 2048, bf16, 4 frames): the oracle cannot run this in seconds, so size-independent
+    properties instead -- finite losses and gradients for every parameter, the five weighted losses in the reference's order,
+    and invariance of the (per-rank mean) losses under a permutation of the frames inside the batch."""
+    import os
+
+    from mgnet_amd import add_mgnet_config, get_cfg
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.registry import build_model
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_cfg()
+    add_mgnet_config(cfg)
+    cfg.merge_from_file(os.path.join(root, "configs", "bench-c4-cityscapes-videosequence.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda", "MODEL.SEM_SEG_HEAD.OHEM_N_MIN", 524287])
+    torch.manual_seed(0)
+    m = build_model(cfg).train()
+    batch = synthetic_batch(4, 1024, 2048, "cuda", seed=21)
+    got = m(batch)
+    assert list(got) == ["loss_sem_seg", "loss_center", "loss_offset", "loss_photometric", "loss_smoothness"]
+    sum(got.values()).backward()
+    vals = {k: float(v.detach()) for k, v in got.items()}
+    assert all(v == v and abs(v) < 1e4 for v in vals.values()), vals
+    for n, p in m.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+    perm = m([batch[2], batch[0], batch[3], batch[1]])
+    for k, v in vals.items():   # batch statistics and masked means are permutation invariant; bf16 + atomics: loose tolerance
+        assert float(perm[k].detach()) == pytest.approx(v, rel=2e-2, abs=2e-4), k
