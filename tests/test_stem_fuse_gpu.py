@@ -129,3 +129,42 @@ def test_full_size_stem_and_block_tail():
     f, u = tail(True), tail(False)
     assert torch.equal(f[0], u[0]) and torch.equal(f[2], u[2])
     assert float((f[1] - u[1]).abs().max()) <= 3e-2 * float(u[1].abs().max())
+
+
+# ---- the world > 1 branch of the norm ops, emulated on one GPU --------------------------------------------------------------
+def test_multi_rank_branch_with_two_identical_ranks(monkeypatch):
+    """Two ranks holding the SAME frames: gathered statistics = the local ones twice, all-reduced sums = twice the local ones,
+    pixel count doubled -> coefficients, outputs and gradients must equal the single-rank result.  Exercises
+    iabn_stats -> gather -> iabn_combine and the all_reduce of the backward sums in _IABNFn, _AbnPoolFn and _AbnAddReluFn."""
+    from mgnet_amd.modeling import ops
+    from mgnet_amd.modeling.layers import InPlaceABNSync
+
+    def three(world2):
+        torch.manual_seed(6)
+        x = torch.randn(2, 64, 24, 40, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        sc = torch.randn_like(x)
+        outs = []
+        for kind in ("plain", "pool", "tail"):
+            norm = InPlaceABNSync(64, momentum=0.01, activation="identity" if kind == "tail" else "leaky_relu").cuda().train()
+            xi = x.clone().requires_grad_(True)
+            if kind == "plain":
+                y = norm(xi * 1.0)
+            elif kind == "pool":
+                y = ops.abn_max_pool(xi * 1.0, norm)
+            else:
+                y = ops.abn_add_relu(xi * 1.0, norm, sc)
+            y.backward(torch.ones_like(y) * 0.5)
+            outs.append((y.detach().float(), xi.grad.float(), norm.weight.grad.clone(), norm.running_var.clone()))
+        return outs
+
+    single = three(False)
+    monkeypatch.setattr(ops, "_dist_active", lambda group: True)
+    monkeypatch.setattr(ops.dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(ops, "_gather_stats", lambda stats, world, group: torch.stack([stats, stats]))
+    monkeypatch.setattr(ops.dist, "all_reduce", lambda t, group=None: t.mul_(2.0))
+    double = three(True)
+    for s, d in zip(single, double):
+        assert torch.equal(s[0], d[0])                                   # same coefficients -> same activations
+        assert torch.allclose(s[1], d[1], rtol=1e-3, atol=1e-3 * float(s[1].abs().max()))
+        assert torch.allclose(s[2], d[2], rtol=1e-5, atol=1e-6)          # local parameter gradients (DDP averages them later)
+        assert torch.allclose(s[3], d[3], rtol=1e-4)                     # running variance: unbiased with the doubled count
