@@ -78,3 +78,34 @@ def test_per_step_tables_survive_a_host_that_runs_ahead():
     torch.cuda.synchronize()
     for p, q in zip(ref_p, my_p):
         assert torch.allclose(p, q, rtol=2e-5, atol=1e-6), float((p - q).abs().max())
+
+
+def test_grad_scale_of_a_two_rank_world():
+    """With average=False the reducer hands the SUM over ranks to the optimizer, which folds 1/world into the clipping pass:
+    a summed gradient of 2 g with world = 2 must give the update of g with world = 1 (same clipping decision, same Adam moments)."""
+    from mgnet_amd import _C
+    from mgnet_amd.engine import GradReducer
+    from mgnet_amd.solver.fused_adam import FusedAdam
+
+    def run(world, scale):
+        torch.manual_seed(3)
+        ps = [torch.nn.Parameter(torch.randn(128, 64, 3, 3, device="cuda")), torch.nn.Parameter(torch.randn(64, device="cuda"))]
+        red = GradReducer(ps, bucket_bytes=1 << 20, align=_C.optim_chunk(), flatten_params=True, average=False)
+        red.world = world
+        opt = FusedAdam([dict(params=[p]) for p in ps], 1e-3, red, max_grad_norm=0.01)
+        gs = [[torch.randn_like(p) for p in ps] for _ in range(3)]
+        for step in range(3):
+            opt.zero_grad()
+            for p, g in zip(ps, gs[step]):
+                p.grad = g * scale
+            red.world = 1          # (no process group here: pack without launching collectives)
+            red.finish()
+            red.world = world
+            opt.step()
+        return [p.detach().clone() for p in ps], float(opt.grad_norm())
+
+    a, na = run(1, 1.0)
+    b, nb = run(2, 2.0)
+    assert na == pytest.approx(nb, rel=1e-6)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
