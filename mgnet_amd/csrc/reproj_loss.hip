@@ -120,6 +120,46 @@ __device__ __forceinline__ float ssim_from_sums(float Sx, float Sy, float Sxx, f
     return fminf(fmaxf(val, 0.f), 1.f);
 }
 
+// The same for BOTH context frames at once (prev, next share the target's sums Sy, Syy): the element-wise algebra on
+// 2-vectors compiles to packed fp32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two frames per VALU issue).  Every component
+// goes through exactly the scalar function's operation sequence (contraction off, explicit fma in the Newton step), so the
+// values -- and the exactness contract above -- are unchanged.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool GRAD>
+__device__ __forceinline__ f32x2 ssim_from_sums2(f32x2 Sx, float Sy, f32x2 Sxx, float Syy, f32x2 Sxy, f32x2& alpha, f32x2& beta,
+                                                 f32x2& gamma, bool& gate0, bool& gate1) {
+#pragma clang fp contract(off)
+    constexpr float r9 = 1.0f / 9.0f;
+    const f32x2 mux = Sx * r9;
+    const float muy = Sy * r9;
+    const f32x2 mxx = mux * mux, mxy = mux * muy;
+    const float myy = muy * muy;
+    const f32x2 sgx = Sxx * r9 - mxx, sgxy = Sxy * r9 - mxy;
+    const float sgy = Syy * r9 - myy;
+    const f32x2 N1 = 2.f * mxy + SSIM_C1, N2 = 2.f * sgxy + SSIM_C2;
+    const f32x2 D1 = mxx + myy + SSIM_C1, D2 = sgx + sgy + SSIM_C2;
+    const f32x2 num = N1 * N2, den = D1 * D2;
+    f32x2 i12;
+    i12.x = frcp(den.x);
+    i12.y = frcp(den.y);
+    const f32x2 q0 = num * i12;
+    const f32x2 s = __builtin_elementwise_fma(__builtin_elementwise_fma(-den, q0, num), i12, q0);
+    const f32x2 val = (1.f - s) * 0.5f;
+    if (GRAD) {
+        gate0 = (val.x >= 0.f) && (val.x <= 1.f);
+        gate1 = (val.y >= 0.f) && (val.y <= 1.f);
+        const f32x2 iD1 = D2 * i12, iD2 = D1 * i12;
+        constexpr float c29 = 2.0f / 9.0f;
+        alpha = c29 * (muy * (N2 - N1) * i12 - s * mux * (iD1 - iD2));
+        beta = c29 * N1 * i12;
+        gamma = -c29 * s * iD2;
+    }
+    f32x2 r;
+    r.x = fminf(fmaxf(val.x, 0.f), 1.f);
+    r.y = fminf(fmaxf(val.y, 0.f), 1.f);
+    return r;
+}
+
 // F.grid_sample(bilinear, zeros, align_corners=True) at pixel position (ix,iy) for the 3 channels of `ref`,
 // plus d out_c / d ix and d out_c / d iy.
 template <bool GRAD>
@@ -267,16 +307,19 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                         const float Syy = hsum3(dot3(y2[c], y1[c], y0[c], y2[c], y1[c], y0[c]));
                         sh[(SH_SY + c) * WAVE] = Sy;
                         sh[(SH_SYY + c) * WAVE] = Syy;
+                        {   // un-warped context images vs target (automask, loss.py:139-144), both frames at once
+                            f32x2 Sx, Sxx, Sxy, d0, d1, d2;
+                            bool g0, g1;
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {  // un-warped context image vs target (automask, loss.py:139-144)
-                            const float a = rf2[j][c], bq = rf1[j][c], cc = rf0[j][c];
-                            const float Sx = hsum3(a + bq + cc);
-                            const float Sxx = hsum3(dot3(a, bq, cc, a, bq, cc));
-                            const float Sxy = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
-                            float d0, d1, d2;
-                            bool g0;
-                            const float v = ssim_from_sums<false>(Sx, Sy, Sxx, Syy, Sxy, d0, d1, d2, g0);
-                            pu[j] += ssim_w3 * v + l1_w3 * fabsf(bq - y1[c]);
+                            for (int j = 0; j < 2; ++j) {
+                                const float a = rf2[j][c], bq = rf1[j][c], cc = rf0[j][c];
+                                Sx[j] = hsum3(a + bq + cc);
+                                Sxx[j] = hsum3(dot3(a, bq, cc, a, bq, cc));
+                                Sxy[j] = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
+                            }
+                            const f32x2 v = ssim_from_sums2<false>(Sx, Sy, Sxx, Syy, Sxy, d0, d1, d2, g0, g1);
+                            pu[0] += ssim_w3 * v.x + l1_w3 * fabsf(rf1[0][c] - y1[c]);
+                            pu[1] += ssim_w3 * v.y + l1_w3 * fabsf(rf1[1][c] - y1[c]);
                         }
                         igx += fabsf(y1[c] - dpp_from_right(y1[c]));
                         igy += fabsf(y1[c] - y0[c]);
@@ -415,14 +458,21 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float Sy = sh[(SH_SY + c) * WAVE], Syy = sh[(SH_SYY + c) * WAVE];
+                    {   // both warped context frames at once (packed fp32)
+                        f32x2 Sx, Sxx, Sxy, a2, b2, g2;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float a = xw2[j][c], bq = xw1[j][c], cc = xw0[j][c];
-                        const float Sx = hsum3(a + bq + cc);
-                        const float Sxx = hsum3(dot3(a, bq, cc, a, bq, cc));
-                        const float Sxy = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
-                        const float v = ssim_from_sums<GRAD>(Sx, Sy, Sxx, Syy, Sxy, al[j][c], be[j][c], ga[j][c], gt[j][c]);
-                        pw[j] += ssim_w3 * v + l1_w3 * fabsf(bq - y1[c]);
+                        for (int j = 0; j < 2; ++j) {
+                            const float a = xw2[j][c], bq = xw1[j][c], cc = xw0[j][c];
+                            Sx[j] = hsum3(a + bq + cc);
+                            Sxx[j] = hsum3(dot3(a, bq, cc, a, bq, cc));
+                            Sxy[j] = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
+                        }
+                        const f32x2 v = ssim_from_sums2<GRAD>(Sx, Sy, Sxx, Syy, Sxy, a2, b2, g2, gt[0][c], gt[1][c]);
+                        if (GRAD) {
+                            al[0][c] = a2.x; al[1][c] = a2.y; be[0][c] = b2.x; be[1][c] = b2.y; ga[0][c] = g2.x; ga[1][c] = g2.y;
+                        }
+                        pw[0] += ssim_w3 * v.x + l1_w3 * fabsf(xw1[0][c] - y1[c]);
+                        pw[1] += ssim_w3 * v.y + l1_w3 * fabsf(xw1[1][c] - y1[c]);
                     }
                 }
                 const float pu0 = sh[SH_PU * WAVE], pu1 = sh[(SH_PU + 1) * WAVE];
