@@ -593,6 +593,8 @@ class _WeightCache:
         dev = None
         for e in self.entries.values():
             w = e["ref"]()
+            if w is None:   # collected since the filter above (a cyclic-garbage pass can run at any allocation)
+                continue
             if dev is None:
                 dev = w.device
             if w.device != dev:
@@ -609,8 +611,11 @@ class _WeightCache:
 
     def refresh(self):
         """re-derive every registered layout from the current parameter values (one launch)"""
-        if any(e["ref"]() is not None and e["ptr"] != e["ref"]().data_ptr() for e in self.entries.values()):
-            self.dirty = True
+        for e in self.entries.values():
+            w = e["ref"]()
+            if w is not None and e["ptr"] != w.data_ptr():
+                self.dirty = True
+                break
         if self.dirty:
             self._rebuild()
         if self.table is None:
