@@ -1,14 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MGNet training hot path on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run, one rank per
-GPU).  A step = one pass of the hot path (forward + backward) over one per-GPU batch of synthetic Cityscapes-shaped
-input that is already resident in HBM.  Rank 0 prints ONE JSON line.
-
-What is inside a step in this round: the self-supervised photometric reprojection loss of MGNet
-(MultiViewPhotometricLoss forward + backward, SURVEY.md 8a group G) at BASELINE.json's C4/C5 shape
-(1024x2048, 8 frames per GPU, 3 scales, 2 context frames).  The network rows (group N) are not in the step yet;
-`config.workload` says exactly what is timed.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no torch.distributed environment the process
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (before anything touches the GPU) and
+exits with its code; under a launcher (RANK/WORLD_SIZE set) it is one rank.  A step = one full MGNet training step
+(2x ResNet-18 + 3 decoders/heads forward + backward, five losses incl. the photometric reprojection loss, gradient
+all-reduce, clip, Adam) over one per-GPU batch of synthetic Cityscapes-shaped input that is already resident in HBM.
+Rank 0 prints ONE JSON line; `config.workload` says exactly what is timed.  `--loss-only` / `--fwd-only` are diagnostics
+that time the reprojection loss alone (not the benchmark).
 """
 import argparse
 import ctypes
@@ -221,6 +220,21 @@ def full_step_bench(args, world, rank, dev):
         torch.distributed.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run the N ranks as a child job (one process per GPU over RCCL) and
+    return its exit code.  Called before any HIP call of this process; the parent never initialises the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,6 +249,8 @@ def main():
                     help="diagnostic: time only the reprojection loss fwd+bwd (round-1 v2 workload); NOT the benchmark")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))   # nothing has touched the GPU in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

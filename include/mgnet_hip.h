@@ -407,6 +407,34 @@ int mgn_nearest_bwd(const void* dy, int N, int h, int w, int H, int W, int C, vo
 int mgn_concat2(const void* a, const void* b, long rows, int Ca, int Cb, void* y, void* stream);
 int mgn_split2(const void* dy, long rows, int Ca, int Cb, void* da, void* db, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Stand-alone geometry stages (mgnet/geometry public functions used outside the fused loss) -- csrc/geometry.hip
+ * Every function takes ONE affine map per image, A [B,9] row-major and t [B,3] (device fp32), formed by the caller
+ * from intrinsics and poses (B x 12 numbers).  Backward entry points also write `partials` [rows,12] fp32 with
+ * rows = mgn_geometry_partial_rows(B,H,W): rows of image b are contiguous (rows/B each); their sum is
+ * (dL/dA [9], dL/dt [3]) of that image.  padding_mode: 0 = "zeros" only (others MGN_ENOTSUP).
+ *
+ * mgn_view_synthesis_*  replaces mgnet/geometry/camera_utils.py:24-55 view_synthesis:
+ *     out[b,c,v,u] = grid_sample(ref[b,c], (X/Z, Y/Z)),  (X,Y,z) = depth[b,v,u] * (A_b.[u,v,1]) + t_b, Z = clamp(z,1e-5)
+ *     with A = K_ref.R.Kinv_cam, t = K_ref.trans, (R,trans) = ref_cam.Tcw o cam.Twc  (camera.py:107-182)
+ *     bwd: d_depth [B,1,H,W] and the partials of (dA, dt); ref carries no gradient (as in loss.py: the images are data)
+ * mgn_reconstruct_*     replaces camera.py:107-141 Camera.reconstruct (+ pose.py:77-83 for frame "w"):
+ *     points[b,k,v,u] = depth * (A_k.[u,v,1]) + t_k,  A = R_wc.Kinv, t = trans_wc
+ * mgn_project_*         replaces camera.py:143-182 Camera.project (+ pose.py:77-83):
+ *     coords[b,v,u,:] = (2 (X/Z)/(W-1) - 1, 2 (Y/Z)/(H-1) - 1), (X,Y,z) = A.P + t,  A = K.R_cw, t = K.trans_cw
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_geometry_partial_rows(int B, int H, int W, size_t* rows);
+int mgn_view_synthesis_fwd(const float* ref, const float* depth, const float* A, const float* t, int B, int C, int H, int W,
+                           int padding_mode, float* out, void* stream);
+int mgn_view_synthesis_bwd(const float* ref, const float* depth, const float* A, const float* t, const float* g_out, int B,
+                           int C, int H, int W, int padding_mode, float* d_depth, float* partials, void* stream);
+int mgn_reconstruct_fwd(const float* depth, const float* A, const float* t, int B, int H, int W, float* points, void* stream);
+int mgn_reconstruct_bwd(const float* depth, const float* A, const float* t, const float* g_points, int B, int H, int W,
+                        float* d_depth, float* partials, void* stream);
+int mgn_project_fwd(const float* points, const float* A, const float* t, int B, int H, int W, float* coords, void* stream);
+int mgn_project_bwd(const float* points, const float* A, const float* t, const float* g_coords, int B, int H, int W,
+                    float* d_points, float* partials, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,9 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
            "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
            "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd",
-           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32"]
+           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32",
+           "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
+           "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd"]
 DEPTH_MAX_FILTER_IDS = 16
 
 
@@ -131,6 +133,13 @@ def lib():
         L.mgn_panoptic_post.argtypes = [ctypes.POINTER(PanopticCfg), vp, vp, vp, vp, vp, vp, sz, vp]
         L.mgn_panoptic_targets_workspace_bytes.argtypes = [ctypes.POINTER(TargetsCfg), ctypes.POINTER(sz)]
         L.mgn_panoptic_targets.argtypes = [ctypes.POINTER(TargetsCfg)] + [vp] * 15 + [sz, vp]
+        L.mgn_geometry_partial_rows.argtypes = [ci, ci, ci, ctypes.POINTER(sz)]
+        L.mgn_view_synthesis_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]
+        L.mgn_view_synthesis_bwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]
+        L.mgn_reconstruct_fwd.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
+        L.mgn_reconstruct_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]
+        L.mgn_project_fwd.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
+        L.mgn_project_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
         _lib = L
@@ -259,9 +268,12 @@ _IABN_WS = {}
 
 
 def _iabn_ws(device):
-    ws = _IABN_WS.get(device)
+    """partials workspace of the single-launch reductions: one per (device, stream) -- launches on the same stream are
+    ordered, launches on different streams (two encoders side by side, multi-scale eval) must not share partials."""
+    key = (device, _stream().value)
+    ws = _IABN_WS.get(key)
     if ws is None:
-        ws = _IABN_WS[device] = torch.empty(2 * 1024 * 1024, dtype=torch.float32, device=device)  # 2*C*1024 floats, C<=1024
+        ws = _IABN_WS[key] = torch.empty(2 * 1024 * 1024, dtype=torch.float32, device=device)  # 2*C*1024 floats, C<=1024
     return ws
 
 
@@ -871,3 +883,71 @@ def split2(dy, Ca, Cb):
     da, db = _cl_like(dy, (N, Ca, H, W)), _cl_like(dy, (N, Cb, H, W))
     check(lib().mgn_split2(dy.data_ptr(), N * H * W, Ca, Cb, da.data_ptr(), db.data_ptr(), _stream()), "mgn_split2")
     return da, db
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stand-alone geometry stages (csrc/geometry.hip)
+# ---------------------------------------------------------------------------------------------------------------
+def _geo_partials(B, H, W, device):
+    n = ctypes.c_size_t(0)
+    check(lib().mgn_geometry_partial_rows(B, H, W, ctypes.byref(n)), "mgn_geometry_partial_rows")
+    return torch.empty((B, n.value // B, 12), dtype=torch.float32, device=device)
+
+
+def _geo_sum(partials):
+    """[B, rows, 12] block partials -> (dA [B,3,3], dt [B,3]); fp64 accumulation, fixed order"""
+    s = partials.double().sum(1).float()
+    return s[:, :9].reshape(-1, 3, 3), s[:, 9:]
+
+
+def view_synthesis_fwd(ref, depth, A, t, padding_mode="zeros"):
+    B, C, H, W = ref.shape
+    out = torch.empty_like(ref)
+    check(lib().mgn_view_synthesis_fwd(_dev_f32(ref, "ref_image").data_ptr(), _dev_f32(depth, "depth").data_ptr(),
+                                       _dev_f32(A, "A").data_ptr(), _dev_f32(t, "t").data_ptr(), B, C, H, W, _PAD[padding_mode],
+                                       out.data_ptr(), _stream()), "mgn_view_synthesis_fwd")
+    return out
+
+
+def view_synthesis_bwd(ref, depth, A, t, g_out, padding_mode="zeros"):
+    B, C, H, W = ref.shape
+    d_depth = torch.empty_like(depth)
+    part = _geo_partials(B, H, W, ref.device)
+    check(lib().mgn_view_synthesis_bwd(ref.data_ptr(), depth.data_ptr(), A.data_ptr(), t.data_ptr(),
+                                       _dev_f32(g_out, "grad").data_ptr(), B, C, H, W, _PAD[padding_mode], d_depth.data_ptr(),
+                                       part.data_ptr(), _stream()), "mgn_view_synthesis_bwd")
+    return (d_depth,) + _geo_sum(part)
+
+
+def reconstruct_fwd(depth, A, t):
+    B, _, H, W = depth.shape
+    pts = torch.empty((B, 3, H, W), dtype=torch.float32, device=depth.device)
+    check(lib().mgn_reconstruct_fwd(_dev_f32(depth, "depth").data_ptr(), _dev_f32(A, "A").data_ptr(), _dev_f32(t, "t").data_ptr(),
+                                    B, H, W, pts.data_ptr(), _stream()), "mgn_reconstruct_fwd")
+    return pts
+
+
+def reconstruct_bwd(depth, A, t, g):
+    B, _, H, W = depth.shape
+    d_depth = torch.empty_like(depth)
+    part = _geo_partials(B, H, W, depth.device)
+    check(lib().mgn_reconstruct_bwd(depth.data_ptr(), A.data_ptr(), t.data_ptr(), _dev_f32(g, "grad").data_ptr(), B, H, W,
+                                    d_depth.data_ptr(), part.data_ptr(), _stream()), "mgn_reconstruct_bwd")
+    return (d_depth,) + _geo_sum(part)
+
+
+def project_fwd(points, A, t):
+    B, _, H, W = points.shape
+    coords = torch.empty((B, H, W, 2), dtype=torch.float32, device=points.device)
+    check(lib().mgn_project_fwd(_dev_f32(points, "points").data_ptr(), _dev_f32(A, "A").data_ptr(), _dev_f32(t, "t").data_ptr(),
+                                B, H, W, coords.data_ptr(), _stream()), "mgn_project_fwd")
+    return coords
+
+
+def project_bwd(points, A, t, g):
+    B, _, H, W = points.shape
+    d_pts = torch.empty_like(points)
+    part = _geo_partials(B, H, W, points.device)
+    check(lib().mgn_project_bwd(points.data_ptr(), A.data_ptr(), t.data_ptr(), _dev_f32(g, "grad").data_ptr(), B, H, W,
+                                d_pts.data_ptr(), part.data_ptr(), _stream()), "mgn_project_bwd")
+    return (d_pts,) + _geo_sum(part)

@@ -165,9 +165,10 @@ __device__ __forceinline__ void column_sums2(long M, int C, float* ws_all, unsig
         }
     }
     // ticket: the last block to arrive finalizes.  No agent-scope fences (a release would write back the whole L2, an
-    // acquire invalidate it): the partials are device-coherent accesses, ordered before the ticket by
-    // waiting for their completion (workgroup-scope release = s_waitcnt) and the barrier.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // acquire invalidate it): the partials are device-coherent (write-through) stores, ordered before the ticket by
+    // an EXPLICIT wait for their completion -- a workgroup-scope release fence does not emit s_waitcnt vmcnt(0) in
+    // non-tgsplit mode, so without this the ticket could be taken while the stores are still in flight -- and the barrier.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
