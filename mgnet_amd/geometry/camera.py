@@ -55,7 +55,7 @@ class Camera(nn.Module):
     def __init__(self, K, Tcw=None):
         super().__init__()
         self.K = K
-        self.Tcw = Pose.identity(len(K)) if Tcw is None else Tcw
+        self.Tcw = Pose.identity(len(K), device=K.device, dtype=K.dtype) if Tcw is None else Tcw   # (the reference builds it on the CPU and relies on .to())
         self._Twc = None
         self._Kinv = None
 
