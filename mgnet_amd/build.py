@@ -45,7 +45,13 @@ def build(force=False, verbose=False):
     todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdr)]
 
     def compile_one(src):
-        cmd = [HIPCC] + CFLAGS + ["-c", src, "-o", _obj(src)]
+        # per-file flags: a line `// hipcc-flags: <flags>` in the first 40 lines of the source
+        extra = []
+        with open(src) as f:
+            for _, line in zip(range(40), f):
+                if line.startswith("// hipcc-flags:"):
+                    extra += line.split(":", 1)[1].split()
+        cmd = [HIPCC] + CFLAGS + extra + ["-c", src, "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

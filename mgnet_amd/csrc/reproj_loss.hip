@@ -160,31 +160,37 @@ __device__ __forceinline__ f32x2 ssim_from_sums2(f32x2 Sx, float Sy, f32x2 Sxx, 
     return r;
 }
 
-// F.grid_sample(bilinear, zeros, align_corners=True) at pixel position (ix,iy) for the 3 channels of `ref`,
-// plus d out_c / d ix and d out_c / d iy.
+// F.grid_sample(bilinear, zeros, align_corners=True) at pixel position (ix,iy) for the 3 channel planes of a context frame,
+// plus d out_c / d ix and d out_c / d iy.  The planes are addressed through buffer resources (base in SGPRs, a 32-bit byte
+// offset per lane: no 64-bit address arithmetic) whose range check supplies the zero padding: a corner outside the image in
+// y is outside the plane's byte range by itself, a corner outside in x gets an out-of-range offset, and the hardware returns
+// 0 for both -- no clamping of the corner coordinates and no select per loaded value.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
+}
+
 template <bool GRAD>
-__device__ __forceinline__ void bilinear3(const float* __restrict__ ref, int HWp, int W, int H, float ix, float iy,
-                                          float out[3], float ex[3], float ey[3]) {
+__device__ __forceinline__ void bilinear3(const rsrc_t (&plane)[3], int W, int H, float ix, float iy, float out[3], float ex[3],
+                                          float ey[3]) {
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     const float tx = ix - fx0, ty = iy - fy0;
-    const int xi = (int)fminf(fmaxf(fx0, -2.f), (float)W);
-    const int yi = (int)fminf(fmaxf(fy0, -2.f), (float)H);
+    const int xi = (int)__builtin_amdgcn_fmed3f(fx0, -2.f, (float)W);   // NaN -> -2: every corner out of range
+    const int yi = (int)__builtin_amdgcn_fmed3f(fy0, -2.f, (float)H);
     const bool x0ok = (unsigned)xi < (unsigned)W, x1ok = (unsigned)(xi + 1) < (unsigned)W;
-    const bool y0ok = (unsigned)yi < (unsigned)H, y1ok = (unsigned)(yi + 1) < (unsigned)H;
-    const int x0 = min(max(xi, 0), W - 1), x1 = min(max(xi + 1, 0), W - 1);
-    const int y0 = min(max(yi, 0), H - 1), y1 = min(max(yi + 1, 0), H - 1);
-    const int o00 = y0 * W + x0, o10 = y0 * W + x1, o01 = y1 * W + x0, o11 = y1 * W + x1;
-    const bool k00 = x0ok && y0ok, k10 = x1ok && y0ok, k01 = x0ok && y1ok, k11 = x1ok && y1ok;
+    constexpr int OUT = (int)0x80000000u;      // beyond any plane (H*W <= 2^28 pixels)
+    const int o00 = (yi * W + xi) * 4;
+    const int a00 = x0ok ? o00 : OUT, a10 = x1ok ? o00 + 4 : OUT;
+    const int a01 = x0ok ? o00 + 4 * W : OUT, a11 = x1ok ? o00 + 4 * W + 4 : OUT;
     const float sx = 1.f - tx, sy = 1.f - ty;
     const float w00 = sx * sy, w10 = tx * sy, w01 = sx * ty, w11 = tx * ty;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float* rc = ref + c * HWp;
-        float v00 = rc[o00], v10 = rc[o10], v01 = rc[o01], v11 = rc[o11];
-        v00 = k00 ? v00 : 0.f;
-        v10 = k10 ? v10 : 0.f;
-        v01 = k01 ? v01 : 0.f;
-        v11 = k11 ? v11 : 0.f;
+        const float v00 = bload(plane[c], a00, 0), v10 = bload(plane[c], a10, 0);
+        const float v01 = bload(plane[c], a01, 0), v11 = bload(plane[c], a11, 0);
         out[c] = v00 * w00 + v10 * w10 + v01 * w01 + v11 * w11;
         if (GRAD) {
             ex[c] = (v10 - v00) * sy + (v11 - v01) * ty;
@@ -377,6 +383,8 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
             kt[j][k] = cam.Kt[j][k];
         }
     const float* refb[2] = {p.prev + (size_t)b * 3 * HWp, p.nxt + (size_t)b * 3 * HWp};
+    const rsrc_t plane[2][3] = {{make_rsrc(refb[0], 4u * HWp), make_rsrc(refb[0] + HWp, 4u * HWp), make_rsrc(refb[0] + 2 * HWp, 4u * HWp)},
+                                {make_rsrc(refb[1], 4u * HWp), make_rsrc(refb[1] + HWp, 4u * HWp), make_rsrc(refb[1] + 2 * HWp, 4u * HWp)}};
     // weights realising the adjoint of F.pad(reflect): a border pixel's adjoint window is seen twice by its neighbour
     const float exp_to_right = (cu == 0) ? 2.f : 1.f;      // value exported to lane+1
     const float exp_to_left = (cu == W - 1) ? 2.f : 1.f;   // value exported to lane-1
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 const float rz = frcp(fmaxf(z, 1e-5f));
                 const float ix = X * rz, iy = Y * rz;   // == ((Xn+1)/2)(W-1) of grid_sample
                 float ex[3], ey[3];
-                bilinear3<GRAD>(refb[j], HWp, W, H, ix, iy, xw0[j], ex, ey);
+                bilinear3<GRAD>(plane[j], W, H, ix, iy, xw0[j], ex, ey);
                 if (GRAD) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
@@ -863,7 +871,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int make_layout(const mgn_reproj_cfg* c, Layout* L) {
     if (!c || c->B < 1 || c->H < 2 || c->W < 2 || c->n_scales < 1 || c->n_scales > MGN_MAX_SCALES) return MGN_EINVAL;
-    if ((long long)c->H * c->W > (1LL << 30)) return MGN_EINVAL;
+    if ((long long)c->H * c->W > (1LL << 28)) return MGN_EINVAL;   // 32-bit byte offsets into one image plane
     L->nstrips = (c->W + STRIP - 1) / STRIP;
     int RH = c->rows_per_wave;
     if (RH <= 0) {
