@@ -34,7 +34,7 @@ constexpr int STRIP = WAVE - 2 * HALO;  // 60 owned columns per wavefront
 constexpr int NACC = 32;                // accumulators per (block, scale)
 constexpr int NSTATE = 19;              // floats of per-pixel state kept for two rows (per scale wave)
 constexpr int NSHARE = 11;              // floats per pixel and row published by the image wave
-constexpr int RING = 3;
+constexpr int RING = 4;                 // rows t+1 (being gathered) .. t-2
 
 // accumulator slots
 constexpr int A_PSUM = 0, A_SX = 1, A_SY = 2, A_SINV = 3, A_NMASK = 4, A_NMX = 5, A_NMY = 6, A_POSE = 8;  // 8..31: [j][12]
@@ -173,11 +173,15 @@ __device__ __forceinline__ float bload(rsrc_t r, int voff_bytes, int soff_bytes)
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
 }
 
-template <bool GRAD>
-__device__ __forceinline__ void bilinear3(const rsrc_t (&plane)[3], int W, int H, float ix, float iy, float out[3], float ex[3],
-                                          float ey[3]) {
+struct Gather {       // the 12 corner values of one sample position (3 channel planes) and its fractional offsets
+    float v[3][4];   // [channel][00, 10, 01, 11]
+    float tx, ty;
+};
+// first half: corner addresses and the 12 loads (nothing waits for them here)
+__device__ __forceinline__ void bilinear3_issue(const rsrc_t (&plane)[3], int W, int H, float ix, float iy, Gather& g) {
     const float fx0 = floorf(ix), fy0 = floorf(iy);
-    const float tx = ix - fx0, ty = iy - fy0;
+    g.tx = ix - fx0;
+    g.ty = iy - fy0;
     const int xi = (int)__builtin_amdgcn_fmed3f(fx0, -2.f, (float)W);   // NaN -> -2: every corner out of range
     const int yi = (int)__builtin_amdgcn_fmed3f(fy0, -2.f, (float)H);
     const bool x0ok = (unsigned)xi < (unsigned)W, x1ok = (unsigned)(xi + 1) < (unsigned)W;
@@ -185,12 +189,22 @@ __device__ __forceinline__ void bilinear3(const rsrc_t (&plane)[3], int W, int H
     const int o00 = (yi * W + xi) * 4;
     const int a00 = x0ok ? o00 : OUT, a10 = x1ok ? o00 + 4 : OUT;
     const int a01 = x0ok ? o00 + 4 * W : OUT, a11 = x1ok ? o00 + 4 * W + 4 : OUT;
-    const float sx = 1.f - tx, sy = 1.f - ty;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        g.v[c][0] = bload(plane[c], a00, 0);
+        g.v[c][1] = bload(plane[c], a10, 0);
+        g.v[c][2] = bload(plane[c], a01, 0);
+        g.v[c][3] = bload(plane[c], a11, 0);
+    }
+}
+// second half: blend
+template <bool GRAD>
+__device__ __forceinline__ void bilinear3_finish(const Gather& g, float out[3], float ex[3], float ey[3]) {
+    const float tx = g.tx, ty = g.ty, sx = 1.f - tx, sy = 1.f - ty;
     const float w00 = sx * sy, w10 = tx * sy, w01 = sx * ty, w11 = tx * ty;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float v00 = bload(plane[c], a00, 0), v10 = bload(plane[c], a10, 0);
-        const float v01 = bload(plane[c], a01, 0), v11 = bload(plane[c], a11, 0);
+        const float v00 = g.v[c][0], v10 = g.v[c][1], v01 = g.v[c][2], v11 = g.v[c][3];
         out[c] = v00 * w00 + v10 * w10 + v01 * w01 + v11 * w11;
         if (GRAD) {
             ex[c] = (v10 - v00) * sy + (v11 - v01) * ty;
@@ -254,6 +268,13 @@ __global__ void reproj_prep(const float* cam, int cam_stride, int cam_ld, const 
 // All waves of a block touch the same image rows at the same time, so the inputs stream from HBM once.
 // ---------------------------------------------------------------------------------------------------
 constexpr int SH_SY = 0, SH_SYY = 3, SH_PU = 6, SH_WX = 8, SH_WY = 9, SH_LIVE = 10;
+
+// The per-row barrier of the march kernel.  Only LDS traffic is exchanged between the waves, so only the LDS counter is
+// drained: __syncthreads() also waits for every outstanding global load (vmcnt(0)), which would end the prefetch of the next
+// row's gathers at each row.
+__device__ __forceinline__ void row_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 template <bool GRAD>
 __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params p) {
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 }
                 m1 = m0;
             }
-            __syncthreads();
+            row_barrier();
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -412,22 +433,46 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
             cA1[j][c] = cB1[j][c] = cC1[j][c] = cA2[j][c] = cB2[j][c] = cC2[j][c] = l1g1[j][c] = 0.f;
         }
 
-    int slot = 0;  // ring slot of row t
-    // the inverse depth row is first touched by this wave (HBM latency): keep it one row ahead of its use
-    float inv_pre = invb[reflect_clamp(r0 - 2, H) * W + ucol];
+    // Software pipeline of the gathers: the vector-memory path costs ~20 cycles per wave-instruction and the 24 corner loads
+    // of a row were consumed right where they were issued, so VALU and memory phases of all waves of a block (in lock step
+    // through the row barrier) alternated instead of overlapping -- with the loads removed the kernel takes 1.4 ms, with
+    // them 2.5.  Now iteration t blends the corners of row t (issued one iteration earlier, carried in registers), then
+    // issues the loads of row t+1, and the SSIM / adjoint stages run while those are in flight.
+    Gather gth[2];
+    float y_pre[3] = {0.f, 0.f, 0.f};
+    float inv_pre = invb[reflect_clamp(r0 - 2, H) * W + ucol];   // inverse depth of row t+1, loaded one iteration ahead
+    float inv_cur = 0.f;                                         // ... of row t
     for (int t = r0 - 3; t <= rend + 1; ++t) {
-        if (t >= r0 - 2 && active) {  // wave-uniform
-            // ------------------------------ stage R: row t ------------------------------
-            const int vrow = reflect_clamp(t, H);
+        const int it = t - (r0 - 3);
+        float y0[3] = {0.f, 0.f, 0.f}, xw0[2][3];
+        // ------------------------------ stage R, second half: blend row t ------------------------------
+        if (t >= r0 - 2) {
+            float* st = ringw + (size_t)(it & (RING - 1)) * NSTATE * WAVE;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float ex[3], ey[3];
+                bilinear3_finish<GRAD>(gth[j], xw0[j], ex, ey);
+                if (GRAD) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        st[(j * 9 + c) * WAVE] = ex[c];
+                        st[(j * 9 + 3 + c) * WAVE] = ey[c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) y0[c] = y_pre[c];
+        }
+        const float inv0 = inv_cur;
+        // ------------------------------ stage R, first half: geometry and loads of row t+1 ------------------------------
+        if (t + 1 <= rend + 1) {  // wave-uniform
+            const int vrow = reflect_clamp(t + 1, H);
             const int off = vrow * W + ucol;
             const float fv = (float)vrow;
-            float y0[3], xw0[2][3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) y0[c] = imgb[c * HWp + off];
-            const float inv0 = inv_pre;
-            inv_pre = invb[reflect_clamp(t + 1, H) * W + ucol];
-            const float d = frcp(fmaxf(inv0, 1e-6f));  // depth.py:15
-            float* st = ringw + (size_t)slot * NSTATE * WAVE;
+            const float inv_n = inv_pre;
+            inv_pre = invb[reflect_clamp(t + 2, H) * W + ucol];
+            const float d = frcp(fmaxf(inv_n, 1e-6f));  // depth.py:15
+            float* st = ringw + (size_t)((it + 1) & (RING - 1)) * NSTATE * WAVE;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float a0 = base[j][0] + col1[j][0] * fv, a1 = base[j][1] + col1[j][1] * fv, a2 = base[j][2] + col1[j][2] * fv;
@@ -435,21 +480,19 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 const bool zf = z >= 1e-5f;             // camera.py:172 clamp(min=1e-5)
                 const float rz = frcp(fmaxf(z, 1e-5f));
                 const float ix = X * rz, iy = Y * rz;   // == ((Xn+1)/2)(W-1) of grid_sample
-                float ex[3], ey[3];
-                bilinear3<GRAD>(plane[j], W, H, ix, iy, xw0[j], ex, ey);
+                bilinear3_issue(plane[j], W, H, ix, iy, gth[j]);
                 if (GRAD) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        st[(j * 9 + c) * WAVE] = ex[c];
-                        st[(j * 9 + 3 + c) * WAVE] = ey[c];
-                    }
                     st[(j * 9 + 6) * WAVE] = zf ? rz : -rz;  // rz > 0: the sign carries the clamp flag
                     st[(j * 9 + 7) * WAVE] = ix;
                     st[(j * 9 + 8) * WAVE] = iy;
                 }
             }
-            if (GRAD) st[18 * WAVE] = (inv0 >= 1e-6f) ? d : -d;  // d > 0: the sign carries "inverse depth not clamped"
-
+            if (GRAD) st[18 * WAVE] = (inv_n >= 1e-6f) ? d : -d;  // d > 0: the sign carries "inverse depth not clamped"
+#pragma unroll
+            for (int c = 0; c < 3; ++c) y_pre[c] = imgb[c * HWp + off];
+            inv_cur = inv_n;
+        }
+        if (t >= r0 - 2 && active) {  // wave-uniform
             // ------------------------------ stage S: row q = t-1 ------------------------------
             float cA0[2][3], cB0[2][3], cC0[2][3], l1g0[2][3];
 #pragma unroll
@@ -524,7 +567,7 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
             if (GRAD && t >= r0 + 2 && t - 2 < rend) {  // wave-uniform
                 const int r = t - 2;
                 const float wu = (r == 1) ? 2.f : 1.f, wd = (r == H - 2) ? 2.f : 1.f;
-                const float* sr = ringw + (size_t)((slot + 1) % RING) * NSTATE * WAVE;  // slot of row t-2
+                const float* sr = ringw + (size_t)((it + 2) & (RING - 1)) * NSTATE * WAVE;  // slot of row t-2
                 const float ds = sr[18 * WAVE];
                 const float dd_ = fabsf(ds), ddf_ = ds > 0.f ? -ds * ds : 0.f;  // d depth / d inv (0 where clamped)
                 const float fr = (float)r;
@@ -576,9 +619,8 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
 #pragma unroll
             for (int c = 0; c < 3; ++c) { y2[c] = y1[c]; y1[c] = y0[c]; }
             inv1 = inv0;
-            slot = (slot + 1) % RING;
         }
-        __syncthreads();
+        row_barrier();
     }
 
     // ---- wave reduction -> partials[bid][i][:]  (every slot written: the finalize kernels read all of them) ----
