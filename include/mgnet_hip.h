@@ -156,6 +156,11 @@ int mgn_clip_coef(const float* partials, int n_partials, float max_norm, float g
                   void* stream);
 int mgn_adam_step(float* p, const float* g, float* m, float* v, long n, const float* chunk_lr, const float* chunk_wd,
                   float beta1, float beta2, float eps, int step, const float* clip_coef, float grad_scale, void* stream);
+/* the same update with the bias corrections read from DEVICE memory: hyper = { 1/(1-beta1^step), 1/sqrt(1-beta2^step) }.
+ * No per-step host scalar is left in the launch, so it can be captured once in a hipGraph and replayed every step. */
+int mgn_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* chunk_lr, const float* chunk_wd,
+                      float beta1, float beta2, float eps, const float* hyper, const float* clip_coef, float grad_scale,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolutions as implicit GEMM on the bf16 matrix cores

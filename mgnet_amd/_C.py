@@ -15,7 +15,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -90,6 +90,7 @@ def lib():
         L.mgn_sqnorm.argtypes = [vp, cl, vp, ci, ctypes.POINTER(ci), vp]
         L.mgn_clip_coef.argtypes = [vp, ci, cf, cf, vp, vp]
         L.mgn_adam_step.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, ci, vp, cf, vp]
+        L.mgn_adam_step_dev.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, vp, vp, cf, vp]
         L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp, vp]
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
@@ -393,6 +394,13 @@ def adam_step(p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, step, coef, gra
           "mgn_adam_step")
 
 
+def adam_step_dev(p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, hyper, coef, grad_scale):
+    """Adam with the bias corrections in device memory (`hyper` = [1/(1-b1^t), 1/sqrt(1-b2^t)]): graph-capturable"""
+    check(lib().mgn_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), chunk_lr.data_ptr(),
+                                  chunk_wd.data_ptr(), beta1, beta2, eps, hyper.data_ptr(), coef.data_ptr(), grad_scale, _stream()),
+          "mgn_adam_step_dev")
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # convolution (implicit GEMM, bf16 MFMA).  Tensors are logical NCHW in channels_last memory format.
 # ---------------------------------------------------------------------------------------------------------------
@@ -625,7 +633,7 @@ class _WeightCache:
         """re-derive every registered layout from the current parameter values (one launch)"""
         for e in self.entries.values():
             w = e["ref"]()
-            if w is not None and e["ptr"] != w.data_ptr():
+            if w is None or e["ptr"] != w.data_ptr():   # a collected parameter's row must leave the table (its memory is gone)
                 self.dirty = True
                 break
         if self.dirty:

@@ -57,8 +57,12 @@ __global__ void clip_coef_kernel(const float* partials, int n, float max_norm, f
 __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, const float* __restrict__ chunk_lr,
                                                    const float* __restrict__ chunk_wd, float beta1, float beta2, float eps,
-                                                   float inv_bc1, float inv_sqrt_bc2, const float* __restrict__ clip,
-                                                   float grad_scale) {
+                                                   float inv_bc1, float inv_sqrt_bc2, const float* __restrict__ hyper,
+                                                   const float* __restrict__ clip, float grad_scale) {
+    if (hyper) {   // bias corrections of the current step from device memory (a captured launch is replayed for every step)
+        inv_bc1 = hyper[0];
+        inv_sqrt_bc2 = hyper[1];
+    }
     const float gs = grad_scale * clip[0];
     const long nv = n / 4;  // buckets are padded to CHUNK multiples, so n % 4 == 0
     for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nv; i += (long)gridDim.x * TPB) {
@@ -116,7 +120,16 @@ int mgn_adam_step(float* p, const float* g, float* m, float* v, long n, const fl
     if (!p || !g || !m || !v || n < 1 || n % CHUNK != 0 || !chunk_lr || !chunk_wd || !clip_coef || step < 1) return MGN_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, chunk_lr, chunk_wd, beta1,
-                       beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), clip_coef, grad_scale);
+                       beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), (const float*)nullptr, clip_coef, grad_scale);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* chunk_lr, const float* chunk_wd,
+                      float beta1, float beta2, float eps, const float* hyper, const float* clip_coef, float grad_scale,
+                      void* stream) {
+    if (!p || !g || !m || !v || n < 1 || n % CHUNK != 0 || !chunk_lr || !chunk_wd || !clip_coef || !hyper) return MGN_EINVAL;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, chunk_lr, chunk_wd, beta1,
+                       beta2, eps, 0.f, 0.f, hyper, clip_coef, grad_scale);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

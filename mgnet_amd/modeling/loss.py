@@ -77,7 +77,10 @@ class _ReprojLossFn(torch.autograd.Function):
         inv = [t.contiguous() for t in inv]
         poses = poses.contiguous()
         fwd = _C.reproj_loss_fwd(cfg, inv, img, prev, nxt, mask, cam, poses, want_grad=want_grad)
-        ctx.cfg, ctx.fwd, ctx.inv, ctx.img, ctx.mask = cfg, fwd, inv, img, mask
+        # (the output tensor must not be reachable from ctx: output -> grad_fn -> ctx -> output would be a reference cycle that
+        #  only the cyclic collector frees -- at an arbitrary later allocation, e.g. in the middle of a hipGraph capture)
+        ctx.cfg, ctx.inv, ctx.img, ctx.mask = cfg, inv, img, mask
+        ctx.fwd = {k: v for k, v in fwd.items() if k != "losses"}
         ctx.want_grad = want_grad
         ctx.used = False
         return fwd["losses"]

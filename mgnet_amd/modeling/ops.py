@@ -8,6 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+STAGING_USED = set()   # names of torch staging ops that actually ran on CUDA tensors (bench.py prints it)
+
 
 # ---------------------------------------------------------------------------------------------------------------
 # InPlaceABNSync (inplace_abn >= 1.1.0, not vendored in the reference; semantics recalled):
@@ -318,6 +320,12 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=Fals
             return _ConvFn.apply(x, weight, bias, stride, padding, relu, True)
         y = _ConvFn.apply(x, weight, bias, stride, padding, relu)
         return (y, x) if with_skip else y
+    if x.is_cuda and not os.environ.get("MGNET_ALLOW_TORCH_STAGING"):
+        raise NotImplementedError(
+            f"conv2d: no HIP kernel for {x.dtype} activations with {tuple(weight.shape)} weights (the conv kernels are bf16, Cin % 32 == 0 "
+            "or the channel-padded stems): enable SOLVER.AMP.ENABLED, or set MGNET_ALLOW_TORCH_STAGING=1 to run this layer on "
+            "torch's convolution (staging, not the product path)")
+    STAGING_USED.add("conv2d:" + str(x.dtype).replace("torch.", ""))
     w = weight.to(x.dtype)
     b = None if bias is None else bias.to(x.dtype)
     y = F.conv2d(x, w, b, stride=stride, padding=padding)

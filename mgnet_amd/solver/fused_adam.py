@@ -19,6 +19,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._v = [torch.zeros_like(b["flat_g"]) for b in reducer.buckets]
         self._lr_dev = [torch.zeros(b["flat_g"].numel() // self.chunk, device=dev) for b in reducer.buckets]
         self._wd_dev = [torch.zeros(b["flat_g"].numel() // self.chunk, device=dev) for b in reducer.buckets]
+        self._hyper = torch.ones(2, device=dev)   # [1/(1-b1^t), 1/sqrt(1-b2^t)] of the current step
         self._stager = _C.PinnedStager()
         self._partials = torch.zeros(1024 * len(reducer.buckets), device=dev)
         self._coef = torch.zeros(2, device=dev)
@@ -27,17 +28,28 @@ class FusedAdam(torch.optim.Optimizer):
         self._reps = [np.array([(p.numel() + self.chunk - 1) // self.chunk for p in b["params"]]) for b in reducer.buckets]
 
     def _upload_tables(self):
+        """per-step host values -> the STATIC device tables the kernels read (lr / weight decay per chunk, bias corrections);
+        staged through pinned memory, stream-ordered, no host stall.  Separate from the launches so that a captured step
+        (hipGraph) only needs this small upload before each replay."""
+        g0 = self.param_groups[0]
         for k, b in enumerate(self.reducer.buckets):
             lr = np.repeat(np.array([self._group_of[p]["lr"] for p in b["params"]], np.float32), self._reps[k])
             wd = np.repeat(np.array([self._group_of[p]["weight_decay"] or 0.0 for p in b["params"]], np.float32), self._reps[k])
             tab = self._stager.stage(torch.from_numpy(np.stack([lr, wd])), self._lr_dev[k].device, slot=k)   # (event-guarded pinned ring)
-            self._lr_dev[k], self._wd_dev[k] = tab[0], tab[1]
+            self._lr_dev[k].copy_(tab[0])
+            self._wd_dev[k].copy_(tab[1])
+        bc1, bc2 = 1.0 - g0["betas"][0] ** self._t, 1.0 - g0["betas"][1] ** self._t
+        hy = self._stager.stage(torch.tensor([1.0 / bc1, 1.0 / np.sqrt(bc2)], dtype=torch.float32), self._hyper.device, slot="hyper")
+        self._hyper.copy_(hy)
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        assert closure is None
+    def prepare_step(self):
+        """host part of a step (step count, tables); `launch_step` is the device part"""
         self._t += 1
         self._upload_tables()
+
+    @torch.no_grad()
+    def launch_step(self):
+        """clip + Adam + weight-layout refresh: launches only (what a captured graph contains)"""
         grad_scale = 1.0 / self.reducer.world
         n = 0
         for b in self.reducer.buckets:
@@ -45,10 +57,16 @@ class FusedAdam(torch.optim.Optimizer):
         _C.clip_coef(self._partials, n, self.max_grad_norm, grad_scale, self._coef)
         g0 = self.param_groups[0]
         for k, b in enumerate(self.reducer.buckets):
-            _C.adam_step(b["flat_p"], b["flat_g"], self._m[k], self._v[k], self._lr_dev[k], self._wd_dev[k],
-                         g0["betas"][0], g0["betas"][1], g0["eps"], self._t, self._coef, grad_scale)
+            _C.adam_step_dev(b["flat_p"], b["flat_g"], self._m[k], self._v[k], self._lr_dev[k], self._wd_dev[k],
+                             g0["betas"][0], g0["betas"][1], g0["eps"], self._hyper, self._coef, grad_scale)
         # the kernel rewrote the flat parameter buffers behind torch's version counters: re-derive the bf16 conv layouts
         _C.weight_cache.refresh()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        self.prepare_step()
+        self.launch_step()
 
     # ---- torch.optim.Adam-compatible (de)serialisation: the reference's `.pth` "optimizer" entry ---------------------
     def _slices(self):

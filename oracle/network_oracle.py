@@ -113,7 +113,7 @@ def pose_cnn(sd, x):  # layers.py:155-167
 def ohem_ce(logits, labels, weights, ignore, thr, n_min):  # loss.py:67-81 (with the full sort, as written)
     pl = (F.cross_entropy(logits, labels, ignore_index=ignore, reduction="none") * weights).contiguous().view(-1)
     pl, _ = torch.sort(pl, descending=True)
-    t = -torch.log(torch.tensor(thr, dtype=torch.float))
+    t = -torch.log(torch.tensor(thr, dtype=torch.float, device=pl.device))
     pl = pl[pl > t] if pl[n_min] > t else pl[:n_min]
     return pl.mean()
 
@@ -124,19 +124,21 @@ class _ReprojOracle(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, prev, nxt, mask, K, poses, *inv):
         import oracle
-        npf = lambda t: t.detach().numpy()
+        dev = img.device   # (tensors of any device / dtype: evaluated on the host in fp32, results returned where they came from)
+        npf = lambda t: t.detach().cpu().numpy() if t.dtype == torch.bool else t.detach().float().cpu().numpy()
         r = oracle.reproj_loss([npf(x) for x in inv], npf(img), npf(prev), npf(nxt), None if mask is None else npf(mask),
                                npf(K), npf(poses), g_photo=1.0, g_smooth=0.0)
         r2 = oracle.reproj_loss([npf(x) for x in inv], npf(img), npf(prev), npf(nxt), None if mask is None else npf(mask),
                                 npf(K), npf(poses), g_photo=0.0, g_smooth=1.0)
-        ctx.gp = ([torch.from_numpy(a) for a in r["d_inv"]], torch.from_numpy(r["d_poses"]))
-        ctx.gs = [torch.from_numpy(a) for a in r2["d_inv"]]
-        return torch.tensor([float(r["loss_photometric"]), float(r["loss_smoothness"])])
+        ctx.gp = ([torch.from_numpy(a).to(dev) for a in r["d_inv"]], torch.from_numpy(r["d_poses"]).to(dev))
+        ctx.gs = [torch.from_numpy(a).to(dev) for a in r2["d_inv"]]
+        ctx.dt = [x.dtype for x in inv] + [poses.dtype]
+        return torch.tensor([float(r["loss_photometric"]), float(r["loss_smoothness"])], device=dev)
 
     @staticmethod
     def backward(ctx, g):
-        d_inv = [g[0] * a + g[1] * b for a, b in zip(ctx.gp[0], ctx.gs)]
-        return (None, None, None, None, None, g[0] * ctx.gp[1]) + tuple(d_inv)
+        d_inv = [(g[0] * a + g[1] * b).to(dt) for a, b, dt in zip(ctx.gp[0], ctx.gs, ctx.dt)]
+        return (None, None, None, None, None, (g[0] * ctx.gp[1]).to(ctx.dt[-1])) + tuple(d_inv)
 
 
 def pad32(t):
@@ -148,8 +150,9 @@ def mgnet_losses(sd, batch, *, pixel_mean, pixel_std, with_panoptic=True, with_d
                  ohem_threshold=0.7, ohem_n_min=100000, ignore_value=255, sem_weight=1.0, center_weight=200.0,
                  offset_weight=0.01):
     """MGNet.forward, training branch (mg_net.py:249-373) on CPU tensors.  sd: name -> fp32 tensor (requires_grad ok)."""
-    mean = torch.tensor([m / 255.0 for m in pixel_mean]).view(-1, 1, 1)
-    std = torch.tensor([s / 255.0 for s in pixel_std]).view(-1, 1, 1)
+    dev = batch[0]["image"].device
+    mean = torch.tensor([m / 255.0 for m in pixel_mean], device=dev).view(-1, 1, 1)
+    std = torch.tensor([s / 255.0 for s in pixel_std], device=dev).view(-1, 1, 1)
     stack = lambda key, f=lambda t: t: torch.stack([pad32(f(x[key])) for x in batch], 0)
     net_in = lambda key: (stack(key, lambda t: t.float() / 255.0) - mean) / std
     out = {}

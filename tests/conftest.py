@@ -42,6 +42,13 @@ def golden_case_inputs(name):
 REPROJ_CASES = ["rand_small", "smooth", "identity_pose", "oob_clamp", "no_mask_odd"]
 
 
+@pytest.fixture
+def torch_staging(monkeypatch):
+    """fp32 activations on the GPU: the product's convolution kernels are bf16, so an fp32 network runs its convolutions on torch's
+    (staging); mgnet_amd refuses that unless explicitly allowed -- tests that exercise fp32 accuracy of everything else opt in"""
+    monkeypatch.setenv("MGNET_ALLOW_TORCH_STAGING", "1")
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _build_oracle():
     import oracle

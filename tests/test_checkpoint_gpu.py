@@ -7,7 +7,7 @@ from test_network_cpu import small_model
 pytestmark = pytest.mark.gpu
 
 
-def test_resume_reproduces_the_trajectory(tmp_path):
+def test_resume_reproduces_the_trajectory(tmp_path, torch_staging):
     from mgnet_amd.data import synthetic_batch
     from mgnet_amd.engine import Trainer
     from mgnet_amd.solver.fused_adam import FusedAdam

@@ -80,7 +80,7 @@ def test_view_synthesis_matches_reference_with_gradients(gold):
         view_synthesis(_t(gold["in_ref"], True), d, ref_cam, cam).sum().backward()
 
 
-@pytest.mark.parametrize("case", REPROJ_CASES + ["survey_192x640"])
+@pytest.mark.parametrize("case", REPROJ_CASES)
 def test_view_synthesis_reproduces_loss_fixture_stages(case):
     """loss.py:156-167 warp_ref_image, stage by stage: Pose.from_vec -> Camera(K, Tcw) -> view_synthesis per scale"""
     from mgnet.geometry import Camera, Pose, inv2depth, view_synthesis
@@ -108,7 +108,7 @@ def test_view_synthesis_full_size_properties():
     depth = torch.rand(B, 1, H, W, device=DEV, generator=g) * 50 + 1
     K = torch.tensor([[2262.52, 0, 1096.98], [0, 2265.30, 513.137], [0, 0, 1]], device=DEV).repeat(B, 1, 1)
     same = view_synthesis(img, depth, Camera(K), Camera(K))
-    assert float((same - img).abs().max()) < 2e-4           # |ix - u| <= ~1e-4 px round-off times slope <= 1
+    assert float((same - img).abs().max()) < 5e-4           # |ix - u| <= ~2e-4 px round-off (u up to 2047) times slope <= 1
     depth1 = torch.ones(B, 1, H, W, device=DEV)
     vec = torch.zeros(B, 6, device=DEV)
     vec[:, 0] = 1.0 / 2262.52                               # X -> X + fx * tx / depth = one pixel at depth 1

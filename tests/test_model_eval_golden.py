@@ -48,7 +48,7 @@ def test_host_mirror_eval_outputs_match_reference_cpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("amp", [False, True])
-def test_eval_outputs_match_reference_gpu(amp):
+def test_eval_outputs_match_reference_gpu(amp, torch_staging):
     single, msc = run("cuda", amp)
     check(single, msc, rtol=8e-2 if amp else 5e-3, atol_frac=4e-2 if amp else 1e-3, inverse_depth=amp)
 

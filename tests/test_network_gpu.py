@@ -19,7 +19,7 @@ def _randomise(m):
 
 
 @pytest.mark.parametrize("amp", [False, True])
-def test_full_step_losses_match_oracle(amp):
+def test_full_step_losses_match_oracle(amp, torch_staging):
     from mgnet_amd.data import synthetic_batch
     from oracle import network_oracle as NO
 
@@ -41,7 +41,7 @@ def test_full_step_losses_match_oracle(amp):
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
 
 
-def test_training_reduces_loss_on_fixed_batch():
+def test_training_reduces_loss_on_fixed_batch(torch_staging):
     """A few optimizer steps on one fixed synthetic batch: the total loss must go down (Adam, clip 0.01, poly LR)."""
     from mgnet_amd.data import synthetic_batch
     from mgnet_amd.engine import Trainer

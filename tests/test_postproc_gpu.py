@@ -138,7 +138,7 @@ def test_depth_argument_checks():
 
 
 # ---- the inference branch of MGNet.forward (mg_net.py:375-425) ----------------------------------------------------------
-def test_eval_forward_runs_the_post_processing():
+def test_eval_forward_runs_the_post_processing(torch_staging):
     """model.eval()(batch) -> per-image dicts; the panoptic ids / metric depth equal the oracle's post-processing of the
     very head outputs the model produced (checks the wiring: argmax, config values, road mask, filtered classes)."""
     from test_network_cpu import make_cfg

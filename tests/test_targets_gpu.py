@@ -114,7 +114,7 @@ def test_errors_are_loud():
         gen(ignore_label=255, thing_ids=[])(pan, [])
 
 
-def test_generated_targets_feed_the_training_step():
+def test_generated_targets_feed_the_training_step(torch_staging):
     """Label images -> device target maps -> MGNet.forward: the per-image dicts hold slices of the batched maps, which the
     batch assembly takes without a copy; losses equal those with the oracle's (host-generated) maps."""
     from test_network_cpu import small_model
