@@ -201,10 +201,31 @@ def full_step_bench(args, world, rank, dev):
             depth_loss.prof_events = ev.pairs[k]
             trainer.run_step(batch)
         fence()
+    dist_info = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+        # what the exchange costs: a few more steps WITHOUT the gradient all-reduce (measurement only, after the timed region;
+        # the ranks' weights drift apart from here on, nothing is timed afterwards)
+        from mgnet_amd.modeling import ops as _ops
+        n_ar, n_bn = trainer.reducer.collectives, _ops.SYNCBN_COLLECTIVES[0]
+        trainer.run_step(batch)
+        n_ar, n_bn = trainer.reducer.collectives - n_ar, _ops.SYNCBN_COLLECTIVES[0] - n_bn
+        trainer.reducer.enabled = False
+        n_extra = max(3, min(10, args.steps))
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n_extra):
+            trainer.run_step(batch)
+        fence()
+        t_no = torch.tensor([(time.perf_counter() - t1) / n_extra], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t_no, op=torch.distributed.ReduceOp.MAX)
+        dist_info = {"backend": torch.distributed.get_backend(), "rccl_world_size": torch.distributed.get_world_size(),
+                     "grad_allreduce_calls_per_step": n_ar, "grad_bytes_per_step": trainer.reducer.grad_bytes(),
+                     "syncbn_collectives_per_step": n_bn,
+                     "ms_per_step_without_grad_allreduce": round(float(t_no.item()) * 1e3, 3),
+                     "exposed_grad_allreduce_ms_per_step": round(dt / args.steps * 1e3 - float(t_no.item()) * 1e3, 3)}
     if rank == 0:
         kern_ms = float(np.median(ev.elapsed_ms()))
         npx = B * H * W
@@ -230,7 +251,8 @@ def full_step_bench(args, world, rank, dev):
                        "frames_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
                        "parallelism": f"dp{world}", "step_execution": mode + (" (one hipGraph replay per step)" if mode == "graph" else " (launches issued from Python)"),
                        "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2), "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
-                       "losses": {k: round(float(v.detach()), 5) for k, v in last.items()}},
+                       "losses": {k: round(float(v.detach()), 5) for k, v in last.items()},
+                       "torch_staging_ops": sorted(__import__("mgnet_amd.modeling.ops", fromlist=["x"]).STAGING_USED)},
             "roofline": {"bound": "hbm", "kernel": "reproj_march<true> (fused reprojection loss + photometric gradient)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -239,6 +261,8 @@ def full_step_bench(args, world, rank, dev):
                                        (f"{args.steps} eager steps run right after the graph-replayed timed region" if mode == "graph"
                                         else "inside the timed steps")},
         }
+        if dist_info is not None:
+            line["config"]["distributed"] = dist_info
         line["roofline_mfma"] = conv_roofline(dev, B)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(H, W, model.state_dict(), cfg)
@@ -285,11 +309,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # one rank per GPU.  (MGNET_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than ranks --
+    # ranks then share devices, which RCCL refuses; a functional check only, never a measurement)
+    backend = os.environ.get("MGNET_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)          # before the process group: RCCL binds the communicator to the current device
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from mgnet_amd import _C
     from mgnet_amd.modeling.loss import _ReprojLossFn

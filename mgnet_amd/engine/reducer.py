@@ -35,6 +35,13 @@ class GradReducer:
         if cur:
             self._seal(cur, flatten_params)
         self._handles = []
+        self._next = 0             # buckets are reduced in index order on every rank (collectives must be issued in the same order)
+        self.collectives = 0       # all-reduce calls issued so far (bench.py reports it)
+        self.enabled = True        # False: skip the exchange (bench.py's "step without all-reduce" leg)
+        if self.world > 1 and flatten_params:
+            # DDP broadcasts rank 0's parameters at construction; same here, on the flat buffers
+            for b in self.buckets:
+                dist.broadcast(b["flat_p"], src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         for p in params:
             p.register_post_accumulate_grad_hook(self._hook)
 
@@ -66,6 +73,7 @@ class GradReducer:
         """Gradients are not zeroed: `.grad` is dropped, so autograd hands over each freshly computed gradient without an
         accumulate kernel per parameter; `_hook` packs a bucket's gradients into its flat buffer with one multi-tensor
         copy when the bucket is complete (parameters that got no gradient are zero-filled in `finish`)."""
+        self._next = 0
         for b in self.buckets:
             b["pending"] = b["n"]
             b["seen"] = set()
@@ -98,16 +106,27 @@ class GradReducer:
         b["pending"] -= 1
         if b["pending"] == 0:
             self._pack(b)
-            if self.world > 1:
+            self._launch_ready()
+
+    def _launch_ready(self, force=False):
+        """Start the all-reduce of every complete bucket that is next in INDEX order (torch DDP's rule): a rank whose gradients
+        become ready in another order -- a data-dependent branch, a loss term missing from its batch -- still issues the same
+        sequence of collectives as the others.  force: the rest of the buckets (finish(): incomplete ones are packed first)."""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b["pending"] > 0:
+                if not force:
+                    return
+                self._pack(b)   # unused parameters this iteration: zero-filled, still reduced to stay in lock step
+            if self.world > 1 and self.enabled:
                 self._handles.append(dist.all_reduce(b["flat_g"], group=self.group, async_op=True))
+                self.collectives += 1
+            self._next += 1
 
     def finish(self):
         """Pack / launch the buckets whose parameters did not all get a gradient this step, wait, average."""
-        for b in self.buckets:
-            if b["pending"] > 0:  # unused parameters this iteration: zero-filled, still reduced to stay in lock step
-                self._pack(b)
-                if self.world > 1:
-                    self._handles.append(dist.all_reduce(b["flat_g"], group=self.group, async_op=True))
+        self._launch_ready(force=True)
+        self._next = 0
         if self.world > 1:
             for h in self._handles:
                 h.wait()

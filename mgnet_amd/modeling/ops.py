@@ -9,6 +9,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 STAGING_USED = set()   # names of torch staging ops that actually ran on CUDA tensors (bench.py prints it)
+SYNCBN_COLLECTIVES = [0]   # cross-rank statistics exchanges issued so far (bench.py reports the count per step)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -42,6 +43,7 @@ def _gather_stats(stats, world, group):
     """[world, 3, C] statistics of all ranks.  RCCL: one all_gather_into_tensor (no per-rank output list and its copies);
     other backends (gloo in the CPU tests): the list form."""
     gathered = torch.empty((world,) + tuple(stats.shape), dtype=stats.dtype, device=stats.device)
+    SYNCBN_COLLECTIVES[0] += 1
     if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(gathered.view(-1), stats.contiguous().view(-1), group=group)
     else:
@@ -99,6 +101,7 @@ class _IABNFn(torch.autograd.Function):
             raise NotImplementedError("backward through eval-mode InPlaceABNSync is not on the training path")
         sums, d_weight, d_bias = _C.iabn_bwd_reduce(y, dy, M, C, w32, b32, eps, act, slope)
         if world > 1:
+            SYNCBN_COLLECTIVES[0] += 1
             dist.all_reduce(sums, group=group)
         _C.iabn_bwd_apply(y, dy, dx, M, C, w32, b32, coef[2:], sums, total, eps, act, slope)
         return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None
@@ -143,6 +146,7 @@ class _AbnPoolFn(torch.autograd.Function):
         # equal the sums over the pooled tensors
         sums, d_weight, d_bias = _C.iabn_bwd_reduce(y, dy, y.numel() // C, C, w32, b32, eps, act, slope)
         if world > 1:
+            SYNCBN_COLLECTIVES[0] += 1
             dist.all_reduce(sums, group=group)
         dx = _C.abn_maxpool_bwd(x, dy, arg, coef, w32, b32, sums, total, eps, act, slope)
         return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None
@@ -184,6 +188,7 @@ class _AbnAddReluFn(torch.autograd.Function):
         dm = _C.relu_mask_bwd(_cl(g), y)   # gradient of both summands
         sums, d_weight, d_bias = _C.iabn_bwd_reduce_x(x, dm, M, C, w32, b32, coef, eps, 0, 0.01)
         if world > 1:
+            SYNCBN_COLLECTIVES[0] += 1
             dist.all_reduce(sums, group=group)
         dx = torch.empty_like(x)
         _C.iabn_bwd_apply_x(x, dm, dx, M, C, w32, b32, coef, sums, total, eps, 0, 0.01)
