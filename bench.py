@@ -153,7 +153,8 @@ def full_step_bench(args, world, rank, dev):
     add_mgnet_config(cfg)
     cfg.merge_from_file(os.path.join(ROOT, "configs", "bench-c4-cityscapes-videosequence.yaml"))
     cfg.merge_from_list(["MODEL.DEVICE", str(dev), "SOLVER.IMS_PER_BATCH", B * world,
-                         "MODEL.SEM_SEG_HEAD.OHEM_N_MIN", min(524287, B * H * W // 4 - 1)])
+                         "MODEL.SEM_SEG_HEAD.OHEM_N_MIN", min(524287, B * H * W // 4 - 1),
+                         "SOLVER.AMP.DTYPE", {"bf16": "bfloat16", "fp16": "float16"}[args.dtype]])
     torch.manual_seed(0)  # identical initial weights on every rank (DDP broadcasts rank 0's; same seed is equivalent)
     model = build_model(cfg)
     trainer = Trainer(cfg, model)
@@ -243,8 +244,8 @@ def full_step_bench(args, world, rank, dev):
             "metric": "training img/s at 1024x2048 Cityscapes, 1/2/4/8 MI355X; reprojection-loss HBM GB/s",
             "value": round(img_s, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"MGNet-Cityscapes-VideoSequence recipe (BASELINE C4/C5): full multi-task training step "
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"MGNet-Cityscapes-VideoSequence recipe (BASELINE {'C5: fp16 + dynamic loss scaling' if args.dtype == 'fp16' else 'C4/C5'}): full multi-task training step "
                                    f"(2x ResNet-18 + 3 decoders/heads fwd+bwd, OHEM CE, centre/offset, photometric "
                                    f"reprojection + smoothness, uncertainty weighting, grad all-reduce, clip, Adam), "
                                    f"{B} frames/GPU of {H}x{W}",
@@ -296,6 +297,9 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="16-bit activation format of the trunk: bf16 (default) or the reference's AMP format fp16 with dynamic loss "
+                         "scaling (BASELINE C5)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the captured step as a hipGraph (auto: with 1 GPU); off = issue every launch from Python")
     ap.add_argument("--fwd-only", action="store_true", help="diagnostic: loss only (no gradient); NOT the benchmark")

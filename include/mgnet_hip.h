@@ -161,6 +161,16 @@ int mgn_adam_step(float* p, const float* g, float* m, float* v, long n, const fl
 int mgn_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* chunk_lr, const float* chunk_wd,
                       float beta1, float beta2, float eps, const float* hyper, const float* clip_coef, float grad_scale,
                       void* stream);
+/* Dynamic loss scaling for fp16 activations -- torch.cuda.amp.GradScaler as used by detectron2's AMPTrainer
+ * (tools/train_net.py:162), evaluated on the device.  The gradients in the buckets are `S` times the true ones
+ * (the caller multiplied the loss by scaler_state[0] before backward).  After mgn_sqnorm:
+ *   coef_norm_found = { clip coefficient / S, true gradient norm, found_inf (1 | 0) }   (coef[0] = 0 when found_inf)
+ *   scaler_state    = { S, clean steps since the last growth, optimizer steps taken }: found_inf -> S / 2 (>= 1), else
+ *                     step count + 1 and S * 2 after `growth_interval` clean steps (GradScaler defaults: 65536, 2000)
+ *   hyper           = Adam bias corrections for the (possibly unchanged) step count, consumed by mgn_adam_step_dev,
+ *                     which leaves parameters and moments untouched when coef_norm_found[2] != 0 (3 floats needed there). */
+int mgn_clip_coef_scaled(const float* partials, int n_partials, float max_norm, float grad_scale, float beta1, float beta2,
+                         int growth_interval, float* scaler_state, float* hyper, float* coef_norm_found, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolutions as implicit GEMM on the bf16 matrix cores
@@ -439,6 +449,79 @@ int mgn_reconstruct_bwd(const float* depth, const float* A, const float* t, cons
 int mgn_project_fwd(const float* points, const float* A, const float* t, int B, int H, int W, float* coords, void* stream);
 int mgn_project_bwd(const float* points, const float* A, const float* t, const float* g_coords, int B, int H, int W,
                     float* d_points, float* partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * IEEE fp16 activations -- the reference's AMP format (configs/MGNet-*.yaml SOLVER.AMP.ENABLED -> torch.cuda.amp: fp16 +
+ * GradScaler, tools/train_net.py:162).  Every entry point above that reads or writes 16-bit activations has a twin with the
+ * suffix _f16, identical in signature and semantics, in which "bf16" reads "IEEE fp16" (weight layouts included:
+ * v_mfma_f32_32x32x16_f16 instead of ..._bf16, round-to-nearest-even conversions, overflow -> inf).  For the mgn_iabn_*
+ * functions the dtype code 1 then means fp16.  Built from the same sources (csrc/x_f16.hip = csrc/x.hip with csrc/h16.h
+ * switched to fp16).
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_weight_layout_f16(const float* w_oihw, void* out_h16, int Cout, int Cin, int KH, int KW, int mode, int Cp,
+    int cout_pad /* > Cout: output channels zero-padded to cout_pad in the layout (few-class predictors) */, void*
+    stream);
+int mgn_weight_layout_batch_f16(const void* table_dev, int n_entries, long total_blocks, void* stream);
+int mgn_conv_igemm_f16(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin,
+    int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, const void*
+    residual /* bf16 [N,OH,OW,Cout] added before rounding (the gradient of a second branch of the same tensor, e.g.
+    the ResNet shortcut), or NULL */, void* stream);
+int mgn_conv_wgrad_f16(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW,
+    int Cout, int KH, int KW, int stride, int pad, int oihw_cin /* >0: dw is [Cout][oihw_cin][KH][KW] */, void*
+    workspace, size_t workspace_bytes, void* stream);
+int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);
+int mgn_abn_add_relu_fwd_f16(const void* x, const float* scale, const float* offset, const void* shortcut, void* y,
+    long M, int C, void* stream);
+int mgn_relu_mask_bwd_f16(const void* dy, const void* y, void* dx, long n_elems, void* stream);
+int mgn_colsum_f16(const void* x, const void* x2 /*nullable*/, int N, long HW, int C, float scale, float* out,
+    float* workspace, size_t workspace_bytes /* >= N*64*C*4 */, void* stream);
+int mgn_bcast_rows_f16(const float* g, int N, long HW, int C, float scale, void* dx, void* stream);
+int mgn_scale_channels_f16(const void* x, const float* s, int N, long HW, int C, int mode, const float* add /*
+    nullable: y += add[n,c] (the pooled branch of the attention backward) */, void* y, void* stream);
+int mgn_nearest_fwd_f16(const void* x, int N, int h, int w, int H, int W, int C, void* y, void* stream);
+int mgn_nearest_bwd_f16(const void* dy, int N, int h, int w, int H, int W, int C, void* dx, void* stream);
+int mgn_abn_maxpool_fwd_f16(const void* x_h16, const float* scale, const float* offset, int activation, float slope,
+    void* y_h16, uint8_t* argmax, int N, int IH, int IW, int C, void* stream);
+int mgn_abn_maxpool_bwd_f16(const void* x_h16, const void* dpool_h16, const uint8_t* argmax, void* dx_h16, const
+    float* scale, const float* offset, const float* weight, const float* bias, const float* rstd, const float* sums,
+    float total_count, float eps, int activation, float slope, int N, int IH, int IW, int C, void* stream);
+int mgn_maxpool3x3s2_fwd_f16(const void* x_h16, void* y_h16, uint8_t* argmax, int N, int IH, int IW, int C, void*
+    stream);
+int mgn_maxpool3x3s2_bwd_f16(const void* dy_h16, const uint8_t* argmax, void* dx_h16, int N, int IH, int IW, int C,
+    void* stream);
+int mgn_upce_fwd_f16(const void* logits_h16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K,
+    const long* labels, const float* weights, int ignore, float thr, float* ce_map, float* partials, float* sums3,
+    void* stream);
+int mgn_upce_bwd_f16(const void* logits_h16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K,
+    int Kp, const long* labels, const float* weights, int ignore, const float* ce_map, const float* sel3, const
+    float* gout, float* dlogits, void* stream);
+int mgn_ins_loss_fwd_f16(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_h16, long osb,
+    long osh, long osw, int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot, const
+    float* ow, float oscale, float* partials, float* out4, void* stream);
+int mgn_ins_loss_bwd_f16(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_h16, long osb,
+    long osh, long osw, int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot, const
+    float* ow, float oscale, const float* out4, const float* gout2, float* dco, void* stream);
+int mgn_prep_input_f16(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
+    const float* pixel_std3, void* out_h16, int Cp, void* stream);
+int mgn_iabn_stats_f16(const void* x, int dtype, long M, int C, float* stats /*[3][C]: count, mean, M2*/, void*
+    workspace, size_t workspace_bytes, void* stream);
+int mgn_iabn_train_coeffs_f16(const void* x, int dtype, long M, int C, const float* weight, const float* bias, float
+    eps, float momentum, float* running_mean, float* running_var, float* coef /*[4][C]*/, void* workspace, size_t
+    workspace_bytes, void* stream);
+int mgn_iabn_apply_f16(const void* x, void* y /*may alias x*/, int dtype, long M, int C, const float* scale, const
+    float* offset, int activation, float slope, void* stream);
+int mgn_iabn_bwd_reduce_f16(const void* y, const void* dy, int dtype, long M, int C, const float* weight, const
+    float* bias, float eps, int activation, float slope, float* sums /*[2][C]*/, float* dwb /*nullable [2][C]:
+    d_weight, d_bias of this rank*/, void* workspace, size_t workspace_bytes, void* stream);
+int mgn_iabn_bwd_reduce_x_f16(const void* x, const void* dy, int dtype, long M, int C, const float* weight, const
+    float* bias, const float* scale, const float* offset, float eps, int activation, float slope, float* sums,
+    float* dwb, void* ws, size_t ws_bytes, void* stream);
+int mgn_iabn_bwd_apply_f16(const void* y, const void* dy, void* dx /*may alias dy*/, int dtype, long M, int C, const
+    float* weight, const float* bias, const float* saved, const float* sums, float total_count, float eps, int
+    activation, float slope, void* stream);
+int mgn_iabn_bwd_apply_x_f16(const void* x, const void* dy, void* dx, int dtype, long M, int C, const float* weight,
+    const float* bias, const float* scale, const float* offset, const float* saved, const float* sums, float
+    total_count, float eps, int activation, float slope, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -26,6 +26,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32",
            "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
            "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd"]
+SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_wgrad', 'mgn_add_relu_fwd', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
 DEPTH_MAX_FILTER_IDS = 16
 
 
@@ -59,6 +60,14 @@ class ReprojCfg(ctypes.Structure):
 
 
 _lib = None
+H16 = (torch.bfloat16, torch.float16)   # the 16-bit activation formats: bf16 entry points, or their _f16 twins (csrc/h16.h)
+F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_wgrad', 'mgn_add_relu_fwd', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']
+
+
+def _fn(name, t):
+    """entry point `name` for the activation format of tensor `t` (or of a dtype): fp16 -> the `_f16` twin"""
+    dt = t if isinstance(t, torch.dtype) else t.dtype
+    return getattr(lib(), name + "_f16") if dt == torch.float16 else getattr(lib(), name)
 
 
 def lib():
@@ -91,6 +100,7 @@ def lib():
         L.mgn_clip_coef.argtypes = [vp, ci, cf, cf, vp, vp]
         L.mgn_adam_step.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, ci, vp, cf, vp]
         L.mgn_adam_step_dev.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, vp, vp, cf, vp]
+        L.mgn_clip_coef_scaled.argtypes = [vp, ci, cf, cf, cf, cf, ci, vp, vp, vp, vp]
         L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp, vp]
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
@@ -143,6 +153,9 @@ def lib():
         L.mgn_project_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
+        for n in F16_TWINS:
+            getattr(L, n + "_f16").restype = ci
+            getattr(L, n + "_f16").argtypes = getattr(L, n).argtypes
         _lib = L
     return _lib
 
@@ -281,16 +294,16 @@ def _iabn_ws(device):
 def _act_dtype(t):
     if t.dtype == torch.float32:
         return 0
-    if t.dtype == torch.bfloat16:
+    if t.dtype in H16:   # 1 = "the 16-bit format of the entry point": bf16, or fp16 in the _f16 twins
         return 1
-    raise ValueError(f"activations must be float32 or bfloat16, got {t.dtype}")
+    raise ValueError(f"activations must be float32, bfloat16 or float16, got {t.dtype}")
 
 
 def iabn_stats(x2d_like, M, C):
     """x: channels-last activation storage -> stats[3,C] = (count, mean, M2) of this rank."""
     stats = torch.empty((3, C), dtype=torch.float32, device=x2d_like.device)
     ws = _iabn_ws(x2d_like.device)
-    check(lib().mgn_iabn_stats(x2d_like.data_ptr(), _act_dtype(x2d_like), M, C, stats.data_ptr(), ws.data_ptr(),
+    check(_fn("mgn_iabn_stats", x2d_like)(x2d_like.data_ptr(), _act_dtype(x2d_like), M, C, stats.data_ptr(), ws.data_ptr(),
                                ws.numel() * 4, _stream()), "mgn_iabn_stats")
     return stats
 
@@ -299,7 +312,7 @@ def iabn_train_coeffs(x, M, C, weight, bias, eps, momentum, running_mean, runnin
     """single-rank training forward: batch statistics -> coef[4,C] = (scale, offset, mean, rstd) in one launch"""
     out = torch.empty((4, C), dtype=torch.float32, device=x.device)
     ws = _iabn_ws(x.device)
-    check(lib().mgn_iabn_train_coeffs(x.data_ptr(), _act_dtype(x), M, C, weight.data_ptr(), bias.data_ptr(), eps, momentum,
+    check(_fn("mgn_iabn_train_coeffs", x)(x.data_ptr(), _act_dtype(x), M, C, weight.data_ptr(), bias.data_ptr(), eps, momentum,
                                       None if running_mean is None else running_mean.data_ptr(),
                                       None if running_var is None else running_var.data_ptr(), out.data_ptr(),
                                       ws.data_ptr(), ws.numel() * 4, _stream()), "mgn_iabn_train_coeffs")
@@ -326,14 +339,14 @@ def iabn_eval_coeffs(weight, bias, running_mean, running_var, eps):
 
 
 def iabn_apply(x, y, M, C, scale, offset, activation, slope):
-    check(lib().mgn_iabn_apply(x.data_ptr(), y.data_ptr(), _act_dtype(x), M, C, scale.data_ptr(), offset.data_ptr(),
+    check(_fn("mgn_iabn_apply", x)(x.data_ptr(), y.data_ptr(), _act_dtype(x), M, C, scale.data_ptr(), offset.data_ptr(),
                                activation, slope, _stream()), "mgn_iabn_apply")
 
 
 def iabn_bwd_reduce(y, dy, M, C, weight, bias, eps, activation, slope):
     out = torch.empty((4, C), dtype=torch.float32, device=y.device)  # sums[2], d_weight, d_bias
     ws = _iabn_ws(y.device)
-    check(lib().mgn_iabn_bwd_reduce(y.data_ptr(), dy.data_ptr(), _act_dtype(y), M, C, weight.data_ptr(), bias.data_ptr(),
+    check(_fn("mgn_iabn_bwd_reduce", y)(y.data_ptr(), dy.data_ptr(), _act_dtype(y), M, C, weight.data_ptr(), bias.data_ptr(),
                                     eps, activation, slope, out.data_ptr(), out[2].data_ptr(), ws.data_ptr(), ws.numel() * 4,
                                     _stream()), "mgn_iabn_bwd_reduce")
     return out[:2], out[2], out[3]
@@ -343,14 +356,14 @@ def iabn_bwd_reduce_x(x, dy, M, C, weight, bias, coef, eps, activation, slope):
     """like iabn_bwd_reduce, from the norm's input x (z = coef[0] * x + coef[1] recomputed)"""
     out = torch.empty((4, C), dtype=torch.float32, device=x.device)
     ws = _iabn_ws(x.device)
-    check(lib().mgn_iabn_bwd_reduce_x(x.data_ptr(), dy.data_ptr(), _act_dtype(x), M, C, weight.data_ptr(), bias.data_ptr(),
+    check(_fn("mgn_iabn_bwd_reduce_x", x)(x.data_ptr(), dy.data_ptr(), _act_dtype(x), M, C, weight.data_ptr(), bias.data_ptr(),
                                       coef[0].data_ptr(), coef[1].data_ptr(), eps, activation, slope, out.data_ptr(),
                                       out[2].data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()), "mgn_iabn_bwd_reduce_x")
     return out[:2], out[2], out[3]
 
 
 def iabn_bwd_apply_x(x, dy, dx, M, C, weight, bias, coef, sums, total_count, eps, activation, slope):
-    check(lib().mgn_iabn_bwd_apply_x(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), _act_dtype(x), M, C, weight.data_ptr(),
+    check(_fn("mgn_iabn_bwd_apply_x", x)(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), _act_dtype(x), M, C, weight.data_ptr(),
                                      bias.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2:].data_ptr(), sums.data_ptr(),
                                      float(total_count), eps, activation, slope, _stream()), "mgn_iabn_bwd_apply_x")
 
@@ -358,13 +371,13 @@ def iabn_bwd_apply_x(x, dy, dx, M, C, weight, bias, coef, sums, total_count, eps
 def abn_add_relu_fwd(x, coef, shortcut):
     N, C, H, W = x.shape
     y = torch.empty_like(x)
-    check(lib().mgn_abn_add_relu_fwd(x.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), shortcut.data_ptr(), y.data_ptr(),
+    check(_fn("mgn_abn_add_relu_fwd", x)(x.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), shortcut.data_ptr(), y.data_ptr(),
                                      N * H * W, C, _stream()), "mgn_abn_add_relu_fwd")
     return y
 
 
 def iabn_bwd_apply(y, dy, dx, M, C, weight, bias, saved, sums, total_count, eps, activation, slope):
-    check(lib().mgn_iabn_bwd_apply(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), _act_dtype(y), M, C, weight.data_ptr(),
+    check(_fn("mgn_iabn_bwd_apply", y)(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), _act_dtype(y), M, C, weight.data_ptr(),
                                    bias.data_ptr(), saved.data_ptr(), sums.data_ptr(), float(total_count), eps,
                                    activation, slope, _stream()), "mgn_iabn_bwd_apply")
 
@@ -394,6 +407,11 @@ def adam_step(p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, step, coef, gra
           "mgn_adam_step")
 
 
+def clip_coef_scaled(partials, n, max_norm, grad_scale, beta1, beta2, growth_interval, scaler_state, hyper, coef):
+    check(lib().mgn_clip_coef_scaled(partials.data_ptr(), n, max_norm, grad_scale, beta1, beta2, int(growth_interval),
+                                     scaler_state.data_ptr(), hyper.data_ptr(), coef.data_ptr(), _stream()), "mgn_clip_coef_scaled")
+
+
 def adam_step_dev(p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, hyper, coef, grad_scale):
     """Adam with the bias corrections in device memory (`hyper` = [1/(1-b1^t), 1/sqrt(1-b2^t)]): graph-capturable"""
     check(lib().mgn_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), chunk_lr.data_ptr(),
@@ -406,7 +424,7 @@ def adam_step_dev(p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, hyper, coef
 # ---------------------------------------------------------------------------------------------------------------
 def conv_supported(x, weight):
     """Cin % 32 == 0, or a channel-padded stem input (Cin 8/16 holding the weight's 3/9 real channels)"""
-    return x.is_cuda and x.dtype == torch.bfloat16 and (weight.shape[1] % 32 == 0 or (x.shape[1] in (8, 16) and weight.shape[1] <= x.shape[1]))
+    return x.is_cuda and x.dtype in H16 and (weight.shape[1] % 32 == 0 or (x.shape[1] in (8, 16) and weight.shape[1] <= x.shape[1]))
 
 
 def u8_frames_to_f32(frames, divisor):
@@ -422,15 +440,15 @@ def u8_frames_to_f32(frames, divisor):
     return out
 
 
-def prep_input(frames_u8, mean3, std3, Cp):
-    """frames: list of [B,3,H,W] uint8 CUDA tensors -> [B,Cp,H,W] bf16 channels_last (normalised, zero-padded channels)"""
+def prep_input(frames_u8, mean3, std3, Cp, dtype=torch.bfloat16):
+    """frames: list of [B,3,H,W] uint8 CUDA tensors -> [B,Cp,H,W] bf16 / fp16 channels_last (normalised, zero-padded channels)"""
     B, _, H, W = frames_u8[0].shape
     frames_u8 = [f.contiguous() for f in frames_u8]
-    out = torch.empty((B, Cp, H, W), dtype=torch.bfloat16, device=frames_u8[0].device, memory_format=torch.channels_last)
+    out = torch.empty((B, Cp, H, W), dtype=dtype, device=frames_u8[0].device, memory_format=torch.channels_last)
     ptrs = (ctypes.c_void_p * 3)(*[f.data_ptr() for f in frames_u8])
     m = (ctypes.c_float * 3)(*[float(v) for v in mean3])
     sd = (ctypes.c_float * 3)(*[float(v) for v in std3])
-    check(lib().mgn_prep_input(ptrs, len(frames_u8), B, H, W, m, sd, out.data_ptr(), Cp, _stream()), "mgn_prep_input")
+    check(_fn("mgn_prep_input", out)(ptrs, len(frames_u8), B, H, W, m, sd, out.data_ptr(), Cp, _stream()), "mgn_prep_input")
     return out
 
 
@@ -521,7 +539,7 @@ def panoptic_targets(cfg, panoptic, seg_ids, seg_attr, seg_count, gauss, want_ma
     return out
 
 
-def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=torch.bfloat16, khw=None, residual=None):
+def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=None, khw=None, residual=None):
     """x [N,Cin,IH,IW] channels_last bf16; w_ohwi [Cout,KH,KW,Cin] bf16 contiguous (or, for Cin 8/16, the packed
     [Cout, Kpad] layout with khw=(KH,KW)) -> out [N,Cout,OH,OW] channels_last"""
     N, Cin, IH, IW = x.shape
@@ -530,8 +548,10 @@ def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dt
     else:
         Cout, (KH, KW) = w_ohwi.shape[0], khw
     OH, OW = out_shape
+    out_dtype = x.dtype if out_dtype is None else out_dtype   # the activation format (bf16 / fp16), or fp32
+    assert w_ohwi.dtype == x.dtype, "weight layout and activations must share the 16-bit format"
     out = torch.empty((N, Cout, OH, OW), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
-    check(lib().mgn_conv_igemm(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(),
+    check(_fn("mgn_conv_igemm", x)(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(),
                                N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, int(relu),
                                int(out_dtype == torch.float32), None if residual is None else residual.data_ptr(), _stream()),
           "mgn_conv_igemm")
@@ -548,34 +568,34 @@ def conv_wgrad(dy, x, kh, kw, stride, pad, cin_real=None):
     nb = ctypes.c_size_t(0)
     check(lib().mgn_conv_wgrad_workspace_bytes(N, OH, OW, Cin, Cout, kh, kw, ctypes.byref(nb)), "mgn_conv_wgrad_workspace_bytes")
     ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device)
-    check(lib().mgn_conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, IH, IW, Cin, OH, OW, Cout, kh, kw, stride, pad,
+    check(_fn("mgn_conv_wgrad", dy)(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, IH, IW, Cin, OH, OW, Cout, kh, kw, stride, pad,
                                cin_real, ws.data_ptr(), nb.value, _stream()), "mgn_conv_wgrad")
     return dw
 
 
-def _layout_empty(w, mode, Cp, cout_pad=0):
+def _layout_empty(w, mode, Cp, cout_pad=0, dtype=torch.bfloat16):
     Cout, Cin, KH, KW = w.shape
     Cout = max(Cout, cout_pad)
     if mode == 0:
-        return torch.empty((Cout, KH, KW, Cin), dtype=torch.bfloat16, device=w.device)
+        return torch.empty((Cout, KH, KW, Cin), dtype=dtype, device=w.device)
     if mode == 1:
-        return torch.empty((Cin, KH, KW, Cout), dtype=torch.bfloat16, device=w.device)
-    return torch.empty((Cout, (KH * KW * Cp + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
+        return torch.empty((Cin, KH, KW, Cout), dtype=dtype, device=w.device)
+    return torch.empty((Cout, (KH * KW * Cp + 31) // 32 * 32), dtype=dtype, device=w.device)
 
 
-def weight_layout(w, mode, Cp=0, cout_pad=0):
+def weight_layout(w, mode, Cp=0, cout_pad=0, dtype=torch.bfloat16):
     """fp32 OIHW parameter -> bf16 kernel layout (0: OHWI, 1: flipped IHWO for the data gradient, 2: packed stem), output
     channels zero-padded to `cout_pad`.  Parameters are served from `weight_cache` (all layouts refreshed by ONE launch
     after the optimizer step)."""
-    return weight_cache.get(w, mode, Cp, cout_pad)
+    return weight_cache.get(w, mode, Cp, cout_pad, dtype)
 
 
-def _weight_layout_now(w, mode, Cp, out=None, cout_pad=0):
+def _weight_layout_now(w, mode, Cp, out=None, cout_pad=0, dtype=torch.bfloat16):
     Cout, Cin, KH, KW = w.shape
-    out = _layout_empty(w, mode, Cp, cout_pad) if out is None else out
+    out = _layout_empty(w, mode, Cp, cout_pad, dtype) if out is None else out
     wc = w.detach()
     wc = wc if (wc.dtype == torch.float32 and wc.is_contiguous()) else wc.float().contiguous()
-    check(lib().mgn_weight_layout(wc.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, mode, Cp, cout_pad, _stream()), "mgn_weight_layout")
+    check(_fn("mgn_weight_layout", out)(wc.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, mode, Cp, cout_pad, _stream()), "mgn_weight_layout")
     return out
 
 
@@ -586,51 +606,57 @@ class _WeightCache:
 
     def __init__(self):
         self.entries = {}     # (id(param), mode, Cp) -> dict(ref, out, version, ptr)
-        self.table = None     # device table of the batched kernel (rebuilt when the entry set changed)
-        self.total_blocks = 0
+        self.tables = {}      # dtype -> (device table of the batched kernel, blocks); rebuilt when the entry set changed
+        self.table = []
         self.dirty = True
         self.off = bool(os.environ.get("MGN_NO_WCACHE"))   # A/B switch: convert per call
 
-    def get(self, w, mode, Cp=0, cout_pad=0):
+    def get(self, w, mode, Cp=0, cout_pad=0, dtype=torch.bfloat16):
         import weakref
         if self.off or not (isinstance(w, torch.nn.Parameter) and w.is_leaf and w.dtype == torch.float32 and w.is_contiguous()):
-            return _weight_layout_now(w, mode, Cp, None, cout_pad)   # temporaries: converted per call
-        key = (id(w), mode, Cp, cout_pad)
+            return _weight_layout_now(w, mode, Cp, None, cout_pad, dtype)   # temporaries: converted per call
+        key = (id(w), mode, Cp, cout_pad, dtype)
         e = self.entries.get(key)
         if e is not None and e["ref"]() is w and e["ptr"] == w.data_ptr() and e["version"] == w._version:
             return e["out"]
-        out = _weight_layout_now(w, mode, Cp, None if e is None or e["ref"]() is not w else e["out"], cout_pad)
+        out = _weight_layout_now(w, mode, Cp, None if e is None or e["ref"]() is not w else e["out"], cout_pad, dtype)
         if e is None or e["ref"]() is not w or e["ptr"] != w.data_ptr():
             self.dirty = True
-        self.entries[key] = dict(ref=weakref.ref(w), out=out, version=w._version, ptr=w.data_ptr(), mode=mode, Cp=Cp, cout_pad=cout_pad)
+        self.entries[key] = dict(ref=weakref.ref(w), out=out, version=w._version, ptr=w.data_ptr(), mode=mode, Cp=Cp, cout_pad=cout_pad, dtype=dtype)
         return out
 
     def _rebuild(self):
-        rows, blocks = [], 0
+        """one table of the batched kernel per 16-bit format (bf16 entries are converted by mgn_weight_layout_batch, fp16 entries
+        by its _f16 twin)"""
         dead = [k for k, e in self.entries.items() if e["ref"]() is None]
         for k in dead:
             del self.entries[k]
+        self.tables = {}
         dev = None
-        for e in self.entries.values():
-            w = e["ref"]()
-            if w is None:   # collected since the filter above (a cyclic-garbage pass can run at any allocation)
-                continue
-            if dev is None:
-                dev = w.device
-            if w.device != dev:
-                continue
-            Cout, Cin, KH, KW = w.shape
-            # work items of the batched kernel: (co, ci) pairs for the plain layouts, output elements for the packed stems
-            n_items = e["out"].numel() if e["mode"] == 2 else max(Cout, e["cout_pad"]) * Cin
-            rows.append([w.data_ptr(), e["out"].data_ptr(), n_items, blocks, Cout | (e["cout_pad"] << 32), Cin, (KH << 32) | KW,
-                         (e["mode"] << 32) | e["Cp"]])
-            e["ptr"] = w.data_ptr()
-            blocks += (n_items + 255) // 256
-        self.table = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None
-        self.total_blocks, self.dirty = blocks, False
+        for dtype in H16:
+            rows, blocks = [], 0
+            for e in self.entries.values():
+                w = e["ref"]()
+                if w is None or e["dtype"] != dtype:   # (collected since the filter above: a cyclic-garbage pass can run at any allocation)
+                    continue
+                if dev is None:
+                    dev = w.device
+                if w.device != dev:
+                    continue
+                Cout, Cin, KH, KW = w.shape
+                # work items of the batched kernel: (co, ci) pairs for the plain layouts, output elements for the packed stems
+                n_items = e["out"].numel() if e["mode"] == 2 else max(Cout, e["cout_pad"]) * Cin
+                rows.append([w.data_ptr(), e["out"].data_ptr(), n_items, blocks, Cout | (e["cout_pad"] << 32), Cin, (KH << 32) | KW,
+                             (e["mode"] << 32) | e["Cp"]])
+                e["ptr"] = w.data_ptr()
+                blocks += (n_items + 255) // 256
+            if rows:
+                self.tables[dtype] = (torch.tensor(rows, dtype=torch.int64).to(dev), blocks)
+        self.table = [t for t, _ in self.tables.values()]   # (kept alive by a captured graph, see Trainer.capture_step)
+        self.dirty = False
 
     def refresh(self):
-        """re-derive every registered layout from the current parameter values (one launch)"""
+        """re-derive every registered layout from the current parameter values (one launch per 16-bit format in use)"""
         for e in self.entries.values():
             w = e["ref"]()
             if w is None or e["ptr"] != w.data_ptr():   # a collected parameter's row must leave the table (its memory is gone)
@@ -638,10 +664,8 @@ class _WeightCache:
                 break
         if self.dirty:
             self._rebuild()
-        if self.table is None:
-            return
-        check(lib().mgn_weight_layout_batch(self.table.data_ptr(), self.table.shape[0], self.total_blocks, _stream()),
-              "mgn_weight_layout_batch")
+        for dtype, (table, blocks) in self.tables.items():
+            check(_fn("mgn_weight_layout_batch", dtype)(table.data_ptr(), table.shape[0], blocks, _stream()), "mgn_weight_layout_batch")
         for e in self.entries.values():
             w = e["ref"]()
             if w is not None:
@@ -662,7 +686,7 @@ def _lr_strides(t):
 
 def upce_supported(lr):
     sb, sh, sw = lr.stride(0), lr.stride(2), lr.stride(3)
-    return (lr.is_cuda and lr.dtype == torch.bfloat16 and lr.stride(1) == 1 and lr.shape[1] <= 32 and sb % 8 == 0 and sh % 8 == 0
+    return (lr.is_cuda and lr.dtype in H16 and lr.stride(1) == 1 and lr.shape[1] <= 32 and sb % 8 == 0 and sh % 8 == 0
             and sw % 8 == 0 and sw >= (lr.shape[1] + 7) // 8 * 8 and lr.shape[2] >= 2 and lr.shape[3] >= 2)
 
 
@@ -672,7 +696,7 @@ def upce_fwd(lr, labels, weights, H, W, ignore, thr):
     ce = torch.empty((B, H, W), dtype=torch.float32, device=lr.device)
     partials = torch.empty(lib().mgn_upce_partials(B, H, W) * 3, dtype=torch.float32, device=lr.device)
     sums = torch.empty(3, dtype=torch.float32, device=lr.device)
-    check(lib().mgn_upce_fwd(lr.data_ptr(), sb, sh, sw, B, h, w, H, W, K, labels.data_ptr(),
+    check(_fn("mgn_upce_fwd", lr)(lr.data_ptr(), sb, sh, sw, B, h, w, H, W, K, labels.data_ptr(),
                              None if weights is None else weights.data_ptr(), ignore, thr, ce.data_ptr(), partials.data_ptr(),
                              sums.data_ptr(), _stream()), "mgn_upce_fwd")
     return ce, sums
@@ -694,7 +718,7 @@ def upce_bwd(lr, labels, weights, H, W, ignore, ce, sel3, gout, Kp):
     B, K, h, w = lr.shape
     sb, sh, sw = _lr_strides(lr)
     dlg = torch.zeros((B, h, w, Kp), dtype=torch.float32, device=lr.device)
-    check(lib().mgn_upce_bwd(lr.data_ptr(), sb, sh, sw, B, h, w, H, W, K, Kp, labels.data_ptr(),
+    check(_fn("mgn_upce_bwd", lr)(lr.data_ptr(), sb, sh, sw, B, h, w, H, W, K, Kp, labels.data_ptr(),
                              None if weights is None else weights.data_ptr(), ignore, ce.data_ptr(), sel3.data_ptr(),
                              gout.data_ptr(), dlg.data_ptr(), _stream()), "mgn_upce_bwd")
     return dlg
@@ -705,7 +729,7 @@ def ins_loss_fwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale):
     partials = torch.empty(lib().mgn_upce_partials(B, H, W) * 4, dtype=torch.float32, device=ct.device)
     out4 = torch.empty(4, dtype=torch.float32, device=ct.device)
     cs, os_ = _lr_strides(center_lr), _lr_strides(offset_lr)
-    check(lib().mgn_ins_loss_fwd(center_lr.data_ptr(), *cs, offset_lr.data_ptr(), *os_, B, h, w, H, W, ct.data_ptr(), cw.data_ptr(),
+    check(_fn("mgn_ins_loss_fwd", offset_lr)(center_lr.data_ptr(), *cs, offset_lr.data_ptr(), *os_, B, h, w, H, W, ct.data_ptr(), cw.data_ptr(),
                                  ot.data_ptr(), ow.data_ptr(), oscale, partials.data_ptr(), out4.data_ptr(), _stream()),
           "mgn_ins_loss_fwd")
     return out4
@@ -715,7 +739,7 @@ def ins_loss_bwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale, out4, gout2
     B, _, h, w = center_lr.shape
     dco = torch.zeros((B, h, w, 4), dtype=torch.float32, device=ct.device)
     cs, os_ = _lr_strides(center_lr), _lr_strides(offset_lr)
-    check(lib().mgn_ins_loss_bwd(center_lr.data_ptr(), *cs, offset_lr.data_ptr(), *os_, B, h, w, H, W, ct.data_ptr(), cw.data_ptr(),
+    check(_fn("mgn_ins_loss_bwd", offset_lr)(center_lr.data_ptr(), *cs, offset_lr.data_ptr(), *os_, B, h, w, H, W, ct.data_ptr(), cw.data_ptr(),
                                  ot.data_ptr(), ow.data_ptr(), oscale, out4.data_ptr(), gout2.data_ptr(), dco.data_ptr(), _stream()),
           "mgn_ins_loss_bwd")
     return dco
@@ -738,9 +762,9 @@ def upsample1_bwd(dfull, h, w):
 def maxpool_fwd(x):
     N, C, IH, IW = x.shape
     OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
-    y = torch.empty((N, C, OH, OW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    y = torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
-    check(lib().mgn_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), arg.data_ptr(), N, IH, IW, C, _stream()), "mgn_maxpool3x3s2_fwd")
+    check(_fn("mgn_maxpool3x3s2_fwd", x)(x.data_ptr(), y.data_ptr(), arg.data_ptr(), N, IH, IW, C, _stream()), "mgn_maxpool3x3s2_fwd")
     return y, arg
 
 
@@ -748,9 +772,9 @@ def abn_maxpool_fwd(x, scale, offset, activation, slope):
     """x [N,C,IH,IW] bf16 channels_last (conv output, left untouched) -> max_pool3x3s2(act(scale*x+offset)), argmax"""
     N, C, IH, IW = x.shape
     OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
-    y = torch.empty((N, C, OH, OW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    y = torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
-    check(lib().mgn_abn_maxpool_fwd(x.data_ptr(), scale.data_ptr(), offset.data_ptr(), activation, slope, y.data_ptr(),
+    check(_fn("mgn_abn_maxpool_fwd", x)(x.data_ptr(), scale.data_ptr(), offset.data_ptr(), activation, slope, y.data_ptr(),
                                     arg.data_ptr(), N, IH, IW, C, _stream()), "mgn_abn_maxpool_fwd")
     return y, arg
 
@@ -758,7 +782,7 @@ def abn_maxpool_fwd(x, scale, offset, activation, slope):
 def abn_maxpool_bwd(x, dpool, arg, coef, weight, bias, sums, total_count, eps, activation, slope):
     N, C, IH, IW = x.shape
     dx = torch.empty_like(x)
-    check(lib().mgn_abn_maxpool_bwd(x.data_ptr(), dpool.data_ptr(), arg.data_ptr(), dx.data_ptr(), coef[0].data_ptr(),
+    check(_fn("mgn_abn_maxpool_bwd", x)(x.data_ptr(), dpool.data_ptr(), arg.data_ptr(), dx.data_ptr(), coef[0].data_ptr(),
                                     coef[1].data_ptr(), weight.data_ptr(), bias.data_ptr(), coef[3].data_ptr(), sums.data_ptr(),
                                     float(total_count), eps, activation, slope, N, IH, IW, C, _stream()), "mgn_abn_maxpool_bwd")
     return dx
@@ -766,8 +790,8 @@ def abn_maxpool_bwd(x, dpool, arg, coef, weight, bias, sums, total_count, eps, a
 
 def maxpool_bwd(dy, arg, in_shape):
     N, C, IH, IW = in_shape
-    dx = torch.empty((N, C, IH, IW), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
-    check(lib().mgn_maxpool3x3s2_bwd(dy.data_ptr(), arg.data_ptr(), dx.data_ptr(), N, IH, IW, C, _stream()), "mgn_maxpool3x3s2_bwd")
+    dx = torch.empty((N, C, IH, IW), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    check(_fn("mgn_maxpool3x3s2_bwd", dy)(dy.data_ptr(), arg.data_ptr(), dx.data_ptr(), N, IH, IW, C, _stream()), "mgn_maxpool3x3s2_bwd")
     return dx
 
 
@@ -776,23 +800,23 @@ def maxpool_bwd(dy, arg, in_shape):
 # ---------------------------------------------------------------------------------------------------------------
 def elt_supported(x):
     C = x.shape[1]
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and C % 8 == 0 and C // 8 <= 256 and 256 % (C // 8) == 0
+    return (x.is_cuda and x.dtype in H16 and x.dim() == 4 and C % 8 == 0 and C // 8 <= 256 and 256 % (C // 8) == 0
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
 def _cl_like(x, shape=None):
-    return torch.empty(tuple(x.shape) if shape is None else shape, dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    return torch.empty(tuple(x.shape) if shape is None else shape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
 
 
 def add_relu_fwd(a, b):
     y = _cl_like(a)
-    check(lib().mgn_add_relu_fwd(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mgn_add_relu_fwd")
+    check(_fn("mgn_add_relu_fwd", a)(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mgn_add_relu_fwd")
     return y
 
 
 def relu_mask_bwd(dy, y):
     dx = _cl_like(y)
-    check(lib().mgn_relu_mask_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), _stream()), "mgn_relu_mask_bwd")
+    check(_fn("mgn_relu_mask_bwd", dy)(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), _stream()), "mgn_relu_mask_bwd")
     return dx
 
 
@@ -800,22 +824,22 @@ def colsum(x, x2, scale):
     N, C, H, W = x.shape
     out = torch.empty((N, C), dtype=torch.float32, device=x.device)
     ws = torch.empty(N * 64 * C, dtype=torch.float32, device=x.device)
-    check(lib().mgn_colsum(x.data_ptr(), None if x2 is None else x2.data_ptr(), N, H * W, C, scale, out.data_ptr(), ws.data_ptr(),
+    check(_fn("mgn_colsum", x)(x.data_ptr(), None if x2 is None else x2.data_ptr(), N, H * W, C, scale, out.data_ptr(), ws.data_ptr(),
                            ws.numel() * 4, _stream()), "mgn_colsum")
     return out
 
 
-def bcast_rows(g, shape, scale):
+def bcast_rows(g, shape, scale, dtype=torch.bfloat16):
     N, C, H, W = shape
-    dx = _cl_like(g, shape)
-    check(lib().mgn_bcast_rows(g.data_ptr(), N, H * W, C, scale, dx.data_ptr(), _stream()), "mgn_bcast_rows")
+    dx = torch.empty(shape, dtype=dtype, device=g.device, memory_format=torch.channels_last)
+    check(_fn("mgn_bcast_rows", dx)(g.data_ptr(), N, H * W, C, scale, dx.data_ptr(), _stream()), "mgn_bcast_rows")
     return dx
 
 
 def scale_channels(x, s, mode, add=None):
     N, C, H, W = x.shape
     y = _cl_like(x)
-    check(lib().mgn_scale_channels(x.data_ptr(), s.data_ptr(), N, H * W, C, mode, None if add is None else add.data_ptr(), y.data_ptr(),
+    check(_fn("mgn_scale_channels", x)(x.data_ptr(), s.data_ptr(), N, H * W, C, mode, None if add is None else add.data_ptr(), y.data_ptr(),
                                    _stream()), "mgn_scale_channels")
     return y
 
@@ -867,14 +891,14 @@ def vec_linear_bwd(dout, out, v, w, act, bn_weight=None, xhat=None, rstd=None, e
 def nearest_fwd(x, H, W):
     N, C, h, w = x.shape
     y = _cl_like(x, (N, C, H, W))
-    check(lib().mgn_nearest_fwd(x.data_ptr(), N, h, w, H, W, C, y.data_ptr(), _stream()), "mgn_nearest_fwd")
+    check(_fn("mgn_nearest_fwd", x)(x.data_ptr(), N, h, w, H, W, C, y.data_ptr(), _stream()), "mgn_nearest_fwd")
     return y
 
 
 def nearest_bwd(dy, h, w):
     N, C, H, W = dy.shape
     dx = _cl_like(dy, (N, C, h, w))
-    check(lib().mgn_nearest_bwd(dy.data_ptr(), N, h, w, H, W, C, dx.data_ptr(), _stream()), "mgn_nearest_bwd")
+    check(_fn("mgn_nearest_bwd", dy)(dy.data_ptr(), N, h, w, H, W, C, dx.data_ptr(), _stream()), "mgn_nearest_bwd")
     return dx
 
 

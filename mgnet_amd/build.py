@@ -42,7 +42,8 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     hdr = headers()
-    todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdr)]
+    base = lambda s: [s[:-8] + ".hip"] if s.endswith("_f16.hip") else []   # x_f16.hip = `#define MGN_F16` + `#include "x.hip"`
+    todo = [s for s in sources() if force or _stale(_obj(s), [s] + base(s) + hdr)]
 
     def compile_one(src):
         # per-file flags: a line `// hipcc-flags: <flags>` in the first 40 lines of the source

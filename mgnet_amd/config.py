@@ -180,7 +180,7 @@ _D2_DEFAULTS = {
                "WARMUP_FACTOR": 1.0 / 1000, "WARMUP_ITERS": 1000, "WARMUP_METHOD": "linear", "CHECKPOINT_PERIOD": 5000,
                "IMS_PER_BATCH": 16, "REFERENCE_WORLD_SIZE": 0, "BIAS_LR_FACTOR": 1.0, "WEIGHT_DECAY_BIAS": None,
                "CLIP_GRADIENTS": {"ENABLED": False, "CLIP_TYPE": "value", "CLIP_VALUE": 1.0, "NORM_TYPE": 2.0},
-               "AMP": {"ENABLED": False}},
+               "AMP": {"ENABLED": False, "DTYPE": "bfloat16", "LOSS_SCALE_INIT": 65536.0, "LOSS_SCALE_GROWTH_INTERVAL": 2000}},
     "TEST": {"EXPECTED_RESULTS": [], "EVAL_PERIOD": 0},
     "OUTPUT_DIR": "./output", "SEED": -1, "CUDNN_BENCHMARK": False, "VIS_PERIOD": 0,
 }

@@ -26,7 +26,7 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#include "h16.h"
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int BM = 128;
@@ -74,24 +74,20 @@ struct UpClass {
     }
 };
 
-__device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)mgn_f2h(f); }   // 16-bit activation format of this TU (h16.h)
 
 // epilogue of the implicit-GEMM kernels: 4 consecutive output channels of one pixel (+ bias, + residual, ReLU)
 __device__ __forceinline__ void emit4(const ConvParams& p, long m, int co, float a0, float a1, float a2, float a3, bool vec_ok) {
     float v[4] = {a0, a1, a2, a3};
     if (p.residual && vec_ok) {  // fused accumulation of a second gradient branch (bf16, same layout as the output)
         const uint2 r = *reinterpret_cast<const uint2*>(p.residual + m * p.Cout + co);
-        v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
-        v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+        v[0] += mgn_lo2f(r.x); v[1] += mgn_hi2f(r.x);
+        v[2] += mgn_lo2f(r.y); v[3] += mgn_hi2f(r.y);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         v[e] += (p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
-        if (p.residual && !vec_ok && co + e < p.Cout) v[e] += __uint_as_float((uint32_t)p.residual[m * p.Cout + co + e] << 16);
+        if (p.residual && !vec_ok && co + e < p.Cout) v[e] += mgn_h2f(p.residual[m * p.Cout + co + e]);
         if (p.relu) v[e] = fmaxf(v[e], 0.f);
     }
     if (vec_ok) {
@@ -123,23 +119,23 @@ __device__ __forceinline__ void mma_tile(const unsigned char* sA, const unsigned
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const int slot = kk * 2 + (lane >> 5);
-        bf16x8 a[MT], b[NT];
+        h16x8 a[MT], b[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = wm * 32 * MT + i * 32 + (lane & 31);
-            a[i] = *reinterpret_cast<const bf16x8*>(sA + row * LPITCH + ((SWZ ? (slot ^ (LPITCH == 64 ? ((row >> 2) & 3) : swz(row))) : slot) << 4));
+            a[i] = *reinterpret_cast<const h16x8*>(sA + row * LPITCH + ((SWZ ? (slot ^ (LPITCH == 64 ? ((row >> 2) & 3) : swz(row))) : slot) << 4));
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int row = wn * 32 * NT + j * 32 + (lane & 31);
-            b[j] = *reinterpret_cast<const bf16x8*>(sB + row * LPITCH + ((SWZ ? (slot ^ (LPITCH == 64 ? ((row >> 2) & 3) : swz(row))) : slot) << 4));
+            b[j] = *reinterpret_cast<const h16x8*>(sB + row * LPITCH + ((SWZ ? (slot ^ (LPITCH == 64 ? ((row >> 2) & 3) : swz(row))) : slot) << 4));
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = SWAP ? MGN_MFMA_32x32x16(b[j], a[i], acc[i][j])
+                                 : MGN_MFMA_32x32x16(a[i], b[j], acc[i][j]);
     }
 }
 
@@ -476,12 +472,12 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Params& p) {
     const int co_w = (blockIdx.y * WN + wn) * 32 * NT;   // this wave's first output channel
 
     // weights -> registers: fragment (t, kk) = W[co_w + 32 t + (lane & 31)][16 kk + 8 hi .. +7]
-    bf16x8 wr[NT][C::KK];
+    h16x8 wr[NT][C::KK];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const uint16_t* wp = p.w + (size_t)(co_w + 32 * t + (lane & 31)) * CIN + 8 * hi;
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) wr[t][kk] = *reinterpret_cast<const bf16x8*>(wp + kk * 16);
+        for (int kk = 0; kk < C::KK; ++kk) wr[t][kk] = *reinterpret_cast<const h16x8*>(wp + kk * 16);
     }
 
     const __amdgpu_buffer_rsrc_t rsI =
@@ -545,9 +541,9 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Params& p) {
                 for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < C::KK; ++kk) {
-                const bf16x8 x = *reinterpret_cast<const bf16x8*>(row + (((2 * kk + hi) ^ sw) << 4));
+                const h16x8 x = *reinterpret_cast<const h16x8*>(row + (((2 * kk + hi) ^ sw) << 4));
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[t][kk], x, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) acc[t] = MGN_MFMA_32x32x16(wr[t][kk], x, acc[t]);
             }
             // D = W-rows x pixels: col = lane & 31 -> pixel, row = (e & 3) + 8 (e >> 2) + 4 hi -> channel; lane pairs swap 4-channel
             // groups so that each lane stores 8 consecutive channels (16 bytes)
@@ -779,13 +775,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
     const int co_w = tile * 64 + wco * 32;   // this wave's 32 output channels
 
     // weights -> registers: fragment (tap, kk) = W[co_w + (lane & 31)][tap][kk*16 + 8*(lane>>5) .. +7]
-    bf16x8 wr[36];
+    h16x8 wr[36];
     {
         const uint16_t* wp = p.w + ((size_t)(co_w + (lane & 31)) * 9) * 64 + 8 * (lane >> 5);
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wr[t * 4 + kk] = *reinterpret_cast<const bf16x8*>(wp + t * 64 + kk * 16);
+            for (int kk = 0; kk < 4; ++kk) wr[t * 4 + kk] = *reinterpret_cast<const h16x8*>(wp + t * 64 + kk * 16);
     }
 
     const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, (uint32_t)((size_t)p.N * p.H * p.W * 64 * 2), 0x00020000);
@@ -859,11 +855,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
             for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowa + aoff[kw][kk]);
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(rowb + aoff[kw][kk]);
+                    const h16x8 a = *reinterpret_cast<const h16x8*>(rowa + aoff[kw][kk]);
+                    const h16x8 b = *reinterpret_cast<const h16x8*>(rowb + aoff[kw][kk]);
                     const int idx = (kh * 3 + kw) * 4 + kk;
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], a, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], b, acc1, 0, 0, 0);
+                    acc0 = MGN_MFMA_32x32x16(wr[idx], a, acc0);
+                    acc1 = MGN_MFMA_32x32x16(wr[idx], b, acc1);
                 }
             }
         }
@@ -882,8 +878,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
                         float v0 = rr2 ? acc1[qd * 4 + 0] : acc0[qd * 4 + 0], v1 = rr2 ? acc1[qd * 4 + 1] : acc0[qd * 4 + 1];
                         float v2 = rr2 ? acc1[qd * 4 + 2] : acc0[qd * 4 + 2], v3 = rr2 ? acc1[qd * 4 + 3] : acc0[qd * 4 + 3];
                         const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (orow - p.out));
-                        v0 += __uint_as_float(rr.x << 16); v1 += __uint_as_float(rr.x & 0xffff0000u);
-                        v2 += __uint_as_float(rr.y << 16); v3 += __uint_as_float(rr.y & 0xffff0000u);
+                        v0 += mgn_lo2f(rr.x); v1 += mgn_hi2f(rr.x);
+                        v2 += mgn_lo2f(rr.y); v3 += mgn_hi2f(rr.y);
                         *reinterpret_cast<uint2*>(orow) =
                             make_uint2((uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16));
                     }
@@ -1099,12 +1095,12 @@ struct Wgrad3Params {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {  // 8 k-values (pixels p, p+4 rows apart by 128 B) of this lane's channel
+__device__ __forceinline__ h16x8 tr_frag(const unsigned char* p) {  // 8 k-values (pixels p, p+4 rows apart by 128 B) of this lane's channel
     typedef __attribute__((address_space(3))) s16x4* lp;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + 512));
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(h16x8, v);
 }
 
 // NG = number of 4-wave groups: the strip is 64*NG pixels wide, group q owns pixels [64q, 64q+64) of every row and the
@@ -1226,15 +1222,15 @@ __device__ __forceinline__ void wgrad3x3_body(const Wgrad3Params& p) {
         const unsigned char* sb2 = w3sm + s2 * C::INROW;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 a = tr_frag(sa + ks * 2048);
+            const h16x8 a = tr_frag(sa + ks * 2048);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const bf16x8 b0 = tr_frag(sb0 + aB[kw] + ks * 2048);
-                const bf16x8 b1 = tr_frag(sb1 + aB[kw] + ks * 2048);
-                const bf16x8 b2 = tr_frag(sb2 + aB[kw] + ks * 2048);
-                acc[0 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[0 + kw], 0, 0, 0);
-                acc[3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[3 + kw], 0, 0, 0);
-                acc[6 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, acc[6 + kw], 0, 0, 0);
+                const h16x8 b0 = tr_frag(sb0 + aB[kw] + ks * 2048);
+                const h16x8 b1 = tr_frag(sb1 + aB[kw] + ks * 2048);
+                const h16x8 b2 = tr_frag(sb2 + aB[kw] + ks * 2048);
+                acc[0 + kw] = MGN_MFMA_32x32x16(a, b0, acc[0 + kw]);
+                acc[3 + kw] = MGN_MFMA_32x32x16(a, b1, acc[3 + kw]);
+                acc[6 + kw] = MGN_MFMA_32x32x16(a, b2, acc[6 + kw]);
             }
         }
         si = s1;
@@ -1411,7 +1407,7 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
         const unsigned char* sa_ = wssm + aA + so * C::OUTROW;
 #pragma unroll
         for (int ks = 0; ks < C::KSW; ++ks) {
-            const bf16x8 a = tr_frag(sa_ + ks * 2048);
+            const h16x8 a = tr_frag(sa_ + ks * 2048);
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 const int t = ngrp * 7 + i, kh = t / C::TPK, qq = t % C::TPK;
@@ -1419,8 +1415,8 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
                 const unsigned char* bp = wssm + sl * C::INROW + bB + qq * 64 + ks * (32 * C::PXB);
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bp));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bp + 8 * C::PXB));
-                const bf16x8 b = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                const h16x8 b = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[i] = MGN_MFMA_32x32x16(a, b, acc[i]);
             }
         }
         s0 = s0 + 2 >= 11 ? s0 - 9 : s0 + 2;
@@ -1600,7 +1596,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgradParams p) {
     auto frag = [&](const unsigned char* q, int row_bytes) {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(q));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(q + 4 * row_bytes));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        return __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
     f32x16 acc[MT][NT];
@@ -1627,7 +1623,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgradParams p) {
         const unsigned char* st = sm + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {   // the swizzle depends on pixel bits 0..1 (and 1): unchanged by +16 pixels
-            bf16x8 a[MT], b[NT];
+            h16x8 a[MT], b[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) a[i] = frag(st + fa[i] + kk * 16 * RA, RA);
 #pragma unroll
@@ -1635,7 +1631,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgradParams p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = MGN_MFMA_32x32x16(a[i], b[j], acc[i][j]);
         }
         buf = buf == 2 ? 0 : buf + 1;
     }
@@ -1768,7 +1764,7 @@ __global__ void weight_layout_batch_kernel(const long long* __restrict__ table, 
 
 extern "C" {
 
-int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp, int cout_pad, void* stream) {
+int MGN_SYM(mgn_weight_layout)(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp, int cout_pad, void* stream) {
     if (!w_oihw || !out_bf16 || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || mode < 0 || mode > 2) return MGN_EINVAL;
     if (mode == 2 && (Cp < Cin || (Cp != 8 && Cp != 16))) return MGN_EINVAL;
     const int CoutP = cout_pad > Cout ? cout_pad : Cout;
@@ -1779,13 +1775,13 @@ int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, in
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_weight_layout_batch(const void* table_dev, int n_entries, long total_blocks, void* stream) {
+int MGN_SYM(mgn_weight_layout_batch)(const void* table_dev, int n_entries, long total_blocks, void* stream) {
     if (!table_dev || n_entries < 1 || total_blocks < 1 || total_blocks > 0x7fffffffL) return MGN_EINVAL;
     hipLaunchKernelGGL(weight_layout_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)table_dev, n_entries);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_conv_igemm(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
+int MGN_SYM(mgn_conv_igemm)(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
                    int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, const void* residual, void* stream) {
     if (!in || !w || !out || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || up < 1)
         return MGN_EINVAL;
@@ -1972,6 +1968,7 @@ static bool wgrad3_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW
     return true;
 }
 
+#ifndef MGN_F16
 int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, size_t* bytes) {
     if (!bytes || N < 1 || OH < 1 || OW < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1) return MGN_EINVAL;
     bool pack; int NT, MT, cit, cot; long mps, gz;
@@ -1990,7 +1987,8 @@ int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int
     return MGN_OK;
 }
 
-int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
+#endif
+int MGN_SYM(mgn_conv_wgrad)(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
                    int KW, int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dout || !in || !dw || !workspace || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || KH < 1 || KW < 1 || stride < 1) return MGN_EINVAL;
     if (Cin % 8 != 0 || Cout % 8 != 0) return MGN_ENOTSUP;

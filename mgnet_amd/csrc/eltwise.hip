@@ -12,28 +12,24 @@
 #include <stdint.h>
 
 #include "mgnet_hip.h"
+#include "h16.h"
 
 namespace {
 
 constexpr int TPB = 256;
 
-__device__ __forceinline__ void unpack8(const uint4& r, float (&v)[8]) {
+__device__ __forceinline__ void unpack8(const uint4& r, float (&v)[8]) {   // 8 activations of this TU's 16-bit format (h16.h)
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        v[2 * k] = __uint_as_float(w[k] << 16);
-        v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+        v[2 * k] = mgn_lo2f(w[k]);
+        v[2 * k + 1] = mgn_hi2f(w[k]);
     }
-}
-__device__ __forceinline__ uint32_t rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     uint4 r;
-    r.x = rne(v[0]) | (rne(v[1]) << 16); r.y = rne(v[2]) | (rne(v[3]) << 16);
-    r.z = rne(v[4]) | (rne(v[5]) << 16); r.w = rne(v[6]) | (rne(v[7]) << 16);
+    r.x = mgn_pack2(v[0], v[1]); r.y = mgn_pack2(v[2], v[3]);
+    r.z = mgn_pack2(v[4], v[5]); r.w = mgn_pack2(v[6], v[7]);
     return r;
 }
 inline unsigned blocks_for(long nvec) {
@@ -245,12 +241,12 @@ inline int chunks_for(long HW) { long c = HW / 512; return (int)(c < 1 ? 1 : (c 
 
 extern "C" {
 
-int mgn_add_relu_fwd(const void* a, const void* b, void* y, long n_elems, void* stream) {
+int MGN_SYM(mgn_add_relu_fwd)(const void* a, const void* b, void* y, long n_elems, void* stream) {
     if (!a || !b || !y || n_elems < 8 || n_elems % 8) return MGN_EINVAL;
     hipLaunchKernelGGL(add_relu_fwd, dim3(blocks_for(n_elems / 8)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b, (uint4*)y, n_elems / 8);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
-int mgn_abn_add_relu_fwd(const void* x, const float* scale, const float* offset, const void* b, void* y, long M, int C, void* stream) {
+int MGN_SYM(mgn_abn_add_relu_fwd)(const void* x, const float* scale, const float* offset, const void* b, void* y, long M, int C, void* stream) {
     if (!x || !scale || !offset || !b || !y || M < 1 || !c_ok(C)) return MGN_EINVAL;
     const long nvec = M * C / 8;
     const int cv = C / 8;
@@ -259,14 +255,14 @@ int mgn_abn_add_relu_fwd(const void* x, const float* scale, const float* offset,
                        (uint4*)y, nvec, cv);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
-int mgn_relu_mask_bwd(const void* dy, const void* y, void* dx, long n_elems, void* stream) {
+int MGN_SYM(mgn_relu_mask_bwd)(const void* dy, const void* y, void* dx, long n_elems, void* stream) {
     if (!dy || !y || !dx || n_elems < 8 || n_elems % 8) return MGN_EINVAL;
     hipLaunchKernelGGL(relu_mask_bwd, dim3(blocks_for(n_elems / 8)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)dy, (const uint4*)y, (uint4*)dx, n_elems / 8);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
 /* out[n, c] = scale * sum_r x[n, r, c] * (x2 ? x2[n, r, c] : 1);  workspace: N * chunks * C floats (chunks <= 64) */
-int mgn_colsum(const void* x, const void* x2, int N, long HW, int C, float scale, float* out, float* workspace, size_t workspace_bytes,
+int MGN_SYM(mgn_colsum)(const void* x, const void* x2, int N, long HW, int C, float scale, float* out, float* workspace, size_t workspace_bytes,
                void* stream) {
     if (!x || !out || !workspace || N < 1 || HW < 1 || !c_ok(C)) return MGN_EINVAL;
     const int chunks = chunks_for(HW);
@@ -277,37 +273,41 @@ int mgn_colsum(const void* x, const void* x2, int N, long HW, int C, float scale
     hipLaunchKernelGGL(colsum_final, dim3((N * C + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, C, N, scale, out);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
-int mgn_bcast_rows(const float* g, int N, long HW, int C, float scale, void* dx, void* stream) {
+int MGN_SYM(mgn_bcast_rows)(const float* g, int N, long HW, int C, float scale, void* dx, void* stream) {
     if (!g || !dx || N < 1 || HW < 1 || !c_ok(C)) return MGN_EINVAL;
     const long nvec = (long)N * HW * (C / 8);
     hipLaunchKernelGGL(bcast_rows, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, g, HW, C, scale, (uint4*)dx, nvec);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
-int mgn_scale_channels(const void* x, const float* s, int N, long HW, int C, int mode, const float* add, void* y, void* stream) {
+int MGN_SYM(mgn_scale_channels)(const void* x, const float* s, int N, long HW, int C, int mode, const float* add, void* y, void* stream) {
     if (!x || !s || !y || N < 1 || HW < 1 || !c_ok(C) || mode < 0 || mode > 1) return MGN_EINVAL;
     const long nvec = (long)N * HW * (C / 8);
     hipLaunchKernelGGL(scale_channels, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)x, s, HW, C, mode, add, (uint4*)y, nvec);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
-int mgn_nearest_fwd(const void* x, int N, int h, int w, int H, int W, int C, void* y, void* stream) {
+int MGN_SYM(mgn_nearest_fwd)(const void* x, int N, int h, int w, int H, int W, int C, void* y, void* stream) {
     if (!x || !y || N < 1 || h < 1 || w < 1 || H < h || W < w || !c_ok(C)) return MGN_EINVAL;
     hipLaunchKernelGGL(nearest_fwd, dim3(blocks_for((long)N * H * W * (C / 8))), dim3(TPB), 0, (hipStream_t)stream, (const uint16_t*)x, N, h, w, H, W, C, (uint4*)y);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
-int mgn_nearest_bwd(const void* dy, int N, int h, int w, int H, int W, int C, void* dx, void* stream) {
+int MGN_SYM(mgn_nearest_bwd)(const void* dy, int N, int h, int w, int H, int W, int C, void* dx, void* stream) {
     if (!dy || !dx || N < 1 || h < 1 || w < 1 || H < h || W < w || !c_ok(C)) return MGN_EINVAL;
     hipLaunchKernelGGL(nearest_bwd, dim3(blocks_for((long)N * h * w * (C / 8))), dim3(TPB), 0, (hipStream_t)stream, (const uint16_t*)dy, N, h, w, H, W, C, (uint4*)dx);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+#ifndef MGN_F16
 int mgn_concat2(const void* a, const void* b, long rows, int Ca, int Cb, void* y, void* stream) {
     if (!a || !b || !y || rows < 1 || Ca < 8 || Cb < 8 || Ca % 8 || Cb % 8) return MGN_EINVAL;
     hipLaunchKernelGGL(concat2, dim3(blocks_for(rows * ((Ca + Cb) / 8))), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b, Ca, Cb, (uint4*)y, rows);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+#endif
+#ifndef MGN_F16
 int mgn_split2(const void* dy, long rows, int Ca, int Cb, void* da, void* db, void* stream) {
     if (!dy || !da || !db || rows < 1 || Ca < 8 || Cb < 8 || Ca % 8 || Cb % 8) return MGN_EINVAL;
     hipLaunchKernelGGL(split2, dim3(blocks_for(rows * ((Ca + Cb) / 8))), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)dy, Ca, Cb, (uint4*)da, (uint4*)db, rows);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+#endif
 
 }  // extern "C"

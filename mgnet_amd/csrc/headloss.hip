@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "mgnet_hip.h"
+#include "h16.h"
 
 namespace {
 
@@ -32,7 +33,7 @@ struct UpGeom {
     float ry, rx;      // (h-1)/(H-1), (w-1)/(W-1)   (align_corners=True)
 };
 
-__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ float bf2f(uint16_t v) { return mgn_h2f(v); }   // this TU's 16-bit format (h16.h)
 
 struct Corner {
     long o00, o10, o01, o11;
@@ -501,9 +502,11 @@ inline UpGeom make_geom(int B, int h, int w, int H, int W, long sb, long sh, lon
 
 extern "C" {
 
+#ifndef MGN_F16
 int mgn_upce_partials(int B, int H, int W) { return B * ((H + 3) / 4) * ((W + 63) / 64); }
+#endif
 
-int mgn_upce_fwd(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K, const long* labels,
+int MGN_SYM(mgn_upce_fwd)(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K, const long* labels,
                  const float* weights, int ignore, float thr, float* ce_map, float* partials, float* sums3, void* stream) {
     if (!logits_bf16 || !labels || !ce_map || !partials || !sums3 || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
     if (K < 1 || K > 32 || sw % 8 != 0 || sh % 8 != 0 || sb % 8 != 0 || sw < ((K + 7) / 8) * 8) return MGN_ENOTSUP;
@@ -521,7 +524,7 @@ int mgn_upce_fwd(const void* logits_bf16, long sb, long sh, long sw, int B, int 
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_upce_bwd(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K, int Kp,
+int MGN_SYM(mgn_upce_bwd)(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K, int Kp,
                  const long* labels, const float* weights, int ignore, const float* ce_map, const float* sel3, const float* gout,
                  float* dlogits, void* stream) {
     if (!logits_bf16 || !labels || !ce_map || !sel3 || !gout || !dlogits || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
@@ -542,12 +545,15 @@ int mgn_upce_bwd(const void* logits_bf16, long sb, long sh, long sw, int B, int 
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
+#ifndef MGN_F16
 int mgn_ohem_select_workspace_bytes(long n, size_t* bytes) {
     if (!bytes || n < 1) return MGN_EINVAL;
     *bytes = sizeof(OhemState) + 256 * sizeof(unsigned) + sizeof(float) * 3 * 1024;
     return MGN_OK;
 }
+#endif
 
+#ifndef MGN_F16
 int mgn_ohem_select(const float* ce_map, long n, const float* sums3, float thr, long n_sel, int force_topk, float* sel3, float* loss,
                     void* workspace, size_t workspace_bytes, void* stream) {
     if (!ce_map || !sums3 || !sel3 || !loss || !workspace || n < 1 || n_sel < 1) return MGN_EINVAL;
@@ -566,8 +572,9 @@ int mgn_ohem_select(const float* ce_map, long n, const float* sums3, float thr, 
     hipLaunchKernelGGL(ohem_final, dim3(1), dim3(TPB), 0, s, sums3, thr, n_sel, (const OhemState*)st, (const float*)partials, nblk, sel3, loss);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+#endif
 
-int mgn_ins_loss_fwd(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh, long osw,
+int MGN_SYM(mgn_ins_loss_fwd)(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh, long osw,
                      int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot, const float* ow,
                      float oscale, float* partials, float* out4, void* stream) {
     if (!center_lr || !offset_lr_bf16 || !ct || !cw || !ot || !ow || !partials || !out4 || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
@@ -582,7 +589,7 @@ int mgn_ins_loss_fwd(const float* center_lr, long csb, long csh, long csw, const
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh, long osw,
+int MGN_SYM(mgn_ins_loss_bwd)(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh, long osw,
                      int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot, const float* ow,
                      float oscale, const float* out4, const float* gout2, float* dco, void* stream) {
     if (!center_lr || !offset_lr_bf16 || !ct || !cw || !ot || !ow || !out4 || !gout2 || !dco || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
@@ -597,13 +604,16 @@ int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
+#ifndef MGN_F16
 int mgn_upsample1_fwd(const float* lr, int B, int h, int w, int H, int W, float* out, void* stream) {
     if (!lr || !out || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
     const UpGeom g = make_geom(B, h, w, H, W, (long)h * w, w, 1);
     hipLaunchKernelGGL(up1_fwd, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(TPB), 0, (hipStream_t)stream, lr, g, out);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+#endif
 
+#ifndef MGN_F16
 int mgn_upsample1_bwd(const float* dfull, int B, int h, int w, int H, int W, float* dlr_zeroed, void* stream) {
     if (!dfull || !dlr_zeroed || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
     if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
@@ -611,5 +621,6 @@ int mgn_upsample1_bwd(const float* dfull, int B, int h, int w, int H, int W, flo
     hipLaunchKernelGGL(up1_bwd, dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B), dim3(TPB), 0, (hipStream_t)stream, dfull, g, dlr_zeroed);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+#endif
 
 }  // extern "C"

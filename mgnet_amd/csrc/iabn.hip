@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "mgnet_hip.h"
+#include "h16.h"
 
 namespace {
 
@@ -34,6 +35,8 @@ template <> struct Vec<float> {
     __device__ static void load(const float* p, float (&v)[4]) { unpack(load_raw(p), v); }
     __device__ static void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
+// 16-bit activations: `__hip_bfloat16` is only the pointer tag of "the 16-bit format of this translation unit" (h16.h:
+// bf16 in iabn.hip, IEEE fp16 in iabn_f16.hip); the conversions below go through h16.h
 template <> struct Vec<__hip_bfloat16> {
     static constexpr int N = 8;
     using Raw = uint4;
@@ -42,19 +45,12 @@ template <> struct Vec<__hip_bfloat16> {
         const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v[2 * k] = __uint_as_float(w[k] << 16);
-            v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+            v[2 * k] = mgn_lo2f(w[k]);
+            v[2 * k + 1] = mgn_hi2f(w[k]);
         }
     }
     __device__ static void load(const __hip_bfloat16* p, float (&v)[8]) { unpack(load_raw(p), v); }
-    __device__ static uint32_t pack(float a, float b) {  // round-to-nearest-even bf16 x2
-        auto rne = [](float f) -> uint32_t {
-            uint32_t u = __float_as_uint(f);
-            if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN
-            return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-        };
-        return rne(a) | (rne(b) << 16);
-    }
+    __device__ static uint32_t pack(float a, float b) { return mgn_pack2(a, b); }   // round-to-nearest-even x2
     __device__ static void store(__hip_bfloat16* p, const float (&v)[8]) {
         uint4 r;
         r.x = pack(v[0], v[1]); r.y = pack(v[2], v[3]); r.z = pack(v[4], v[5]); r.w = pack(v[6], v[7]);
@@ -484,6 +480,7 @@ unsigned* next_counter() {
 
 extern "C" {
 
+#ifndef MGN_F16
 int mgn_iabn_workspace_bytes(long M, int C, int dtype, size_t* bytes) {
     int rc = check_shape(M, C, dtype);
     if (rc != MGN_OK) return rc;
@@ -491,8 +488,9 @@ int mgn_iabn_workspace_bytes(long M, int C, int dtype, size_t* bytes) {
     *bytes = sizeof(float) * 2 * (size_t)C * 1024;
     return MGN_OK;
 }
+#endif
 
-int mgn_iabn_stats(const void* x, int dtype, long M, int C, float* stats, void* ws, size_t ws_bytes, void* stream_) {
+int MGN_SYM(mgn_iabn_stats)(const void* x, int dtype, long M, int C, float* stats, void* ws, size_t ws_bytes, void* stream_) {
     int rc = check_shape(M, C, dtype);
     if (rc != MGN_OK) return rc;
     if (!x || !stats || !ws) return MGN_EINVAL;
@@ -507,7 +505,7 @@ int mgn_iabn_stats(const void* x, int dtype, long M, int C, float* stats, void* 
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_iabn_train_coeffs(const void* x, int dtype, long M, int C, const float* weight, const float* bias, float eps, float momentum,
+int MGN_SYM(mgn_iabn_train_coeffs)(const void* x, int dtype, long M, int C, const float* weight, const float* bias, float eps, float momentum,
                           float* running_mean, float* running_var, float* coef, void* ws, size_t ws_bytes, void* stream_) {
     int rc = check_shape(M, C, dtype);
     if (rc != MGN_OK) return rc;
@@ -523,6 +521,7 @@ int mgn_iabn_train_coeffs(const void* x, int dtype, long M, int C, const float* 
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
+#ifndef MGN_F16
 int mgn_iabn_combine(const float* gathered, int n_ranks, int C, const float* weight, const float* bias, float eps,
                      float momentum, float* running_mean, float* running_var, float* scale, float* offset, float* saved,
                      void* stream_) {
@@ -531,7 +530,9 @@ int mgn_iabn_combine(const float* gathered, int n_ranks, int C, const float* wei
                        momentum, running_mean, running_var, scale, offset, saved);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+#endif
 
+#ifndef MGN_F16
 int mgn_iabn_eval_coeffs(int C, const float* weight, const float* bias, const float* running_mean, const float* running_var,
                          float eps, float* scale, float* offset, void* stream_) {
     if (C < 1 || !weight || !bias || !running_mean || !running_var || !scale || !offset) return MGN_EINVAL;
@@ -539,8 +540,9 @@ int mgn_iabn_eval_coeffs(int C, const float* weight, const float* bias, const fl
                        running_var, eps, scale, offset);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+#endif
 
-int mgn_iabn_apply(const void* x, void* y, int dtype, long M, int C, const float* scale, const float* offset, int activation,
+int MGN_SYM(mgn_iabn_apply)(const void* x, void* y, int dtype, long M, int C, const float* scale, const float* offset, int activation,
                    float slope, void* stream_) {
     int rc = check_shape(M, C, dtype);
     if (rc != MGN_OK) return rc;
@@ -555,13 +557,13 @@ int mgn_iabn_apply(const void* x, void* y, int dtype, long M, int C, const float
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_iabn_bwd_reduce(const void* y, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
+int MGN_SYM(mgn_iabn_bwd_reduce)(const void* y, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
                         float eps, int activation, float slope, float* sums, float* dwb, void* ws, size_t ws_bytes, void* stream_) {
-    return mgn_iabn_bwd_reduce_x(y, dy, dtype, M, C, weight, bias, nullptr, nullptr, eps, activation, slope, sums, dwb, ws, ws_bytes,
+    return MGN_SYM(mgn_iabn_bwd_reduce_x)(y, dy, dtype, M, C, weight, bias, nullptr, nullptr, eps, activation, slope, sums, dwb, ws, ws_bytes,
                                  stream_);
 }
 
-int mgn_iabn_bwd_reduce_x(const void* y, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
+int MGN_SYM(mgn_iabn_bwd_reduce_x)(const void* y, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
                           const float* scale, const float* offset, float eps, int activation, float slope, float* sums, float* dwb,
                           void* ws, size_t ws_bytes, void* stream_) {
     int rc = check_shape(M, C, dtype);
@@ -581,14 +583,14 @@ int mgn_iabn_bwd_reduce_x(const void* y, const void* dy, int dtype, long M, int 
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_iabn_bwd_apply(const void* y, const void* dy, void* dx, int dtype, long M, int C, const float* weight, const float* bias,
+int MGN_SYM(mgn_iabn_bwd_apply)(const void* y, const void* dy, void* dx, int dtype, long M, int C, const float* weight, const float* bias,
                        const float* saved, const float* sums, float total_count, float eps, int activation, float slope,
                        void* stream_) {
-    return mgn_iabn_bwd_apply_x(y, dy, dx, dtype, M, C, weight, bias, nullptr, nullptr, saved, sums, total_count, eps, activation, slope,
+    return MGN_SYM(mgn_iabn_bwd_apply_x)(y, dy, dx, dtype, M, C, weight, bias, nullptr, nullptr, saved, sums, total_count, eps, activation, slope,
                                 stream_);
 }
 
-int mgn_iabn_bwd_apply_x(const void* y, const void* dy, void* dx, int dtype, long M, int C, const float* weight, const float* bias,
+int MGN_SYM(mgn_iabn_bwd_apply_x)(const void* y, const void* dy, void* dx, int dtype, long M, int C, const float* weight, const float* bias,
                          const float* scale, const float* offset, const float* saved, const float* sums, float total_count, float eps,
                          int activation, float slope, void* stream_) {
     int rc = check_shape(M, C, dtype);

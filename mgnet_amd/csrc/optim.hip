@@ -54,6 +54,52 @@ __global__ void clip_coef_kernel(const float* partials, int n, float max_norm, f
     }
 }
 
+// The same with dynamic loss scaling (torch.cuda.amp.GradScaler semantics, all on the device: no host synchronisation, and the
+// launch can live in a captured graph).  The gradients in the buckets are S times the true ones:
+//   total    = ||g|| * grad_scale / S;  found_inf = !isfinite(total)
+//   out      = { clip coefficient / S (so the optimizer's g * grad_scale * out[0] is the clipped TRUE gradient), total, found_inf }
+//   scaler   = { S, growth tracker, t }:  found_inf -> S *= 0.5, tracker = 0, t unchanged (the optimizer skips the step);
+//              else t += 1, tracker += 1, and after `growth_interval` clean steps S *= 2
+//   hyper    = Adam's bias corrections for the new t
+__global__ void clip_coef_scaled_kernel(const float* partials, int n, float max_norm, float grad_scale, float beta1, float beta2,
+                                        int growth_interval, float* scaler, float* hyper, float* out) {
+    __shared__ double sh[TPB];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += TPB) acc += (double)partials[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float S = scaler[0];
+        const float total = (float)sqrt(sh[0]) * grad_scale / S;
+        const bool bad = !(fabsf(total) <= 3.0e38f);     // inf or NaN anywhere in the gradients
+        float coef = max_norm > 0.f ? max_norm / (total + 1e-6f) : 1.f;
+        out[0] = bad ? 0.f : fminf(coef, 1.f) / S;
+        out[1] = total;
+        out[2] = bad ? 1.f : 0.f;
+        float tracker = scaler[1], t = scaler[2];
+        if (bad) {
+            scaler[0] = fmaxf(S * 0.5f, 1.f);
+            tracker = 0.f;
+        } else {
+            t += 1.f;
+            tracker += 1.f;
+            if (tracker >= (float)growth_interval) {
+                scaler[0] = fminf(S * 2.f, 16777216.f);
+                tracker = 0.f;
+            }
+        }
+        scaler[1] = tracker;
+        scaler[2] = t;
+        const double tt = t < 1.f ? 1.0 : (double)t;
+        hyper[0] = (float)(1.0 / (1.0 - pow((double)beta1, tt)));
+        hyper[1] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, tt)));
+    }
+}
+
 __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, const float* __restrict__ chunk_lr,
                                                    const float* __restrict__ chunk_wd, float beta1, float beta2, float eps,
@@ -62,6 +108,7 @@ __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const 
     if (hyper) {   // bias corrections of the current step from device memory (a captured launch is replayed for every step)
         inv_bc1 = hyper[0];
         inv_sqrt_bc2 = hyper[1];
+        if (clip[2] != 0.f) return;   // dynamic loss scaling found inf/NaN gradients: the step is skipped (GradScaler.step)
     }
     const float gs = grad_scale * clip[0];
     const long nv = n / 4;  // buckets are padded to CHUNK multiples, so n % 4 == 0
@@ -112,6 +159,14 @@ int mgn_clip_coef(const float* partials, int n_partials, float max_norm, float g
     if (!partials || n_partials < 1 || !coef_and_norm) return MGN_EINVAL;
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)stream, partials, n_partials, max_norm, grad_scale,
                        coef_and_norm);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_clip_coef_scaled(const float* partials, int n_partials, float max_norm, float grad_scale, float beta1, float beta2,
+                         int growth_interval, float* scaler_state, float* hyper, float* coef_norm_found, void* stream) {
+    if (!partials || n_partials < 1 || !scaler_state || !hyper || !coef_norm_found || growth_interval < 1) return MGN_EINVAL;
+    hipLaunchKernelGGL(clip_coef_scaled_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)stream, partials, n_partials, max_norm, grad_scale,
+                       beta1, beta2, growth_interval, scaler_state, hyper, coef_norm_found);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

@@ -16,10 +16,11 @@
 #include <stdint.h>
 
 #include "mgnet_hip.h"
+#include "h16.h"
 
 namespace {
 
-__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ float bf2f(uint16_t v) { return mgn_h2f(v); }   // this TU's 16-bit format (h16.h)
 
 // one thread: 8 channels (16 bytes) of one output pixel
 __global__ __launch_bounds__(256) void maxpool_fwd(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, uint8_t* __restrict__ idx,
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd(const uint16_t* __restrict__ 
     uint16_t bits[8];
     uint8_t arg[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { best[k] = -3.4e38f; bits[k] = 0xff7f; arg[k] = 0; }
+    for (int k = 0; k < 8; ++k) { best[k] = -3.4e38f; bits[k] = MGN_H16_LOWEST; arg[k] = 0; }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int ih = oh * 2 - 1 + kh;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd(const uint16_t* __restrict__ 
             }
         }
     }
-    auto f2bf = [](float f) -> uint32_t { uint32_t u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+    auto f2bf = [](float f) -> uint32_t { return mgn_f2h(f); };
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int ih = 2 * i + a;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd(const uint16_t* __restrict__ 
 }
 
 // ---- fused with the activated batch norm of the stem --------------------------------------------------------------------
-__device__ __forceinline__ uint32_t f2bf_rne(float f) { uint32_t u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; }
+__device__ __forceinline__ uint32_t f2bf_rne(float f) { return mgn_f2h(f); }
 
 __global__ __launch_bounds__(256) void abn_maxpool_fwd(const uint16_t* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ offset, int leaky, float slope,
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void abn_maxpool_fwd(const uint16_t* __restric
     uint16_t bits[8];
     uint8_t arg[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { sc[k] = scale[c8 * 8 + k]; of[k] = offset[c8 * 8 + k]; best[k] = -3.4e38f; bits[k] = 0xff7f; arg[k] = 0; }
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[c8 * 8 + k]; of[k] = offset[c8 * 8 + k]; best[k] = -3.4e38f; bits[k] = MGN_H16_LOWEST; arg[k] = 0; }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int ih = oh * 2 - 1 + kh;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void abn_maxpool_bwd(const uint16_t* __restric
 
 extern "C" {
 
-int mgn_abn_maxpool_fwd(const void* x_bf16, const float* scale, const float* offset, int activation, float slope, void* y_bf16,
+int MGN_SYM(mgn_abn_maxpool_fwd)(const void* x_bf16, const float* scale, const float* offset, int activation, float slope, void* y_bf16,
                         uint8_t* argmax, int N, int IH, int IW, int C, void* stream) {
     if (!x_bf16 || !scale || !offset || !y_bf16 || !argmax || N < 1 || IH < 1 || IW < 1 || C < 8 || C % 8) return MGN_EINVAL;
     if (activation != 0 && activation != 1) return MGN_EINVAL;
@@ -284,7 +285,7 @@ int mgn_abn_maxpool_fwd(const void* x_bf16, const float* scale, const float* off
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_abn_maxpool_bwd(const void* x_bf16, const void* dpool_bf16, const uint8_t* argmax, void* dx_bf16, const float* scale,
+int MGN_SYM(mgn_abn_maxpool_bwd)(const void* x_bf16, const void* dpool_bf16, const uint8_t* argmax, void* dx_bf16, const float* scale,
                         const float* offset, const float* weight, const float* bias, const float* rstd, const float* sums,
                         float total_count, float eps, int activation, float slope, int N, int IH, int IW, int C, void* stream) {
     if (!x_bf16 || !dpool_bf16 || !argmax || !dx_bf16 || !scale || !offset || !weight || !bias || !rstd || !sums) return MGN_EINVAL;
@@ -297,7 +298,7 @@ int mgn_abn_maxpool_bwd(const void* x_bf16, const void* dpool_bf16, const uint8_
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_maxpool3x3s2_fwd(const void* x_bf16, void* y_bf16, uint8_t* argmax, int N, int IH, int IW, int C, void* stream) {
+int MGN_SYM(mgn_maxpool3x3s2_fwd)(const void* x_bf16, void* y_bf16, uint8_t* argmax, int N, int IH, int IW, int C, void* stream) {
     if (!x_bf16 || !y_bf16 || !argmax || N < 1 || IH < 1 || IW < 1 || C < 8 || C % 8) return MGN_EINVAL;
     const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
     const long n = (long)N * OH * OW * (C / 8);
@@ -306,7 +307,7 @@ int mgn_maxpool3x3s2_fwd(const void* x_bf16, void* y_bf16, uint8_t* argmax, int 
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_maxpool3x3s2_bwd(const void* dy_bf16, const uint8_t* argmax, void* dx_bf16, int N, int IH, int IW, int C, void* stream) {
+int MGN_SYM(mgn_maxpool3x3s2_bwd)(const void* dy_bf16, const uint8_t* argmax, void* dx_bf16, int N, int IH, int IW, int C, void* stream) {
     if (!dy_bf16 || !dx_bf16 || !argmax || N < 1 || IH < 1 || IW < 1 || C < 8 || C % 8) return MGN_EINVAL;
     const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
     const long n = (long)N * ((IH + 1) / 2) * ((IW + 1) / 2) * (C / 8);

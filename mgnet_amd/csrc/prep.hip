@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include "mgnet_hip.h"
+#include "h16.h"
 
 namespace {
 
@@ -18,10 +19,7 @@ struct PrepParams {
     uint16_t* out;             // [B, H, W, Cp] bf16
 };
 
-__device__ __forceinline__ uint32_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
+__device__ __forceinline__ uint32_t f2bf(float f) { return mgn_f2h(f); }   // this TU's 16-bit format (h16.h)
 
 __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
     const long hw = (long)p.H * p.W;
@@ -61,6 +59,7 @@ __global__ __launch_bounds__(256) void u8_frames_to_f32(U8Frames fr, long n16, f
 
 }  // namespace
 
+#ifndef MGN_F16
 extern "C" int mgn_u8_frames_to_f32(const void* const* frames_u8, int n_frames, long n_per_frame, float divisor, float* out,
                                     void* stream) {
     if (!frames_u8 || n_frames < 1 || n_frames > 16 || n_per_frame < 16 || n_per_frame % 16 || !(divisor != 0.f) || !out) return MGN_EINVAL;
@@ -75,8 +74,9 @@ extern "C" int mgn_u8_frames_to_f32(const void* const* frames_u8, int n_frames, 
     hipLaunchKernelGGL(u8_frames_to_f32, dim3((unsigned)bx, (unsigned)n_frames), dim3(256), 0, (hipStream_t)stream, fr, n16, divisor, out);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+#endif
 
-extern "C" int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
+extern "C" int MGN_SYM(mgn_prep_input)(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
                               const float* pixel_std3, void* out_bf16, int Cp, void* stream) {
     if (!frames_u8 || n_frames < 1 || n_frames > 3 || B < 1 || H < 1 || W < 1 || !pixel_mean3 || !pixel_std3 || !out_bf16) return MGN_EINVAL;
     if ((Cp != 8 && Cp != 16) || n_frames * 3 > Cp) return MGN_EINVAL;

@@ -1,6 +1,7 @@
 """Thin training loop reproducing what tools/train_net.py delegates to detectron2 (SURVEY 3.1 hot loop): forward ->
 sum of the loss dict -> backward (bucketed all-reduce overlapped) -> full-model clip -> Adam -> poly LR.
-bf16 autocast replaces the reference's fp16 + GradScaler: no loss scaling / inf check needed."""
+SOLVER.AMP: bf16 activations by default (no loss scaling needed); SOLVER.AMP.DTYPE "float16" runs the reference's fp16 with
+GradScaler's dynamic loss scaling evaluated on the device (solver/fused_adam.py, csrc/optim.hip: no host synchronisation)."""
 import torch
 
 from ..events import EventStorage
@@ -63,7 +64,7 @@ class Trainer:
             self.reducer.zero_grad()
             with self.storage:
                 loss_dict = self.model(batched_inputs)
-                sum(loss_dict.values()).backward()
+                self._backward(loss_dict)
             self.reducer.finish()
             self.optimizer.launch_step()
         self._graph, self._graph_losses = graph, loss_dict
@@ -78,13 +79,19 @@ class Trainer:
         self.storage.step()
         return self._graph_losses
 
+    def _backward(self, loss_dict):
+        """sum of the loss dict -> backward; with fp16 activations the sum is multiplied by the dynamic loss scale first
+        (GradScaler.scale(losses).backward(), detectron2 AMPTrainer.run_step)"""
+        losses = sum(loss_dict.values())
+        scale = self.optimizer.loss_scale() if hasattr(self.optimizer, "loss_scale") else None
+        (losses if scale is None else losses * scale).backward()
+
     def run_step(self, batched_inputs):
         self.model.train()
         self.reducer.zero_grad()
         with self.storage:
             loss_dict = self.model(batched_inputs)
-            losses = sum(loss_dict.values())
-            losses.backward()
+            self._backward(loss_dict)
         self.reducer.finish()
         self.optimizer.step()
         self.scheduler.step()

@@ -22,6 +22,16 @@ __all__ = ["MGNet", "INS_EMBED_HEADS_REGISTRY", "build_ins_embed_head", "DEPTH_H
            "MGNetSemSegHead", "MGNetInsEmbedHead", "MGNetSelfSupervisedDepthHead"]
 
 
+def _amp_dtype(cfg):
+    """SOLVER.AMP.ENABLED -> the 16-bit activation format of the trunk.  detectron2's AMPTrainer (torch.cuda.amp) is IEEE fp16 +
+    GradScaler (tools/train_net.py:162); this stack defaults to bf16 (no loss scaling needed, same MFMA rate) and runs the
+    reference's fp16 + dynamic loss scaling with SOLVER.AMP.DTYPE "float16" (a key added by mgnet_amd)."""
+    if not cfg.SOLVER.AMP.ENABLED:
+        return None
+    name = str(cfg.SOLVER.AMP.get("DTYPE", "bfloat16")) if hasattr(cfg.SOLVER.AMP, "get") else "bfloat16"
+    return {"bfloat16": torch.bfloat16, "bf16": torch.bfloat16, "float16": torch.float16, "fp16": torch.float16}[name]
+
+
 def _decoder_kwargs(node, input_shape, feature_node=None):
     feats = (feature_node or node).IN_FEATURES
     return dict(input_shape={k: v for k, v in input_shape.items() if k in feats}, common_stride=node.COMMON_STRIDE,
@@ -88,7 +98,7 @@ class MGNet(nn.Module):
                     pixel_std=cfg.MODEL.PIXEL_STD, backbone=backbone, global_context=gcm, sem_seg_head=sem,
                     ins_embed_head=ins, depth_head=dep, pose_net=pose, with_panoptic=cfg.WITH_PANOPTIC,
                     with_depth=cfg.WITH_DEPTH, with_uncertainty=cfg.WITH_UNCERTAINTY, msc_flip_eval=cfg.TEST.MSC_FLIP_EVAL,
-                    amp_dtype=torch.bfloat16 if cfg.SOLVER.AMP.ENABLED else None, predict_instances=cfg.TEST.EVAL_INSTANCE,
+                    amp_dtype=_amp_dtype(cfg), predict_instances=cfg.TEST.EVAL_INSTANCE,
                     panoptic_post_proc_func=pan_fn, depth_post_proc_func=dep_fn)
 
     @property
@@ -129,15 +139,15 @@ class MGNet(nn.Module):
 
     def forward(self, batched_inputs):
         inputs, outputs, targets = {}, {}, {}
-        fused_prep = self.pixel_mean.is_cuda and self.amp_dtype == torch.bfloat16 and batched_inputs[0]["image"].dtype == torch.uint8
+        fused_prep = self.pixel_mean.is_cuda and self.amp_dtype in (torch.bfloat16, torch.float16) and batched_inputs[0]["image"].dtype == torch.uint8
         if fused_prep:  # [HIP] uint8 frames -> normalised, channel-padded NHWC bf16 in one pass (csrc/prep.hip)
             from .. import _C
             mean, std = self._mean01, self._std01   # (host constants: reading the device buffers would sync every step)
             frames = [self._stack(batched_inputs, "image")]
-            inputs["image"] = _C.prep_input(frames, mean, std, 8)
+            inputs["image"] = _C.prep_input(frames, mean, std, 8, self.amp_dtype)
             if self.training and self.with_depth:
                 frames += [self._stack(batched_inputs, "image_prev"), self._stack(batched_inputs, "image_next")]
-                outputs["poses"] = self.pose_net(_C.prep_input(frames, mean, std, 16))  # channels: image, prev, next (:264)
+                outputs["poses"] = self.pose_net(_C.prep_input(frames, mean, std, 16, self.amp_dtype))  # channels: image, prev, next (:264)
         else:
             inputs["image"] = self._net_input(batched_inputs, "image")
             if self.training and self.with_depth:
@@ -206,7 +216,7 @@ def _as_net_input(self, x):
     """fp32 NCHW normalised frames -> what the backbone's stem consumes: under bf16 on the GPU the channels are zero-padded
     to 8 (the packed-tap stem kernel's layout, like csrc/prep.hip produces), channels-last."""
     if self.amp_dtype is not None:
-        if x.is_cuda and self.amp_dtype == torch.bfloat16:
+        if x.is_cuda and self.amp_dtype in (torch.bfloat16, torch.float16):
             x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 8 - x.shape[1]))
         x = x.to(self.amp_dtype)
     return x.contiguous(memory_format=torch.channels_last) if x.is_cuda else x.contiguous()

@@ -141,7 +141,7 @@ class _AbnPoolFn(torch.autograd.Function):
         M, C, eps, act, slope, group, world, training, total, wdtype = ctx.cfg
         if not training:
             raise NotImplementedError("backward through eval-mode InPlaceABNSync is not on the training path")
-        dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dy = dy.to(y.dtype).contiguous(memory_format=torch.channels_last)
         # d y is zero away from the arg-max positions and y there is the pooled value: the channel sums over the full map
         # equal the sums over the pooled tensors
         sums, d_weight, d_bias = _C.iabn_bwd_reduce(y, dy, y.numel() // C, C, w32, b32, eps, act, slope)
@@ -185,7 +185,7 @@ class _AbnAddReluFn(torch.autograd.Function):
         M, C, eps, group, world, training, total, wdtype = ctx.cfg
         if not training:
             raise NotImplementedError("backward through eval-mode InPlaceABNSync is not on the training path")
-        dm = _C.relu_mask_bwd(_cl(g), y)   # gradient of both summands
+        dm = _C.relu_mask_bwd(_cl(g, y), y)   # gradient of both summands
         sums, d_weight, d_bias = _C.iabn_bwd_reduce_x(x, dm, M, C, w32, b32, coef, eps, 0, 0.01)
         if world > 1:
             SYNCBN_COLLECTIVES[0] += 1
@@ -208,7 +208,7 @@ def abn_add_relu(x, norm, shortcut):
 def abn_max_pool(x, norm):
     """`max_pool_3x3_s2(norm(x))` for an InPlaceABNSync `norm` (BasicStem); fused on the GPU path."""
     from .. import _C
-    if (x.is_cuda and x.dtype == torch.bfloat16 and _C.elt_supported(x) and not os.environ.get("MGN_NO_STEMFUSE")
+    if (x.is_cuda and x.dtype in _C.H16 and _C.elt_supported(x) and not os.environ.get("MGN_NO_STEMFUSE")
             and norm.activation in ("identity", "leaky_relu")):
         return _AbnPoolFn.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.training, norm.momentum,
                                 norm.eps, norm.activation, norm.activation_param, norm.group)
@@ -265,11 +265,11 @@ class _ConvFn(torch.autograd.Function):
         b = None if bias is None else bias.detach().float().contiguous()
         packed = Cin in (8, 16)
         if packed:  # stem on a channel-padded input: k = tap*Cin + c, row padded to a multiple of 32
-            out = _C.conv_igemm(xs, _C.weight_layout(weight, 2, Cin), (OH, OW), b, stride, pad, 1, relu, khw=(KH, KW))
+            out = _C.conv_igemm(xs, _C.weight_layout(weight, 2, Cin, dtype=xs.dtype), (OH, OW), b, stride, pad, 1, relu, khw=(KH, KW))
         else:
             if cout_pad and b is not None:
                 b = torch.cat([b, b.new_zeros(cout_pad - Cout)])
-            out = _C.conv_igemm(xs, _C.weight_layout(weight, 0, 0, cout_pad), (OH, OW), b, stride, pad, 1, relu)
+            out = _C.conv_igemm(xs, _C.weight_layout(weight, 0, 0, cout_pad, dtype=xs.dtype), (OH, OW), b, stride, pad, 1, relu)
         ctx.save_for_backward(xs, weight, out if relu else None)
         ctx.cfg = (stride, pad, relu, bias is not None, cout_pad)
         if cout_pad:    # few-class predictors: the kernels work on 32-padded output channels, the caller sees the real ones
@@ -286,7 +286,7 @@ class _ConvFn(torch.autograd.Function):
         stride, pad, relu, has_bias, cout_pad = ctx.cfg
         Cout, Cin, KH, KW = weight.shape
         Cx = xs.shape[1]
-        dy = dy.to(torch.bfloat16)
+        dy = dy.to(xs.dtype)
         if cout_pad:    # zero gradient for the padding channels
             dyp = torch.zeros((dy.shape[0], cout_pad) + tuple(dy.shape[2:]), dtype=dy.dtype, device=dy.device).contiguous(memory_format=torch.channels_last)
             dyp[:, :Cout] = dy
@@ -298,8 +298,8 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             assert Cx == Cin, "no data gradient for the channel-padded stem input"
             # the gradient of the skip branch is added in the kernel's epilogue instead of by a separate accumulate pass
-            res = None if dskip is None else dskip.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            dx = _C.conv_igemm(dy, _C.weight_layout(weight, 1, 0, cout_pad), xs.shape[2:], None, 1, KH - 1 - pad, up=stride, residual=res)
+            res = None if dskip is None else dskip.to(xs.dtype).contiguous(memory_format=torch.channels_last)
+            dx = _C.conv_igemm(dy, _C.weight_layout(weight, 1, 0, cout_pad, dtype=xs.dtype), xs.shape[2:], None, 1, KH - 1 - pad, up=stride, residual=res)
         if ctx.needs_input_grad[1]:
             dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad, cin_real=Cin)[:Cout]
         if has_bias and ctx.needs_input_grad[2]:
@@ -346,25 +346,31 @@ class _MaxPoolFn(torch.autograd.Function):
         from .. import _C
         y, arg = _C.maxpool_fwd(x.contiguous(memory_format=torch.channels_last))
         ctx.save_for_backward(arg)
-        ctx.in_shape = tuple(x.shape)
+        ctx.in_shape, ctx.dtype = tuple(x.shape), x.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from .. import _C
         (arg,) = ctx.saved_tensors
-        return _C.maxpool_bwd(dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), arg, ctx.in_shape)
+        return _C.maxpool_bwd(dy.to(ctx.dtype).contiguous(memory_format=torch.channels_last), arg, ctx.in_shape)
 
 
 def max_pool_3x3_s2(x):
     """F.max_pool2d(x, 3, stride 2, padding 1) (res_net.py:109).  bf16 CUDA: [HIP]; otherwise [torch-staging]."""
-    if x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0:
+    if x.is_cuda and x.dtype in _C_H16() and x.shape[1] % 8 == 0:
         return _MaxPoolFn.apply(x)
     return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
 
 
-def _cl(t):
-    return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+def _C_H16():
+    from .. import _C
+    return _C.H16
+
+
+def _cl(t, like):
+    """gradient `t` in the 16-bit activation format of `like` (a tensor or a dtype), channels-last"""
+    return t.to(like if isinstance(like, torch.dtype) else like.dtype).contiguous(memory_format=torch.channels_last)
 
 
 class _GapFn(torch.autograd.Function):
@@ -373,7 +379,7 @@ class _GapFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         from .. import _C
-        ctx.shape = tuple(x.shape)
+        ctx.shape, ctx.dtype = tuple(x.shape), x.dtype
         N, C, H, W = x.shape
         return _C.colsum(x, None, 1.0 / (H * W)).to(x.dtype).view(N, C, 1, 1)
 
@@ -381,7 +387,7 @@ class _GapFn(torch.autograd.Function):
     def backward(ctx, g):
         from .. import _C
         N, C, H, W = ctx.shape
-        return _C.bcast_rows(g.float().reshape(N, C).contiguous(), ctx.shape, 1.0 / (H * W))
+        return _C.bcast_rows(g.float().reshape(N, C).contiguous(), ctx.shape, 1.0 / (H * W), ctx.dtype)
 
 
 def global_avg_pool(x):
@@ -396,13 +402,13 @@ class _NearestFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, H, W):
         from .. import _C
-        ctx.hw = x.shape[2:]
+        ctx.hw, ctx.dtype = x.shape[2:], x.dtype
         return _C.nearest_fwd(x, H, W)
 
     @staticmethod
     def backward(ctx, g):
         from .. import _C
-        g = _cl(g)
+        g = _cl(g, ctx.dtype)
         if ctx.hw[0] == 1 and ctx.hw[1] == 1:  # broadcast of a pooled vector (GlobalContextModule): its adjoint is a column sum
             N, C = g.shape[:2]
             return _C.colsum(g, None, 1.0).to(g.dtype).view(N, C, 1, 1).contiguous(memory_format=torch.channels_last), None, None
@@ -430,7 +436,7 @@ class _AddReluFn(torch.autograd.Function):
     def backward(ctx, g):
         from .. import _C
         (y,) = ctx.saved_tensors
-        dx = _C.relu_mask_bwd(_cl(g), y)
+        dx = _C.relu_mask_bwd(_cl(g, y), y)
         return dx, dx
 
 
@@ -455,7 +461,7 @@ class _ScaleFn(torch.autograd.Function):
     def backward(ctx, g):
         from .. import _C
         x, s32 = ctx.saved_tensors
-        g = _cl(g)
+        g = _cl(g, x)
         dx = _C.scale_channels(g, s32, ctx.mode)
         ds = _C.colsum(g, x, 1.0).to(ctx.sdtype).view(ctx.sshape)
         return dx, ds, None
@@ -498,7 +504,7 @@ class _ChannelAttentionFn(torch.autograd.Function):
     def backward(ctx, g):
         from .. import _C
         kind, residual, eps, w1s, p2s = ctx.cfg
-        g = _cl(g)
+        g = _cl(g, ctx.saved_tensors[0])
         if kind == "arm":
             x, pooled, s, w1c, bnw, xhat, rstd = ctx.saved_tensors
             ds = _C.colsum(g, x, 1.0)
@@ -536,13 +542,13 @@ class _CatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         from .. import _C
-        ctx.c = (a.shape[1], b.shape[1])
+        ctx.c, ctx.dtype = (a.shape[1], b.shape[1]), a.dtype
         return _C.concat2(a, b)
 
     @staticmethod
     def backward(ctx, g):
         from .. import _C
-        return _C.split2(_cl(g), *ctx.c)
+        return _C.split2(_cl(g, ctx.dtype), *ctx.c)
 
 
 def concat_channels(a, b):

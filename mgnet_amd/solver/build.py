@@ -65,7 +65,10 @@ def build_optimizer(cfg, model, reducer=None):
     wrap = (lambda c: _with_full_model_clipping(c, clip.CLIP_VALUE, clip.NORM_TYPE)) if enable else (lambda c: c)
     if reducer is not None and s.OPTIMIZER == "ADAM":
         from .fused_adam import FusedAdam
-        return FusedAdam(groups, s.BASE_LR, reducer, max_grad_norm=clip.CLIP_VALUE if enable else 0.0)
+        fp16 = getattr(model, "amp_dtype", None) == torch.float16   # the reference's AMP: fp16 needs GradScaler's dynamic loss scale
+        return FusedAdam(groups, s.BASE_LR, reducer, max_grad_norm=clip.CLIP_VALUE if enable else 0.0,
+                         loss_scale=float(s.AMP.LOSS_SCALE_INIT) if fp16 else None,
+                         growth_interval=int(s.AMP.LOSS_SCALE_GROWTH_INTERVAL))
     if s.OPTIMIZER == "SGD":
         return wrap(torch.optim.SGD)(groups, s.BASE_LR, momentum=s.MOMENTUM, nesterov=s.NESTEROV)
     if s.OPTIMIZER == "ADAM":

@@ -8,7 +8,8 @@ from .. import _C
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr, reducer, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=0.0):
+    def __init__(self, params, lr, reducer, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=0.0, loss_scale=None,
+                 growth_interval=2000):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.reducer, self.max_grad_norm = reducer, float(max_grad_norm)
         assert reducer.align == _C.optim_chunk() and all(b["flat_p"] is not None for b in reducer.buckets)
@@ -22,7 +23,12 @@ class FusedAdam(torch.optim.Optimizer):
         self._hyper = torch.ones(2, device=dev)   # [1/(1-b1^t), 1/sqrt(1-b2^t)] of the current step
         self._stager = _C.PinnedStager()
         self._partials = torch.zeros(1024 * len(reducer.buckets), device=dev)
-        self._coef = torch.zeros(2, device=dev)
+        self._coef = torch.zeros(4, device=dev)    # clip coefficient (/ loss scale), gradient norm, found_inf
+        # dynamic loss scaling (fp16 activations; torch.cuda.amp.GradScaler semantics evaluated on the device): the loss is
+        # multiplied by scaler[0] before backward, mgn_clip_coef_scaled unscales / detects inf / adapts the scale and counts
+        # the optimizer steps actually taken
+        self.growth_interval = int(growth_interval)
+        self.scaler = None if loss_scale is None else torch.tensor([float(loss_scale), 0.0, 0.0], device=dev)
         self._group_of = {p: g for g in self.param_groups for p in g["params"]}
         # chunks owned by each parameter
         self._reps = [np.array([(p.numel() + self.chunk - 1) // self.chunk for p in b["params"]]) for b in reducer.buckets]
@@ -38,9 +44,10 @@ class FusedAdam(torch.optim.Optimizer):
             tab = self._stager.stage(torch.from_numpy(np.stack([lr, wd])), self._lr_dev[k].device, slot=k)   # (event-guarded pinned ring)
             self._lr_dev[k].copy_(tab[0])
             self._wd_dev[k].copy_(tab[1])
-        bc1, bc2 = 1.0 - g0["betas"][0] ** self._t, 1.0 - g0["betas"][1] ** self._t
-        hy = self._stager.stage(torch.tensor([1.0 / bc1, 1.0 / np.sqrt(bc2)], dtype=torch.float32), self._hyper.device, slot="hyper")
-        self._hyper.copy_(hy)
+        if self.scaler is None:   # (with loss scaling the device counts the steps taken: a step with inf gradients is skipped)
+            bc1, bc2 = 1.0 - g0["betas"][0] ** self._t, 1.0 - g0["betas"][1] ** self._t
+            hy = self._stager.stage(torch.tensor([1.0 / bc1, 1.0 / np.sqrt(bc2)], dtype=torch.float32), self._hyper.device, slot="hyper")
+            self._hyper.copy_(hy)
 
     def prepare_step(self):
         """host part of a step (step count, tables); `launch_step` is the device part"""
@@ -54,8 +61,12 @@ class FusedAdam(torch.optim.Optimizer):
         n = 0
         for b in self.reducer.buckets:
             n += _C.sqnorm(b["flat_g"], self._partials, n)
-        _C.clip_coef(self._partials, n, self.max_grad_norm, grad_scale, self._coef)
         g0 = self.param_groups[0]
+        if self.scaler is None:
+            _C.clip_coef(self._partials, n, self.max_grad_norm, grad_scale, self._coef)
+        else:
+            _C.clip_coef_scaled(self._partials, n, self.max_grad_norm, grad_scale, g0["betas"][0], g0["betas"][1], self.growth_interval,
+                                self.scaler, self._hyper, self._coef)
         for k, b in enumerate(self.reducer.buckets):
             _C.adam_step_dev(b["flat_p"], b["flat_g"], self._m[k], self._v[k], self._lr_dev[k], self._wd_dev[k],
                              g0["betas"][0], g0["betas"][1], g0["eps"], self._hyper, self._coef, grad_scale)
@@ -105,6 +116,10 @@ class FusedAdam(torch.optim.Optimizer):
                 idx += 1
         assert len(steps) <= 1, "per-parameter step counts differ: not a full-model Adam state"
         self._t = steps.pop() if steps else 0
+
+    def loss_scale(self):
+        """device scalar S the loss must be multiplied with before backward (None: no loss scaling)"""
+        return None if self.scaler is None else self.scaler[0]
 
     def grad_norm(self):
         """total gradient norm of the last step (device scalar; no sync)"""
