@@ -282,7 +282,21 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x >> 6;  // 0 = image wave, 1..n = scale waves
-    const int bid = blockIdx.x;
+    // XCD-aware tile order.  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2);
+    // with tile = blockIdx the horizontally adjacent strips of a row segment -- which share 128-byte lines, because a strip is
+    // 240 bytes wide and starts 8 bytes before a multiple of 240 -- land on 8 different L2s and every shared line is fetched
+    // once per XCD (measured: 1.81 GB read per launch against 0.82 GB of input).  Here the tiles are dealt in groups of
+    // 8 row segments: XCD k takes ALL strips of the k-th segment of the group, so neighbours in x share an L2 while the
+    // 8 XCDs still walk through the same part of the frame together (one contiguous eighth of the tile list per XCD removed
+    // the re-reads as well but ran 6 % slower: eight frames in flight at once).
+    int bid = blockIdx.x;
+    {
+        const int G = p.nstrips, super = 8 * G, first = (bid / super) * super;
+        if (first + super <= (int)gridDim.x) {   // (the last, partial group keeps the identity order)
+            const int r = bid - first;
+            bid = first + (r & 7) * G + (r >> 3);
+        }
+    }
     const int strip = bid % p.nstrips;
     const int seg = (bid / p.nstrips) % p.nseg;
     const int b = bid / (p.nstrips * p.nseg);
