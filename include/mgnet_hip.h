@@ -195,6 +195,12 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
                    int KH, int KW, int stride, int pad, int oihw_cin /* >0: dw is [Cout][oihw_cin][KH][KW] */,
                    void* workspace, size_t workspace_bytes, void* stream);
 int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, size_t* bytes);
+/* 3x3 / stride 1 / pad 1 convolution (forward, or data gradient on flipped+transposed weights) with Cin % 32 == 0 and
+ * Cout % 128 == 0 as a WINDOWED implicit GEMM (csrc/conv_win.hip): a block owns a patch of patch_rows (8 | 16) x 32 output pixels
+ * and keeps the input window in LDS for all nine taps.  Same tensors as mgn_conv_igemm (which dispatches here for the
+ * 128/256/512-channel layers of res_net.py:28-60 and layers.py:53-72,110-118,201-210,283-311); MGN_ENOTSUP for other shapes. */
+int mgn_conv3x3_win(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
+                    int patch_rows, void* stream);
 /* fp32 OIHW master weights -> bf16 kernel layout. mode 0: [Cout][KH][KW][Cin]; 1: [Cin][KH][KW][Cout] with flipped taps
  * (data gradient); 2: packed-tap stem layout [Cout][ceil(KH*KW*Cp/32)*32] for a Cp-channel (8|16) padded input */
 int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp,
@@ -469,6 +475,8 @@ int mgn_conv_igemm_f16(const void* in, const void* w, void* out, const float* bi
 int mgn_conv_wgrad_f16(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW,
     int Cout, int KH, int KW, int stride, int pad, int oihw_cin /* >0: dw is [Cout][oihw_cin][KH][KW] */, void*
     workspace, size_t workspace_bytes, void* stream);
+int mgn_conv3x3_win_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
+    int patch_rows, void* stream);
 int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);
 int mgn_abn_add_relu_fwd_f16(const void* x, const float* scale, const float* offset, const void* shortcut, void* y,
     long M, int C, void* stream);

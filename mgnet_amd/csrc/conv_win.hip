@@ -1,0 +1,266 @@
+// conv_win.hip -- 3x3 / stride 1 / pad 1 convolutions with >= 128 output channels as a WINDOWED implicit GEMM (gfx950).
+//
+// Replaces, for the 128/256/512-channel layers of mgnet/modeling/res_net.py:28-60 (BasicBlock conv1/conv2 of res3..res5) and
+// layers.py:53-72,110-118,201-210,283-311 (decoder / head 3x3 convs), the generic implicit GEMM of conv.hip.  Same contract as
+// mgn_conv_igemm (NHWC 16-bit activations, weights [Cout][3][3][Cin], fp32 accumulation, optional 16-bit residual); the data
+// gradient of those layers is this kernel on the flipped / transposed weights.
+//
+// Why: the implicit GEMM gathers the A operand once per TAP (every input pixel travels L2 -> LDS nine times) and the
+// global -> LDS fill rate of a CU (~12 B/clk) bounds it at ~36 % MFMA utilisation for a 256 x 256 tile, ~25 % for the 128-channel
+// layers.  Here a block owns a 2-D PATCH of PH x 32 output pixels and keeps the (PH+2) x 34 input window
+// of one 32-channel chunk in LDS for all nine taps: a tap is an address offset into the window, so A is fetched ~1.2x instead
+// of 9x.  With A nearly free the tile is tall and narrow -- 512 pixels x 128 output channels -- which halves the weight bytes
+// per flop as well: 8 KB of weights + 4.4 KB of window per k-step (512 x 128 x 32 MACs) instead of 32 KB.
+//
+//   block : 8 waves = 4 (pixel rows) x 2 (64 output channels); wave tile (PH/4 rows x 32 px) x 64 co = PH/4 x 2 MFMA tiles
+//           (v_mfma_f32_32x32x16, operands swapped: D rows = output channels, so a lane holds 4 consecutive channels of a pixel)
+//   k loop: channel chunk outer (32 channels), tap inner; one barrier per k-step
+//   LDS   : window [2 buffers][640 px][64 B] (pixel-major, 16-byte slots XOR-swizzled by (px >> 2) & 3: every fragment read is
+//           conflict-free for ANY tap shift), weights [4 stages][128 co][64 B]; everything arrives by LDS-DMA
+//           (buffer_load_dwordx4 ... lds, zero padding from the buffer bounds check), the next chunk's window is fetched while the
+//           nine taps of the current one run; counted vmcnt waits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "mgnet_hip.h"
+
+namespace {
+
+#include "h16.h"
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct WinParams {
+    const uint16_t* in;        // [N, H, W, Cin]
+    const uint16_t* w;         // [Cout, 3, 3, Cin]
+    uint16_t* out;             // [N, H, W, Cout]
+    const uint16_t* residual;  // [N, H, W, Cout] added before rounding, or null
+    int N, H, W, Cin, Cout;
+    int py, px;                // patches per image (rows, columns)
+    int xcd;                   // 1: deal contiguous bands of patches to the XCDs
+};
+
+constexpr int PW = 32, WW = PW + 2;
+constexpr int WIN_PIECES = 40;                 // 1-KB DMA pieces of 16 pixels x 64 B: 5 per wave (612 of the 640 pixels are real)
+constexpr int WIN_BYTES = WIN_PIECES * 1024;
+constexpr int WST_BYTES = 128 * 64;            // one weight stage: 128 output channels x 32 input channels
+constexpr int NWST = 4;
+constexpr int WIN_LDS = 2 * WIN_BYTES + NWST * WST_BYTES;
+
+__device__ __forceinline__ int xcd_tile(int b, int nb) {   // block b -> XCD b % 8; XCD k works on a contiguous band of tiles
+    const int k = b & 7, j = b >> 3, q = nb >> 3, r = nb & 7;
+    return k * q + (k < r ? k : r) + j;
+}
+
+// PH = 16: patch 16 x 32 (4 rows per wave); PH = 8: patch 8 x 32 (2 rows per wave) for layers with few pixels
+template <int PH>
+__device__ __forceinline__ void conv_win_body(const WinParams& p) {
+    constexpr int RPW = PH / 4;               // pixel rows (= MFMA tiles) per wave
+    constexpr int WPX = (PH + 2) * WW;        // real window pixels
+    constexpr int NWP = (WPX + 127) / 128;    // window pieces per wave and chunk (5 for PH = 16, 3 for PH = 8)
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    unsigned char* const winb = wsm;
+    unsigned char* const wst = wsm + 2 * WIN_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int patch = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x, bn = blockIdx.y;
+    const int ppi = p.py * p.px;
+    const int n = patch / ppi, prem = patch - n * ppi, pyi = prem / p.px, pxi = prem - pyi * p.px;
+    const int y0 = pyi * PH, x0 = pxi * PW;
+
+    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.H * p.W * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * 9 * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, w_bytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    // window pieces of this wave: piece q = wave + 8 i covers window pixels 16 q .. 16 q + 15 (lane >> 2), 16-byte slot lane & 3
+    int wvoff[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int pp = (wave + 8 * i) * 16 + (lane >> 2);
+        const int sseg = (lane & 3) ^ ((pp >> 2) & 3);    // source segment that lands in slot lane & 3
+        const int wy = pp / WW, wx = pp - wy * WW;
+        const int iy = y0 - 1 + wy, ix = x0 - 1 + wx;
+        const bool ok = pp < WPX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        wvoff[i] = ok ? (((n * p.H + iy) * p.W + ix) * p.Cin + sseg * 8) * 2 : OOB;
+    }
+    int wbase;
+    {
+        const int row = wave * 16 + (lane >> 2);
+        const int sseg = (lane & 3) ^ ((row >> 2) & 3);
+        wbase = ((bn * 128 + row) * 9 * p.Cin + sseg * 8) * 2;
+    }
+    const int nch = p.Cin / 32, ksteps = nch * 9;
+    auto issue_w = [&](int c, int t, int stage) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(wst + stage * WST_BYTES + wave * 1024), 16, wbase, (t * p.Cin + c * 32) * 2, 0, 0);
+    };
+    auto issue_win = [&](int c, int i, int buf) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(winb + buf * WIN_BYTES + (wave + 8 * i) * 1024), 16, wvoff[i], c * 64, 0, 0);
+    };
+
+    // fragment byte offsets (kk = 0; kk = 1 flips bit 5): A from the window at (row 4*wm*RPW/4.. + dy, column l31 + kw)
+    int aoff[RPW + 2][3];
+#pragma unroll
+    for (int dy = 0; dy < RPW + 2; ++dy)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int pp = (wm * RPW + dy) * WW + l31 + kw;
+            aoff[dy][kw] = pp * 64 + ((hi ^ ((pp >> 2) & 3)) << 4);
+        }
+    int boff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wn * 64 + j * 32 + l31;
+        boff[j] = row * 64 + ((hi ^ ((row >> 2) & 3)) << 4);
+    }
+
+    f32x16 acc[RPW][2];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // Pipeline.  Loads are issued in the order [window piece] W per k-step; W(s + 3) is issued at step s (ring of 4 stages) and
+    // the wait at the top of step s is for W(s + 1): after the barrier every wave may therefore read the fragments of step s + 1
+    // already, and the first half (kk = 0) of the NEXT step's fragments is fetched from LDS while the second half of this
+    // step's MFMAs run -- no LDS latency is exposed after a barrier.  Loads younger than W(s + 1) at that point: what step s - 1
+    // issued = [its window piece] + W(s + 2).
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) issue_win(0, i, 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    issue_w(0, 2, 2);
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    auto load_frags = [&](const unsigned char* win, const unsigned char* ws, int kh, int kw, int kk, h16x8 (&a)[RPW], h16x8 (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) a[i] = *reinterpret_cast<const h16x8*>(win + (aoff[i + kh][kw] ^ (kk << 5)));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const h16x8*>(ws + (boff[j] ^ (kk << 5)));
+    };
+    auto mma = [&](const h16x8 (&a)[RPW], const h16x8 (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = MGN_MFMA_32x32x16(b[j], a[i], acc[i][j]);
+    };
+
+    h16x8 a0[RPW], b0[2], a1[RPW], b1[2];
+    load_frags(winb, wst, 0, 0, 0, a0, b0);
+    int stage = 0;   // stage of k-step s = s & 3
+    auto chunk = [&](int c, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const unsigned char* win = winb + (c & 1) * WIN_BYTES;
+        const unsigned char* win_next = winb + ((c + 1) & 1) * WIN_BYTES;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (LAST) {
+                if (t + 2 <= 8) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (t >= 1 && t - 1 < NWP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (!LAST && t < NWP) issue_win(c + 1, t, (c + 1) & 1);
+            if (!LAST || t + 3 <= 8) {
+                const int t3 = t + 3 >= 9 ? t + 3 - 9 : t + 3, c3 = t + 3 >= 9 ? c + 1 : c;
+                issue_w(c3, t3, (stage + 3) & 3);
+            }
+            const int kh = t / 3, kw = t - kh * 3;
+            const unsigned char* ws = wst + stage * WST_BYTES;
+            const unsigned char* ws_next = wst + ((stage + 1) & 3) * WST_BYTES;
+            load_frags(win, ws, kh, kw, 1, a1, b1);
+            mma(a0, b0);
+            if (t < 8) load_frags(win, ws_next, (t + 1) / 3, (t + 1) % 3, 0, a0, b0);
+            else if (!LAST) load_frags(win_next, ws_next, 0, 0, 0, a0, b0);
+            mma(a1, b1);
+            stage = (stage + 1) & 3;
+        }
+    };
+    for (int c = 0; c + 1 < nch; ++c) chunk(c, std::false_type{});
+    chunk(nch - 1, std::true_type{});
+
+    // D = W-rows x pixels: column = lane & 31 -> pixel of the row, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel
+    const int ox = x0 + l31;
+    if (ox < p.W) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int oy = y0 + wm * RPW + i;
+            if (oy >= p.H) break;
+            const size_t m = ((size_t)n * p.H + oy) * p.W + ox;
+            uint16_t* opix = p.out + m * p.Cout + bn * 128 + wn * 64;
+            if (p.residual) {
+                const uint16_t* rpix = p.residual + m * p.Cout + bn * 128 + wn * 64;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = j * 32 + 8 * q + 4 * hi;
+                        const uint2 r = *reinterpret_cast<const uint2*>(rpix + co);
+                        const float v0 = acc[i][j][q * 4 + 0] + mgn_lo2f(r.x), v1 = acc[i][j][q * 4 + 1] + mgn_hi2f(r.x);
+                        const float v2 = acc[i][j][q * 4 + 2] + mgn_lo2f(r.y), v3 = acc[i][j][q * 4 + 3] + mgn_hi2f(r.y);
+                        *reinterpret_cast<uint2*>(opix + co) = make_uint2(mgn_pack2(v0, v1), mgn_pack2(v2, v3));
+                    }
+            } else {
+                // v_permlane32_swap exchanges the 4-channel groups of lane l and lane l + 32: every lane then owns 8 consecutive
+                // channels of its pixel (16-byte stores, half the store instructions)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qp = 0; qp < 2; ++qp) {
+                        uint32_t pk[2][2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int q = 2 * qp + u;
+                            pk[u][0] = mgn_pack2(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1]);
+                            pk[u][1] = mgn_pack2(acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+                        }
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                        *reinterpret_cast<uint4*>(opix + j * 32 + 16 * qp + 8 * hi) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void conv3x3_win16(WinParams p) { conv_win_body<16>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_win8(WinParams p) { conv_win_body<8>(p); }
+
+}  // namespace
+
+extern "C" {
+
+int MGN_SYM(mgn_conv3x3_win)(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
+                             int patch_rows, void* stream) {
+    if (!in || !w || !out || N < 1 || H < 1 || W < 1) return MGN_EINVAL;
+    if (Cin < 32 || Cin % 32 != 0 || Cout < 128 || Cout % 128 != 0) return MGN_ENOTSUP;
+    if ((size_t)N * H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fffffffu) return MGN_ENOTSUP;   // 32-bit byte offsets
+    if (patch_rows != 8 && patch_rows != 16) return MGN_EINVAL;
+    WinParams p;
+    p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = (uint16_t*)out; p.residual = (const uint16_t*)residual;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.py = (H + patch_rows - 1) / patch_rows; p.px = (W + PW - 1) / PW;
+    const long npatch = (long)N * p.py * p.px;
+    if (npatch > 0x7fffffffL) return MGN_EINVAL;
+    p.xcd = (npatch >= 16 && !getenv("MGN_CONV_NOXCD")) ? 1 : 0;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_win16), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_win8), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+        attr = true;
+    }
+    const dim3 grid((unsigned)npatch, (unsigned)(Cout / 128));
+    if (patch_rows == 16) hipLaunchKernelGGL(conv3x3_win16, grid, dim3(512), WIN_LDS, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv3x3_win8, grid, dim3(512), WIN_LDS, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+}  // extern "C"

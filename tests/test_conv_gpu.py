@@ -223,3 +223,39 @@ def test_row_march_conv_large_and_repeatable(shape):
     assert float((outs[0].float() - ref).abs().max() / ref.abs().max()) < 1e-2
     dw_ref = torch.nn.grad.conv2d_weight(x.float(), w.shape, dy.float(), stride=1, padding=1)
     assert float((dws[0] - dw_ref).abs().max() / dw_ref.abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows", ["16", "8"])
+@pytest.mark.parametrize("case", [(1, 32, 128, 16, 32), (2, 128, 128, 12, 20), (1, 96, 256, 33, 70), (3, 128, 128, 7, 5),
+                                  (2, 256, 384, 19, 37), (1, 512, 128, 9, 40)])
+def test_windowed_3x3(monkeypatch, case, rows, dtype):
+    """csrc/conv_win.hip (the input window of a 2-D pixel patch stays in LDS for the nine taps), forced through MGN_CONV_WIN on
+    ragged shapes (partial patches in both directions, several channel chunks, 1-3 output-channel tiles): forward, data gradient
+    WITH the fused second gradient branch (`with_skip`, the residual epilogue) and weight gradient against F.conv2d in fp64."""
+    from mgnet_amd.modeling import ops
+
+    monkeypatch.setenv("MGN_CONV_WIN", rows)
+    N, Cin, Cout, H, W = case
+    torch.manual_seed(sum(case))
+    x0 = torch.randn(N, Cin, H, W).to(dtype)
+    w0 = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    x_r = x0.double().requires_grad_(True)
+    w_r = w0.to(dtype).double().requires_grad_(True)
+    y_r = F.conv2d(x_r, w_r, None, stride=1, padding=1)
+    g1 = torch.randn(*y_r.shape).to(dtype)
+    g2 = torch.randn(N, Cin, H, W).to(dtype)
+    ((y_r * g1.double()).sum() + (x_r * g2.double()).sum()).backward()
+    x = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = w0.cuda().requires_grad_(True)
+    y, skip = ops.conv2d(x, w, None, stride=1, padding=1, with_skip=True)
+    assert y.dtype == dtype
+    ((y.float() * g1.cuda().float()).sum() + (skip.float() * g2.cuda().float()).sum()).backward()
+
+    def rel(a, r):
+        return float((a.detach().float().cpu().double() - r).abs().max() / (r.abs().max() + 1e-12))
+    assert rel(y, y_r.detach()) < 1e-2 and rel(x.grad, x_r.grad) < 1e-2 and rel(w.grad, w_r.grad) < 2e-3
+    # the same call on the generic implicit-GEMM kernels: same products, another summation order
+    monkeypatch.setenv("MGN_CONV_WIN", "0")
+    y2, _ = ops.conv2d(x, w, None, stride=1, padding=1, with_skip=True)
+    assert rel(y, y2.detach().float().cpu().double()) < 1e-2
