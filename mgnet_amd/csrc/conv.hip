@@ -1825,7 +1825,7 @@ int MGN_SYM(mgn_conv_igemm)(const void* in, const void* w, void* out, const floa
         int pr = ewin ? atoi(ewin) : -1;
         if (pr < 0) {
             const long pc = (long)N * ((OW + 31) / 32) * (Cout / 128);
-            pr = pc * ((OH + 15) / 16) >= 200 ? 16 : (pc * ((OH + 7) / 8) >= 128 ? 8 : 0);
+            pr = pc * ((OH + 15) / 16) >= 200 ? 16 : (pc * ((OH + 7) / 8) >= 64 ? 8 : 0);
         }
         if (pr == 8 || pr == 16) {
             const int rcw = MGN_SYM(mgn_conv3x3_win)(in, w, out, N, OH, OW, Cin, Cout, residual, pr, stream);

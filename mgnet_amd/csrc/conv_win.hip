@@ -16,7 +16,7 @@
 //           (v_mfma_f32_32x32x16, operands swapped: D rows = output channels, so a lane holds 4 consecutive channels of a pixel)
 //   k loop: channel chunk outer (32 channels), tap inner; one barrier per k-step
 //   LDS   : window [2 buffers][640 px][64 B] (pixel-major, 16-byte slots XOR-swizzled by (px >> 2) & 3: every fragment read is
-//           conflict-free for ANY tap shift), weights [4 stages][128 co][64 B]; everything arrives by LDS-DMA
+//           conflict-free for ANY tap shift), weights [8 stages][128 co][64 B]; everything arrives by LDS-DMA
 //           (buffer_load_dwordx4 ... lds, zero padding from the buffer bounds check), the next chunk's window is fetched while the
 //           nine taps of the current one run; counted vmcnt waits.
 #include <hip/hip_runtime.h>
@@ -46,8 +46,11 @@ constexpr int PW = 32, WW = PW + 2;
 constexpr int WIN_PIECES = 40;                 // 1-KB DMA pieces of 16 pixels x 64 B: 5 per wave (612 of the 640 pixels are real)
 constexpr int WIN_BYTES = WIN_PIECES * 1024;
 constexpr int WST_BYTES = 128 * 64;            // one weight stage: 128 output channels x 32 input channels
-constexpr int NWST = 4;
-constexpr int WIN_LDS = 2 * WIN_BYTES + NWST * WST_BYTES;
+constexpr int NWST = 8;                        // weight stages (power of two)
+constexpr int PD = 6;                          // W(s + PD) is issued at k-step s (PD + 1 <= NWST)
+constexpr int WIN_LDS = 2 * WIN_BYTES + NWST * WST_BYTES + 1024;   // + one scratch KB for the dummy loads
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ int xcd_tile(int b, int nb) {   // block b -> XCD b % 8; XCD k works on a contiguous band of tiles
     const int k = b & 7, j = b >> 3, q = nb >> 3, r = nb & 7;
@@ -125,17 +128,25 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // Pipeline.  Loads are issued in the order [window piece] W per k-step; W(s + 3) is issued at step s (ring of 4 stages) and
-    // the wait at the top of step s is for W(s + 1): after the barrier every wave may therefore read the fragments of step s + 1
-    // already, and the first half (kk = 0) of the NEXT step's fragments is fetched from LDS while the second half of this
-    // step's MFMAs run -- no LDS latency is exposed after a barrier.  Loads younger than W(s + 1) at that point: what step s - 1
-    // issued = [its window piece] + W(s + 2).
+    // Pipeline.  Every k-step issues exactly TWO LDS-DMA loads per wave, in the order [window piece of the next chunk | dummy]
+    // [W(s + PD) | dummy]; a dummy is an out-of-range load (no memory request, zeros into a scratch KB), which keeps the number
+    // of loads younger than any given one a compile-time constant.  Barriers stand at the even taps of a chunk (5 per 9 k-steps:
+    // with a barrier per step both waves of a SIMD sit in the same bubble); the wait before the barrier of step s is for
+    // W(s + 2), issued at step s + 2 - PD (younger: 2 (PD - 3) loads): the two steps up to the next barrier read W(s), W(s + 1)
+    // and -- the first half (kk = 0) of the NEXT step's fragments is fetched from LDS while the second half of a step's MFMAs
+    // run -- W(s + 2).  Ring hazards: step s writes the stage of step s + PD - NWST = s - 2 and, at taps 0 .. NWP-1, the window
+    // buffer last read in the previous chunk; a barrier separates both from their last readers (tap 0 always has one).
+    auto issue_dummy = [&]() {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(wsm + WIN_LDS - 1024), 16, OOB, 0, 0, 0);
+    };
 #pragma unroll
     for (int i = 0; i < NWP; ++i) issue_win(0, i, 0);
-    issue_w(0, 0, 0);
-    issue_w(0, 1, 1);
-    issue_w(0, 2, 2);
-    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < PD; ++k) {   // what steps -PD .. -1 would have issued (ksteps >= 9 > PD)
+        issue_dummy();
+        issue_w(0, k, k);
+    }
+    wait_vmcnt<2 * (PD - 3)>();
     __builtin_amdgcn_s_barrier();
 
     auto load_frags = [&](const unsigned char* win, const unsigned char* ws, int kh, int kw, int kk, h16x8 (&a)[RPW], h16x8 (&b)[2]) {
@@ -153,39 +164,46 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
 
     h16x8 a0[RPW], b0[2], a1[RPW], b1[2];
     load_frags(winb, wst, 0, 0, 0, a0, b0);
-    int stage = 0;   // stage of k-step s = s & 3
+    int stage = 0;   // stage of k-step s = s % NWST
     auto chunk = [&](int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const unsigned char* win = winb + (c & 1) * WIN_BYTES;
         const unsigned char* win_next = winb + ((c + 1) & 1) * WIN_BYTES;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            if (LAST) {
-                if (t + 2 <= 8) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                if (t >= 1 && t - 1 < NWP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (t % 2 == 0) {   // one barrier per TWO k-steps (taps 0|1, 2|3, 4|5, 6|7, 8): see the pipeline comment
+                wait_vmcnt<2 * (PD - 3)>();
+                __builtin_amdgcn_s_barrier();
             }
-            __builtin_amdgcn_s_barrier();
             if (!LAST && t < NWP) issue_win(c + 1, t, (c + 1) & 1);
-            if (!LAST || t + 3 <= 8) {
-                const int t3 = t + 3 >= 9 ? t + 3 - 9 : t + 3, c3 = t + 3 >= 9 ? c + 1 : c;
-                issue_w(c3, t3, (stage + 3) & 3);
+            else issue_dummy();
+            if (!LAST || t + PD <= 8) {
+                const int tn = t + PD >= 9 ? t + PD - 9 : t + PD, cn = t + PD >= 9 ? c + 1 : c;
+                if (LAST || cn < nch) issue_w(cn, tn, (stage + PD) & (NWST - 1));
+                else issue_dummy();
+            } else {
+                issue_dummy();
             }
             const int kh = t / 3, kw = t - kh * 3;
             const unsigned char* ws = wst + stage * WST_BYTES;
-            const unsigned char* ws_next = wst + ((stage + 1) & 3) * WST_BYTES;
+            const unsigned char* ws_next = wst + ((stage + 1) & (NWST - 1)) * WST_BYTES;
+            // (sched_barrier: keep the two fragment sets in separate registers and each batch of LDS reads a full batch of MFMAs
+            //  ahead of its use -- left alone, the scheduler re-serialises read -> wait -> MFMA to save registers)
             load_frags(win, ws, kh, kw, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
             mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
             if (t < 8) load_frags(win, ws_next, (t + 1) / 3, (t + 1) % 3, 0, a0, b0);
             else if (!LAST) load_frags(win_next, ws_next, 0, 0, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
             mma(a1, b1);
-            stage = (stage + 1) & 3;
+            __builtin_amdgcn_sched_barrier(0);
+            stage = (stage + 1) & (NWST - 1);
         }
     };
     for (int c = 0; c + 1 < nch; ++c) chunk(c, std::false_type{});
     chunk(nch - 1, std::true_type{});
+    wait_vmcnt<0>();   // (the dummies of the last steps still write their zeros: nothing may land after the block has ended)
 
     // D = W-rows x pixels: column = lane & 31 -> pixel of the row, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel
     const int ox = x0 + l31;
