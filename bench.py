@@ -168,10 +168,11 @@ def full_step_bench(args, world, rank, dev):
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    # Execution mode of the timed steps: "graph" = the whole step (forward, backward, clip, Adam) captured once in a hipGraph
-    # and replayed (one process per GPU without a gradient exchange: the default for 1 GPU), "eager" = ~950 launches issued
-    # from Python per step (always used with > 1 rank, where the bucketed all-reduce runs between the launches).
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    # Execution mode of the timed steps: "eager" (default) = the launches of a step issued from Python, with the independent
+    # branches of MGNet.forward on side streams (pose network | backbone, three heads: concurrent short kernels, hidden dispatch
+    # latency); "graph" (--graph on, one rank only) = the whole step captured once in a hipGraph on ONE stream and replayed.
+    # Measured: eager + side streams 32.3 ms, graph 35.8 ms (capturing the side-stream branches crashes hipGraph on ROCm 7.0).
+    use_graph = args.graph == "on" and world == 1
     mode = "eager"
     for _ in range(max(args.warmup, 3) if use_graph else args.warmup):
         trainer.run_step(batch)
@@ -250,7 +251,9 @@ def full_step_bench(args, world, rank, dev):
                                    f"reprojection + smoothness, uncertainty weighting, grad all-reduce, clip, Adam), "
                                    f"{B} frames/GPU of {H}x{W}",
                        "frames_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
-                       "parallelism": f"dp{world}", "step_execution": mode + (" (one hipGraph replay per step)" if mode == "graph" else " (launches issued from Python)"),
+                       "parallelism": f"dp{world}", "step_execution": mode + (" (one hipGraph replay per step, one stream)" if mode == "graph" else
+                                                  " (launches issued from Python; side streams for the independent branches: " +
+                                                  ("on" if getattr(model, "_streams", None) else "off") + ")"),
                        "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2), "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
                        "losses": {k: round(float(v.detach()), 5) for k, v in last.items()},
                        "torch_staging_ops": sorted(__import__("mgnet_amd.modeling.ops", fromlist=["x"]).STAGING_USED)},
@@ -301,7 +304,8 @@ def main():
                     help="16-bit activation format of the trunk: bf16 (default) or the reference's AMP format fp16 with dynamic loss "
                          "scaling (BASELINE C5)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the captured step as a hipGraph (auto: with 1 GPU); off = issue every launch from Python")
+                    help="on: replay the captured step as a hipGraph (1 GPU, one stream); auto/off: issue every launch from Python "
+                         "with the independent branches on side streams (the faster mode)")
     ap.add_argument("--fwd-only", action="store_true", help="diagnostic: loss only (no gradient); NOT the benchmark")
     ap.add_argument("--loss-only", action="store_true",
                     help="diagnostic: time only the reprojection loss fwd+bwd (round-1 v2 workload); NOT the benchmark")

@@ -18,6 +18,7 @@
 // order; only the footprint cells shared between tiles are combined with global fp32 atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mgnet_hip.h"
 #include "h16.h"
@@ -29,6 +30,7 @@ constexpr int TX = 32, TY = 16;      // backward pixel tile
 
 struct UpGeom {
     int B, h, w, H, W;
+    int bx0, by0;      // tile offset of this launch (0 unless MGN_SERIAL_SCATTER: one tile per launch, see serial_scatter())
     long sb, sh, sw;   // element strides of the low-res map (channel stride 1)
     float ry, rx;      // (h-1)/(H-1), (w-1)/(W-1)   (align_corners=True)
 };
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(TPB) void upce_bwd(const uint16_t* __restrict__ lg,
                                                 const float* __restrict__ sel, const float* __restrict__ gout, float* dlg) {
     extern __shared__ float res[];  // [K8*8][TY][RP] residuals g*(p_k - onehot)
     constexpr int KK = K8 * 8;
-    const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY, b = blockIdx.z;
+    const int X0 = (blockIdx.x + g.bx0) * TX, Y0 = (blockIdx.y + g.by0) * TY, b = blockIdx.z;
     const float tau = sel[0], tie_w = sel[1], scale = sel[2] * gout[0];
     // ---- phase 1: residual vectors of the tile's pixels
     for (int t = threadIdx.x; t < TX * TY; t += TPB) {
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(SUMT) void sum4_kernel(const float* partials, int n
 // gout = {d/d loss_center, d/d loss_offset}; sums = output of sum4_kernel
 __global__ __launch_bounds__(TPB) void ins_bwd(InsMaps m, const float* __restrict__ sums, const float* __restrict__ gout, float* dco) {
     __shared__ float res[4 * TY * RP + 4 * TY * MAXC];
-    const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY, b = blockIdx.z;
+    const int X0 = (blockIdx.x + m.gc.bx0) * TX, Y0 = (blockIdx.y + m.gc.by0) * TY, b = blockIdx.z;
     const UpGeom& g = m.gc;  // centre and offset maps share the geometry
     const float sc = sums[2] > 0.f ? gout[0] / sums[2] : 0.f, so = sums[3] > 0.f ? gout[1] / sums[3] : 0.f;
     for (int t = threadIdx.x; t < TX * TY; t += TPB) {
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(TPB) void up1_fwd(const float* __restrict__ lr, UpG
 
 __global__ __launch_bounds__(TPB) void up1_bwd(const float* __restrict__ dfull, UpGeom g, float* dlr) {
     __shared__ float res[TY * RP + TY * MAXC];
-    const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY, b = blockIdx.z;
+    const int X0 = (blockIdx.x + g.bx0) * TX, Y0 = (blockIdx.y + g.by0) * TY, b = blockIdx.z;
     for (int t = threadIdx.x; t < TX * TY; t += TPB) {
         const int X = X0 + (t % TX), Y = Y0 + (t / TX);
         res[res_idx(0, t / TX, t % TX)] = (X < g.W && Y < g.H) ? dfull[((long)b * g.H + Y) * g.W + X] : 0.f;
@@ -488,11 +490,22 @@ __global__ void ohem_final(const float* sums3, float thr, long n_sel, const Ohem
     }
 }
 
+// The backward kernels add the low-resolution footprints of neighbouring pixel tiles with float atomics: the sum of the <= 4
+// contributions to a border pixel depends on the arrival order in its last bit (the only run-to-run variation of the training
+// step; the reference's F.interpolate backward uses atomics too).  MGN_SERIAL_SCATTER=1 (debugging / reproducibility checks,
+// slow) launches one tile per launch in a fixed order instead: bit-reproducible.
+template <typename F>
+inline void serial_scatter(dim3 grid, F&& launch) {   // launch(grid, bx0, by0)
+    if (!getenv("MGN_SERIAL_SCATTER")) { launch(grid, 0, 0); return; }
+    for (unsigned by = 0; by < grid.y; ++by)
+        for (unsigned bx = 0; bx < grid.x; ++bx) launch(dim3(1, 1, grid.z), (int)bx, (int)by);
+}
+
 inline int geom_ok(int B, int h, int w, int H, int W) { return B >= 1 && h >= 2 && w >= 2 && H >= h && W >= w; }
 
 inline UpGeom make_geom(int B, int h, int w, int H, int W, long sb, long sh, long sw) {
     UpGeom g;
-    g.B = B; g.h = h; g.w = w; g.H = H; g.W = W; g.sb = sb; g.sh = sh; g.sw = sw;
+    g.B = B; g.h = h; g.w = w; g.H = H; g.W = W; g.sb = sb; g.sh = sh; g.sw = sw; g.bx0 = g.by0 = 0;
     g.ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     g.rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     return g;
@@ -536,12 +549,16 @@ int MGN_SYM(mgn_upce_bwd)(const void* logits_bf16, long sb, long sh, long sw, in
     const uint16_t* lg = (const uint16_t*)logits_bf16;
     const int k8 = (K + 7) / 8;
     const size_t lds = sizeof(float) * (TY * RP + TY * MAXC) * k8 * 8;
-    switch (k8) {
-        case 1: hipLaunchKernelGGL(upce_bwd<1>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
-        case 2: hipLaunchKernelGGL(upce_bwd<2>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
-        case 3: hipLaunchKernelGGL(upce_bwd<3>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
-        default: hipLaunchKernelGGL(upce_bwd<4>, grid, dim3(TPB), lds, s, lg, g, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
-    }
+    serial_scatter(grid, [&](dim3 gr, int bx0, int by0) {
+        UpGeom gg = g;
+        gg.bx0 = bx0; gg.by0 = by0;
+        switch (k8) {
+            case 1: hipLaunchKernelGGL(upce_bwd<1>, gr, dim3(TPB), lds, s, lg, gg, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
+            case 2: hipLaunchKernelGGL(upce_bwd<2>, gr, dim3(TPB), lds, s, lg, gg, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
+            case 3: hipLaunchKernelGGL(upce_bwd<3>, gr, dim3(TPB), lds, s, lg, gg, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
+            default: hipLaunchKernelGGL(upce_bwd<4>, gr, dim3(TPB), lds, s, lg, gg, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
+        }
+    });
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -600,7 +617,11 @@ int MGN_SYM(mgn_ins_loss_bwd)(const float* center_lr, long csb, long csh, long c
     m.go = make_geom(B, h, w, H, W, osb, osh, osw);
     m.ct = ct; m.cw = cw; m.ot = ot; m.ow = ow; m.oscale = oscale;
     const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
-    hipLaunchKernelGGL(ins_bwd, grid, dim3(TPB), 0, (hipStream_t)stream, m, out4, gout2, dco);
+    serial_scatter(grid, [&](dim3 gr, int bx0, int by0) {
+        InsMaps mm = m;
+        mm.gc.bx0 = bx0; mm.gc.by0 = by0;
+        hipLaunchKernelGGL(ins_bwd, gr, dim3(TPB), 0, (hipStream_t)stream, mm, out4, gout2, dco);
+    });
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -618,7 +639,11 @@ int mgn_upsample1_bwd(const float* dfull, int B, int h, int w, int H, int W, flo
     if (!dfull || !dlr_zeroed || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
     if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
     const UpGeom g = make_geom(B, h, w, H, W, (long)h * w, w, 1);
-    hipLaunchKernelGGL(up1_bwd, dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B), dim3(TPB), 0, (hipStream_t)stream, dfull, g, dlr_zeroed);
+    serial_scatter(dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B), [&](dim3 gr, int bx0, int by0) {
+        UpGeom gg = g;
+        gg.bx0 = bx0; gg.by0 = by0;
+        hipLaunchKernelGGL(up1_bwd, gr, dim3(TPB), 0, (hipStream_t)stream, dfull, gg, dlr_zeroed);
+    });
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 #endif

@@ -64,7 +64,7 @@ class GradReducer:
                 p.data = flat_p[o:o + p.numel()].view(p.shape)
         for p, o in zip(plist, offsets):
             p.grad = flat_g[o:o + p.numel()].view(p.shape)
-        b = dict(flat_g=flat_g, flat_p=flat_p, params=plist, offsets=offsets, pending=len(plist), n=len(plist), seen=set(), packed=True)
+        b = dict(flat_g=flat_g, flat_p=flat_p, params=plist, offsets=offsets, pending=len(plist), n=len(plist), seen=set(), gstream={}, packed=True)
         self.buckets.append(b)
         for p in plist:
             self._bucket_of[p] = b
@@ -77,6 +77,7 @@ class GradReducer:
         for b in self.buckets:
             b["pending"] = b["n"]
             b["seen"] = set()
+            b["gstream"] = {}
             for p in b["params"]:
                 p.grad = None
 
@@ -87,6 +88,18 @@ class GradReducer:
     def _pack(self, b):
         idx = [i for i, p in enumerate(b["params"]) if p.grad is not None]
         views = [self._view(b, i) for i in idx]
+        if idx and b["flat_g"].is_cuda and b["gstream"]:
+            # MGNet.forward runs its independent branches on side streams and autograd replays every node (and this hook) on
+            # the stream of its forward: a bucket mixes gradients produced on several streams, and the packing copy runs on the
+            # stream of whichever arrived last -- it has to wait for the others and keep their memory from being recycled
+            cur = torch.cuda.current_stream(b["flat_g"].device)
+            for st in {s.cuda_stream: s for s in b["gstream"].values()}.values():
+                if st != cur:
+                    cur.wait_stream(st)
+            for i in idx:
+                st = b["gstream"].get(id(b["params"][i]))
+                if st is not None and st != cur:
+                    b["params"][i].grad.record_stream(cur)
         if idx:
             torch._foreach_copy_(views, [b["params"][i].grad for i in idx])
         got = set(idx)
@@ -102,6 +115,8 @@ class GradReducer:
         if id(p) in b["seen"]:   # second accumulation into the same parameter: already counted
             return
         b["seen"].add(id(p))
+        if p.is_cuda:
+            b["gstream"][id(p)] = torch.cuda.current_stream(p.device)
         b["packed"] = False
         b["pending"] -= 1
         if b["pending"] == 0:

@@ -60,6 +60,9 @@ class Trainer:
         _C.weight_cache.refresh()  # drop the rows of collected models now: the captured refresh launch keeps this table
         self._graph_keepalive = [_C.weight_cache.table]
         torch.cuda.synchronize()
+        # (the captured step stays on ONE stream: capturing the side-stream branches of MGNet.forward crashes hipGraph
+        #  instantiation on ROCm 7.0; the eager step with side streams is the faster of the two)
+        self.model._no_side_streams = True
         with torch.cuda.graph(graph):
             self.reducer.zero_grad()
             with self.storage:
@@ -67,6 +70,7 @@ class Trainer:
                 self._backward(loss_dict)
             self.reducer.finish()
             self.optimizer.launch_step()
+        self.model._no_side_streams = False
         self._graph, self._graph_losses = graph, loss_dict
         return graph
 

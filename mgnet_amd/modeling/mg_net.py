@@ -3,6 +3,8 @@ path (mg_net.py:220-373) with the same registries, `@configurable`/`from_config`
 (=> state-dict keys) and loss dict keys, and for single-scale INFERENCE (mg_net.py:375-425): per-image
 `sem_seg_postprocess`, panoptic fusion and DGC depth rescaling through mgnet_amd.postprocessing (HIP), and multi-scale +
 flip inference (mg_net.py:427-520, row f4: `TEST.MSC_FLIP_EVAL`)."""
+import contextlib
+import os
 from typing import Dict, List
 
 import torch
@@ -137,9 +139,48 @@ class MGNet(nn.Module):
             x = x.to(self.amp_dtype)
         return x.contiguous(memory_format=torch.channels_last) if x.is_cuda else x.contiguous()
 
+    def _side_streams(self):
+        """Two side streams for the independent branches of the training step (pose network | backbone, then the three heads with
+        their losses): most launches of the step are short and under-fill the chip one at a time, and every dependent launch
+        costs ~3 us of dispatch latency -- concurrent branches hide both.  The autograd engine replays each node on the stream
+        of its forward and orders the streams itself.  MGNET_STREAMS=0 keeps everything on the current stream."""
+        if not (self.training and self.pixel_mean.is_cuda) or os.environ.get("MGNET_STREAMS", "1") == "0" or getattr(self, "_no_side_streams", False):
+            return None
+        st = self.__dict__.get("_streams")
+        if st is None:
+            st = self.__dict__["_streams"] = [torch.cuda.Stream(self.device) for _ in range(2)]
+        return st
+
     def forward(self, batched_inputs):
         inputs, outputs, targets = {}, {}, {}
+        side = self._side_streams()
+        main = torch.cuda.current_stream() if side else None
+
+        def on(k):
+            return torch.cuda.stream(side[k]) if side else contextlib.nullcontext()
+
+        def tensors(obj):
+            if isinstance(obj, torch.Tensor):
+                yield obj
+            elif isinstance(obj, dict):
+                for v in obj.values():
+                    yield from tensors(v)
+            elif isinstance(obj, (list, tuple)):
+                for v in obj:
+                    yield from tensors(v)
+            elif hasattr(obj, "tensors"):       # lazy wrappers of ops.py (LazyUpsample ...) list what they hold
+                yield from tensors(obj.tensors())
+
+        def handover(src, dst, *objs):
+            """stream `dst` continues after what `src` has been given so far and will read `objs` (made on `src`)"""
+            if side:
+                dst.wait_stream(src)
+                for t in tensors(objs):
+                    if t.is_cuda:
+                        t.record_stream(dst)
+
         fused_prep = self.pixel_mean.is_cuda and self.amp_dtype in (torch.bfloat16, torch.float16) and batched_inputs[0]["image"].dtype == torch.uint8
+        pose_in = None
         if fused_prep:  # [HIP] uint8 frames -> normalised, channel-padded NHWC bf16 in one pass (csrc/prep.hip)
             from .. import _C
             mean, std = self._mean01, self._std01   # (host constants: reading the device buffers would sync every step)
@@ -147,25 +188,29 @@ class MGNet(nn.Module):
             inputs["image"] = _C.prep_input(frames, mean, std, 8, self.amp_dtype)
             if self.training and self.with_depth:
                 frames += [self._stack(batched_inputs, "image_prev"), self._stack(batched_inputs, "image_next")]
-                outputs["poses"] = self.pose_net(_C.prep_input(frames, mean, std, 16, self.amp_dtype))  # channels: image, prev, next (:264)
+                pose_in = _C.prep_input(frames, mean, std, 16, self.amp_dtype)   # channels: image, prev, next (:264)
         else:
             inputs["image"] = self._net_input(batched_inputs, "image")
             if self.training and self.with_depth:
                 inputs["image_prev"] = self._net_input(batched_inputs, "image_prev")
                 inputs["image_next"] = self._net_input(batched_inputs, "image_next")
-                outputs["poses"] = self.pose_net(torch.cat(list(inputs.values()), 1))  # mg_net.py:264
+                pose_in = torch.cat(list(inputs.values()), 1)  # mg_net.py:264
+        if pose_in is not None:
+            handover(main, side[0] if side else None, pose_in)
+            with on(0):
+                outputs["poses"] = self.pose_net(pose_in)
 
         if self.msc_flip_eval and not self.training:   # mg_net.py:267-268
             norm = (self._stack(batched_inputs, "image", 255.0) - self.pixel_mean) / self.pixel_std
             return self._inference(batched_inputs, self.forward_multi_scale_flip(norm))
         features = self.backbone(inputs["image"])
         features["global_context"] = self.global_context(features[self.bb_features[-1]])
-        if self.with_panoptic:
-            outputs["sem_seg"] = self.sem_seg_head(features)
-            outputs["center"], outputs["offset"] = self.ins_embed_head(features)
-        if self.with_depth:
-            outputs["depth"] = self.depth_head(features)
         if not self.training:
+            if self.with_panoptic:
+                outputs["sem_seg"] = self.sem_seg_head(features)
+                outputs["center"], outputs["offset"] = self.ins_embed_head(features)
+            if self.with_depth:
+                outputs["depth"] = self.depth_head(features)
             return self._inference(batched_inputs, outputs)
 
         if self.with_panoptic:
@@ -186,12 +231,29 @@ class MGNet(nn.Module):
                 "reprojection_mask": self._stack(batched_inputs, "reprojection_mask").unsqueeze(1),
             })
 
+        # the three heads and their losses: semantic on the current stream, instance on side stream 0 (after the pose network),
+        # depth on side stream 1 (its loss reads the poses of stream 0)
         losses = {}
+        if side:
+            handover(main, side[0], features, targets)
+            handover(main, side[1], features, targets)
         if self.with_panoptic:
+            outputs["sem_seg"] = self.sem_seg_head(features)
             losses.update(self.sem_seg_head.losses(outputs, targets))
-            losses.update(self.ins_embed_head.losses(outputs, targets))
+            with on(0):
+                outputs["center"], outputs["offset"] = self.ins_embed_head(features)
+                l_ins = self.ins_embed_head.losses(outputs, targets)
+            losses.update(l_ins)
         if self.with_depth:
-            losses.update(self.depth_head.losses(outputs, targets))
+            with on(1):
+                outputs["depth"] = self.depth_head(features)
+                if side:
+                    handover(side[0], side[1], outputs.get("poses"))
+                l_depth = self.depth_head.losses(outputs, targets)
+            losses.update(l_depth)
+        if side:
+            handover(side[0], main, losses)
+            handover(side[1], main, losses)
 
         if self.with_uncertainty:  # mg_net.py:360-372 -- same scalar names, but no .item() host syncs inside forward
             # evaluated for all tasks at once (a handful of launches instead of ~20 scalar kernels per task):

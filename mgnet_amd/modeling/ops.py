@@ -601,6 +601,9 @@ class LazyUpsample:
         y = upsample_bilinear(self.lr, self.scale)
         return y * self.mult if self.mult != 1.0 else y
 
+    def tensors(self):
+        return [self.lr]
+
 
 def materialize(x):
     return x.materialize() if isinstance(x, LazyUpsample) else x
