@@ -119,7 +119,7 @@ def cpu_baseline(H, W, state_dict=None, cfg=None):
 
 def conv_roofline(dev, B):
     """Second roofline object (informative): the convolution kernel that takes the largest share of the step -- the 3x3
-    256->256 head/refine layers at 1/8 resolution (conv_igemm_big256) -- timed live with events on the launch stream."""
+    256->256 head/refine layers at 1/8 resolution (conv3x3_win16, csrc/conv_win.hip) -- timed live with events on the launch stream."""
     from mgnet_amd import _C
     x = torch.randn(B, 256, 128, 256, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = torch.nn.Parameter(torch.randn(256, 256, 3, 3, device=dev) * 0.02)
@@ -136,7 +136,7 @@ def conv_roofline(dev, B):
     ms = e0.elapsed_time(e1) / n
     flops = 2.0 * B * 128 * 256 * 256 * 256 * 9
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_big256 (3x3, 256->256 channels, 8x128x256 pixels; 43 launches/step of this kernel)",
+    return {"bound": "mfma", "kernel": "conv3x3_win16 (windowed 3x3, 256->256 channels, 8x128x256 pixels: the layer shape with the largest share of the step)",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
             "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
 

@@ -112,6 +112,13 @@ int mgn_iabn_stats(const void* x, int dtype, long M, int C, float* stats /*[3][C
                    void* workspace, size_t workspace_bytes, void* stream);
 /* single-rank training forward: statistics AND the coefficients of one process in ONE launch (= stats + combine with
  * n_ranks = 1; coef[4][C] = scale, offset, mean, rstd; running statistics updated when non-null) */
+/* the same outputs as mgn_iabn_stats (stats[3][C], may be NULL) and / or mgn_iabn_train_coeffs (coef[4][C] + running statistics,
+ * may be NULL) from the per-tile partial sums a convolution left behind (mgn_conv3x3_win: partials[rows][C][2] of (r - shift),
+ * (r - shift)^2 over its rounded outputs; shift as given to the convolution): the statistics pass over the activation becomes a
+ * read of rows*C*8 bytes.  M = N*H*W of the activation; C % 16 == 0. */
+int mgn_iabn_coeffs_from_partials(const float* partials, int rows, int C, long M, const float* shift, const float* weight,
+                                  const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                                  float* coef /*[4][C] or NULL*/, float* stats /*[3][C] or NULL*/, void* stream);
 int mgn_iabn_train_coeffs(const void* x, int dtype, long M, int C, const float* weight, const float* bias, float eps,
                           float momentum, float* running_mean, float* running_var, float* coef /*[4][C]*/,
                           void* workspace, size_t workspace_bytes, void* stream);
@@ -200,7 +207,13 @@ int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int
  * and keeps the input window in LDS for all nine taps.  Same tensors as mgn_conv_igemm (which dispatches here for the
  * 128/256/512-channel layers of res_net.py:28-60 and layers.py:53-72,110-118,201-210,283-311); MGN_ENOTSUP for other shapes. */
 int mgn_conv3x3_win(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
-                    int patch_rows, void* stream);
+                    int patch_rows,
+                    float* stat_partials /* NULL, or [N * ceil(H/patch_rows) * ceil(W/32)][Cout][2]: per-patch sums of (r - shift) and
+                                            (r - shift)^2 over the ROUNDED outputs r, the input of mgn_iabn_coeffs_from_partials: the
+                                            statistics pass of the InPlaceABNSync that follows the conv (res_net.py:35,49,59) */,
+                    const float* stat_shift /* [Cout] or NULL (= 0): e.g. the layer's running_mean */, void* stream);
+/* patch height mgn_conv_igemm picks for a 3x3 / stride 1 / pad 1 layer of this shape: 16, 8, or 0 (= it uses another kernel) */
+int mgn_conv_win_patch_rows(int N, int OH, int OW, int Cin, int Cout);
 /* fp32 OIHW master weights -> bf16 kernel layout. mode 0: [Cout][KH][KW][Cin]; 1: [Cin][KH][KW][Cout] with flipped taps
  * (data gradient); 2: packed-tap stem layout [Cout][ceil(KH*KW*Cp/32)*32] for a Cp-channel (8|16) padded input */
 int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp,
@@ -476,7 +489,7 @@ int mgn_conv_wgrad_f16(const void* dout, const void* in, float* dw, int N, int I
     int Cout, int KH, int KW, int stride, int pad, int oihw_cin /* >0: dw is [Cout][oihw_cin][KH][KW] */, void*
     workspace, size_t workspace_bytes, void* stream);
 int mgn_conv3x3_win_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
-    int patch_rows, void* stream);
+    int patch_rows, float* stat_partials, const float* stat_shift, void* stream);
 int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);
 int mgn_abn_add_relu_fwd_f16(const void* x, const float* scale, const float* offset, const void* shortcut, void* y,
     long M, int C, void* stream);

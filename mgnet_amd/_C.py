@@ -15,7 +15,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv3x3_win", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv3x3_win", "mgn_conv_win_patch_rows", "mgn_iabn_coeffs_from_partials", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -102,7 +102,9 @@ def lib():
         L.mgn_adam_step_dev.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, vp, vp, cf, vp]
         L.mgn_clip_coef_scaled.argtypes = [vp, ci, cf, cf, cf, cf, ci, vp, vp, vp, vp]
         L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp, vp]
-        L.mgn_conv3x3_win.argtypes = [vp, vp, vp] + [ci] * 5 + [vp, ci, vp]
+        L.mgn_conv3x3_win.argtypes = [vp, vp, vp] + [ci] * 5 + [vp, ci, vp, vp, vp]
+        L.mgn_conv_win_patch_rows.argtypes = [ci] * 5
+        L.mgn_iabn_coeffs_from_partials.argtypes = [vp, ci, ci, cl, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
         L.mgn_weight_layout.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
@@ -540,18 +542,38 @@ def panoptic_targets(cfg, panoptic, seg_ids, seg_attr, seg_count, gauss, want_ma
     return out
 
 
-def conv3x3_win(x, w_ohwi, residual=None, patch_rows=16):
-    """csrc/conv_win.hip directly (tests / tools; the product reaches it through mgn_conv_igemm's dispatch): 3x3, stride 1, pad 1"""
+def conv3x3_win(x, w_ohwi, residual=None, patch_rows=16, stats_shift=None, want_stats=False):
+    """csrc/conv_win.hip directly (tests / tools; the product reaches it through mgn_conv_igemm's dispatch): 3x3, stride 1, pad 1.
+    want_stats: also return the per-patch partial sums [rows, Cout, 2] of (r - shift), (r - shift)^2 over the rounded outputs."""
     N, Cin, H, W = x.shape
     Cout = w_ohwi.shape[0]
     assert w_ohwi.dtype == x.dtype and tuple(w_ohwi.shape[1:]) == (3, 3, Cin)
     out = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    part = None
+    if want_stats:
+        rows = N * ((H + patch_rows - 1) // patch_rows) * ((W + 31) // 32)
+        part = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
     check(_fn("mgn_conv3x3_win", x)(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), N, H, W, Cin, Cout,
-                                    None if residual is None else residual.data_ptr(), patch_rows, _stream()), "mgn_conv3x3_win")
+                                    None if residual is None else residual.data_ptr(), patch_rows,
+                                    None if part is None else part.data_ptr(), None if stats_shift is None else stats_shift.data_ptr(),
+                                    _stream()), "mgn_conv3x3_win")
+    return (out, part) if want_stats else out
+
+
+def iabn_from_partials(partials, C, M, shift, w32=None, b32=None, eps=1e-5, momentum=0.0, running_mean=None, running_var=None, stats_only=False):
+    """Statistics of an activation from the partial sums its producing convolution left behind (mgn_iabn_coeffs_from_partials):
+    the coefficient block [4, C] (+ running statistics) like iabn_train_coeffs, or stats [3, C] like iabn_stats."""
+    rows = partials.shape[0]
+    out = torch.empty((3 if stats_only else 4, C), dtype=torch.float32, device=partials.device)
+    p = lambda t: None if t is None else t.data_ptr()
+    check(lib().mgn_iabn_coeffs_from_partials(partials.data_ptr(), rows, C, M, p(shift), p(w32), p(b32), eps, momentum,
+                                              None if stats_only else p(running_mean), None if stats_only else p(running_var),
+                                              None if stats_only else out.data_ptr(), out.data_ptr() if stats_only else None, _stream()),
+          "mgn_iabn_coeffs_from_partials")
     return out
 
 
-def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=None, khw=None, residual=None):
+def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=None, khw=None, residual=None, stats=None):
     """x [N,Cin,IH,IW] channels_last bf16; w_ohwi [Cout,KH,KW,Cin] bf16 contiguous (or, for Cin 8/16, the packed
     [Cout, Kpad] layout with khw=(KH,KW)) -> out [N,Cout,OH,OW] channels_last"""
     N, Cin, IH, IW = x.shape
@@ -562,6 +584,15 @@ def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dt
     OH, OW = out_shape
     out_dtype = x.dtype if out_dtype is None else out_dtype   # the activation format (bf16 / fp16), or fp32
     assert w_ohwi.dtype == x.dtype, "weight layout and activations must share the 16-bit format"
+    if (stats is not None and khw is None and (KH, KW, stride, pad, up) == (3, 3, 1, 1, 1) and bias is None and not relu and residual is None
+            and out_dtype == x.dtype and (OH, OW) == (IH, IW)):
+        # stats = (shift [Cout] fp32 or None, holder list): a layer of the windowed kernel also leaves the partial sums of its output's
+        # batch statistics behind (the following InPlaceABNSync then skips its statistics pass); other layers ignore the request
+        pr = lib().mgn_conv_win_patch_rows(N, OH, OW, Cin, Cout)
+        if pr > 0:
+            out, part = conv3x3_win(x, w_ohwi, patch_rows=pr, stats_shift=stats[0], want_stats=True)
+            stats[1].append((part, stats[0]))
+            return out
     out = torch.empty((N, Cout, OH, OW), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
     check(_fn("mgn_conv_igemm", x)(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(),
                                N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, int(relu),

@@ -1817,18 +1817,11 @@ int MGN_SYM(mgn_conv_igemm)(const void* in, const void* w, void* out, const floa
         else if (Cin == 512 && Cout % 128 == 0) rc1 = launch_conv1x1<512, 1, 4>(conv1x1_s_512_1_4, q, st);
         if (rc1 <= 0) return rc1;
     }
-    if (!pack && KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 1 && Cin != 64 && Cout % 128 == 0 && IH == OH && IW == OW && !bias &&
-        !relu && !out_f32) {
-        // windowed kernel (csrc/conv_win.hip): the input window of a 2-D pixel patch stays in LDS for all nine taps.  16-row
-        // patches when they fill the chip, 8-row patches for the low-resolution layers, else the generic kernels below.
-        const char* ewin = getenv("MGN_CONV_WIN");   // "0" disables, "8" / "16" force a patch height
-        int pr = ewin ? atoi(ewin) : -1;
-        if (pr < 0) {
-            const long pc = (long)N * ((OW + 31) / 32) * (Cout / 128);
-            pr = pc * ((OH + 15) / 16) >= 200 ? 16 : (pc * ((OH + 7) / 8) >= 64 ? 8 : 0);
-        }
-        if (pr == 8 || pr == 16) {
-            const int rcw = MGN_SYM(mgn_conv3x3_win)(in, w, out, N, OH, OW, Cin, Cout, residual, pr, stream);
+    if (!pack && KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 1 && IH == OH && IW == OW && !bias && !relu && !out_f32) {
+        // windowed kernel (csrc/conv_win.hip): the input window of a 2-D pixel patch stays in LDS for all nine taps
+        const int pr = mgn_conv_win_patch_rows(N, OH, OW, Cin, Cout);
+        if (pr > 0) {
+            const int rcw = MGN_SYM(mgn_conv3x3_win)(in, w, out, N, OH, OW, Cin, Cout, residual, pr, nullptr, nullptr, stream);
             if (rcw != MGN_ENOTSUP) return rcw;
         }
     }

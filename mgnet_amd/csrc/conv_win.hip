@@ -38,6 +38,8 @@ struct WinParams {
     uint16_t* out;             // [N, H, W, Cout]
     const uint16_t* residual;  // [N, H, W, Cout] added before rounding, or null
     int N, H, W, Cin, Cout;
+    float* stat_part;          // [N*py*px][Cout][2] per-patch sums of (r - shift), (r - shift)^2 of the rounded outputs, or null
+    const float* stat_shift;   // [Cout] or null (= 0)
     int py, px;                // patches per image (rows, columns)
     int xcd;                   // 1: deal contiguous bands of patches to the XCDs
 };
@@ -207,44 +209,102 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
 
     // D = W-rows x pixels: column = lane & 31 -> pixel of the row, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel
     const int ox = x0 + l31;
-    if (ox < p.W) {
+    // optional per-channel statistics of the ROUNDED output (what the following InPlaceABNSync normalises with): a lane sums
+    // (r - shift) and (r - shift)^2 of its 32 channels over its RPW pixels; see the reduction below the stores
+    const bool stats = p.stat_part != nullptr;
+    float s1[2][4][4], s2[2][4][4], sh[2][4][4];
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int oy = y0 + wm * RPW + i;
-            if (oy >= p.H) break;
-            const size_t m = ((size_t)n * p.H + oy) * p.W + ox;
-            uint16_t* opix = p.out + m * p.Cout + bn * 128 + wn * 64;
-            if (p.residual) {
-                const uint16_t* rpix = p.residual + m * p.Cout + bn * 128 + wn * 64;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+        for (int q = 0; q < 4; ++q) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (stats && p.stat_shift) t = *reinterpret_cast<const float4*>(p.stat_shift + bn * 128 + wn * 64 + j * 32 + 8 * q + 4 * hi);
+            sh[j][q][0] = t.x; sh[j][q][1] = t.y; sh[j][q][2] = t.z; sh[j][q][3] = t.w;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int co = j * 32 + 8 * q + 4 * hi;
-                        const uint2 r = *reinterpret_cast<const uint2*>(rpix + co);
-                        const float v0 = acc[i][j][q * 4 + 0] + mgn_lo2f(r.x), v1 = acc[i][j][q * 4 + 1] + mgn_hi2f(r.x);
-                        const float v2 = acc[i][j][q * 4 + 2] + mgn_lo2f(r.y), v3 = acc[i][j][q * 4 + 3] + mgn_hi2f(r.y);
-                        *reinterpret_cast<uint2*>(opix + co) = make_uint2(mgn_pack2(v0, v1), mgn_pack2(v2, v3));
-                    }
-            } else {
-                // v_permlane32_swap exchanges the 4-channel groups of lane l and lane l + 32: every lane then owns 8 consecutive
-                // channels of its pixel (16-byte stores, half the store instructions)
+            for (int e = 0; e < 4; ++e) s1[j][q][e] = s2[j][q][e] = 0.f;
+        }
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < RPW; ++i) {
+        const int oy = y0 + wm * RPW + i;
+        if (oy >= p.H) break;   // wave-uniform
+        const bool ok = ox < p.W;
+        const size_t m = ((size_t)n * p.H + oy) * p.W + (ok ? ox : 0);
+        uint16_t* opix = p.out + m * p.Cout + bn * 128 + wn * 64;
+        if (p.residual) {
+            if (!ok) continue;
+            const uint16_t* rpix = p.residual + m * p.Cout + bn * 128 + wn * 64;
 #pragma unroll
-                    for (int qp = 0; qp < 2; ++qp) {
-                        uint32_t pk[2][2];
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int q = 2 * qp + u;
-                            pk[u][0] = mgn_pack2(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1]);
-                            pk[u][1] = mgn_pack2(acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+                for (int q = 0; q < 4; ++q) {
+                    const int co = j * 32 + 8 * q + 4 * hi;
+                    const uint2 r = *reinterpret_cast<const uint2*>(rpix + co);
+                    const float v0 = acc[i][j][q * 4 + 0] + mgn_lo2f(r.x), v1 = acc[i][j][q * 4 + 1] + mgn_hi2f(r.x);
+                    const float v2 = acc[i][j][q * 4 + 2] + mgn_lo2f(r.y), v3 = acc[i][j][q * 4 + 3] + mgn_hi2f(r.y);
+                    *reinterpret_cast<uint2*>(opix + co) = make_uint2(mgn_pack2(v0, v1), mgn_pack2(v2, v3));
+                }
+        } else {
+            // v_permlane32_swap exchanges the 4-channel groups of lane l and lane l + 32: every lane then owns 8 consecutive
+            // channels of its pixel (16-byte stores, half the store instructions)
+            const float msk = ok ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    uint32_t pk[2][2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int q = 2 * qp + u;
+                        pk[u][0] = mgn_pack2(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1]);
+                        pk[u][1] = mgn_pack2(acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+                        if (stats) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const float d0 = (mgn_lo2f(pk[u][h]) - sh[j][q][2 * h]) * msk, d1 = (mgn_hi2f(pk[u][h]) - sh[j][q][2 * h + 1]) * msk;
+                                s1[j][q][2 * h] += d0; s2[j][q][2 * h] = fmaf(d0, d0, s2[j][q][2 * h]);
+                                s1[j][q][2 * h + 1] += d1; s2[j][q][2 * h + 1] = fmaf(d1, d1, s2[j][q][2 * h + 1]);
+                            }
                         }
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
-                        *reinterpret_cast<uint4*>(opix + j * 32 + 16 * qp + 8 * hi) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                     }
-            }
+                    const auto w0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                    const auto w1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                    if (ok) *reinterpret_cast<uint4*>(opix + j * 32 + 16 * qp + 8 * hi) = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+                }
+        }
+    }
+    if (stats) {
+        // 16-lane butterflies (DPP: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror): every lane of a 16-lane row
+        // then holds the row's sum; lanes 0 / 16 / 32 / 48 park it in LDS (rows 0,1 = channels 4*hi.., two pixel halves), and
+        // after a block barrier 256 threads add the 8 parts (4 pixel waves x 2 rows) of one (channel, moment) each in a fixed
+        // order and store the block's partial row: stat_part[patch][Cout][2].  The window memory is free by then.
+        auto row_sum = [](float v) {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+            return v;
+        };
+        float* red = reinterpret_cast<float*>(wsm);   // [wm 4][row 2][128 channels][2]
+        __syncthreads();                               // every wave has left the k loop: the window buffers are dead
+        const int rw = (lane >> 4) & 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = row_sum(s1[j][q][e]), b = row_sum(s2[j][q][e]);
+                    if ((lane & 15) == 0) {
+                        const int ch = wn * 64 + j * 32 + 8 * q + 4 * hi + e;
+                        *reinterpret_cast<float2*>(red + ((wm * 2 + rw) * 128 + ch) * 2) = make_float2(a, b);
+                    }
+                }
+        __syncthreads();
+        if (tid < 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 256 + tid];
+            p.stat_part[((size_t)patch * p.Cout + bn * 128) * 2 + tid] = t;
         }
     }
 }
@@ -256,8 +316,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_win8(WinParams p) { conv_win_b
 
 extern "C" {
 
+#ifndef MGN_F16
+/* patch height the dispatcher uses for this layer: 16-row patches when they fill the chip, 8-row patches for the low-resolution
+ * layers, 0 = not a layer for this kernel (MGN_CONV_WIN = "0" | "8" | "16" overrides: tests, A/B runs) */
+int mgn_conv_win_patch_rows(int N, int OH, int OW, int Cin, int Cout) {
+    if (N < 1 || OH < 1 || OW < 1 || Cin < 32 || Cin % 32 != 0 || Cin == 64 || Cout < 128 || Cout % 128 != 0) return 0;
+    if ((size_t)N * OH * OW * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fffffffu) return 0;
+    const char* ewin = getenv("MGN_CONV_WIN");
+    if (ewin) {
+        const int pr = atoi(ewin);
+        return pr == 8 || pr == 16 ? pr : 0;
+    }
+    const long pc = (long)N * ((OW + 31) / 32) * (Cout / 128);
+    return pc * ((OH + 15) / 16) >= 200 ? 16 : (pc * ((OH + 7) / 8) >= 64 ? 8 : 0);
+}
+#endif
+
 int MGN_SYM(mgn_conv3x3_win)(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
-                             int patch_rows, void* stream) {
+                             int patch_rows, float* stat_partials, const float* stat_shift, void* stream) {
     if (!in || !w || !out || N < 1 || H < 1 || W < 1) return MGN_EINVAL;
     if (Cin < 32 || Cin % 32 != 0 || Cout < 128 || Cout % 128 != 0) return MGN_ENOTSUP;
     if ((size_t)N * H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fffffffu) return MGN_ENOTSUP;   // 32-bit byte offsets
@@ -265,6 +341,8 @@ int MGN_SYM(mgn_conv3x3_win)(const void* in, const void* w, void* out, int N, in
     WinParams p;
     p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = (uint16_t*)out; p.residual = (const uint16_t*)residual;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.stat_part = stat_partials; p.stat_shift = stat_shift;
+    if (stat_partials && residual) return MGN_ENOTSUP;
     p.py = (H + patch_rows - 1) / patch_rows; p.px = (W + PW - 1) / PW;
     const long npatch = (long)N * p.py * p.px;
     if (npatch > 0x7fffffffL) return MGN_EINVAL;

@@ -54,10 +54,11 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x, with_skip=False):
         skip = None
+        sf = self.norm if isinstance(self.norm, InPlaceABNSync) else None
         if with_skip:   # also hand back the input for a second consumer (its gradient is fused into the conv's backward)
-            x, skip = ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, with_skip=True)
+            x, skip = ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, with_skip=True, stats_for=sf)
         else:
-            x = ops.conv2d(x, self.weight, self.bias, self.stride, self.padding)
+            x = ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, stats_for=sf)
         if self.norm is not None:
             x = self.norm(x)
         if self.activation is not None:

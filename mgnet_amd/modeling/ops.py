@@ -51,12 +51,32 @@ def _gather_stats(stats, world, group):
     return gathered
 
 
+def _train_coef(x, M, C, w32, b32, eps, momentum, running_mean, running_var, world, group, pstats=None):
+    """Coefficient block [scale, offset, mean, rstd] of a training-mode InPlaceABNSync over x [M, C] (+ running statistics).
+    pstats = (partials, shift) from the producing convolution (csrc/conv_win.hip): no statistics pass over x."""
+    from .. import _C
+    if pstats is not None:
+        part, shift = pstats
+        if world > 1:
+            stats = _C.iabn_from_partials(part, C, M, shift, stats_only=True)
+            return _C.iabn_combine(_gather_stats(stats, world, group), w32, b32, eps, momentum, running_mean, running_var)
+        return _C.iabn_from_partials(part, C, M, shift, w32, b32, eps, momentum, running_mean, running_var)
+    if world > 1:
+        return _C.iabn_combine(_gather_stats(_C.iabn_stats(x, M, C), world, group), w32, b32, eps, momentum, running_mean, running_var)
+    return _C.iabn_train_coeffs(x, M, C, w32, b32, eps, momentum, running_mean, running_var)   # statistics + coefficients in one launch
+
+
+def _pstats(x):
+    """partial statistics the producing conv attached to its output (ops.conv2d(..., stats_for=norm)), consumed once"""
+    return x.__dict__.pop("_mgn_stats", None) if isinstance(x, torch.Tensor) and hasattr(x, "__dict__") else None
+
+
 class _IABNFn(torch.autograd.Function):
     """[HIP] mgnet_amd/csrc/iabn.hip through the C-ABI.  In place: the output overwrites the input's storage (the
     producing conv does not need its output for its own backward) and the backward re-derives x_hat from y."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, activation, slope, group):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, activation, slope, group, pstats=None):
         from .. import _C
 
         N, C, H, W = x.shape
@@ -67,12 +87,7 @@ class _IABNFn(torch.autograd.Function):
         w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
         world = dist.get_world_size(group) if _dist_active(group) else 1
         if training:
-            if world > 1:
-                stats = _C.iabn_stats(xs, M, C)
-                gathered = _gather_stats(stats, world, group)
-                coef = _C.iabn_combine(gathered, w32, b32, eps, momentum, running_mean, running_var)
-            else:  # one process: statistics and coefficients in one launch
-                coef = _C.iabn_train_coeffs(xs, M, C, w32, b32, eps, momentum, running_mean, running_var)
+            coef = _train_coef(xs, M, C, w32, b32, eps, momentum, running_mean, running_var, world, group, pstats)
             # every rank holds the same number of pixels (same per-GPU batch shape), as in the reference's DDP recipe;
             # the forward statistics themselves are combined with the true per-rank counts (Chan), this is only the
             # 1/n of the backward and avoids a host sync per layer
@@ -104,7 +119,7 @@ class _IABNFn(torch.autograd.Function):
             SYNCBN_COLLECTIVES[0] += 1
             dist.all_reduce(sums, group=group)
         _C.iabn_bwd_apply(y, dy, dx, M, C, w32, b32, coef[2:], sums, total, eps, act, slope)
-        return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None
+        return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None, None
 
 
 class _AbnPoolFn(torch.autograd.Function):
@@ -112,7 +127,7 @@ class _AbnPoolFn(torch.autograd.Function):
     the normalised map (the conv output is kept instead; see the header of pool.hip for the traffic accounting)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, activation, slope, group):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, activation, slope, group, pstats=None):
         from .. import _C
 
         N, C, H, W = x.shape
@@ -121,11 +136,7 @@ class _AbnPoolFn(torch.autograd.Function):
         w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
         world = dist.get_world_size(group) if _dist_active(group) else 1
         if training:   # statistics exactly as _IABNFn
-            if world > 1:
-                coef = _C.iabn_combine(_gather_stats(_C.iabn_stats(x, M, C), world, group), w32, b32, eps, momentum,
-                                       running_mean, running_var)
-            else:
-                coef = _C.iabn_train_coeffs(x, M, C, w32, b32, eps, momentum, running_mean, running_var)
+            coef = _train_coef(x, M, C, w32, b32, eps, momentum, running_mean, running_var, world, group, pstats)
         else:
             coef = _C.iabn_eval_coeffs(w32, b32, running_mean, running_var, eps)
         y, arg = _C.abn_maxpool_fwd(x, coef[0], coef[1], act, slope)
@@ -149,7 +160,7 @@ class _AbnPoolFn(torch.autograd.Function):
             SYNCBN_COLLECTIVES[0] += 1
             dist.all_reduce(sums, group=group)
         dx = _C.abn_maxpool_bwd(x, dy, arg, coef, w32, b32, sums, total, eps, act, slope)
-        return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None
+        return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None, None
 
 
 class _AbnAddReluFn(torch.autograd.Function):
@@ -157,7 +168,7 @@ class _AbnAddReluFn(torch.autograd.Function):
     written (x, the conv output, is kept and the norm's backward recomputes z = scale * x + offset)."""
 
     @staticmethod
-    def forward(ctx, x, shortcut, weight, bias, running_mean, running_var, training, momentum, eps, group):
+    def forward(ctx, x, shortcut, weight, bias, running_mean, running_var, training, momentum, eps, group, pstats=None):
         from .. import _C
 
         N, C, H, W = x.shape
@@ -165,11 +176,7 @@ class _AbnAddReluFn(torch.autograd.Function):
         w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
         world = dist.get_world_size(group) if _dist_active(group) else 1
         if training:
-            if world > 1:
-                coef = _C.iabn_combine(_gather_stats(_C.iabn_stats(x, M, C), world, group), w32, b32, eps, momentum,
-                                       running_mean, running_var)
-            else:
-                coef = _C.iabn_train_coeffs(x, M, C, w32, b32, eps, momentum, running_mean, running_var)
+            coef = _train_coef(x, M, C, w32, b32, eps, momentum, running_mean, running_var, world, group, pstats)
         else:
             coef = _C.iabn_eval_coeffs(w32, b32, running_mean, running_var, eps)
         y = _C.abn_add_relu_fwd(x, coef, shortcut)
@@ -192,7 +199,7 @@ class _AbnAddReluFn(torch.autograd.Function):
             dist.all_reduce(sums, group=group)
         dx = torch.empty_like(x)
         _C.iabn_bwd_apply_x(x, dm, dx, M, C, w32, b32, coef, sums, total, eps, 0, 0.01)
-        return dx, dm, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None
+        return dx, dm, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None
 
 
 def abn_add_relu(x, norm, shortcut):
@@ -201,7 +208,7 @@ def abn_add_relu(x, norm, shortcut):
     if (_C.elt_supported(x) and _C.elt_supported(shortcut) and x.shape == shortcut.shape and norm.activation == "identity"
             and not os.environ.get("MGN_NO_TAILFUSE")):
         return _AbnAddReluFn.apply(x, shortcut, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.training,
-                                   norm.momentum, norm.eps, norm.group)
+                                   norm.momentum, norm.eps, norm.group, _pstats(x))
     return add_relu(norm(x), shortcut)
 
 
@@ -211,7 +218,7 @@ def abn_max_pool(x, norm):
     if (x.is_cuda and x.dtype in _C.H16 and _C.elt_supported(x) and not os.environ.get("MGN_NO_STEMFUSE")
             and norm.activation in ("identity", "leaky_relu")):
         return _AbnPoolFn.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.training, norm.momentum,
-                                norm.eps, norm.activation, norm.activation_param, norm.group)
+                                norm.eps, norm.activation, norm.activation_param, norm.group, _pstats(x))
     return max_pool_3x3_s2(norm(x))
 
 
@@ -219,7 +226,7 @@ def iabn(x, weight, bias, running_mean, running_var, training, momentum, eps, ac
     """Fused batch-norm + activation with cross-rank statistics.  CUDA tensors: [HIP]; CPU tensors (host-logic tests
     only): torch restatement below."""
     if x.is_cuda:
-        return _IABNFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps, activation, slope, group)
+        return _IABNFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps, activation, slope, group, _pstats(x))
     xf = x.float()
     C = x.shape[1]
     gamma = weight.abs() + eps
@@ -255,7 +262,7 @@ class _ConvFn(torch.autograd.Function):
     gradient on the bf16 matrix cores.  Master weights stay fp32 OIHW; the kernel layouts are derived per call."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, with_skip=False, cout_pad=0):
+    def forward(ctx, x, weight, bias, stride, pad, relu, with_skip=False, cout_pad=0, stats=None):
         from .. import _C
 
         N, Cin, IH, IW = x.shape   # Cin of the ACTIVATION (8/16 = channel-padded stem input)
@@ -269,7 +276,7 @@ class _ConvFn(torch.autograd.Function):
         else:
             if cout_pad and b is not None:
                 b = torch.cat([b, b.new_zeros(cout_pad - Cout)])
-            out = _C.conv_igemm(xs, _C.weight_layout(weight, 0, 0, cout_pad, dtype=xs.dtype), (OH, OW), b, stride, pad, 1, relu)
+            out = _C.conv_igemm(xs, _C.weight_layout(weight, 0, 0, cout_pad, dtype=xs.dtype), (OH, OW), b, stride, pad, 1, relu, stats=stats)
         ctx.save_for_backward(xs, weight, out if relu else None)
         ctx.cfg = (stride, pad, relu, bias is not None, cout_pad)
         if cout_pad:    # few-class predictors: the kernels work on 32-padded output channels, the caller sees the real ones
@@ -304,10 +311,10 @@ class _ConvFn(torch.autograd.Function):
             dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad, cin_real=Cin)[:Cout]
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum((0, 2, 3))[:Cout]
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=False):
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=False, stats_for=None):
     """Convolution in the activation dtype (bf16 under AMP) from fp32 master weights.
     bf16 CUDA activations with Cin % 32 == 0: [HIP] implicit GEMM (Cout is zero-padded to a multiple of 32 for the
     few-class predictors).  Otherwise (fp32 activations, the 3/9-channel 7x7 stems, CPU tests): [torch-staging].
@@ -321,10 +328,20 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=Fals
         if Cout % 32:
             assert not with_skip
             return _ConvFn.apply(x, weight, bias, stride, padding, relu, False, (Cout + 31) // 32 * 32)
+        # stats_for: the InPlaceABNSync that consumes the output next; in training the conv kernel then leaves the partial sums of
+        # the batch statistics behind (attached to the output, taken by ops.iabn / abn_add_relu / abn_max_pool)
+        holder = []
+        stats = None
+        if (stats_for is not None and stats_for.training and torch.is_grad_enabled() and not os.environ.get("MGN_NO_STATFUSE")
+                and stats_for.running_mean.dtype == torch.float32):
+            stats = (stats_for.running_mean, holder)
         if with_skip and x.requires_grad and x.shape[1] == weight.shape[1] and not os.environ.get("MGN_NO_SKIPFUSE"):
-            return _ConvFn.apply(x, weight, bias, stride, padding, relu, True)
-        y = _ConvFn.apply(x, weight, bias, stride, padding, relu)
-        return (y, x) if with_skip else y
+            y, skip = _ConvFn.apply(x, weight, bias, stride, padding, relu, True, 0, stats)
+        else:
+            y, skip = _ConvFn.apply(x, weight, bias, stride, padding, relu, False, 0, stats), x
+        if holder:
+            y._mgn_stats = holder[0]
+        return (y, skip) if with_skip else y
     if x.is_cuda and not os.environ.get("MGNET_ALLOW_TORCH_STAGING"):
         raise NotImplementedError(
             f"conv2d: no HIP kernel for {x.dtype} activations with {tuple(weight.shape)} weights (the conv kernels are bf16, Cin % 32 == 0 "

@@ -36,7 +36,7 @@ class BasicBlock(nn.Module):  # res_net.py:11-79
         out, skip = self.conv1(x, with_skip=True)   # res_net.py:62-79; `skip` is x: the shortcut's gradient joins conv1's dgrad
         sc = skip if self.shortcut is None else self.shortcut(skip)
         c2 = self.conv2   # conv -> InPlaceABNSync(identity) -> + shortcut -> ReLU; norm, add and ReLU run as one fused op on the GPU
-        return ops.abn_add_relu(ops.conv2d(out, c2.weight, c2.bias, c2.stride, c2.padding), c2.norm, sc)
+        return ops.abn_add_relu(ops.conv2d(out, c2.weight, c2.bias, c2.stride, c2.padding, stats_for=c2.norm), c2.norm, sc)
 
 
 class BasicStem(nn.Module):  # res_net.py:82-110
@@ -48,7 +48,7 @@ class BasicStem(nn.Module):  # res_net.py:82-110
 
     def forward(self, x):
         c = self.conv1   # conv -> InPlaceABNSync(leaky) -> max pool; norm + pooling run as one fused op on the GPU
-        return ops.abn_max_pool(ops.conv2d(x, c.weight, c.bias, c.stride, c.padding), c.norm)
+        return ops.abn_max_pool(ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, stats_for=c.norm), c.norm)
 
 
 class ResNet(nn.Module):

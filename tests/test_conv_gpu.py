@@ -259,3 +259,57 @@ def test_windowed_3x3(monkeypatch, case, rows, dtype):
     monkeypatch.setenv("MGN_CONV_WIN", "0")
     y2, _ = ops.conv2d(x, w, None, stride=1, padding=1, with_skip=True)
     assert rel(y, y2.detach().float().cpu().double()) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows", [16, 8])
+@pytest.mark.parametrize("case", [(2, 64 + 32, 128, 21, 45), (1, 128, 256, 40, 64), (3, 32, 128, 7, 5)])
+def test_windowed_3x3_fused_statistics(case, rows, dtype):
+    """The windowed kernel's partial sums -> mgn_iabn_coeffs_from_partials against the statistics of its own (rounded) output
+    evaluated in fp64: count, mean, sum of squared deviations per channel, with and without a shift, ragged patches."""
+    from mgnet_amd import _C
+
+    N, Cin, Cout, H, W = case
+    torch.manual_seed(sum(case))
+    x = (torch.randn(N, Cin, H, W, device="cuda") + 0.3).to(dtype).contiguous(memory_format=torch.channels_last)
+    wl = (torch.randn(Cout, 3, 3, Cin, device="cuda") / (Cin * 9) ** 0.5).to(dtype)
+    for shift in (None, torch.randn(Cout, device="cuda") * 0.5):
+        y, part = _C.conv3x3_win(x, wl, patch_rows=rows, stats_shift=shift, want_stats=True)
+        y0 = _C.conv3x3_win(x, wl, patch_rows=rows)
+        assert torch.equal(y, y0)                                   # the statistics epilogue does not touch the output
+        M = N * H * W
+        st = _C.iabn_from_partials(part, Cout, M, shift, stats_only=True).double().cpu()
+        yd = y.double().permute(1, 0, 2, 3).reshape(Cout, -1).cpu()
+        mean, m2 = yd.mean(1), ((yd - yd.mean(1, keepdim=True)) ** 2).sum(1)
+        assert torch.equal(st[0], torch.full((Cout,), float(M), dtype=torch.float64))
+        assert float((st[1] - mean).abs().max()) < 2e-6 * float(yd.abs().max())
+        assert float(((st[2] - m2) / m2).abs().max()) < 2e-5, float(((st[2] - m2) / m2).abs().max())
+        # coefficient form + running statistics (= iabn_train_coeffs over the tensor)
+        g, b = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        rm2, rv2 = rm.clone(), rv.clone()
+        c1 = _C.iabn_from_partials(part, Cout, M, shift, g, b, 1e-5, 0.01, rm, rv)
+        c2 = _C.iabn_train_coeffs(y, M, Cout, g, b, 1e-5, 0.01, rm2, rv2)
+        assert torch.allclose(c1, c2, rtol=2e-5, atol=2e-6) and torch.allclose(rm, rm2, rtol=1e-5, atol=1e-7) and torch.allclose(rv, rv2, rtol=2e-5)
+
+
+def test_conv_norm_module_with_fused_statistics(monkeypatch):
+    """layers.Conv2d(conv -> InPlaceABNSync) in training mode: the statistics taken from the conv kernel's epilogue give the same
+    output and gradients as the separate statistics pass (same kernels otherwise)."""
+    from mgnet_amd.modeling.layers import Conv2d, InPlaceABNSync
+
+    monkeypatch.setenv("MGN_CONV_WIN", "8")
+    torch.manual_seed(5)
+    outs = []
+    for nofuse in ("", "1"):
+        if nofuse:
+            monkeypatch.setenv("MGN_NO_STATFUSE", "1")
+        torch.manual_seed(5)
+        m = Conv2d(128, 128, kernel_size=3, padding=1, bias=False, norm=InPlaceABNSync(128, momentum=0.01)).cuda().train()
+        x = torch.randn(2, 128, 19, 37, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = m(x)
+        (y.float() ** 2).sum().backward()
+        outs.append((y.detach().float(), x.grad.float(), m.weight.grad.clone(), m.norm.weight.grad.clone(), m.norm.running_var.clone()))
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
+    assert float((outs[0][0] - outs[1][0]).abs().mean()) < 1e-4 * float(outs[1][0].abs().mean())

