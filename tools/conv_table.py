@@ -23,9 +23,9 @@ trainer.run_step(batch)
 calls = collections.Counter()
 o_ig, o_wg = _C.conv_igemm, _C.conv_wgrad
 
-def r_ig(x, w, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=torch.bfloat16, khw=None, residual=None):
+def r_ig(x, w, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=torch.bfloat16, khw=None, residual=None, stats=None):
     calls[("igemm", tuple(x.shape), tuple(w.shape), tuple(out_shape), stride, pad, up, khw, out_dtype)] += 1
-    return o_ig(x, w, out_shape, bias, stride, pad, up, relu, out_dtype, khw, residual)
+    return o_ig(x, w, out_shape, bias, stride, pad, up, relu, out_dtype, khw, residual, stats)
 
 def r_wg(dy, x, kh, kw, stride, pad, cin_real=None):
     calls[("wgrad", tuple(dy.shape), tuple(x.shape), kh, kw, stride, pad, cin_real)] += 1
