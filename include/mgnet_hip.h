@@ -359,6 +359,34 @@ int mgn_panoptic_post(const mgn_panoptic_cfg* cfg, const int64_t* sem_seg, const
                       int64_t* panoptic, int32_t* info, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Instance predictions from a panoptic prediction (TEST.EVAL_INSTANCE)
+ *   replaces mgnet/postprocessing/instance_post_proc.py:11-72  get_instance_predictions
+ * sem_logits fp32 [C,H,W] (the per-image semantic logits, softmax is taken inside), center_heatmap fp32 [H,W], panoptic int64
+ * [H,W]; a segment is a thing when (id / label_divisor) is a set bit of thing_mask.  Outputs (device), segments in ascending id
+ * order (np.unique): labels int64[n], classes int32[n], scores fp32[n] = mean softmax probability of the class over the mask *
+ * center_heatmap[int(mean y), int(mean x)], boxes fp32[n][4] = x_min, y_min, x_max + 1, y_max + 1; info int32[2] = {n, overflow};
+ * every array holds MGN_INSTANCE_MAX entries.  mgn_instance_masks fills masks uint8 [n][H][W] (zero-initialised by the caller).
+ * Integer accumulation (32.32 fixed point for the probabilities): results do not depend on the launch shape.
+ * ---------------------------------------------------------------------------------------------- */
+#define MGN_INSTANCE_MAX 4096
+typedef struct {
+    int H, W, C;
+    int label_divisor;
+    uint64_t thing_mask;      /* bit c set: class c is a thing (thing_ids of the dataset metadata); C <= 64 */
+} mgn_instance_cfg;
+int mgn_instance_post_workspace_bytes(const mgn_instance_cfg* cfg, size_t* bytes);
+int mgn_instance_post(const mgn_instance_cfg* cfg, const float* sem_logits, const float* center_heatmap, const int64_t* panoptic,
+                      int64_t* labels, int32_t* classes, float* scores, float* boxes, int32_t* info, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int mgn_instance_masks(const mgn_instance_cfg* cfg, const int64_t* panoptic, const int64_t* labels, int n, uint8_t* masks_zeroed,
+                       void* stream);
+/* Pseudo-label images -- replaces the id arithmetic of tools/generate_pseudo_labels.py:100-118: a panoptic
+ * prediction in train ids (int64, void = -1) -> the dataset's `instanceIds` image (uint16): stuff -> id_map[class], things ->
+ * id_map[class] * label_divisor + instance.  id_map256: uint8[256] on the device (trainId -> id, zeros elsewhere). */
+int mgn_pseudo_label_ids(const int64_t* panoptic, long n_pixels, int label_divisor, const uint8_t* id_map256, uint16_t* out,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Depth post-processing with DGC metric rescaling
  *   replaces mgnet/postprocessing/depth_post_proc.py:11-185  get_depth_prediction (+ _get_scale_recovery,
  *   _get_surface_normal with nei = 1, _get_ground_mask with 5 degrees) and Camera.reconstruct (geometry/camera.py:107-141).

@@ -21,7 +21,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
            "mgn_nearest_bwd", "mgn_concat2", "mgn_split2", "mgn_vec_linear_fwd", "mgn_vec_linear_bwd_workspace_bytes", "mgn_vec_linear_bwd",
            "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
-           "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
+           "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_instance_post_workspace_bytes", "mgn_instance_post", "mgn_instance_masks", "mgn_pseudo_label_ids", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
            "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd",
            "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32",
            "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
@@ -470,6 +470,68 @@ def panoptic_post(cfg, sem_seg, center, offsets):
     check(lib().mgn_panoptic_post(ctypes.byref(cfg), sem_seg.data_ptr(), center.data_ptr(), offsets.data_ptr(), pan.data_ptr(),
                                   info.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "mgn_panoptic_post")
     return pan, info
+
+
+INSTANCE_MAX = 4096
+
+
+class InstanceCfg(ctypes.Structure):
+    _fields_ = [("H", ctypes.c_int), ("W", ctypes.c_int), ("C", ctypes.c_int), ("label_divisor", ctypes.c_int),
+                ("thing_mask", ctypes.c_uint64)]
+
+
+def instance_post(sem_logits, center, panoptic, thing_ids, label_divisor, want_masks=True):
+    """mgn_instance_post (+ mgn_instance_masks): sem_logits f32 [C,H,W], center f32 [H,W], panoptic int64 [H,W] (CUDA) ->
+    (labels int64 [n], classes int64 [n], scores f32 [n], boxes f32 [n,4], masks bool [n,H,W] or None).  One host read-back of n
+    (the reference copies the whole panoptic image to the host for np.unique)."""
+    C, H, W = sem_logits.shape
+    assert sem_logits.is_cuda and sem_logits.dtype == torch.float32 and sem_logits.is_contiguous()
+    assert center.dtype == torch.float32 and center.is_contiguous() and tuple(center.shape) == (H, W)
+    assert panoptic.dtype == torch.int64 and panoptic.is_contiguous() and tuple(panoptic.shape) == (H, W)
+    mask = 0
+    for t in thing_ids:
+        if not 0 <= int(t) < 64:
+            raise ValueError(f"thing id {t} outside [0, 64)")
+        mask |= 1 << int(t)
+    cfg = InstanceCfg(H, W, C, int(label_divisor), mask)
+    L = lib()
+    L.mgn_instance_post_workspace_bytes.argtypes = [ctypes.POINTER(InstanceCfg), ctypes.POINTER(ctypes.c_size_t)]
+    L.mgn_instance_post.argtypes = [ctypes.POINTER(InstanceCfg)] + [ctypes.c_void_p] * 9 + [ctypes.c_size_t, ctypes.c_void_p]
+    L.mgn_instance_masks.argtypes = [ctypes.POINTER(InstanceCfg), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    nbytes = ctypes.c_size_t()
+    check(L.mgn_instance_post_workspace_bytes(ctypes.byref(cfg), ctypes.byref(nbytes)), "mgn_instance_post_workspace_bytes")
+    dev = sem_logits.device
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    labels = torch.empty(INSTANCE_MAX, dtype=torch.int64, device=dev)
+    classes = torch.empty(INSTANCE_MAX, dtype=torch.int32, device=dev)
+    scores = torch.empty(INSTANCE_MAX, dtype=torch.float32, device=dev)
+    boxes = torch.empty((INSTANCE_MAX, 4), dtype=torch.float32, device=dev)
+    info = torch.empty(2, dtype=torch.int32, device=dev)
+    check(L.mgn_instance_post(ctypes.byref(cfg), sem_logits.data_ptr(), center.data_ptr(), panoptic.data_ptr(), labels.data_ptr(),
+                              classes.data_ptr(), scores.data_ptr(), boxes.data_ptr(), info.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "mgn_instance_post")
+    n, overflow = (int(v) for v in info.tolist())
+    if overflow:
+        raise RuntimeError(f"more than {INSTANCE_MAX} thing segments in one panoptic image")
+    masks = None
+    if want_masks and n > 0:
+        masks = torch.zeros((n, H, W), dtype=torch.uint8, device=dev)
+        check(L.mgn_instance_masks(ctypes.byref(cfg), panoptic.data_ptr(), labels.data_ptr(), n, masks.data_ptr(), _stream()), "mgn_instance_masks")
+        masks = masks.view(torch.bool)
+    return labels[:n], classes[:n].long(), scores[:n], boxes[:n], masks
+
+
+def pseudo_label_ids(panoptic, label_divisor, id_map):
+    """mgn_pseudo_label_ids: panoptic int64 [H,W] (CUDA, train ids) + id_map (256 ints: trainId -> dataset id) -> int16-typed uint16 image
+    (torch has no uint16 arithmetic: the tensor is int16 storage holding the uint16 bit patterns; `.cpu().numpy().view(np.uint16)`)."""
+    assert panoptic.is_cuda and panoptic.dtype == torch.int64 and panoptic.is_contiguous()
+    lut = torch.as_tensor(id_map, dtype=torch.uint8).reshape(256).to(panoptic.device)
+    out = torch.empty(panoptic.shape, dtype=torch.int16, device=panoptic.device)
+    L = lib()
+    L.mgn_pseudo_label_ids.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    check(L.mgn_pseudo_label_ids(panoptic.data_ptr(), panoptic.numel(), int(label_divisor), lut.data_ptr(), out.data_ptr(), _stream()),
+          "mgn_pseudo_label_ids")
+    return out
 
 
 def depth_metrics(pred, label, min_depth, max_depth, use_gt_scale, crop):

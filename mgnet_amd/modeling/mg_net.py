@@ -46,8 +46,8 @@ class MGNet(nn.Module):
     @configurable
     def __init__(self, *, size_divisibility, pixel_mean, pixel_std, backbone, global_context, sem_seg_head,
                  ins_embed_head, depth_head, pose_net, with_panoptic, with_depth, with_uncertainty, msc_flip_eval=False,
-                 amp_dtype=None, predict_instances=False, panoptic_post_proc_func=None, depth_post_proc_func=None,
-                 **unused_inference_kwargs):
+                 amp_dtype=None, predict_instances=False, instance_post_proc_func=None, panoptic_post_proc_func=None,
+                 depth_post_proc_func=None, **unused_inference_kwargs):
         super().__init__()
         self.size_divisibility = size_divisibility
         self._mean01, self._std01 = [float(x) / 255.0 for x in pixel_mean], [float(x) / 255.0 for x in pixel_std]  # host copies
@@ -63,6 +63,7 @@ class MGNet(nn.Module):
             self.register_parameter("log_vars", nn.Parameter(torch.zeros(5), requires_grad=True))
         self.msc_flip_eval = msc_flip_eval
         self.predict_instances = predict_instances
+        self.instance_post_proc_func = instance_post_proc_func
         self.panoptic_post_proc_func, self.depth_post_proc_func = panoptic_post_proc_func, depth_post_proc_func
         self.amp_dtype = amp_dtype  # activation dtype of the conv trunk (None = fp32); SOLVER.AMP.ENABLED -> bf16
 
@@ -78,7 +79,13 @@ class MGNet(nn.Module):
         if cfg.WITH_DEPTH:
             dep, pose = build_depth_head(cfg, shapes), PoseCNN(cfg)
         meta = MetadataCatalog.get(cfg.DATASETS.TRAIN[0] if len(cfg.DATASETS.TRAIN) else "cityscapes")  # mg_net.py:147
-        pan_fn = dep_fn = None
+        pan_fn = dep_fn = ins_fn = None
+        if cfg.TEST.EVAL_INSTANCE:   # mg_net.py:145-153
+            from functools import partial
+
+            from ..postprocessing import get_instance_predictions
+            ins_fn = partial(get_instance_predictions, thing_ids=list(meta.thing_dataset_id_to_contiguous_id.values()),
+                             label_divisor=meta.label_divisor)
         if cfg.WITH_PANOPTIC:   # mg_net.py:155-170
             from ..postprocessing import get_panoptic_prediction
             pp = cfg.MODEL.POST_PROCESSING
@@ -100,7 +107,7 @@ class MGNet(nn.Module):
                     pixel_std=cfg.MODEL.PIXEL_STD, backbone=backbone, global_context=gcm, sem_seg_head=sem,
                     ins_embed_head=ins, depth_head=dep, pose_net=pose, with_panoptic=cfg.WITH_PANOPTIC,
                     with_depth=cfg.WITH_DEPTH, with_uncertainty=cfg.WITH_UNCERTAINTY, msc_flip_eval=cfg.TEST.MSC_FLIP_EVAL,
-                    amp_dtype=_amp_dtype(cfg), predict_instances=cfg.TEST.EVAL_INSTANCE,
+                    amp_dtype=_amp_dtype(cfg), predict_instances=cfg.TEST.EVAL_INSTANCE, instance_post_proc_func=ins_fn,
                     panoptic_post_proc_func=pan_fn, depth_post_proc_func=dep_fn)
 
     @property
@@ -337,8 +344,6 @@ def sem_seg_postprocess(result, img_size, output_height, output_width):
 
 def _inference(self, batched_inputs, outputs):
     """mg_net.py:375-425: per image (the post-processing is not batched in the reference either)."""
-    if self.predict_instances:
-        raise NotImplementedError("TEST.EVAL_INSTANCE (instance_post_proc.py, detectron2 Instances/BitMasks) is not built")
     results = []
     for idx, inp in enumerate(batched_inputs):
         size = tuple(inp["image"].shape[-2:])
@@ -349,6 +354,11 @@ def _inference(self, batched_inputs, outputs):
             o = sem_seg_postprocess(outputs["offset"][idx], size, height, width)
             pan = self.panoptic_post_proc_func(sem_seg=r.argmax(dim=0, keepdim=True), center_heatmap=c, offsets=o)
             results.append({"sem_seg": r, "panoptic_seg": (pan, None)})
+            if self.predict_instances:   # mg_net.py:394-402: instance segmentation evaluation, disabled by default
+                from ..structures import Instances
+                instances = self.instance_post_proc_func(sem_seg=r, center_heatmap=c, panoptic_image=pan)
+                if len(instances) > 0:
+                    results[-1]["instances"] = Instances.cat(instances)
         if self.with_depth:
             d = sem_seg_postprocess(outputs["depth"][idx], size, height, width)
             first = batched_inputs[0]   # sic: mg_net.py:409-414 read the camera of the FIRST input

@@ -4,6 +4,74 @@ import torch
 import torch.nn.functional as F
 
 
+class Boxes:
+    """detectron2.structures.Boxes equivalent (the part instance_post_proc.py:68 produces): `tensor` [N, 4] = x1, y1, x2, y2."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor.reshape(-1, 4)
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    @staticmethod
+    def cat(boxes_list):
+        return Boxes(torch.cat([b.tensor for b in boxes_list], 0))
+
+
+class Instances:
+    """detectron2.structures.Instances equivalent (what mg_net.py:394-402 returns under `"instances"`): an image size plus
+    per-instance fields of equal length set as attributes (`pred_classes`, `pred_masks`, `scores`, `pred_boxes`)."""
+
+    def __init__(self, image_size, **fields):
+        object.__setattr__(self, "_image_size", tuple(image_size))
+        object.__setattr__(self, "_fields", {})
+        for k, v in fields.items():
+            self.set(k, v)
+
+    @property
+    def image_size(self):
+        return self._image_size
+
+    def __setattr__(self, name, val):
+        self.set(name, val)
+
+    def __getattr__(self, name):
+        if name == "_fields" or name not in self._fields:
+            raise AttributeError(f"Cannot find field '{name}' in the given Instances!")
+        return self._fields[name]
+
+    def set(self, name, value):
+        if self._fields:
+            assert len(self) == len(value), f"Adding a field of length {len(value)} to Instances of length {len(self)}"
+        self._fields[name] = value
+
+    def has(self, name):
+        return name in self._fields
+
+    def get(self, name):
+        return self._fields[name]
+
+    def get_fields(self):
+        return self._fields
+
+    def __len__(self):
+        for v in self._fields.values():
+            return len(v)
+        raise NotImplementedError("Empty Instances does not support __len__!")
+
+    @staticmethod
+    def cat(instance_lists):
+        assert len(instance_lists) > 0 and all(i.image_size == instance_lists[0].image_size for i in instance_lists)
+        if len(instance_lists) == 1:
+            return instance_lists[0]
+        ret = Instances(instance_lists[0].image_size)
+        for k in instance_lists[0]._fields:
+            vals = [i.get(k) for i in instance_lists]
+            v0 = vals[0]
+            ret.set(k, torch.cat(vals, 0) if isinstance(v0, torch.Tensor) else type(v0).cat(vals))
+        return ret
+
+
 class ImageList:
     def __init__(self, tensor, image_sizes):
         self.tensor = tensor

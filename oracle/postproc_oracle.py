@@ -124,3 +124,46 @@ def depth_prediction(depth, use_dgc_scaling, K=None, real_camera_height=None, pa
             if xyz is not None:
                 xyz[:, panoptic == cid] = np.nan
     return d, xyz, scale
+
+
+def instance_predictions(sem_seg, center_heatmap, panoptic, thing_ids, label_divisor):
+    """instance_post_proc.py:11-72 get_instance_predictions.  sem_seg [C,H,W] logits, center_heatmap [1,H,W] or [H,W], panoptic
+    [H,W] -> (labels, classes, scores, boxes [n,4], masks [n,H,W] bool), segments in np.unique order (:38)."""
+    sem = np.asarray(sem_seg, dtype=np.float32)
+    heat = np.asarray(center_heatmap, dtype=np.float32).reshape(sem.shape[1:])
+    pan = np.asarray(panoptic)
+    z = sem - sem.max(0, keepdims=True)
+    prob = np.exp(z, dtype=np.float32)
+    prob = prob / prob.sum(0, keepdims=True, dtype=np.float32)                  # F.softmax(sem_seg, dim=0) (:36)
+    labels, classes, scores, boxes, masks = [], [], [], [], []
+    for lab in np.unique(pan):                                                    # :38
+        if lab == -1:
+            continue
+        c = int(lab // label_divisor)                                             # :41
+        if c not in thing_ids:                                                    # :42-44
+            continue
+        m = pan == lab                                                            # :50
+        sem_score = np.float32(prob[c][m].mean(dtype=np.float64))                 # :53-54
+        ys, xs = np.nonzero(m)                                                    # :56
+        cy, cx = int(np.float32(ys.mean(dtype=np.float64))), int(np.float32(xs.mean(dtype=np.float64)))   # :57-61 (float32 means, int())
+        scores.append(np.float32(sem_score * heat[cy, cx]))                       # :61-65
+        boxes.append(np.array([xs.min(), ys.min(), xs.max() + 1, ys.max() + 1], np.float32))   # BitMasks.get_bounding_boxes (:67)
+        labels.append(int(lab)); classes.append(c); masks.append(m)
+    n = len(labels)
+    return (np.array(labels, np.int64), np.array(classes, np.int64), np.array(scores, np.float32),
+            np.stack(boxes) if n else np.zeros((0, 4), np.float32), np.stack(masks) if n else np.zeros((0,) + pan.shape, bool))
+
+
+def pseudo_label_ids(panoptic, label_divisor, id_map):
+    """tools/generate_pseudo_labels.py:100-118: panoptic prediction in train ids -> uint16 `instanceIds` image (the three masked
+    assignments in the reference's order; id_map: uint8[256], trainId -> dataset id)."""
+    p = np.asarray(panoptic).copy()
+    id_map = np.asarray(id_map, dtype=np.uint8)
+    sel = p % label_divisor == 0                                  # :103-106 stuff segments -> class train id
+    p[sel] = p[sel] // label_divisor
+    sel = p < label_divisor                                       # :107-109 train id -> id (numpy negative index for void = -1)
+    p[sel] = id_map[p[sel]]
+    sel = p >= label_divisor                                      # :110-118 things: id * divisor + instance
+    # (uint8 * Python int: value-based promotion under the reference's NumPy < 2, exact for ids <= 65; int64 here)
+    p[sel] = id_map[p[sel] // label_divisor].astype(np.int64) * label_divisor + p[sel] % label_divisor
+    return p.astype(np.uint16)

@@ -197,3 +197,108 @@ def test_eval_forward_runs_the_post_processing(torch_staging):
         assert np.array_equal(got == 0, d_ref == 0)
         np.testing.assert_allclose(got, d_ref, rtol=1e-4)
         assert tuple(xyz.shape) == (3, H, W) and np.array_equal(np.isnan(xyz.cpu().numpy()), np.isnan(xyz_ref))
+
+
+INS = sorted(glob.glob(os.path.join(GOLDEN, "instances_*.npz")))
+
+
+@pytest.mark.parametrize("path", INS, ids=[os.path.basename(p)[10:-4] for p in INS])
+def test_instance_predictions_match_reference(path):
+    """mgnet_amd.postprocessing.get_instance_predictions (csrc/instances.hip) against the reference's own outputs: classes, boxes
+    and masks exactly, scores to fp32 round-off (the mean class probability is an order-independent fixed-point sum here)."""
+    from mgnet_amd.postprocessing import get_instance_predictions
+    from mgnet_amd.structures import Instances
+
+    z = np.load(path)
+    sem, heat, pan = (torch.from_numpy(z[k]).cuda() for k in ("sem", "heat", "pan"))
+    out = get_instance_predictions(sem, heat, pan, list(z["thing_ids"]), int(z["label_divisor"]))
+    n = len(z["classes"])
+    assert len(out) == n
+    if n == 0:
+        return
+    cat = Instances.cat(out)
+    assert cat.image_size == tuple(pan.shape) and len(cat) == n
+    assert np.array_equal(cat.pred_classes.cpu().numpy(), z["classes"])
+    assert np.array_equal(cat.pred_boxes.tensor.cpu().numpy(), z["boxes"])
+    np.testing.assert_allclose(cat.scores.cpu().numpy(), z["scores"], rtol=1e-5, atol=1e-8)
+    masks = cat.pred_masks.cpu().numpy()
+    assert masks.dtype == np.bool_ and np.array_equal(np.packbits(masks.reshape(n, -1), axis=1), z["masks"])
+
+
+def test_instance_predictions_large_frame_vs_oracle():
+    """1024x2048 frame with ~200 thing segments against the numpy oracle; result independent of repetition"""
+    from mgnet_amd import _C
+    from oracle import postproc_oracle as PO
+
+    rs = np.random.RandomState(0)
+    H, W, C = 1024, 2048, 19
+    blk = rs.randint(0, 11, size=(H // 16, W // 16))
+    pan = (np.kron(blk, np.ones((16, 16), dtype=np.int64)) * 1000).astype(np.int64)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for k in range(200):
+        cy, cx, r = rs.randint(H), rs.randint(W), rs.randint(3, 90)
+        pan[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = rs.randint(11, 19) * 1000 + k + 1
+    sem = rs.randn(C, H, W).astype(np.float32)
+    heat = rs.rand(H, W).astype(np.float32)
+    ref = PO.instance_predictions(sem, heat, pan, list(range(11, 19)), 1000)
+    args = (torch.from_numpy(sem).cuda(), torch.from_numpy(heat).cuda(), torch.from_numpy(pan).cuda(), list(range(11, 19)), 1000)
+    a = _C.instance_post(*args)
+    b = _C.instance_post(*args)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert np.array_equal(a[0].cpu().numpy(), ref[0]) and np.array_equal(a[1].cpu().numpy(), ref[1])
+    assert np.array_equal(a[3].cpu().numpy(), ref[3])
+    np.testing.assert_allclose(a[2].cpu().numpy(), ref[2], rtol=2e-5)
+    assert np.array_equal(a[4].cpu().numpy(), ref[4])
+
+
+def test_pseudo_label_ids_match_reference():
+    """mgn_pseudo_label_ids against the reference's own arithmetic (fixture) and the oracle on a full frame"""
+    from mgnet_amd import _C
+
+    z = np.load(os.path.join(GOLDEN, "pseudo_labels.npz"))
+    out = _C.pseudo_label_ids(torch.from_numpy(z["pan"]).cuda(), int(z["label_divisor"]), z["id_map"])
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), z["out"])
+    rs = np.random.RandomState(1)
+    pan = (rs.randint(0, 19, size=(1024, 2048)) * 1000 + rs.randint(0, 40, size=(1024, 2048)) * (rs.rand(1024, 2048) < 0.5)).astype(np.int64)
+    pan[rs.rand(1024, 2048) < 0.02] = -1
+    ref = PO.pseudo_label_ids(pan, 1000, z["id_map"])
+    got = _C.pseudo_label_ids(torch.from_numpy(pan).cuda(), 1000, z["id_map"]).cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, ref)
+
+
+def test_eval_forward_with_instances():
+    """TEST.EVAL_INSTANCE (mg_net.py:145-153, 394-402): `model.eval()(batch)` carries an `instances` entry that is consistent with
+    its own panoptic prediction (one instance per thing segment in ascending id order, class = id // divisor, mask = segment,
+    tight box) -- the scores are pinned by the fixtures above."""
+    from mgnet_amd import add_mgnet_config, get_cfg
+    from mgnet_amd.registry import build_model
+    from conftest import ROOT
+
+    cfg = get_cfg()
+    add_mgnet_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "bench-c4-cityscapes-videosequence.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda:0", "WITH_DEPTH", False, "TEST.EVAL_INSTANCE", True, "MODEL.POST_PROCESSING.CENTER_THRESHOLD", 0.0001])
+    torch.manual_seed(1)
+    model = build_model(cfg).eval()
+    g = torch.Generator().manual_seed(2)
+    batch = [{"image": torch.randint(0, 256, (3, 128, 256), generator=g, dtype=torch.uint8).cuda()} for _ in range(2)]
+    with torch.no_grad():
+        out = model(batch)
+    n_total = 0
+    for r in out:
+        pan = r["panoptic_seg"][0]
+        ids = [int(v) for v in torch.unique(pan).tolist() if v != -1 and 12 <= v // 1000 <= 19]   # Cityscapes thing train ids (20 classes)
+        if not ids:
+            assert "instances" not in r
+            continue
+        ins = r["instances"]
+        assert len(ins) == len(ids) and ins.image_size == tuple(pan.shape)
+        assert ins.pred_classes.tolist() == [v // 1000 for v in ids]
+        for k, v in enumerate(ids):
+            m = pan == v
+            assert torch.equal(ins.pred_masks[k], m)
+            ys, xs = torch.nonzero(m, as_tuple=True)
+            assert ins.pred_boxes.tensor[k].tolist() == [float(xs.min()), float(ys.min()), float(xs.max() + 1), float(ys.max() + 1)]
+        assert torch.isfinite(ins.scores).all() and (ins.scores >= 0).all()
+        n_total += len(ids)
+    assert n_total > 0, "the random model produced no thing segment: lower the centre threshold of this test"
