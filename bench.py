@@ -334,6 +334,11 @@ def main():
     if not (args.loss_only or args.fwd_only):
         return full_step_bench(args, world, rank, dev)
     d = synth_batch(B, H, W, 1234 + rank, dev)
+    if os.environ.get("MGN_REPROJ_RGBX"):   # diagnostic: context frames pixel-interleaved ([B,H,W,4] in memory, 4th channel unused)
+        for k in ("prev", "nxt"):
+            t = torch.zeros((B, 4, H, W), device=dev).contiguous(memory_format=torch.channels_last)
+            t[:, :3] = d[k]
+            d[k] = t
     inv = [x.requires_grad_(not args.fwd_only) for x in d["inv"]]
     poses = d["poses"].requires_grad_(not args.fwd_only)
     nsteps = args.warmup + args.steps

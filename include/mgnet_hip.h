@@ -72,6 +72,9 @@ typedef struct {
     int photometric_reduce_op;/* 0 = "min" (only supported value), 1 = "mean" */
     int padding_mode;         /* 0 = "zeros" (only supported value), 1 = "border", 2 = "reflection" */
     int rows_per_wave;        /* 0 = choose automatically; else rows each wavefront owns (>=4) */
+    int ctx_interleaved;      /* 0: prev / next are [B,3,H,W] planes like the reference's tensors; 1: [B,H,W,4] RGBx (a 4-channel
+                                 channels_last tensor, 4th channel ignored; mgn_u8_frames_to_f32_nhwc4 produces it): one 16-byte
+                                 gather per bilinear corner instead of three 4-byte ones, same results */
     void* prof_begin;         /* optional hipEvent_t recorded on `stream` right before the dominant kernel */
     void* prof_end;           /* optional hipEvent_t recorded right after it (bench.py's roofline leg); NULL = off */
 } mgn_reproj_cfg;
@@ -275,6 +278,9 @@ int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int
  * of the photometric loss and their stacking (mg_net.py:320-335).  frames_u8: HOST array of n_frames (<= 16) device pointers
  * (16-byte aligned) to n_per_frame bytes each (n_per_frame % 16 == 0); out: [n_frames, n_per_frame] fp32.  IEEE division. */
 int mgn_u8_frames_to_f32(const void* const* frames_u8, int n_frames, long n_per_frame, float divisor, float* out, void* stream);
+/* the same conversion of n_frames [3,H,W] uint8 frames (hw = H*W, a multiple of 4) into ONE pixel-interleaved RGBx batch
+ * [n_frames][H][W][4] fp32 (4th channel 0): the context-frame layout of mgn_reproj_cfg.ctx_interleaved */
+int mgn_u8_frames_to_f32_nhwc4(const void* const* frames_u8, int n_frames, long hw, float divisor, float* out, void* stream);
 
 /* The stem's activated batch norm folded into the pooling (BasicStem, res_net.py:82-110: conv -> InPlaceABNSync -> max_pool):
  * forward pools y = act(scale * x + offset) evaluated on the fly (bf16-rounded like mgn_iabn_apply stores it; the

@@ -178,6 +178,11 @@ struct Gather {       // the 12 corner values of one sample position (3 channel 
     float tx, ty;
 };
 // first half: corner addresses and the 12 loads (nothing waits for them here)
+// ILV: the context frame is pixel-interleaved RGBx ([H][W][4] fp32 = a 4-channel channels_last torch tensor, 4th channel unused):
+// ONE 16-byte load per corner through one resource instead of three dword loads through three plane resources -- the same 12
+// values, a third of the vector-memory instructions (the kernel's second limiter after VALU issue).  (The compiler
+// narrows the 16-byte load to buffer_load_dwordx3 since only three elements are used; the 16-byte pixel keeps every load aligned.)
+template <bool ILV>
 __device__ __forceinline__ void bilinear3_issue(const rsrc_t (&plane)[3], int W, int H, float ix, float iy, Gather& g) {
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     g.tx = ix - fx0;
@@ -186,9 +191,24 @@ __device__ __forceinline__ void bilinear3_issue(const rsrc_t (&plane)[3], int W,
     const int yi = (int)__builtin_amdgcn_fmed3f(fy0, -2.f, (float)H);
     const bool x0ok = (unsigned)xi < (unsigned)W, x1ok = (unsigned)(xi + 1) < (unsigned)W;
     constexpr int OUT = (int)0x80000000u;      // beyond any plane (H*W <= 2^28 pixels)
-    const int o00 = (yi * W + xi) * 4;
-    const int a00 = x0ok ? o00 : OUT, a10 = x1ok ? o00 + 4 : OUT;
-    const int a01 = x0ok ? o00 + 4 * W : OUT, a11 = x1ok ? o00 + 4 * W + 4 : OUT;
+    constexpr int PX = ILV ? 16 : 4;           // bytes from a pixel to its right neighbour
+    const int o00 = (yi * W + xi) * PX;
+    const int a00 = x0ok ? o00 : OUT, a10 = x1ok ? o00 + PX : OUT;
+    const int a01 = x0ok ? o00 + PX * W : OUT, a11 = x1ok ? o00 + PX * W + PX : OUT;
+    if (ILV) {
+        // (the result goes through a float vector and .x/.y/.z: indexing an unsigned ext-vector of this builtin's result and
+        //  bit-casting the element is miscompiled by this toolchain into ONE dword load splatted over the elements)
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 c00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(plane[0], a00, 0, 0));
+        const f32x4 c10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(plane[0], a10, 0, 0));
+        const f32x4 c01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(plane[0], a01, 0, 0));
+        const f32x4 c11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(plane[0], a11, 0, 0));
+        g.v[0][0] = c00.x; g.v[1][0] = c00.y; g.v[2][0] = c00.z;
+        g.v[0][1] = c10.x; g.v[1][1] = c10.y; g.v[2][1] = c10.z;
+        g.v[0][2] = c01.x; g.v[1][2] = c01.y; g.v[2][2] = c01.z;
+        g.v[0][3] = c11.x; g.v[1][3] = c11.y; g.v[2][3] = c11.z;
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         g.v[c][0] = bload(plane[c], a00, 0);
@@ -276,7 +296,7 @@ __device__ __forceinline__ void row_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool GRAD>
+template <bool GRAD, bool ILV = false>
 __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -316,7 +336,7 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
 
     if (wave == 0) {
         // =========================================== image wave ===========================================
-        const float* refb[2] = {p.prev + (size_t)b * 3 * HWp, p.nxt + (size_t)b * 3 * HWp};
+        const float* refb[2] = {p.prev + (size_t)b * (ILV ? 4 : 3) * HWp, p.nxt + (size_t)b * (ILV ? 4 : 3) * HWp};
         const uint8_t* maskb = p.mask ? p.mask + (size_t)b * HWp : nullptr;
         float y1[3] = {0.f, 0.f, 0.f}, y2[3] = {0.f, 0.f, 0.f}, rf1[2][3], rf2[2][3];
 #pragma unroll
@@ -333,8 +353,8 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     y0[c] = imgb[c * HWp + off];
-                    rf0[0][c] = refb[0][c * HWp + off];
-                    rf0[1][c] = refb[1][c * HWp + off];
+                    rf0[0][c] = ILV ? refb[0][off * 4 + c] : refb[0][c * HWp + off];
+                    rf0[1][c] = ILV ? refb[1][off * 4 + c] : refb[1][c * HWp + off];
                 }
                 const bool m0 = maskb ? (maskb[off] != 0) : true;
                 if (s >= r0 - 1) {
@@ -417,9 +437,12 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
             col1[j][k] = cam.M[j][k * 3 + 1];
             kt[j][k] = cam.Kt[j][k];
         }
-    const float* refb[2] = {p.prev + (size_t)b * 3 * HWp, p.nxt + (size_t)b * 3 * HWp};
-    const rsrc_t plane[2][3] = {{make_rsrc(refb[0], 4u * HWp), make_rsrc(refb[0] + HWp, 4u * HWp), make_rsrc(refb[0] + 2 * HWp, 4u * HWp)},
-                                {make_rsrc(refb[1], 4u * HWp), make_rsrc(refb[1] + HWp, 4u * HWp), make_rsrc(refb[1] + 2 * HWp, 4u * HWp)}};
+    const float* refb[2] = {p.prev + (size_t)b * (ILV ? 4 : 3) * HWp, p.nxt + (size_t)b * (ILV ? 4 : 3) * HWp};
+    // (ILV: one resource over the whole interleaved frame, 16 bytes per pixel; the other two entries are unused)
+    const uint32_t pbytes = ILV ? 16u * HWp : 4u * HWp;
+    const int pstep = ILV ? 0 : HWp;
+    const rsrc_t plane[2][3] = {{make_rsrc(refb[0], pbytes), make_rsrc(refb[0] + pstep, pbytes), make_rsrc(refb[0] + 2 * pstep, pbytes)},
+                                {make_rsrc(refb[1], pbytes), make_rsrc(refb[1] + pstep, pbytes), make_rsrc(refb[1] + 2 * pstep, pbytes)}};
     // weights realising the adjoint of F.pad(reflect): a border pixel's adjoint window is seen twice by its neighbour
     const float exp_to_right = (cu == 0) ? 2.f : 1.f;      // value exported to lane+1
     const float exp_to_left = (cu == W - 1) ? 2.f : 1.f;   // value exported to lane-1
@@ -494,7 +517,7 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 const bool zf = z >= 1e-5f;             // camera.py:172 clamp(min=1e-5)
                 const float rz = frcp(fmaxf(z, 1e-5f));
                 const float ix = X * rz, iy = Y * rz;   // == ((Xn+1)/2)(W-1) of grid_sample
-                bilinear3_issue(plane[j], W, H, ix, iy, gth[j]);
+                bilinear3_issue<ILV>(plane[j], W, H, ix, iy, gth[j]);
                 if (GRAD) {
                     st[(j * 9 + 6) * WAVE] = zf ? rz : -rz;  // rz > 0: the sign carries the clamp flag
                     st[(j * 9 + 7) * WAVE] = ix;
@@ -1005,10 +1028,14 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
     hipLaunchKernelGGL(reproj_prep, dim3((cfg->B + 63) / 64), dim3(64), 0, stream, cam, cam_stride, cam_ld, pose, cfg->B,
                        (CamConst*)(ws + L.off_cam));
     if (cfg->prof_begin) (void)hipEventRecord((hipEvent_t)cfg->prof_begin, stream);
-    if (want_grad)
-        hipLaunchKernelGGL(reproj_march<true>, dim3(L.nblocks), dim3(WAVE * (cfg->n_scales + 1)), L.lds_bytes, stream, p);
-    else
-        hipLaunchKernelGGL(reproj_march<false>, dim3(L.nblocks), dim3(WAVE * (cfg->n_scales + 1)), L.lds_bytes, stream, p);
+    const dim3 mgrid(L.nblocks), mblock(WAVE * (cfg->n_scales + 1));
+    if (cfg->ctx_interleaved) {   // prev / next are [B][H][W][4] (4-channel channels_last, 4th channel unused)
+        if (want_grad) hipLaunchKernelGGL((reproj_march<true, true>), mgrid, mblock, L.lds_bytes, stream, p);
+        else hipLaunchKernelGGL((reproj_march<false, true>), mgrid, mblock, L.lds_bytes, stream, p);
+    } else {
+        if (want_grad) hipLaunchKernelGGL((reproj_march<true, false>), mgrid, mblock, L.lds_bytes, stream, p);
+        else hipLaunchKernelGGL((reproj_march<false, false>), mgrid, mblock, L.lds_bytes, stream, p);
+    }
     if (cfg->prof_end) (void)hipEventRecord((hipEvent_t)cfg->prof_end, stream);
     hipLaunchKernelGGL(reproj_fin1, dim3(cfg->B, cfg->n_scales), dim3(256), 0, stream, (const float*)(ws + L.off_partials),
                        cfg->n_scales, L.nseg * L.nstrips, (double*)(ws + L.off_persum));

@@ -142,7 +142,13 @@ class MultiViewPhotometricLoss(nn.Module):
         if mask is not None:
             mask = mask.contiguous()
         f32 = lambda t: t.float().contiguous()
-        losses = _ReprojLossFn.apply(cfg, f32(img), f32(targets["image_prev_orig"]), f32(targets["image_next_orig"]),
+        # context frames may arrive pixel-interleaved ([B,4,H,W] channels_last, 4th channel unused; MGNet.forward produces them
+        # straight from the uint8 frames): the kernel then gathers 16 bytes per bilinear corner instead of 3 x 4
+        rgbx = lambda t: t.dim() == 4 and t.shape[1] == 4 and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(memory_format=torch.channels_last)
+        prev, nxt = targets["image_prev_orig"], targets["image_next_orig"]
+        if not (rgbx(prev) and rgbx(nxt)):
+            prev, nxt = f32(prev[:, :3]), f32(nxt[:, :3])
+        losses = _ReprojLossFn.apply(cfg, f32(img), prev, nxt,
                                      mask, f32(targets["camera_matrix"]), pose_results.float(),
                                      *[x.float() for x in inv_depths])
         return {"loss_photometric": losses[0], "loss_smoothness": losses[1]}

@@ -233,3 +233,44 @@ def test_full_size_properties():
         np.testing.assert_allclose(r2["d_inv"][i][0], 0.5 * r1["d_inv"][i][0], rtol=1e-5, atol=1e-12)
         np.testing.assert_array_equal(r2["d_inv"][i][0], r2["d_inv"][i][1])
     np.testing.assert_allclose(r2["d_pose"][0], 0.5 * r1["d_pose"][0], rtol=1e-4, atol=1e-9)
+
+
+def _rgbx(t):
+    """[B,3,H,W] -> [B,4,H,W] channels_last with a junk 4th channel (the kernel must ignore it)"""
+    B, _, H, W = t.shape
+    out = torch.full((B, 4, H, W), 7.0, device=t.device).contiguous(memory_format=torch.channels_last)
+    out[:, :3] = t
+    return out
+
+
+@pytest.mark.parametrize("name", ["rand_small", "oob_clamp", "no_mask_odd"])
+def test_interleaved_context_frames_are_bit_identical(name):
+    """prev / next handed over pixel-interleaved ([B,H,W,4] in memory: one 16-byte gather per bilinear corner, reproj_march<.., ILV>)
+    give the same bits as the reference's planar layout: losses, pose gradient and every inverse-depth gradient."""
+    from mgnet_amd import _C
+
+    c = golden_case_inputs(name)
+    d = _dev(c)
+    B, _, H, W = c["img"].shape
+    outs = []
+    for il in (False, True):
+        prev, nxt = (_rgbx(d["prev"]), _rgbx(d["nxt"])) if il else (d["prev"], d["nxt"])
+        cfg = _C.make_reproj_cfg(B, H, W, len(d["inv"]))
+        fwd = _C.reproj_loss_fwd(cfg, d["inv"], d["img"], prev, nxt, d.get("mask"), d["K"], d["poses"], want_grad=True)
+        assert cfg.ctx_interleaved == int(il)
+        g, dp = _C.reproj_loss_bwd(cfg, d["inv"], d["img"], d.get("mask"), torch.ones(2, device="cuda"), fwd)
+        outs.append((fwd["losses"].clone(), dp.clone(), [x.clone() for x in g]))
+    (l0, p0, g0), (l1, p1, g1) = outs
+    assert torch.equal(l0, l1) and torch.equal(p0, p1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+
+def test_u8_frames_to_rgbx():
+    from mgnet_amd import _C
+
+    g = torch.Generator().manual_seed(0)
+    frames = [torch.randint(0, 256, (3, 24, 40), generator=g, dtype=torch.uint8).cuda() for _ in range(3)]
+    out = _C.u8_frames_to_f32_rgbx(frames, 255.0)
+    assert out.shape == (3, 4, 24, 40) and out.is_contiguous(memory_format=torch.channels_last)
+    # (IEEE division like the reference's CPU arithmetic and mgn_u8_frames_to_f32; torch's GPU kernel multiplies by the reciprocal)
+    assert torch.equal(out[:, :3].cpu(), torch.stack([f.cpu() for f in frames]).float() / 255.0) and float(out[:, 3].abs().max()) == 0.0
+    assert torch.equal(out[:, :3], _C.u8_frames_to_f32(frames, 255.0))
