@@ -118,7 +118,7 @@ int mgn_iabn_stats(const void* x, int dtype, long M, int C, float* stats /*[3][C
 /* the same outputs as mgn_iabn_stats (stats[3][C], may be NULL) and / or mgn_iabn_train_coeffs (coef[4][C] + running statistics,
  * may be NULL) from the per-tile partial sums a convolution left behind (mgn_conv3x3_win: partials[rows][C][2] of (r - shift),
  * (r - shift)^2 over its rounded outputs; shift as given to the convolution): the statistics pass over the activation becomes a
- * read of rows*C*8 bytes.  M = N*H*W of the activation; C % 16 == 0. */
+ * read of rows*C*8 bytes.  M = N*H*W of the activation; C % 4 == 0. */
 int mgn_iabn_coeffs_from_partials(const float* partials, int rows, int C, long M, const float* shift, const float* weight,
                                   const float* bias, float eps, float momentum, float* running_mean, float* running_var,
                                   float* coef /*[4][C] or NULL*/, float* stats /*[3][C] or NULL*/, void* stream);
@@ -215,6 +215,15 @@ int mgn_conv3x3_win(const void* in, const void* w, void* out, int N, int H, int 
                                             (r - shift)^2 over the ROUNDED outputs r, the input of mgn_iabn_coeffs_from_partials: the
                                             statistics pass of the InPlaceABNSync that follows the conv (res_net.py:35,49,59) */,
                     const float* stat_shift /* [Cout] or NULL (= 0): e.g. the layer's running_mean */, void* stream);
+/* Convolution + the batch statistics of its output in one launch (forward of conv -> InPlaceABNSync, res_net.py:35,49,59,
+ * layers.py:63,71): mgn_conv_stat_rows says how many partial rows the kernel mgn_conv_igemm would pick for this layer leaves behind
+ * (0: that kernel has no statistics epilogue -- run mgn_iabn_train_coeffs over the output instead; *shifted = 1: the sums are taken
+ * around stat_shift, else around 0); mgn_conv_igemm_stats is mgn_conv_igemm (no bias / ReLU / residual, 16-bit output) that also
+ * fills stat_partials [rows][Cout][2] = sums of r, r^2 over the ROUNDED outputs, the input of mgn_iabn_coeffs_from_partials.
+ * Kernels with the epilogue: the windowed 3x3 kernel (csrc/conv_win.hip) and the 64-channel row-march kernel (conv3x3_c64). */
+int mgn_conv_stat_rows(int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int* shifted);
+int mgn_conv_igemm_stats(const void* in, const void* w, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
+                         int KW, int stride, int pad, float* stat_partials, const float* stat_shift, void* stream);
 /* patch height mgn_conv_igemm picks for a 3x3 / stride 1 / pad 1 layer of this shape: 16, 8, or 0 (= it uses another kernel) */
 int mgn_conv_win_patch_rows(int N, int OH, int OW, int Cin, int Cout);
 /* fp32 OIHW master weights -> bf16 kernel layout. mode 0: [Cout][KH][KW][Cin]; 1: [Cin][KH][KW][Cout] with flipped taps
@@ -522,6 +531,8 @@ int mgn_conv_igemm_f16(const void* in, const void* w, void* out, const float* bi
 int mgn_conv_wgrad_f16(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW,
     int Cout, int KH, int KW, int stride, int pad, int oihw_cin /* >0: dw is [Cout][oihw_cin][KH][KW] */, void*
     workspace, size_t workspace_bytes, void* stream);
+int mgn_conv_igemm_stats_f16(const void* in, const void* w, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
+    int KW, int stride, int pad, float* stat_partials, const float* stat_shift, void* stream);
 int mgn_conv3x3_win_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
     int patch_rows, float* stat_partials, const float* stat_shift, void* stream);
 int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);

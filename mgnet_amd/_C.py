@@ -15,7 +15,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv3x3_win", "mgn_conv_win_patch_rows", "mgn_iabn_coeffs_from_partials", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv_win_patch_rows", "mgn_iabn_coeffs_from_partials", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -26,7 +26,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4",
            "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
            "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd"]
-SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv3x3_win', 'mgn_conv_wgrad', 'mgn_add_relu_fwd', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
+SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_wgrad', 'mgn_add_relu_fwd', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
 DEPTH_MAX_FILTER_IDS = 16
 
 
@@ -61,7 +61,7 @@ class ReprojCfg(ctypes.Structure):
 
 _lib = None
 H16 = (torch.bfloat16, torch.float16)   # the 16-bit activation formats: bf16 entry points, or their _f16 twins (csrc/h16.h)
-F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv3x3_win', 'mgn_conv_wgrad', 'mgn_add_relu_fwd', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']
+F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_wgrad', 'mgn_add_relu_fwd', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']
 
 
 def _fn(name, t):
@@ -104,6 +104,8 @@ def lib():
         L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp, vp]
         L.mgn_conv3x3_win.argtypes = [vp, vp, vp] + [ci] * 5 + [vp, ci, vp, vp, vp]
         L.mgn_conv_win_patch_rows.argtypes = [ci] * 5
+        L.mgn_conv_stat_rows.argtypes = [ci] * 11 + [ctypes.POINTER(ci)]
+        L.mgn_conv_igemm_stats.argtypes = [vp, vp, vp] + [ci] * 11 + [vp, vp, vp]
         L.mgn_iabn_coeffs_from_partials.argtypes = [vp, ci, ci, cl, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
@@ -668,14 +670,19 @@ def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dt
     OH, OW = out_shape
     out_dtype = x.dtype if out_dtype is None else out_dtype   # the activation format (bf16 / fp16), or fp32
     assert w_ohwi.dtype == x.dtype, "weight layout and activations must share the 16-bit format"
-    if (stats is not None and khw is None and (KH, KW, stride, pad, up) == (3, 3, 1, 1, 1) and bias is None and not relu and residual is None
-            and out_dtype == x.dtype and (OH, OW) == (IH, IW)):
-        # stats = (shift [Cout] fp32 or None, holder list): a layer of the windowed kernel also leaves the partial sums of its output's
-        # batch statistics behind (the following InPlaceABNSync then skips its statistics pass); other layers ignore the request
-        pr = lib().mgn_conv_win_patch_rows(N, OH, OW, Cin, Cout)
-        if pr > 0:
-            out, part = conv3x3_win(x, w_ohwi, patch_rows=pr, stats_shift=stats[0], want_stats=True)
-            stats[1].append((part, stats[0]))
+    if stats is not None and khw is None and up == 1 and bias is None and not relu and residual is None and out_dtype == x.dtype:
+        # stats = (shift [Cout] fp32 or None, holder list): a layer whose kernel has the statistics epilogue (windowed 3x3, 64-channel
+        # row march) also leaves the partial sums of its output's batch statistics behind (the following InPlaceABNSync then skips its
+        # statistics pass); other layers ignore the request
+        shifted = ctypes.c_int(0)
+        rows = lib().mgn_conv_stat_rows(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, ctypes.byref(shifted))
+        if rows > 0:
+            out = torch.empty((N, Cout, OH, OW), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
+            part = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
+            shift = stats[0] if shifted.value else None
+            check(_fn("mgn_conv_igemm_stats", x)(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad,
+                                                 part.data_ptr(), None if shift is None else shift.data_ptr(), _stream()), "mgn_conv_igemm_stats")
+            stats[1].append((part, shift))
             return out
     out = torch.empty((N, Cout, OH, OW), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
     check(_fn("mgn_conv_igemm", x)(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(),

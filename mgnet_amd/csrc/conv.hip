@@ -754,6 +754,8 @@ struct Conv64Params {
     const uint16_t* w;     // [Cout, 3, 3, 64] bf16
     uint16_t* out;         // [N, H, W, Cout] bf16
     const uint16_t* residual;  // like ConvParams::residual
+    float* stat_part;          // [nslices][Cout][2] per-slice sums of r, r^2 over the ROUNDED outputs (the statistics pass of the
+                               // InPlaceABNSync that follows, see conv_win.hip / mgn_iabn_coeffs_from_partials), or null
     int N, H, W, Cout;
     int strips, chunks, rows_per_chunk, nslices, co_tiles;
 };
@@ -820,6 +822,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
         for (int kk = 0; kk < 4; ++kk) aoff[kw][kk] = px * 128 + ((((kk * 2 + hi) ^ ((px >> 1) & 7))) << 4);
     }
 
+    float st1[4][4], st2[4][4];   // statistics of this lane's 16 channels over its pixels (only with p.stat_part)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st1[q][e] = st2[q][e] = 0.f;
     // TWO output rows per step (72 MFMAs per wave between barriers; the weight registers serve both rows)
 #pragma unroll
     for (int k = 0; k < 6; ++k) issue_in(r0 - 1 + k, k);   // rows r0-1 .. r0+4: the first step's four rows + one step ahead
@@ -894,6 +901,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
                             const float v2 = rr2 ? acc1[qd * 4 + 2] : acc0[qd * 4 + 2], v3 = rr2 ? acc1[qd * 4 + 3] : acc0[qd * 4 + 3];
                             pk[u][0] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
                             pk[u][1] = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+                            if (p.stat_part) {   // (block-uniform; every lane in here owns a valid pixel)
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    const float d0 = mgn_lo2f(pk[u][h]), d1 = mgn_hi2f(pk[u][h]);
+                                    st1[qd][2 * h] += d0; st2[qd][2 * h] = fmaf(d0, d0, st2[qd][2 * h]);
+                                    st1[qd][2 * h + 1] += d1; st2[qd][2 * h + 1] = fmaf(d1, d1, st2[qd][2 * h + 1]);
+                                }
+                            }
                         }
                         const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
@@ -903,6 +918,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
             }
         }
         si = slot(si + 2);
+    }
+    if (p.stat_part) {
+        // 16-lane DPP butterflies, the 8 parts of a channel (4 pixel groups x 2 lane rows) through LDS, one partial row per slice
+        auto row_sum = [](float v) {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+            return v;
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows prefetched past the chunk still land in the ring
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(c64sm);       // [wpx 4][lane row 2][64 channels][2]
+        const int rw = (lane >> 4) & 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = row_sum(st1[q][e]), b = row_sum(st2[q][e]);
+                if ((lane & 15) == 0)
+                    *reinterpret_cast<float2*>(red + ((wpx * 2 + rw) * 64 + wco * 32 + 8 * q + 4 * hi + e) * 2) = make_float2(a, b);
+            }
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 128 + tid];
+            p.stat_part[((size_t)slice * p.Cout + tile * 64) * 2 + tid] = t;
+        }
     }
 }
 
@@ -1781,8 +1825,25 @@ int MGN_SYM(mgn_weight_layout_batch)(const void* table_dev, int n_entries, long 
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int MGN_SYM(mgn_conv_igemm)(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
-                   int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, const void* residual, void* stream) {
+// the slice plan of conv3x3_c64 (one 8-wave block per CU): also the number of partial statistics rows it writes
+static void c64_plan(int N, int OH, int OW, int Cout, Conv64Params* q) {
+    q->N = N; q->H = OH; q->W = OW; q->Cout = Cout;
+    q->strips = (OW + 127) / 128; q->co_tiles = Cout / 64;
+    int chunks = (256 / q->co_tiles) / (N * q->strips);
+    if (chunks > OH / 4) chunks = OH / 4;
+    if (chunks < 1) chunks = 1;
+    q->rows_per_chunk = (OH + chunks - 1) / chunks;
+    q->chunks = (OH + q->rows_per_chunk - 1) / q->rows_per_chunk;
+    q->nslices = N * q->strips * q->chunks;
+}
+static bool c64_eligible(int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int up) {
+    return KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 1 && Cin == 64 && Cout % 64 == 0 && IH == OH && IW == OW &&
+           (size_t)N * OH * OW * (Cout > 64 ? Cout : 64) * 2 < 0x7fffffffu && !getenv("MGN_CONV_NOC64");
+}
+
+static int conv_igemm_impl(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
+                           int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, const void* residual,
+                           float* stat_part, const float* stat_shift, void* stream) {
     if (!in || !w || !out || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || up < 1)
         return MGN_EINVAL;
     const bool pack = (Cin == 8 || Cin == 16);            // small-Cin stems: taps packed into the k-slab
@@ -1821,10 +1882,12 @@ int MGN_SYM(mgn_conv_igemm)(const void* in, const void* w, void* out, const floa
         // windowed kernel (csrc/conv_win.hip): the input window of a 2-D pixel patch stays in LDS for all nine taps
         const int pr = mgn_conv_win_patch_rows(N, OH, OW, Cin, Cout);
         if (pr > 0) {
-            const int rcw = MGN_SYM(mgn_conv3x3_win)(in, w, out, N, OH, OW, Cin, Cout, residual, pr, nullptr, nullptr, stream);
-            if (rcw != MGN_ENOTSUP) return rcw;
+            const int rcw = MGN_SYM(mgn_conv3x3_win)(in, w, out, N, OH, OW, Cin, Cout, residual, pr, stat_part, stat_shift, stream);
+            if (rcw != MGN_ENOTSUP || stat_part) return rcw;
         }
     }
+    const bool c64 = !pack && !bias && !relu && !out_f32 && c64_eligible(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up);
+    if (stat_part && !c64) return MGN_ENOTSUP;   // (mgn_conv_stat_rows says which layers leave statistics behind)
     if (pack && !getenv("MGN_CONV_NOPACKDMA") && stride >= 1 && up == 1 && (size_t)N * IH * IW * Cin * 2 < 0x7fffffffu) {
         // the stems on the LDS-DMA kernel (per-lane tap gather); grid like the generic LDS-DMA launch
         p.xcd_bands = xcd_ok(gx, (long)(Cout <= 64 ? (Cout + 63) / 64 : (Cout + 127) / 128));
@@ -1835,17 +1898,10 @@ int MGN_SYM(mgn_conv_igemm)(const void* in, const void* w, void* out, const floa
     if (pack) {
         if (Cout <= 64) hipLaunchKernelGGL((conv_igemm<1, 2, true>), dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm<2, 2, true>), dim3((unsigned)gx, (Cout + 127) / 128), dim3(256), 0, st, p);
-    } else if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 1 && Cin == 64 && Cout % 64 == 0 && IH == OH && IW == OW && !bias &&
-               !relu && !out_f32 && (size_t)N * OH * OW * (Cout > 64 ? Cout : 64) * 2 < 0x7fffffffu && !getenv("MGN_CONV_NOC64")) {
+    } else if (c64) {
         Conv64Params q;
-        q.in = p.in; q.w = p.w; q.out = (uint16_t*)out; q.residual = p.residual; q.N = N; q.H = OH; q.W = OW; q.Cout = Cout;
-        q.strips = (OW + 127) / 128; q.co_tiles = Cout / 64;
-        int chunks = (256 / q.co_tiles) / (N * q.strips);      // one 8-wave block per CU
-        if (chunks > OH / 4) chunks = OH / 4;
-        if (chunks < 1) chunks = 1;
-        q.rows_per_chunk = (OH + chunks - 1) / chunks;
-        q.chunks = (OH + q.rows_per_chunk - 1) / q.rows_per_chunk;
-        q.nslices = N * q.strips * q.chunks;
+        q.in = p.in; q.w = p.w; q.out = (uint16_t*)out; q.residual = p.residual; q.stat_part = stat_part;
+        c64_plan(N, OH, OW, Cout, &q);
         static bool cattr = false;
         if (!cattr) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
@@ -1915,6 +1971,37 @@ int MGN_SYM(mgn_conv_igemm)(const void* in, const void* w, void* out, const floa
     }
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+
+int MGN_SYM(mgn_conv_igemm)(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
+                   int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, const void* residual, void* stream) {
+    return conv_igemm_impl(in, w, out, bias, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32, residual, nullptr, nullptr, stream);
+}
+
+int MGN_SYM(mgn_conv_igemm_stats)(const void* in, const void* w, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
+                                  int KW, int stride, int pad, float* stat_partials, const float* stat_shift, void* stream) {
+    if (!stat_partials) return MGN_EINVAL;
+    return conv_igemm_impl(in, w, out, nullptr, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, 1, 0, 0, nullptr, stat_partials, stat_shift, stream);
+}
+
+#ifndef MGN_F16
+int mgn_conv_stat_rows(int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int* shifted) {
+    if (shifted) *shifted = 0;
+    if (N < 1 || OH < 1 || OW < 1 || Cout < 1) return 0;
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && IH == OH && IW == OW) {
+        const int pr = mgn_conv_win_patch_rows(N, OH, OW, Cin, Cout);
+        if (pr > 0) {
+            if (shifted) *shifted = 1;
+            return N * ((OH + pr - 1) / pr) * ((OW + 31) / 32);
+        }
+    }
+    if (c64_eligible(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, 1)) {
+        Conv64Params q;
+        c64_plan(N, OH, OW, Cout, &q);
+        return q.nslices;
+    }
+    return 0;
+}
+#endif
 
 static void wgrad_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, bool* pack, int* NT, int* MT, int* ci_tiles,
                        int* co_tiles, long* m_per_split, long* gz) {

@@ -479,32 +479,33 @@ unsigned* next_counter() {
 
 // ------------------------------------------------------------------------------------------------------
 // statistics from the per-tile partial sums a convolution left behind (csrc/conv_win.hip: stat_part[rows][C][2] = sums of
-// (r - shift), (r - shift)^2 of its rounded outputs): a block per 16 channels adds the rows in a fixed order (fp64) and writes
+// (r - shift), (r - shift)^2 of its rounded outputs): a block per 4 channels adds the rows in a fixed order (fp64) and writes
 // the same outputs as iabn_stats_kernel's last block: stats[3][C] = {count, mean, M2} and / or the coefficient block + running
 // statistics.  Replaces the statistics pass over the tensor (one read of the whole activation) by a read of rows*C*8 bytes.
 // ------------------------------------------------------------------------------------------------------
 #ifndef MGN_F16
 __global__ __launch_bounds__(256) void iabn_from_partials_kernel(const float* __restrict__ part, int rows, int C, long M, const float* __restrict__ shift, StatsOut o) {
-    __shared__ double sh[8][32];
-    const int c0 = blockIdx.x * 16;
-    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 32 floats = 16 channels x {s1, s2} per row; 8 row groups
+    // a block per 4 channels (C / 4 blocks: 16 .. 128 of them): 8 floats = 32 bytes per partial row, 32 row groups
+    __shared__ double sh[32][8];
+    const int c0 = blockIdx.x * 4;
+    const int col = threadIdx.x & 7, rg = threadIdx.x >> 3;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const float* src = part + (size_t)c0 * 2 + col;
     int r = rg;
-    for (; r + 24 < rows; r += 32) {
+    for (; r + 96 < rows; r += 128) {
         a0 += (double)src[(size_t)r * C * 2];
-        a1 += (double)src[(size_t)(r + 8) * C * 2];
-        a2 += (double)src[(size_t)(r + 16) * C * 2];
-        a3 += (double)src[(size_t)(r + 24) * C * 2];
+        a1 += (double)src[(size_t)(r + 32) * C * 2];
+        a2 += (double)src[(size_t)(r + 64) * C * 2];
+        a3 += (double)src[(size_t)(r + 96) * C * 2];
     }
-    for (; r < rows; r += 8) a0 += (double)src[(size_t)r * C * 2];
+    for (; r < rows; r += 32) a0 += (double)src[(size_t)r * C * 2];
     sh[rg][col] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < 4) {
         const int c = c0 + threadIdx.x;
         double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 32; ++k) {
             t1 += sh[k][2 * threadIdx.x];
             t2 += sh[k][2 * threadIdx.x + 1];
         }
@@ -582,10 +583,10 @@ int MGN_SYM(mgn_iabn_train_coeffs)(const void* x, int dtype, long M, int C, cons
 int mgn_iabn_coeffs_from_partials(const float* partials, int rows, int C, long M, const float* shift, const float* weight, const float* bias,
                                   float eps, float momentum, float* running_mean, float* running_var, float* coef, float* stats,
                                   void* stream_) {
-    if (!partials || rows < 1 || C < 16 || C % 16 != 0 || M < 1 || (!coef && !stats)) return MGN_EINVAL;
+    if (!partials || rows < 1 || C < 4 || C % 4 != 0 || M < 1 || (!coef && !stats)) return MGN_EINVAL;
     if (coef && (!weight || !bias)) return MGN_EINVAL;
     StatsOut o = {stats, coef, weight, bias, running_mean, running_var, eps, momentum};
-    hipLaunchKernelGGL(iabn_from_partials_kernel, dim3(C / 16), dim3(256), 0, (hipStream_t)stream_, partials, rows, C, M, shift, o);
+    hipLaunchKernelGGL(iabn_from_partials_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream_, partials, rows, C, M, shift, o);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 #endif

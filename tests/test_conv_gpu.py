@@ -313,3 +313,26 @@ def test_conv_norm_module_with_fused_statistics(monkeypatch):
     for a, b in zip(*outs):
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
     assert float((outs[0][0] - outs[1][0]).abs().mean()) < 1e-4 * float(outs[1][0].abs().mean())
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 37, 150), (1, 64, 128, 64, 256), (3, 64, 64, 9, 40)])
+def test_row_march_c64_fused_statistics(case):
+    """conv3x3_c64's statistics epilogue (mgn_conv_igemm_stats -> mgn_iabn_coeffs_from_partials) against the fp64 statistics of
+    its own rounded output; the output itself is unchanged by the epilogue."""
+    from mgnet_amd import _C
+
+    N, Cin, Cout, H, W = case
+    torch.manual_seed(sum(case))
+    x = (torch.randn(N, Cin, H, W, device="cuda") + 0.2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wl = (torch.randn(Cout, 3, 3, Cin, device="cuda") / (Cin * 9) ** 0.5).to(torch.bfloat16)
+    holder = []
+    y = _C.conv_igemm(x, wl, (H, W), None, 1, 1, stats=(torch.zeros(Cout, device="cuda"), holder))
+    assert len(holder) == 1, "the 64-channel row-march kernel did not take the statistics request"
+    part, shift = holder[0]
+    assert shift is None and torch.equal(y, _C.conv_igemm(x, wl, (H, W), None, 1, 1))
+    M = N * H * W
+    st = _C.iabn_from_partials(part, Cout, M, None, stats_only=True).double().cpu()
+    yd = y.double().permute(1, 0, 2, 3).reshape(Cout, -1).cpu()
+    mean, m2 = yd.mean(1), ((yd - yd.mean(1, keepdim=True)) ** 2).sum(1)
+    assert float((st[1] - mean).abs().max()) < 2e-6 * float(yd.abs().max())
+    assert float(((st[2] - m2) / m2).abs().max()) < 2e-5
