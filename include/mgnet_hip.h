@@ -205,6 +205,16 @@ int mgn_conv_wgrad(const void* dout, const void* in, float* dw, int N, int IH, i
                    int KH, int KW, int stride, int pad, int oihw_cin /* >0: dw is [Cout][oihw_cin][KH][KW] */,
                    void* workspace, size_t workspace_bytes, void* stream);
 int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, size_t* bytes);
+/* Deferred split-K reduction: mgn_conv_wgrad_partial is mgn_conv_wgrad without the final reduction -- the per-split partial tiles
+ * stay in `workspace` (the caller keeps it alive) and desc8 (HOST, 8 x int64) receives {partial, 0, splits, Cout, taps, Cin, oihw,
+ * cin_real}; MGN_ENOTSUP for the stem shapes (they keep their own reduction).  mgn_conv_wgrad_reduce_batch then performs the
+ * reductions of MANY weight gradients in ONE launch from a device table of 10 x int64 per entry: {partial, dst (fp32 gradient in the
+ * layout oihw/cin_real select), splits, Cout, taps, Cin, oihw, cin_real, first block, blocks along the (tap, ci) axis =
+ * ceil(taps*Cin/256)}, entry k owning blocks [first_k, first_k + Cout_k * gy_k).  Same sums in the same fixed order as mgn_conv_wgrad.
+ * The gradient reducer (mgnet_amd/engine/reducer.py) batches a bucket's convolutions this way: ~70 launches per step become ~5. */
+int mgn_conv_wgrad_partial(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
+                           int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
+int mgn_conv_wgrad_reduce_batch(const void* table_dev, int n_entries, long total_blocks, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution (forward, or data gradient on flipped+transposed weights) with Cin % 32 == 0 and
  * Cout % 128 == 0 as a WINDOWED implicit GEMM (csrc/conv_win.hip): a block owns a patch of patch_rows (8 | 16) x 32 output pixels
  * and keeps the input window in LDS for all nine taps.  Same tensors as mgn_conv_igemm (which dispatches here for the
@@ -535,6 +545,8 @@ int mgn_conv_igemm_stats_f16(const void* in, const void* w, void* out, int N, in
     int KW, int stride, int pad, float* stat_partials, const float* stat_shift, void* stream);
 int mgn_conv3x3_win_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
     int patch_rows, float* stat_partials, const float* stat_shift, void* stream);
+int mgn_conv_wgrad_partial_f16(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
+    int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
 int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);
 int mgn_abn_add_relu_fwd_f16(const void* x, const float* scale, const float* offset, const void* shortcut, void* y,
     long M, int C, void* stream);

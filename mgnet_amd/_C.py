@@ -15,7 +15,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv_win_patch_rows", "mgn_iabn_coeffs_from_partials", "mgn_conv_wgrad", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv_win_patch_rows", "mgn_iabn_coeffs_from_partials", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -26,7 +26,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4",
            "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
            "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd"]
-SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_wgrad', 'mgn_add_relu_fwd', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
+SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
 DEPTH_MAX_FILTER_IDS = 16
 
 
@@ -61,7 +61,7 @@ class ReprojCfg(ctypes.Structure):
 
 _lib = None
 H16 = (torch.bfloat16, torch.float16)   # the 16-bit activation formats: bf16 entry points, or their _f16 twins (csrc/h16.h)
-F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_wgrad', 'mgn_add_relu_fwd', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']
+F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']
 
 
 def _fn(name, t):
@@ -109,6 +109,8 @@ def lib():
         L.mgn_iabn_coeffs_from_partials.argtypes = [vp, ci, ci, cl, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
+        L.mgn_conv_wgrad_partial.argtypes = [vp, vp] + [ci] * 12 + [vp, sz, ctypes.POINTER(ctypes.c_longlong), vp]
+        L.mgn_conv_wgrad_reduce_batch.argtypes = [vp, ci, cl, vp]
         L.mgn_weight_layout.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
         L.mgn_weight_layout_batch.argtypes = [vp, ci, cl, vp]
         L.mgn_upce_partials.argtypes = [ci, ci, ci]
@@ -692,7 +694,32 @@ def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dt
     return out
 
 
-def conv_wgrad(dy, x, kh, kw, stride, pad, cin_real=None):
+# Deferred split-K reductions (engine/reducer.py): while WGRAD_LAZY[0] is set, conv_wgrad(lazy=True) leaves the partial tiles in their
+# workspace, returns an UNWRITTEN gradient tensor and registers the reduction under the tensor's address; the gradient reducer
+# collects the entries of a bucket's parameters and runs them as ONE launch that writes straight into the bucket (wgrad_reduce_batch)
+WGRAD_LAZY = [False]
+WGRAD_PENDING = {}
+_wgrad_stager = None
+
+
+def wgrad_reduce_batch(entries):
+    """entries: [(desc8 list, workspace tensor, dst tensor)] -> one launch performing every reduction into its dst"""
+    global _wgrad_stager
+    rows, start = [], 0
+    for desc, _ws, dst in entries:
+        gy = (desc[4] * desc[5] // 4 + 63) // 64
+        rows.append([desc[0], dst.data_ptr(), desc[2], desc[3], desc[4], desc[5], desc[6], desc[7], start, gy])
+        start += desc[3] * gy
+    table = torch.tensor(rows, dtype=torch.int64)
+    dev = entries[0][2].device
+    if _wgrad_stager is None:
+        _wgrad_stager = PinnedStager(depth=8)
+    tdev = _wgrad_stager.stage(table, dev, slot=("wgrad", len(rows)))
+    check(lib().mgn_conv_wgrad_reduce_batch(tdev.data_ptr(), len(rows), start, _stream()), "mgn_conv_wgrad_reduce_batch")
+    return tdev
+
+
+def conv_wgrad(dy, x, kh, kw, stride, pad, cin_real=None, lazy=False):
     """dy [N,Cout,OH,OW], x [N,Cin,IH,IW] (channels_last bf16) -> dw fp32 in the torch parameter layout
     [Cout, cin_real, KH, KW] (cin_real < Cin for the channel-padded stem inputs)"""
     N, Cout, OH, OW = dy.shape
@@ -702,6 +729,15 @@ def conv_wgrad(dy, x, kh, kw, stride, pad, cin_real=None):
     nb = ctypes.c_size_t(0)
     check(lib().mgn_conv_wgrad_workspace_bytes(N, OH, OW, Cin, Cout, kh, kw, ctypes.byref(nb)), "mgn_conv_wgrad_workspace_bytes")
     ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device)
+    if lazy and WGRAD_LAZY[0]:
+        desc = (ctypes.c_longlong * 8)()
+        rc = _fn("mgn_conv_wgrad_partial", dy)(dy.data_ptr(), x.data_ptr(), N, IH, IW, Cin, OH, OW, Cout, kh, kw, stride, pad, cin_real,
+                                               ws.data_ptr(), nb.value, desc, _stream())
+        if rc == 0:
+            WGRAD_PENDING[dw.data_ptr()] = (list(desc), ws, tuple(dw.shape))
+            return dw
+        if rc != -95:
+            check(rc, "mgn_conv_wgrad_partial")
     check(_fn("mgn_conv_wgrad", dy)(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, IH, IW, Cin, OH, OW, Cout, kh, kw, stride, pad,
                                cin_real, ws.data_ptr(), nb.value, _stream()), "mgn_conv_wgrad")
     return dw

@@ -1700,12 +1700,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgradParams p) {
 // splits z = g, g+4, ... with two independent accumulators; the groups are combined in a fixed order through LDS): ~8
 // sixteen-byte loads in flight per thread and Cout * ceil(taps*Cin/256) blocks.  (The first version had a thread per element:
 // 4-byte loads in a dependent chain -- 0.6 TB/s, 1.6 ms per training step.)
-__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw,
-                                                         int cin_real, float* __restrict__ dw) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw,
+                                                  int cin_real, float* __restrict__ dw, int bx, int by) {
     __shared__ float4 scratch[4][64];
-    const int per = taps * Cin, co = blockIdx.x, el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int per = taps * Cin, co = bx, el = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long wsize = (long)Cout * per;
-    const int e4 = blockIdx.y * 64 + el;
+    const int e4 = by * 64 + el;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     if (e4 < per / 4) {
         const float* q = partial + (long)co * per + (long)e4 * 4;
@@ -1735,6 +1735,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (ci + k < cin_real) dw[((long)co * cin_real + ci + k) * taps + tap] = v[k];
+}
+__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw,
+                                                         int cin_real, float* __restrict__ dw) {
+    wgrad_reduce_body(partial, splits, Cout, taps, Cin, oihw, cin_real, dw, blockIdx.x, blockIdx.y);
+}
+// The reductions of MANY weight gradients in one launch (the gradient reducer batches the split-K sums of a bucket's convolutions:
+// 70 launches of ~10 us per training step become one per bucket).  table: 10 x int64 per entry = {partial, dst, splits, Cout, taps,
+// Cin, oihw, cin_real, first block, blocks along the (tap, ci) axis}; a block finds its entry by binary search on `first block`.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_batch(const long long* __restrict__ table, int n_entries) {
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(size_t)mid * 10 + 8] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* e = table + (size_t)lo * 10;
+    const int local = (int)((long long)blockIdx.x - e[8]), gy = (int)e[9];
+    wgrad_reduce_body(reinterpret_cast<const float*>(e[0]), (int)e[2], (int)e[3], (int)e[4], (int)e[5], (int)e[6], (int)e[7],
+                      reinterpret_cast<float*>(e[1]), local / gy, local % gy);
 }
 static inline dim3 wgrad_reduce_grid(int Cout, int taps, int Cin) { return dim3((unsigned)Cout, (unsigned)((taps * Cin / 4 + 63) / 64)); }
 
@@ -2083,9 +2101,11 @@ int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int
 }
 
 #endif
-int MGN_SYM(mgn_conv_wgrad)(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
-                   int KW, int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!dout || !in || !dw || !workspace || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || KH < 1 || KW < 1 || stride < 1) return MGN_EINVAL;
+// desc != null: "partial only" -- the split-K partials stay in the workspace, no reduction is launched, desc[0..7] = {partial,
+// 0, splits, Cout, taps, Cin, oihw, cin_real} describes the reduction for mgn_conv_wgrad_reduce_batch (dw is not written)
+static int wgrad_impl(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
+                      int KW, int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc, void* stream) {
+    if (!dout || !in || (!dw && !desc) || !workspace || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || KH < 1 || KW < 1 || stride < 1) return MGN_EINVAL;
     if (Cin % 8 != 0 || Cout % 8 != 0) return MGN_ENOTSUP;
     WgradParams p;
     p.dout = (const uint16_t*)dout; p.in = (const uint16_t*)in; p.dw = dw;
@@ -2096,6 +2116,7 @@ int MGN_SYM(mgn_conv_wgrad)(const void* dout, const void* in, float* dw, int N, 
     const size_t wsize = (size_t)Cout * KH * KW * Cin;
     WgradStemParams ps;
     if (oihw_cin > 0 && wgrad_stem_plan(N, OH, OW, Cin, Cout, KH, KW, stride, pad, IH, IW, &ps)) {
+        if (desc) return MGN_ENOTSUP;   // (the stems keep their own reduction kernel)
         if (workspace_bytes < sizeof(float) * (size_t)ps.nslices * Cout * 56 * Cin) return MGN_ENOSPC;
         ps.dout = p.dout; ps.in = p.in; ps.partial = (float*)workspace;
         static bool attrs = false;
@@ -2124,8 +2145,13 @@ int MGN_SYM(mgn_conv_wgrad)(const void* dout, const void* in, float* dw, int N, 
         const unsigned nblk = (unsigned)((p3.nslices + 7) / 8) * 8 * p3.co_tiles * p3.ci_tiles;
         if (p3.ng == 2) hipLaunchKernelGGL(conv_wgrad3x3_s128, dim3(nblk), dim3(512), W3<2>::LDS, st, p3);
         else hipLaunchKernelGGL(conv_wgrad3x3_s64, dim3(nblk), dim3(256), W3<1>::LDS, st, p3);
-        hipLaunchKernelGGL(conv_wgrad_reduce, wgrad_reduce_grid(Cout, 9, Cin), dim3(256), 0, st, (const float*)workspace, p3.nslices, Cout, 9,
-                           Cin, p.oihw, p.cin_real, dw);
+        if (desc) {
+            desc[0] = (long long)(uintptr_t)workspace; desc[1] = 0; desc[2] = p3.nslices; desc[3] = Cout; desc[4] = 9; desc[5] = Cin;
+            desc[6] = p.oihw; desc[7] = p.cin_real;
+        } else {
+            hipLaunchKernelGGL(conv_wgrad_reduce, wgrad_reduce_grid(Cout, 9, Cin), dim3(256), 0, st, (const float*)workspace, p3.nslices, Cout, 9,
+                               Cin, p.oihw, p.cin_real, dw);
+        }
         return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
     }
     bool pack; int NT, MT, co_tiles; long gz;
@@ -2159,9 +2185,34 @@ int MGN_SYM(mgn_conv_wgrad)(const void* dout, const void* in, float* dw, int N, 
     else if (MT == 1) hipLaunchKernelGGL((conv_wgrad<1, 2>), grid, dim3(256), lds, st, p);
     else if (NT == 1) hipLaunchKernelGGL((conv_wgrad<2, 1>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((conv_wgrad<2, 2>), grid, dim3(256), lds, st, p);
-    hipLaunchKernelGGL(conv_wgrad_reduce, wgrad_reduce_grid(Cout, KH * KW, Cin), dim3(256), 0, st, (const float*)workspace, (int)gz, Cout,
-                       KH * KW, Cin, p.oihw, p.cin_real, dw);
+    if (desc) {
+        desc[0] = (long long)(uintptr_t)workspace; desc[1] = 0; desc[2] = gz; desc[3] = Cout; desc[4] = KH * KW; desc[5] = Cin;
+        desc[6] = p.oihw; desc[7] = p.cin_real;
+    } else {
+        hipLaunchKernelGGL(conv_wgrad_reduce, wgrad_reduce_grid(Cout, KH * KW, Cin), dim3(256), 0, st, (const float*)workspace, (int)gz, Cout,
+                           KH * KW, Cin, p.oihw, p.cin_real, dw);
+    }
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
+
+int MGN_SYM(mgn_conv_wgrad)(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
+                   int KW, int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dw) return MGN_EINVAL;
+    return wgrad_impl(dout, in, dw, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, oihw_cin, workspace, workspace_bytes, nullptr, stream);
+}
+
+int MGN_SYM(mgn_conv_wgrad_partial)(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
+                                    int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream) {
+    if (!desc8) return MGN_EINVAL;
+    return wgrad_impl(dout, in, nullptr, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, oihw_cin, workspace, workspace_bytes, desc8, stream);
+}
+
+#ifndef MGN_F16
+int mgn_conv_wgrad_reduce_batch(const void* table_dev, int n_entries, long total_blocks, void* stream) {
+    if (!table_dev || n_entries < 1 || total_blocks < 1 || total_blocks > 0x7fffffffL) return MGN_EINVAL;
+    hipLaunchKernelGGL(conv_wgrad_reduce_batch, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)table_dev, n_entries);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+#endif
 
 }  // extern "C"

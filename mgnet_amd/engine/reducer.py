@@ -69,6 +69,12 @@ class GradReducer:
         for p in plist:
             self._bucket_of[p] = b
 
+    def lazy_wgrad(self, on):
+        """(de)activate deferred split-K reductions for the backward that follows (Trainer); leftovers are an error"""
+        from .. import _C
+        if self.buckets and self.buckets[0]["flat_g"].is_cuda:
+            _C.WGRAD_LAZY[0] = bool(on)
+
     def zero_grad(self):
         """Gradients are not zeroed: `.grad` is dropped, so autograd hands over each freshly computed gradient without an
         accumulate kernel per parameter; `_hook` packs a bucket's gradients into its flat buffer with one multi-tensor
@@ -101,7 +107,25 @@ class GradReducer:
                 if st is not None and st != cur:
                     b["params"][i].grad.record_stream(cur)
         if idx:
-            torch._foreach_copy_(views, [b["params"][i].grad for i in idx])
+            # weight gradients whose split-K reduction was deferred (_C.conv_wgrad(lazy=True)): all of the bucket's in ONE launch that
+            # writes the sums straight into the bucket; everything else is copied
+            from .. import _C
+            lazy, plain = [], []
+            for k, i in enumerate(idx):
+                g = b["params"][i].grad
+                ent = _C.WGRAD_PENDING.pop(g.data_ptr(), None) if g.is_cuda else None
+                if ent is not None and ent[2] == tuple(g.shape):
+                    lazy.append((ent[0], ent[1], views[k]))
+                else:
+                    plain.append(k)
+            if lazy:
+                if b["flat_g"].is_cuda:
+                    cur = torch.cuda.current_stream(b["flat_g"].device)
+                    for _d, ws, _v in lazy:
+                        ws.record_stream(cur)
+                _C.wgrad_reduce_batch(lazy)
+            if plain:
+                torch._foreach_copy_([views[k] for k in plain], [b["params"][idx[k]].grad for k in plain])
         got = set(idx)
         for i, p in enumerate(b["params"]):
             v = views[idx.index(i)] if i in got else self._view(b, i)
@@ -142,6 +166,10 @@ class GradReducer:
         """Pack / launch the buckets whose parameters did not all get a gradient this step, wait, average."""
         self._launch_ready(force=True)
         self._next = 0
+        if self.buckets and self.buckets[0]["flat_g"].is_cuda:
+            from .. import _C
+            # (an entry left over means autograd handed a COPY of a deferred gradient to its parameter: its values were never computed)
+            assert not _C.WGRAD_PENDING, "weight gradients with a deferred split-K reduction were never packed into a bucket"
         if self.world > 1:
             for h in self._handles:
                 h.wait()

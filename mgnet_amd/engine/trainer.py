@@ -2,6 +2,8 @@
 sum of the loss dict -> backward (bucketed all-reduce overlapped) -> full-model clip -> Adam -> poly LR.
 SOLVER.AMP: bf16 activations by default (no loss scaling needed); SOLVER.AMP.DTYPE "float16" runs the reference's fp16 with
 GradScaler's dynamic loss scaling evaluated on the device (solver/fused_adam.py, csrc/optim.hip: no host synchronisation)."""
+import os
+
 import torch
 
 from ..events import EventStorage
@@ -88,7 +90,12 @@ class Trainer:
         (GradScaler.scale(losses).backward(), detectron2 AMPTrainer.run_step)"""
         losses = sum(loss_dict.values())
         scale = self.optimizer.loss_scale() if hasattr(self.optimizer, "loss_scale") else None
-        (losses if scale is None else losses * scale).backward()
+        # split-K sums of a bucket's convs as one launch (reducer._pack); not under hipGraph capture (the table upload uses events)
+        self.reducer.lazy_wgrad(not os.environ.get("MGN_NO_LAZY_WGRAD") and not getattr(self.model, "_no_side_streams", False))
+        try:
+            (losses if scale is None else losses * scale).backward()
+        finally:
+            self.reducer.lazy_wgrad(False)
 
     def run_step(self, batched_inputs):
         self.model.train()

@@ -308,7 +308,8 @@ class _ConvFn(torch.autograd.Function):
             res = None if dskip is None else dskip.to(xs.dtype).contiguous(memory_format=torch.channels_last)
             dx = _C.conv_igemm(dy, _C.weight_layout(weight, 1, 0, cout_pad, dtype=xs.dtype), xs.shape[2:], None, 1, KH - 1 - pad, up=stride, residual=res)
         if ctx.needs_input_grad[1]:
-            dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad, cin_real=Cin)[:Cout]
+            # (lazy: under a gradient reducer the split-K sums of a whole bucket run as one launch, engine/reducer.py)
+            dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad, cin_real=Cin, lazy=not cout_pad)[:Cout]
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum((0, 2, 3))[:Cout]
         return dx, dw, db, None, None, None, None, None, None

@@ -26,6 +26,21 @@ def main(db, out=None):
             last_end = max(last_end, en)
         lines.append(f"steady-state window: span {span/1e6:.2f} ms, kernel time {busy/1e6:.2f} ms, idle between kernels {gaps/1e6:.2f} ms "
                      f"({100*gaps/span:.1f} %), {len(ks)} launches, mean gap {gaps/len(ks)/1e3:.2f} us")
+    # overlapped execution (side streams): union of the kernel intervals vs their sum over the same steady-state window
+    if len(ks) > 100:
+        ev = sorted(ks)
+        union, cur_s, cur_e = 0, ev[0][0], ev[0][1]
+        for st, en in ev[1:]:
+            if st > cur_e:
+                union += cur_e - cur_s
+                cur_s, cur_e = st, en
+            else:
+                cur_e = max(cur_e, en)
+        union += cur_e - cur_s
+        tot = sum(en - st for st, en in ev)
+        span = max(e for _, e in ev) - ev[0][0]
+        lines.append(f"concurrency: span {span/1e6:.2f} ms, at least one kernel running {union/1e6:.2f} ms ({100*union/span:.1f} %), "
+                     f"sum of kernel times {tot/1e6:.2f} ms (mean concurrency {tot/union:.2f})")
     txt = "\n".join(lines)
     print(txt)
     if out:
