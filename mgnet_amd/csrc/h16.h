@@ -17,6 +17,13 @@ __device__ __forceinline__ float mgn_lo2f(uint32_t w) { return (float)__builtin_
 __device__ __forceinline__ float mgn_hi2f(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
 __device__ __forceinline__ float mgn_h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 __device__ __forceinline__ uint32_t mgn_f2h(float f) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f); }   // v_cvt_f16_f32: RNE, overflow -> inf
+typedef float mgn_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 mgn_f16x2 __attribute__((ext_vector_type(2)));
+#define MGN_HAVE_PACK2 1
+__device__ __forceinline__ uint32_t mgn_pack2(float a, float b) {   // v_cvt_pk_f16_f32 (gfx950): both values in one instruction
+    const mgn_f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mgn_f16x2));
+}
 #else
 #define MGN_SYM(name) name
 typedef __bf16 h16x8 __attribute__((ext_vector_type(8)));

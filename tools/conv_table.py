@@ -27,9 +27,9 @@ def r_ig(x, w, out_shape, bias, stride, pad, up=1, relu=False, out_dtype=torch.b
     calls[("igemm", tuple(x.shape), tuple(w.shape), tuple(out_shape), stride, pad, up, khw, out_dtype)] += 1
     return o_ig(x, w, out_shape, bias, stride, pad, up, relu, out_dtype, khw, residual, stats)
 
-def r_wg(dy, x, kh, kw, stride, pad, cin_real=None):
+def r_wg(dy, x, kh, kw, stride, pad, cin_real=None, lazy=False):
     calls[("wgrad", tuple(dy.shape), tuple(x.shape), kh, kw, stride, pad, cin_real)] += 1
-    return o_wg(dy, x, kh, kw, stride, pad, cin_real)
+    return o_wg(dy, x, kh, kw, stride, pad, cin_real, lazy=lazy)
 
 _C.conv_igemm, _C.conv_wgrad = r_ig, r_wg
 trainer.run_step(batch)
