@@ -39,7 +39,7 @@ def run_hip(c, g=(1.0, 1.0), rows_per_wave=0, want_grad=True, want_minmap=False)
     return out
 
 
-def grad_close(got, ref, name, rtol=2e-3, frac_tol=5e-3, agg_tol=2e-2):
+def grad_close(got, ref, name, rtol=2e-3, frac_tol=5e-4, agg_tol=1e-3):
     scale = np.abs(ref).max() + 1e-30
     if scale < 1e-10:  # degenerate (identity pose, identical frames): round-off noise in the reference too
         assert np.abs(got).max() < 1e-7, (name, np.abs(got).max())
@@ -274,3 +274,36 @@ def test_u8_frames_to_rgbx():
     # (IEEE division like the reference's CPU arithmetic and mgn_u8_frames_to_f32; torch's GPU kernel multiplies by the reciprocal)
     assert torch.equal(out[:, :3].cpu(), torch.stack([f.cpu() for f in frames]).float() / 255.0) and float(out[:, 3].abs().max()) == 0.0
     assert torch.equal(out[:, :3], _C.u8_frames_to_f32(frames, 255.0))
+
+
+def _grad_err(got, ref64):
+    """(fraction of elements off by more than 2e-3 of the largest gradient, aggregate relative L1 error) against the fp64 oracle"""
+    scale = np.abs(ref64).max() + 1e-300
+    err = np.abs(got.astype(np.float64) - ref64)
+    return float((err / scale > 2e-3).mean()), float(err.sum() / (np.abs(ref64).sum() + 1e-300))
+
+
+@pytest.mark.parametrize("name", [n for n in REPROJ_CASES if n != "identity_pose"])
+def test_gradient_error_against_fp64_is_what_fp32_costs(name, capsys):
+    """The allowance of test_gradients_match_reference (2e-3 of the largest gradient on >= 99.5 % of the elements, 2 % aggregate) as
+    EVIDENCE: both the HIP fp32 gradients and the REFERENCE's own fp32 gradients (the fixture) are compared with the fp64 build of the
+    oracle on the same inputs.  The loss is piecewise (floor of the sample position, arg-min over four maps, sign of the L1 term), so
+    two fp32 evaluation orders flip isolated pixels; the HIP kernel must not be further from fp64 than the reference itself is
+    (factor 2 + a floor for fixtures where both are exact to round-off)."""
+    c = golden_case_inputs(name)
+    _, out = load_golden("reproj_" + name)
+    o64 = oracle.reproj_loss(c["inv"], c["img"], c["prev"], c["nxt"], c["mask"], c["K"], c["poses"], g_photo=1.0, g_smooth=0.0, prec="f64")
+    hip = run_hip(c, g=(1.0, 0.0))
+    rows = []
+    for i in range(3):
+        fh, ah = _grad_err(hip["d_inv"][i], o64["d_inv"][i])
+        fr, ar = _grad_err(out[f"dphot_dinv{i}"], o64["d_inv"][i])
+        rows.append((i, fh, ah, fr, ar))
+        assert fh <= 2.0 * fr + 2e-3 and ah <= 2.0 * ar + 2e-3, (name, i, "HIP", fh, ah, "reference fp32", fr, ar)
+    ph, pr = np.abs(hip["d_pose"] - o64["d_poses"]).max(), np.abs(out["dphot_dposes"] - o64["d_poses"]).max()
+    ps = np.abs(o64["d_poses"]).max()
+    assert ph <= 2.0 * pr + 2e-3 * ps, (name, "pose", ph, pr, ps)
+    with capsys.disabled():
+        for i, fh, ah, fr, ar in rows:
+            print(f"\n[reproj grad vs fp64] {name} scale {i}: HIP off-fraction {fh:.2e} aggregate {ah:.2e} | reference fp32 {fr:.2e} {ar:.2e}", end="")
+        print(f"\n[reproj grad vs fp64] {name} pose: HIP {ph / ps:.2e} | reference fp32 {pr / ps:.2e} (of the largest component)", end="")
