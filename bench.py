@@ -203,6 +203,23 @@ def full_step_bench(args, world, rank, dev):
             depth_loss.prof_events = ev.pairs[k]
             trainer.run_step(batch)
         fence()
+    # What the host needs to ISSUE a step, measured where the GPU cannot back-pressure the launch queue: the same model and launch
+    # sequence on two 512x1024 frames (an eighth of the device work, the same host work).  `host_issue_ms_per_step` above is the
+    # wall time of the launch loop at the benchmark size, which mostly waits for queue slots once the GPU is the bottleneck.
+    host_unloaded = None
+    if rank == 0 and world == 1 and mode == "eager":
+        try:
+            small = synthetic_batch(2, 512, 1024, dev, seed=7)
+            for _ in range(2):
+                trainer.run_step(small)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for _ in range(5):
+                trainer.run_step(small)
+            host_unloaded = (time.perf_counter() - th) / 5 * 1e3
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- informative only
+            print(f"[bench] unloaded host-issue measurement skipped ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
     dist_info = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -254,7 +271,8 @@ def full_step_bench(args, world, rank, dev):
                        "parallelism": f"dp{world}", "step_execution": mode + (" (one hipGraph replay per step, one stream)" if mode == "graph" else
                                                   " (launches issued from Python; side streams for the independent branches: " +
                                                   ("on" if getattr(model, "_streams", None) else "off") + ")"),
-                       "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2), "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
+                       "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2),
+                       "host_issue_ms_per_step_unloaded": None if host_unloaded is None else round(host_unloaded, 2), "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
                        "losses": {k: round(float(v.detach()), 5) for k, v in last.items()},
                        "torch_staging_ops": sorted(__import__("mgnet_amd.modeling.ops", fromlist=["x"]).STAGING_USED)},
             "roofline": {"bound": "hbm", "kernel": "reproj_march<true> (fused reprojection loss + photometric gradient)",
