@@ -102,10 +102,11 @@ class GradReducer:
             for st in {s.cuda_stream: s for s in b["gstream"].values()}.values():
                 if st != cur:
                     cur.wait_stream(st)
-            for i in idx:
-                st = b["gstream"].get(id(b["params"][i]))
-                if st is not None and st != cur:
-                    b["params"][i].grad.record_stream(cur)
+            if not torch.cuda.is_current_stream_capturing():
+                for i in idx:
+                    st = b["gstream"].get(id(b["params"][i]))
+                    if st is not None and st != cur:
+                        b["params"][i].grad.record_stream(cur)
         if idx:
             # weight gradients whose split-K reduction was deferred (_C.conv_wgrad(lazy=True)): all of the bucket's in ONE launch that
             # writes the sums straight into the bucket; everything else is copied

@@ -157,7 +157,7 @@ class MGNet(nn.Module):
         their losses): most launches of the step are short and under-fill the chip one at a time, and every dependent launch
         costs ~3 us of dispatch latency -- concurrent branches hide both.  The autograd engine replays each node on the stream
         of its forward and orders the streams itself.  MGNET_STREAMS=0 keeps everything on the current stream."""
-        if not (self.training and self.pixel_mean.is_cuda) or os.environ.get("MGNET_STREAMS", "1") == "0" or getattr(self, "_no_side_streams", False):
+        if not (self.training and self.pixel_mean.is_cuda) or os.environ.get("MGNET_STREAMS", "1") == "0" or (getattr(self, "_no_side_streams", False) and not os.environ.get("MGN_GRAPH_STREAMS")):
             return None
         st = self.__dict__.get("_streams")
         if st is None:
@@ -188,9 +188,10 @@ class MGNet(nn.Module):
             """stream `dst` continues after what `src` has been given so far and will read `objs` (made on `src`)"""
             if side:
                 dst.wait_stream(src)
-                for t in tensors(objs):
-                    if t.is_cuda:
-                        t.record_stream(dst)
+                if not torch.cuda.is_current_stream_capturing():   # (a capture's private pool never recycles memory between its nodes)
+                    for t in tensors(objs):
+                        if t.is_cuda:
+                            t.record_stream(dst)
 
         fused_prep = self.pixel_mean.is_cuda and self.amp_dtype in (torch.bfloat16, torch.float16) and batched_inputs[0]["image"].dtype == torch.uint8
         pose_in = None
