@@ -672,7 +672,7 @@ def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dt
     OH, OW = out_shape
     out_dtype = x.dtype if out_dtype is None else out_dtype   # the activation format (bf16 / fp16), or fp32
     assert w_ohwi.dtype == x.dtype, "weight layout and activations must share the 16-bit format"
-    if stats is not None and khw is None and up == 1 and bias is None and not relu and residual is None and out_dtype == x.dtype:
+    if stats is not None and up == 1 and bias is None and not relu and residual is None and out_dtype == x.dtype:
         # stats = (shift [Cout] fp32 or None, holder list): a layer whose kernel has the statistics epilogue (windowed 3x3, 64-channel
         # row march) also leaves the partial sums of its output's batch statistics behind (the following InPlaceABNSync then skips its
         # statistics pass); other layers ignore the request

@@ -39,6 +39,8 @@ struct ConvParams {
     const uint16_t* residual;  // [N, OH, OW, Cout] bf16 added to the result before rounding, or null
     int N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32;
     int xcd_bands;        // 1: remap blockIdx.x so that every XCD works on one contiguous band of pixel tiles (see xcd_tile)
+    float* stat_part;     // [pixel tiles][Cout][2]: per-tile sums of r, r^2 over the ROUNDED outputs (statistics of the InPlaceABNSync that
+                          // follows; only without bias / ReLU / residual / fp32 output), or null
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8, observed; MI355X_MICROARCH.md) and every XCD has its
@@ -106,6 +108,41 @@ __device__ __forceinline__ void emit4(const ConvParams& p, long m, int co, float
     }
 }
 
+
+// Statistics epilogue of the implicit-GEMM kernels (D = W-rows x pixels: lane & 31 = pixel, registers = channels 8q + 4(lane>>5) + e of
+// the wave's NJ 32-channel tiles).  A lane has summed r and r^2 of its channels over its pixels; 16-lane DPP butterflies (quad_perm
+// [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror) give every lane its row's sum, lanes 0/16/32/48 park it in LDS, and after a block
+// barrier one thread per (channel, moment) adds the WM*2 parts in a fixed order and stores the tile's partial row.
+template <int NJ>
+__device__ __forceinline__ void stats_flush(float (&s1)[NJ][4][4], float (&s2)[NJ][4][4], float* red, int wm, int WM, int ch_wave, int BNch,
+                                            int lane, int tid, float* dst, int nvalid_ch) {
+    auto row_sum = [](float v) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+        return v;
+    };
+    __syncthreads();   // every wave has left the k loop: the tile memory is free
+    const int rw = (lane >> 4) & 1, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = row_sum(s1[j][q][e]), b = row_sum(s2[j][q][e]);
+                if ((lane & 15) == 0)
+                    *reinterpret_cast<float2*>(red + ((wm * 2 + rw) * BNch + ch_wave + j * 32 + 8 * q + 4 * hi + e) * 2) = make_float2(a, b);
+            }
+    __syncthreads();
+    for (int t = tid; t < BNch * 2; t += blockDim.x) {
+        if ((t >> 1) >= nvalid_ch) continue;
+        float v = 0.f;
+        for (int k = 0; k < WM * 2; ++k) v += red[k * BNch * 2 + t];
+        dst[t] = v;
+    }
+}
 
 // XOR swizzle of the 16-byte slot inside a 128-byte LDS row (found by exhaustive search: conflict-free for both the
 // 8-lane ds_write_b128 groups of the transposing loader and the 16-lane ds_read_b128 groups of the fragment reads)
@@ -406,6 +443,13 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
     }
 
     const bool vec_ok = (p.Cout % 4) == 0;
+    float st1[NT][4][4], st2[NT][4][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st1[j][q][e] = st2[j][q][e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const long mc = (long)bm * BM + wm * 64 + i * 32 + (lane & 31);
@@ -418,8 +462,19 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
                 const int co = bn * BN + wn * 32 * NT + j * 32 + 8 * q + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
                 emit4(p, m, co, acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3], vec_ok);
+                if (p.stat_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r = mgn_h2f(f2bf(acc[i][j][q * 4 + e]));
+                        st1[j][q][e] += r;
+                        st2[j][q][e] = fmaf(r, r, st2[j][q][e]);
+                    }
+                }
             }
     }
+    if (p.stat_part)
+        stats_flush<NT>(st1, st2, reinterpret_cast<float*>(&smem[0][0][0]), wm, 2, wn * 32 * NT, BN, lane, tid,
+                        p.stat_part + ((size_t)bm * p.Cout + (size_t)bn * BN) * 2, p.Cout - bn * BN);
 }
 
 
@@ -579,7 +634,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_s_128_2_4(Conv1Params p) { con
 __global__ __launch_bounds__(256, 1) void conv1x1_s_512_1_4(Conv1Params p) { conv1x1_body<512, 1, 4>(p); }
 
 template <int CIN, int NT, int WN, typename K>
-static int launch_conv1x1(K kernel, Conv1Params& q, hipStream_t st) {
+static int launch_conv1x1(K kernel, Conv1Params& q, hipStream_t st, bool plan_only = false) {
     using C = C1<CIN, NT, WN>;
     static bool attr = false;
     if (!attr) {
@@ -593,6 +648,7 @@ static int launch_conv1x1(K kernel, Conv1Params& q, hipStream_t st) {
     // the register-resident weights pay off over several tiles per block; small layers (one tile per CU or less) are
     // faster on the generic kernel (measured 19.7 vs 17.9 us for 512 -> 256 at 32 x 64)
     if (tiles * gy < 512 && !getenv("MGN_CONV_FORCE1X1")) return 1;
+    if (plan_only) return 2;
     const int gx = (int)(tiles < 256 ? tiles : 256);   // persistent: one block per CU
     hipLaunchKernelGGL(kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), C::LDS, st, q);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
@@ -718,6 +774,13 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
     }
 
     const bool vec_ok = (p.Cout % 4) == 0;
+    float st1[2][4][4], st2[2][4][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st1[j][q][e] = st2[j][q][e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long mc = (long)bm * C::BMB + wm * 128 + i * 32 + (lane & 31);
@@ -730,8 +793,19 @@ __device__ __forceinline__ void igemm_big_body(const ConvParams& p) {
                 const int co = bn * C::BN + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
                 emit4(p, m, co, acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3], vec_ok);
+                if (p.stat_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r = mgn_h2f(f2bf(acc[i][j][q * 4 + e]));
+                        st1[j][q][e] += r;
+                        st2[j][q][e] = fmaf(r, r, st2[j][q][e]);
+                    }
+                }
             }
     }
+    if (p.stat_part)
+        stats_flush<2>(st1, st2, reinterpret_cast<float*>(bsm), wm, NWM, wn * 64, C::BN, lane, tid,
+                       p.stat_part + ((size_t)bm * p.Cout + (size_t)bn * C::BN) * 2, p.Cout - bn * C::BN);
 }
 __global__ __launch_bounds__(256, 2) void conv_igemm_big128(ConvParams p) { igemm_big_body<2>(p); }
 __global__ __launch_bounds__(512, 1) void conv_igemm_big256(ConvParams p) { igemm_big_body<4>(p); }
@@ -1861,8 +1935,11 @@ static bool c64_eligible(int N, int IH, int IW, int Cin, int OH, int OW, int Cou
 
 static int conv_igemm_impl(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
                            int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, const void* residual,
-                           float* stat_part, const float* stat_shift, void* stream) {
-    if (!in || !w || !out || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || up < 1)
+                           float* stat_part, const float* stat_shift, int* plan_rows, void* stream) {
+    // plan_rows != null: nothing is launched; *plan_rows = number of statistics rows the kernel chosen for this layer would write
+    // (0 = that kernel has no statistics epilogue).  One decision path for launching and planning.
+    if (plan_rows) *plan_rows = 0;
+    if ((!plan_rows && (!in || !w || !out)) || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || up < 1)
         return MGN_EINVAL;
     const bool pack = (Cin == 8 || Cin == 16);            // small-Cin stems: taps packed into the k-slab
     if (!pack && (Cin < 32 || Cin % 32 != 0)) return MGN_ENOTSUP;  // k-slab = 32 or 64 input channels of one tap
@@ -1871,7 +1948,8 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
     p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = out; p.bias = bias; p.residual = (const uint16_t*)residual;
     if (residual && out_f32) return MGN_ENOTSUP;
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
-    p.stride = stride; p.pad = pad; p.up = up; p.relu = relu; p.out_f32 = out_f32; p.xcd_bands = 0;
+    p.stride = stride; p.pad = pad; p.up = up; p.relu = relu; p.out_f32 = out_f32; p.xcd_bands = 0; p.stat_part = stat_part;
+    const bool stats_ok = !bias && !relu && !out_f32 && !residual && up == 1;   // what a statistics epilogue may be asked for
     // block -> XCD is (linear block id) % 8: the x-only remap is a per-XCD banding when the x extent is a multiple of 8 or the
     // grid is one-dimensional
     const bool no_xcd = getenv("MGN_CONV_NOXCD") != nullptr;
@@ -1883,36 +1961,45 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
     hipStream_t st = (hipStream_t)stream;
     if (!pack && KH == 1 && KW == 1 && pad == 0 && up == 1 && !bias && !relu && !out_f32 && !residual && (stride == 1 || stride == 2) &&
         OH == (IH - 1) / stride + 1 && OW == (IW - 1) / stride + 1 && (size_t)N * IH * IW * Cin * 2 < 0x7fffffffu && M < 0x7fffffffL &&
-        !getenv("MGN_CONV_NO1X1")) {
+        !getenv("MGN_CONV_NO1X1") && !stat_part) {
         Conv1Params q;
         q.in = p.in; q.w = p.w; q.out = (uint16_t*)out; q.N = N; q.IH = IH; q.IW = IW; q.OH = OH; q.OW = OW; q.Cout = Cout;
         q.stride = stride; q.M = M; q.ntiles = 0;
         int rc1 = 1;   // 1 = not taken (shape without an instantiation, or too small): fall through to the generic kernels
-        if (Cin == 256 && Cout % 256 == 0) rc1 = launch_conv1x1<256, 2, 4>(conv1x1_s_256_2_4, q, st);
-        else if (Cin == 256 && Cout == 32) rc1 = launch_conv1x1<256, 1, 1>(conv1x1_s_256_1_1, q, st);
-        else if (Cin == 32 && Cout % 256 == 0) rc1 = launch_conv1x1<32, 2, 4>(conv1x1_s_32_2_4, q, st);
-        else if (Cin == 64 && Cout % 128 == 0) rc1 = launch_conv1x1<64, 1, 4>(conv1x1_s_64_1_4, q, st);
-        else if (Cin == 128 && Cout % 256 == 0) rc1 = launch_conv1x1<128, 2, 4>(conv1x1_s_128_2_4, q, st);
-        else if (Cin == 512 && Cout % 128 == 0) rc1 = launch_conv1x1<512, 1, 4>(conv1x1_s_512_1_4, q, st);
+        const bool pl = plan_rows != nullptr;   // (planning: 2 = would be taken -- the streaming kernel has no statistics epilogue)
+        if (Cin == 256 && Cout % 256 == 0) rc1 = launch_conv1x1<256, 2, 4>(conv1x1_s_256_2_4, q, st, pl);
+        else if (Cin == 256 && Cout == 32) rc1 = launch_conv1x1<256, 1, 1>(conv1x1_s_256_1_1, q, st, pl);
+        else if (Cin == 32 && Cout % 256 == 0) rc1 = launch_conv1x1<32, 2, 4>(conv1x1_s_32_2_4, q, st, pl);
+        else if (Cin == 64 && Cout % 128 == 0) rc1 = launch_conv1x1<64, 1, 4>(conv1x1_s_64_1_4, q, st, pl);
+        else if (Cin == 128 && Cout % 256 == 0) rc1 = launch_conv1x1<128, 2, 4>(conv1x1_s_128_2_4, q, st, pl);
+        else if (Cin == 512 && Cout % 128 == 0) rc1 = launch_conv1x1<512, 1, 4>(conv1x1_s_512_1_4, q, st, pl);
+        if (rc1 == 2) return MGN_OK;
         if (rc1 <= 0) return rc1;
     }
     if (!pack && KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 1 && IH == OH && IW == OW && !bias && !relu && !out_f32) {
         // windowed kernel (csrc/conv_win.hip): the input window of a 2-D pixel patch stays in LDS for all nine taps
         const int pr = mgn_conv_win_patch_rows(N, OH, OW, Cin, Cout);
+        if (pr > 0 && plan_rows) {
+            *plan_rows = stats_ok ? N * ((OH + pr - 1) / pr) * ((OW + 31) / 32) : 0;
+            return MGN_OK;
+        }
         if (pr > 0) {
             const int rcw = MGN_SYM(mgn_conv3x3_win)(in, w, out, N, OH, OW, Cin, Cout, residual, pr, stat_part, stat_shift, stream);
             if (rcw != MGN_ENOTSUP || stat_part) return rcw;
         }
     }
     const bool c64 = !pack && !bias && !relu && !out_f32 && c64_eligible(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up);
-    if (stat_part && !c64) return MGN_ENOTSUP;   // (mgn_conv_stat_rows says which layers leave statistics behind)
+    if (stat_part && !stats_ok) return MGN_ENOTSUP;   // (mgn_conv_stat_rows says which layers leave statistics behind)
     if (pack && !getenv("MGN_CONV_NOPACKDMA") && stride >= 1 && up == 1 && (size_t)N * IH * IW * Cin * 2 < 0x7fffffffu) {
         // the stems on the LDS-DMA kernel (per-lane tap gather); grid like the generic LDS-DMA launch
         p.xcd_bands = xcd_ok(gx, (long)(Cout <= 64 ? (Cout + 63) / 64 : (Cout + 127) / 128));
+        if (plan_rows) { *plan_rows = stats_ok ? (int)gx : 0; return MGN_OK; }
         if (Cout <= 64) hipLaunchKernelGGL((conv_igemm_glds<1, true>), dim3((unsigned)gx, (Cout + 63) / 64, 1), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm_glds<2, true>), dim3((unsigned)gx, (Cout + 127) / 128, 1), dim3(256), 0, st, p);
         return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
     }
+    if (stat_part && (pack || (!c64 && getenv("MGN_CONV_NOGLDS")))) return MGN_ENOTSUP;   // (the register-staged kernels have no epilogue)
+    if (plan_rows && (pack || (!c64 && getenv("MGN_CONV_NOGLDS")))) return MGN_OK;
     if (pack) {
         if (Cout <= 64) hipLaunchKernelGGL((conv_igemm<1, 2, true>), dim3((unsigned)gx, (Cout + 63) / 64), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm<2, 2, true>), dim3((unsigned)gx, (Cout + 127) / 128), dim3(256), 0, st, p);
@@ -1920,6 +2007,7 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
         Conv64Params q;
         q.in = p.in; q.w = p.w; q.out = (uint16_t*)out; q.residual = p.residual; q.stat_part = stat_part;
         c64_plan(N, OH, OW, Cout, &q);
+        if (plan_rows) { *plan_rows = stats_ok ? q.nslices : 0; return MGN_OK; }
         static bool cattr = false;
         if (!cattr) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
@@ -1953,6 +2041,7 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
                 // (BN = 128 measured slower than the 128 x 128 kernel on the 128-channel layers: only on request)
             }
             if (pick == 256) {
+                if (plan_rows) { *plan_rows = stats_ok ? (int)gxb : 0; return MGN_OK; }
                 p.xcd_bands = xcd_ok(gxb, (long)(Cout / 256) * gz);
                 hipLaunchKernelGGL(conv_igemm_big256, dim3((unsigned)gxb, Cout / 256, gz), dim3(512), IgemmBig<4>::LDS, st, p);
                 return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
@@ -1960,6 +2049,7 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
             // 512 x 128 tile: measured slower than the 128 x 128 kernel on the 128-channel layers (130 vs 122 us) -- the small-N
             // layers are bound by the 9x re-gathered A operand, not by the weight tile; only on request
             if (pick == 0 && Cout == 128 && fbig == 512) {
+                if (plan_rows) { *plan_rows = stats_ok ? (int)((Mc + 511) / 512) : 0; return MGN_OK; }
                 static bool a512 = false;
                 constexpr int L512 = IgemmBig<2, 4>::LDS;
                 if (!a512) {
@@ -1970,12 +2060,14 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
                 return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
             }
             if (pick == 128) {
+                if (plan_rows) { *plan_rows = stats_ok ? (int)gxb : 0; return MGN_OK; }
                 p.xcd_bands = xcd_ok(gxb, (long)(Cout / 128) * gz);
                 hipLaunchKernelGGL(conv_igemm_big128, dim3((unsigned)gxb, Cout / 128, gz), dim3(256), IgemmBig<2>::LDS, st, p);
                 return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
             }
         }
         p.xcd_bands = xcd_ok(gxc, (long)(Cout <= 64 ? (Cout + 63) / 64 : (Cout + 127) / 128) * gz);
+        if (plan_rows) { *plan_rows = stats_ok ? (int)gxc : 0; return MGN_OK; }
         if (Cout <= 64) hipLaunchKernelGGL((conv_igemm_glds<1>), dim3((unsigned)gxc, (Cout + 63) / 64, gz), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm_glds<2>), dim3((unsigned)gxc, (Cout + 127) / 128, gz), dim3(256), 0, st, p);
     } else if (Cout <= 64) {
@@ -1992,32 +2084,28 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
 
 int MGN_SYM(mgn_conv_igemm)(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
                    int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, const void* residual, void* stream) {
-    return conv_igemm_impl(in, w, out, bias, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32, residual, nullptr, nullptr, stream);
+    return conv_igemm_impl(in, w, out, bias, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32, residual, nullptr, nullptr, nullptr, stream);
 }
 
 int MGN_SYM(mgn_conv_igemm_stats)(const void* in, const void* w, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
                                   int KW, int stride, int pad, float* stat_partials, const float* stat_shift, void* stream) {
     if (!stat_partials) return MGN_EINVAL;
-    return conv_igemm_impl(in, w, out, nullptr, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, 1, 0, 0, nullptr, stat_partials, stat_shift, stream);
+    return conv_igemm_impl(in, w, out, nullptr, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, 1, 0, 0, nullptr, stat_partials, stat_shift, nullptr, stream);
 }
 
 #ifndef MGN_F16
 int mgn_conv_stat_rows(int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int* shifted) {
     if (shifted) *shifted = 0;
     if (N < 1 || OH < 1 || OW < 1 || Cout < 1) return 0;
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && IH == OH && IW == OW) {
-        const int pr = mgn_conv_win_patch_rows(N, OH, OW, Cin, Cout);
-        if (pr > 0) {
-            if (shifted) *shifted = 1;
-            return N * ((OH + pr - 1) / pr) * ((OW + 31) / 32);
-        }
-    }
-    if (c64_eligible(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, 1)) {
-        Conv64Params q;
-        c64_plan(N, OH, OW, Cout, &q);
-        return q.nslices;
-    }
-    return 0;
+    // the sums are taken around stat_shift only by the windowed kernel
+    if (shifted && KH == 3 && KW == 3 && stride == 1 && pad == 1 && IH == OH && IW == OW && mgn_conv_win_patch_rows(N, OH, OW, Cin, Cout) > 0)
+        *shifted = 1;
+    int rows = 0;
+    // (the same decision path as the launch: conv_igemm_impl in planning mode; the 16-bit format does not enter the decision)
+    if (conv_igemm_impl(nullptr, nullptr, nullptr, nullptr, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, 1, 0, 0, nullptr, nullptr, nullptr,
+                        &rows, nullptr) != MGN_OK)
+        return 0;
+    return rows;
 }
 #endif
 

@@ -484,28 +484,28 @@ unsigned* next_counter() {
 // statistics.  Replaces the statistics pass over the tensor (one read of the whole activation) by a read of rows*C*8 bytes.
 // ------------------------------------------------------------------------------------------------------
 #ifndef MGN_F16
-__global__ __launch_bounds__(256) void iabn_from_partials_kernel(const float* __restrict__ part, int rows, int C, long M, const float* __restrict__ shift, StatsOut o) {
-    // a block per 4 channels (C / 4 blocks: 16 .. 128 of them): 8 floats = 32 bytes per partial row, 32 row groups
-    __shared__ double sh[32][8];
-    const int c0 = blockIdx.x * 4;
+__global__ __launch_bounds__(1024) void iabn_from_partials_kernel(const float* __restrict__ part, int rows, int C, long M, const float* __restrict__ shift, StatsOut o) {
+    // a block per 4 channels (C / 4 blocks: 16 .. 128 of them): 8 floats = 32 bytes per partial row, blockDim / 8 row groups
+    // (256 threads; 1024 for the layers with tens of thousands of pixel tiles: the stems)
+    __shared__ double sh[128][8];
+    const int c0 = blockIdx.x * 4, nrg = blockDim.x >> 3;
     const int col = threadIdx.x & 7, rg = threadIdx.x >> 3;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const float* src = part + (size_t)c0 * 2 + col;
     int r = rg;
-    for (; r + 96 < rows; r += 128) {
+    for (; r + 3 * nrg < rows; r += 4 * nrg) {
         a0 += (double)src[(size_t)r * C * 2];
-        a1 += (double)src[(size_t)(r + 32) * C * 2];
-        a2 += (double)src[(size_t)(r + 64) * C * 2];
-        a3 += (double)src[(size_t)(r + 96) * C * 2];
+        a1 += (double)src[(size_t)(r + nrg) * C * 2];
+        a2 += (double)src[(size_t)(r + 2 * nrg) * C * 2];
+        a3 += (double)src[(size_t)(r + 3 * nrg) * C * 2];
     }
-    for (; r < rows; r += 32) a0 += (double)src[(size_t)r * C * 2];
+    for (; r < rows; r += nrg) a0 += (double)src[(size_t)r * C * 2];
     sh[rg][col] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (threadIdx.x < 4) {
         const int c = c0 + threadIdx.x;
         double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
+        for (int k = 0; k < nrg; ++k) {
             t1 += sh[k][2 * threadIdx.x];
             t2 += sh[k][2 * threadIdx.x + 1];
         }
@@ -586,7 +586,7 @@ int mgn_iabn_coeffs_from_partials(const float* partials, int rows, int C, long M
     if (!partials || rows < 1 || C < 4 || C % 4 != 0 || M < 1 || (!coef && !stats)) return MGN_EINVAL;
     if (coef && (!weight || !bias)) return MGN_EINVAL;
     StatsOut o = {stats, coef, weight, bias, running_mean, running_var, eps, momentum};
-    hipLaunchKernelGGL(iabn_from_partials_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream_, partials, rows, C, M, shift, o);
+    hipLaunchKernelGGL(iabn_from_partials_kernel, dim3(C / 4), dim3(rows > 4096 ? 1024 : 256), 0, (hipStream_t)stream_, partials, rows, C, M, shift, o);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 #endif

@@ -336,3 +336,33 @@ def test_row_march_c64_fused_statistics(case):
     mean, m2 = yd.mean(1), ((yd - yd.mean(1, keepdim=True)) ** 2).sum(1)
     assert float((st[1] - mean).abs().max()) < 2e-6 * float(yd.abs().max())
     assert float(((st[2] - m2) / m2).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("case", [(2, 64, 128, 33, 47, 3, 2, 1), (1, 128, 256, 24, 40, 3, 2, 1), (2, 96, 64, 17, 23, 1, 1, 0), (2, 256, 512, 16, 24, 3, 2, 1),
+                                  (2, 8, 64, 40, 56, 7, 2, 3), (1, 16, 64, 34, 46, 7, 2, 3)])
+def test_implicit_gemm_fused_statistics(case, monkeypatch):
+    """Statistics epilogue of the generic implicit-GEMM kernels (conv_igemm_glds incl. the packed-tap stems, conv_igemm_big*):
+    strided 3x3, small 1x1 and 7x7 stem layers against the fp64 statistics of the kernel's own rounded output."""
+    from mgnet_amd import _C
+
+    N, Cin, Cout, H, W, k, s, p = case
+    if Cout % 256 == 0:
+        monkeypatch.setenv("MGN_CONV_BIG", "256")
+    torch.manual_seed(sum(case))
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = (torch.randn(N, Cin, H, W, device="cuda") + 0.2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(Cout, min(Cin, 9) if Cin in (8, 16) else Cin, k, k, device="cuda") / (Cin * k * k) ** 0.5)
+    packed = Cin in (8, 16)
+    wl = _C.weight_layout(w, 2, Cin) if packed else _C.weight_layout(w, 0)
+    holder = []
+    kw = dict(khw=(k, k)) if packed else {}
+    y = _C.conv_igemm(x, wl, (OH, OW), None, s, p, stats=(None, holder), **kw)
+    assert len(holder) == 1, "no statistics epilogue for this layer"
+    part, shift = holder[0]
+    assert shift is None and torch.equal(y, _C.conv_igemm(x, wl, (OH, OW), None, s, p, **kw))
+    M = N * OH * OW
+    st = _C.iabn_from_partials(part, Cout, M, None, stats_only=True).double().cpu()
+    yd = y.double().permute(1, 0, 2, 3).reshape(Cout, -1).cpu()
+    mean, m2 = yd.mean(1), ((yd - yd.mean(1, keepdim=True)) ** 2).sum(1)
+    assert float((st[1] - mean).abs().max()) < 2e-6 * float(yd.abs().max())
+    assert float(((st[2] - m2) / m2).abs().max()) < 2e-5
