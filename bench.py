@@ -207,7 +207,7 @@ def full_step_bench(args, world, rank, dev):
     # sequence on two 512x1024 frames (an eighth of the device work, the same host work).  `host_issue_ms_per_step` above is the
     # wall time of the launch loop at the benchmark size, which mostly waits for queue slots once the GPU is the bottleneck.
     host_unloaded = None
-    if rank == 0 and world == 1 and mode == "eager":
+    if rank == 0 and world == 1 and mode == "eager" and not args.no_host_probe:
         try:
             small = synthetic_batch(2, 512, 1024, dev, seed=7)
             for _ in range(2):
@@ -318,6 +318,7 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-probe", action="store_true", help="skip the small-batch steps that time the unloaded launch loop (profiling runs)")
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
                     help="16-bit activation format of the trunk: bf16 (default) or the reference's AMP format fp16 with dynamic loss "
                          "scaling (BASELINE C5)")

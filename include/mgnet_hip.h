@@ -119,6 +119,9 @@ int mgn_iabn_stats(const void* x, int dtype, long M, int C, float* stats /*[3][C
  * may be NULL) from the per-tile partial sums a convolution left behind (mgn_conv3x3_win: partials[rows][C][2] of (r - shift),
  * (r - shift)^2 over its rounded outputs; shift as given to the convolution): the statistics pass over the activation becomes a
  * read of rows*C*8 bytes.  M = N*H*W of the activation; C % 4 == 0. */
+/* optional first stage for very many partial rows (the stems' 32768 pixel tiles): out [rows_out][C][2] = the rows k, k + rows_out, ...
+ * added in fp64; mgn_iabn_coeffs_from_partials then runs on `out` (rows_out <= 1024). */
+int mgn_iabn_partials_reduce(const float* partials, int rows, int C, int rows_out, float* out, void* stream);
 int mgn_iabn_coeffs_from_partials(const float* partials, int rows, int C, long M, const float* shift, const float* weight,
                                   const float* bias, float eps, float momentum, float* running_mean, float* running_var,
                                   float* coef /*[4][C] or NULL*/, float* stats /*[3][C] or NULL*/, void* stream);

@@ -15,7 +15,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv_win_patch_rows", "mgn_iabn_coeffs_from_partials", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv_win_patch_rows", "mgn_iabn_coeffs_from_partials", "mgn_iabn_partials_reduce", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -107,6 +107,7 @@ def lib():
         L.mgn_conv_stat_rows.argtypes = [ci] * 11 + [ctypes.POINTER(ci)]
         L.mgn_conv_igemm_stats.argtypes = [vp, vp, vp] + [ci] * 11 + [vp, vp, vp]
         L.mgn_iabn_coeffs_from_partials.argtypes = [vp, ci, ci, cl, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]
+        L.mgn_iabn_partials_reduce.argtypes = [vp, ci, ci, ci, vp, vp]
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
         L.mgn_conv_wgrad_partial.argtypes = [vp, vp] + [ci] * 12 + [vp, sz, ctypes.POINTER(ctypes.c_longlong), vp]
@@ -652,6 +653,10 @@ def iabn_from_partials(partials, C, M, shift, w32=None, b32=None, eps=1e-5, mome
     """Statistics of an activation from the partial sums its producing convolution left behind (mgn_iabn_coeffs_from_partials):
     the coefficient block [4, C] (+ running statistics) like iabn_train_coeffs, or stats [3, C] like iabn_stats."""
     rows = partials.shape[0]
+    if rows > 8192:   # the stems: two stages (64 blocks per channel group instead of one)
+        stage = torch.empty((64, C, 2), dtype=torch.float32, device=partials.device)
+        check(lib().mgn_iabn_partials_reduce(partials.data_ptr(), rows, C, 64, stage.data_ptr(), _stream()), "mgn_iabn_partials_reduce")
+        partials, rows = stage, 64
     out = torch.empty((3 if stats_only else 4, C), dtype=torch.float32, device=partials.device)
     p = lambda t: None if t is None else t.data_ptr()
     check(lib().mgn_iabn_coeffs_from_partials(partials.data_ptr(), rows, C, M, p(shift), p(w32), p(b32), eps, momentum,

@@ -484,6 +484,30 @@ unsigned* next_counter() {
 // statistics.  Replaces the statistics pass over the tensor (one read of the whole activation) by a read of rows*C*8 bytes.
 // ------------------------------------------------------------------------------------------------------
 #ifndef MGN_F16
+// first stage for layers with tens of thousands of partial rows (the stems: 32768 pixel tiles): block (x, y) adds the rows y, y + Y, ...
+// of 4 channels (fp64) and writes ONE row of a [Y][C][2] table, which iabn_from_partials_kernel then finishes
+__global__ __launch_bounds__(256) void iabn_partials_reduce_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out) {
+    __shared__ double sh[32][8];
+    const int c0 = blockIdx.x * 4, col = threadIdx.x & 7, rg = threadIdx.x >> 3;
+    const float* src = part + (size_t)c0 * 2 + col;
+    double a0 = 0.0, a1 = 0.0;
+    const int step = 32 * gridDim.y;
+    int r = blockIdx.y + rg * gridDim.y;
+    for (; r + step < rows; r += 2 * step) {
+        a0 += (double)src[(size_t)r * C * 2];
+        a1 += (double)src[(size_t)(r + step) * C * 2];
+    }
+    if (r < rows) a0 += (double)src[(size_t)r * C * 2];
+    sh[rg][col] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += sh[k][threadIdx.x];
+        out[((size_t)blockIdx.y * C + c0) * 2 + threadIdx.x] = (float)t;
+    }
+}
+
 __global__ __launch_bounds__(1024) void iabn_from_partials_kernel(const float* __restrict__ part, int rows, int C, long M, const float* __restrict__ shift, StatsOut o) {
     // a block per 4 channels (C / 4 blocks: 16 .. 128 of them): 8 floats = 32 bytes per partial row, blockDim / 8 row groups
     // (256 threads; 1024 for the layers with tens of thousands of pixel tiles: the stems)
@@ -580,13 +604,19 @@ int MGN_SYM(mgn_iabn_train_coeffs)(const void* x, int dtype, long M, int C, cons
 }
 
 #ifndef MGN_F16
+int mgn_iabn_partials_reduce(const float* partials, int rows, int C, int rows_out, float* out, void* stream_) {
+    if (!partials || !out || rows < 1 || rows_out < 1 || rows_out > 1024 || C < 4 || C % 4 != 0) return MGN_EINVAL;
+    hipLaunchKernelGGL(iabn_partials_reduce_kernel, dim3(C / 4, rows_out), dim3(256), 0, (hipStream_t)stream_, partials, rows, C, out);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
 int mgn_iabn_coeffs_from_partials(const float* partials, int rows, int C, long M, const float* shift, const float* weight, const float* bias,
                                   float eps, float momentum, float* running_mean, float* running_var, float* coef, float* stats,
                                   void* stream_) {
     if (!partials || rows < 1 || C < 4 || C % 4 != 0 || M < 1 || (!coef && !stats)) return MGN_EINVAL;
     if (coef && (!weight || !bias)) return MGN_EINVAL;
     StatsOut o = {stats, coef, weight, bias, running_mean, running_var, eps, momentum};
-    hipLaunchKernelGGL(iabn_from_partials_kernel, dim3(C / 4), dim3(rows > 4096 ? 1024 : 256), 0, (hipStream_t)stream_, partials, rows, C, M, shift, o);
+    hipLaunchKernelGGL(iabn_from_partials_kernel, dim3(C / 4), dim3(rows > 2048 ? 1024 : 256), 0, (hipStream_t)stream_, partials, rows, C, M, shift, o);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 #endif

@@ -272,7 +272,7 @@ class _ConvFn(torch.autograd.Function):
         b = None if bias is None else bias.detach().float().contiguous()
         packed = Cin in (8, 16)
         if packed:  # stem on a channel-padded input: k = tap*Cin + c, row padded to a multiple of 32
-            out = _C.conv_igemm(xs, _C.weight_layout(weight, 2, Cin, dtype=xs.dtype), (OH, OW), b, stride, pad, 1, relu, khw=(KH, KW))
+            out = _C.conv_igemm(xs, _C.weight_layout(weight, 2, Cin, dtype=xs.dtype), (OH, OW), b, stride, pad, 1, relu, khw=(KH, KW), stats=stats)
         else:
             if cout_pad and b is not None:
                 b = torch.cat([b, b.new_zeros(cout_pad - Cout)])

