@@ -237,6 +237,16 @@ int mgn_conv3x3_win(const void* in, const void* w, void* out, int N, int H, int 
 int mgn_conv_stat_rows(int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int* shifted);
 int mgn_conv_igemm_stats(const void* in, const void* w, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
                          int KW, int stride, int pad, float* stat_partials, const float* stat_shift, void* stream);
+/* The 7x7 / stride 2 / pad 3 stems with 64 output channels (res_net.py:96-104 BasicStem conv1; the 9-channel pose-net stem,
+ * res_net.py:169-181) on the channel-padded input of mgn_prep_input (Cin = 8 | 16) and the layout-mode-2 weights of
+ * mgn_weight_layout: persistent windowed kernel with the weights in registers (csrc/conv_stem.hip); mgn_conv_igemm dispatches
+ * here.  stat_partials: NULL or [mgn_conv_stem7_blocks(...)][64][2] sums of r, r^2 over the rounded outputs.  MGN_ENOTSUP for
+ * other shapes (mgn_conv_stem7_blocks == 0). */
+int mgn_conv_stem7(const void* in, const void* w_packed, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout,
+                   float* stat_partials, void* stream);
+int mgn_conv_stem7_f16(const void* in, const void* w_packed, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout,
+                       float* stat_partials, void* stream);
+int mgn_conv_stem7_blocks(int N, int IH, int IW, int Cin, int OH, int OW, int Cout);
 /* patch height mgn_conv_igemm picks for a 3x3 / stride 1 / pad 1 layer of this shape: 16, 8, or 0 (= it uses another kernel) */
 int mgn_conv_win_patch_rows(int N, int OH, int OW, int Cin, int Cout);
 /* fp32 OIHW master weights -> bf16 kernel layout. mode 0: [Cout][KH][KW][Cin]; 1: [Cin][KH][KW][Cout] with flipped taps

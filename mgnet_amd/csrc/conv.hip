@@ -1990,6 +1990,14 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
     }
     const bool c64 = !pack && !bias && !relu && !out_f32 && c64_eligible(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up);
     if (stat_part && !stats_ok) return MGN_ENOTSUP;   // (mgn_conv_stat_rows says which layers leave statistics behind)
+    if (pack && KH == 7 && KW == 7 && stride == 2 && pad == 3 && stats_ok) {
+        // the 64-channel stems: persistent windowed kernel with the weights in registers (csrc/conv_stem.hip), one statistics row per block
+        const int sb = mgn_conv_stem7_blocks(N, IH, IW, Cin, OH, OW, Cout);
+        if (sb > 0) {
+            if (plan_rows) { *plan_rows = sb; return MGN_OK; }
+            return MGN_SYM(mgn_conv_stem7)(in, w, out, N, IH, IW, Cin, OH, OW, Cout, stat_part, stream);
+        }
+    }
     if (pack && !getenv("MGN_CONV_NOPACKDMA") && stride >= 1 && up == 1 && (size_t)N * IH * IW * Cin * 2 < 0x7fffffffu) {
         // the stems on the LDS-DMA kernel (per-lane tap gather); grid like the generic LDS-DMA launch
         p.xcd_bands = xcd_ok(gx, (long)(Cout <= 64 ? (Cout + 63) / 64 : (Cout + 127) / 128));

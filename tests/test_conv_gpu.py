@@ -108,6 +108,46 @@ def test_stem_7x7_packed_taps(cfg):
     assert rel(w.grad, w_r.grad) < 2e-3, rel(w.grad, w_r.grad)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(2, 3, 8, 40, 56), (1, 9, 16, 34, 46), (3, 3, 8, 17, 130), (1, 3, 8, 7, 9), (9, 9, 16, 50, 200),
+                                 (3, 3, 8, 256, 512), (8, 9, 16, 512, 320), (2, 3, 8, 1024, 2048)])
+def test_stem_persistent_window_kernel(cfg, dtype, monkeypatch):
+    """csrc/conv_stem.hip (64-channel 7x7/s2 stems, weights in registers, blocks walking over patches): ragged shapes, several
+    patches per block (the double-buffered window + counted waits), both formats; against fp64 and, bit for bit (same k order,
+    fp32 accumulation), against the packed-tap implicit GEMM it replaces; its statistics rows against the fp64 statistics."""
+    from mgnet_amd import _C
+
+    N, Cr, Cp, H, W = cfg
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    torch.manual_seed(H + W)
+    x = torch.zeros(N, Cp, H, W, device="cuda")
+    x[:, :Cr] = torch.randn(N, Cr, H, W, device="cuda") + 0.3
+    x = x.to(dtype).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(64, Cr, 7, 7, device="cuda") / (Cr * 49) ** 0.5)
+    wl = _C.weight_layout(w, 2, Cp, dtype=dtype)
+    rows = _C.lib().mgn_conv_stem7_blocks(N, H, W, Cp, OH, OW, 64)
+    assert rows > 0 and rows == _C.lib().mgn_conv_stat_rows(N, H, W, Cp, OH, OW, 64, 7, 7, 2, 3, None)
+    holder = []
+    y = _C.conv_igemm(x, wl, (OH, OW), None, 2, 3, khw=(7, 7), stats=(None, holder))
+    part = holder[0][0]
+    assert part.shape == (rows, 64, 2)
+    assert torch.equal(y, _C.conv_igemm(x, wl, (OH, OW), None, 2, 3, khw=(7, 7)))
+    monkeypatch.setenv("MGN_CONV_NOSTEM7", "1")
+    assert _C.lib().mgn_conv_stem7_blocks(N, H, W, Cp, OH, OW, 64) == 0
+    y_old = _C.conv_igemm(x, wl, (OH, OW), None, 2, 3, khw=(7, 7))
+    monkeypatch.delenv("MGN_CONV_NOSTEM7")
+    assert torch.equal(y, y_old)
+    if N * H * W <= 2 ** 21:
+        ref = F.conv2d(x[:, :Cr].double(), w.detach().to(dtype).double(), stride=2, padding=3)
+        assert float((y.double() - ref).abs().max() / ref.abs().max()) < 6e-3
+    st = _C.iabn_from_partials(part, 64, N * OH * OW, None, stats_only=True).double()
+    yd = y.permute(1, 0, 2, 3).reshape(64, -1).double()
+    mean = yd.mean(1)
+    m2 = ((yd - mean[:, None]) ** 2).sum(1)
+    assert float((st[1] - mean).abs().max()) < 2e-6 * float(yd.abs().max())
+    assert float(((st[2] - m2) / m2).abs().max()) < 2e-5
+
+
 def test_prep_input_matches_reference_normalisation():
     """mg_net.py:250-264: x/255, (x-mean)/std, cat(image, prev, next) -- against torch ops."""
     from mgnet_amd import _C
