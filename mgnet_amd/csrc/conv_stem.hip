@@ -17,8 +17,9 @@
 //
 //   window : [21 rows][CP/8 channel halves][2 column parities][36] x 16 B.  Column parity planes make the stride-2 gather of a
 //            fragment read (32 lanes = 32 output columns, input column 2*ox + kw) 512 contiguous bytes -> conflict-free ds_read_b128
-//   CP = 8 : wave = 2 output rows x 64 channels; k-slab of 16 = two taps (lane halves), 25 slabs; 1 fragment read per 2 MFMAs
-//   CP = 16: wave = 4 output rows x 32 channels (2 x 2 waves); k-slab = one tap, 49 slabs; 1 fragment read per MFMA
+//   CP = 8 : wave = 2 output rows x 64 channels; k-slab of 16 = two taps (lane halves), 25 slabs; 32 fragment reads per 100 MFMAs
+//   CP = 16: wave = 4 output rows x 32 channels (2 x 2 waves); k-slab = one tap, 49 slabs; 91 fragment reads per 196 MFMAs
+//            (a fragment of a window row serves every (output row, kernel row) pair that meets on it)
 //   stores : 16-byte buffer stores (out-of-range pixels dropped by the bounds check: the instruction count per patch is
 //            constant, so `s_waitcnt vmcnt(8)` at the top of the next patch waits for the window DMA but not for the stores)
 //   stats  : per-lane running sums over ALL patches of the block, one partial row per block at the end
@@ -153,50 +154,52 @@ __device__ __forceinline__ void stem_body(const StemParams& p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][cb][e] = 0.f;
         const unsigned char* win = sm + buf * G::WBUF + lbase;
-        auto frag = [&](int s, int i) {
-            int off;
-            if (CP == 8) {   // slab = taps 2s, 2s+1 (lane halves); tap 49 of the last slab has zero weights: read tap 48 again
-                const int t0 = 2 * s, t1 = 2 * s + 1 < 49 ? 2 * s + 1 : 48;
-                off = hi ? tap_off<CP>(t1) : tap_off<CP>(t0);
-            } else {
-                off = tap_off<CP>(s);
-            }
-            return *reinterpret_cast<const h16x8*>(win + off + i * (2 * G::ROWP * 16));
-        };
         if (CP == 8) {
-            h16x8 a[2][RW];
+            // slab = two taps (lane halves).  Output row i at slab s reads what output row 0 reads at slab s + 7 (two window rows =
+            // 14 taps further down): ONE fragment stream F(t), t = s + 7 i, serves all rows -- 25 + 7 (RW - 1) reads for 25 RW CB
+            // MFMAs.  The odd tap of the last slab (tap 49) has zero weights: any finite window element will do.
+            constexpr int T = S + 7 * (RW - 1), PF = 2;   // PF: fragments in flight ahead of the matrix cores
+            constexpr int RMAX = 6 + 2 * (RW - 1);        // last window row of a wave
+            auto sfrag = [&](int t) {
+                const int u0 = 2 * t, u1 = (2 * t + 1) / 7 <= RMAX ? 2 * t + 1 : 2 * t;
+                return *reinterpret_cast<const h16x8*>(win + (hi ? tap_off<CP>(u1) : tap_off<CP>(u0)));
+            };
+            h16x8 a[PF + 1];
 #pragma unroll
-            for (int i = 0; i < RW; ++i) a[0][i] = frag(0, i);
+            for (int d = 0; d < PF; ++d) a[d] = sfrag(d);
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if (s + 1 < S) {
+            for (int t = 0; t < T; ++t) {
+                if (t + PF < T) a[(t + PF) % (PF + 1)] = sfrag(t + PF);
 #pragma unroll
-                    for (int i = 0; i < RW; ++i) a[(s + 1) & 1][i] = frag(s + 1, i);
+                for (int i = 0; i < RW; ++i) {
+                    const int sl = t - 7 * i;
+                    if (sl >= 0 && sl < S) {
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) acc[i][cb] = MGN_MFMA_32x32x16(wf[sl][cb], a[t % (PF + 1)], acc[i][cb]);
+                    }
                 }
-#pragma unroll
-                for (int i = 0; i < RW; ++i)
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) acc[i][cb] = MGN_MFMA_32x32x16(wf[s][cb], a[s & 1][i], acc[i][cb]);
             }
         } else {
             // one tap per slab: the fragment of window row r = kh + 2 i and column tap kw serves every (output row i, kernel row kh)
             // pair on that window row -- 91 fragment reads for the 196 MFMAs of a patch, each consumed at once by up to four
             // independent accumulators
             constexpr int NR = 7 + 2 * (RW - 1);   // window rows a wave touches
+            constexpr int PF = 3;
             auto rfrag = [&](int f) {              // f = r * 7 + kw
                 const int r = f / 7, kw = f % 7;
                 return *reinterpret_cast<const h16x8*>(win + (r * G::ROWP + (kw & 1) * PLANE + (kw >> 1)) * 16);
             };
-            h16x8 a[2];
-            a[0] = rfrag(0);
+            h16x8 a[PF + 1];
+#pragma unroll
+            for (int d = 0; d < PF; ++d) a[d] = rfrag(d);
 #pragma unroll
             for (int f = 0; f < NR * 7; ++f) {
-                if (f + 1 < NR * 7) a[(f + 1) & 1] = rfrag(f + 1);
+                if (f + PF < NR * 7) a[(f + PF) % (PF + 1)] = rfrag(f + PF);
                 const int r = f / 7, kw = f % 7;
 #pragma unroll
                 for (int i = 0; i < RW; ++i) {
                     const int kh = r - 2 * i;
-                    if (kh >= 0 && kh < 7) acc[i][0] = MGN_MFMA_32x32x16(wf[kh * 7 + kw][0], a[f & 1], acc[i][0]);
+                    if (kh >= 0 && kh < 7) acc[i][0] = MGN_MFMA_32x32x16(wf[kh * 7 + kw][0], a[f % (PF + 1)], acc[i][0]);
                 }
             }
         }
