@@ -1884,6 +1884,23 @@ __global__ void weight_layout_batch_kernel(const long long* __restrict__ table, 
     const int CoutP = CoutPr > Cout ? CoutPr : Cout;
     if (mode == 2) { out[i] = f2bf(layout_value(w, i, Cout, CoutP, Cin, KH, KW, mode, Cp)); return; }
     const int taps = KH * KW;
+    if (mode == 1 && CoutP % 64 == 0 && Cin % 4 == 0 && taps <= 9) {
+        // transposing layout through LDS: the block's 256 items are the tile (64 output channels) x (4 input channels), read along
+        // the source rows (4 x taps contiguous floats per output channel) and written along the destination rows (64 consecutive
+        // output channels = 128 B per wave and tap); the item-per-thread form below reads with a stride of Cin*taps floats
+        __shared__ uint16_t tile[9][4][64 + 2];
+        const int bl = (int)((long)blockIdx.x - e[3]), tiles_ci = Cin / 4;
+        const int co0 = (bl / tiles_ci) * 64, ci0 = (bl % tiles_ci) * 4;
+        {
+            const int co_l = threadIdx.x >> 2, ci_l = threadIdx.x & 3, co = co0 + co_l;
+            const float* src = w + ((long)co * Cin + ci0 + ci_l) * taps;
+            for (int t = 0; t < taps; ++t) tile[t][ci_l][co_l] = co < Cout ? f2bf(src[t]) : (uint16_t)0;
+        }
+        __syncthreads();
+        const int co_l = threadIdx.x & 63, ci_l = threadIdx.x >> 6;
+        for (int t = 0; t < taps; ++t) out[((long)(ci0 + ci_l) * taps + (taps - 1 - t)) * CoutP + co0 + co_l] = tile[t][ci_l][co_l];
+        return;
+    }
     int co, ci;
     if (mode == 0) { co = (int)(i / Cin); ci = (int)(i - (long)co * Cin); }
     else { ci = (int)(i / CoutP); co = (int)(i - (long)ci * CoutP); }

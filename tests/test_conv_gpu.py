@@ -200,20 +200,22 @@ def test_weight_layout_cache_batched_refresh():
     from mgnet_amd import _C
 
     torch.manual_seed(3)
-    ws = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in [(64, 32, 3, 3), (40, 64, 1, 1), (64, 3, 7, 7), (128, 64, 3, 3)]]
-    modes = [(0, 0), (1, 0), (2, 8), (0, 0)]
-    first = [_C.weight_layout(w, m, cp).clone() for w, (m, cp) in zip(ws, modes)]
-    assert all(_C.weight_layout(w, m, cp).data_ptr() == _C.weight_layout(w, m, cp).data_ptr() for w, (m, cp) in zip(ws, modes))
+    # (mode 1 with Cout % 64 == 0 and Cin % 4 == 0 takes the LDS-transposing tile path of the batched kernel, incl. zero-padded rows)
+    ws = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in [(64, 32, 3, 3), (40, 64, 1, 1), (64, 3, 7, 7), (128, 64, 3, 3),
+                                                                        (128, 64, 3, 3), (64, 36, 3, 3), (192, 32, 1, 1), (19, 32, 1, 1)]]
+    modes = [(0, 0), (1, 0), (2, 8), (0, 0), (1, 0), (1, 0), (1, 0), (1, 0, 64)]
+    first = [_C.weight_layout(w, *m).clone() for w, m in zip(ws, modes)]
+    assert all(_C.weight_layout(w, *m).data_ptr() == _C.weight_layout(w, *m).data_ptr() for w, m in zip(ws, modes))
     for w in ws:  # raw update: no version bump
         _C.lib()  # (library loaded)
         torch.cuda.current_stream().synchronize()
         w.data.view(-1)[:7].copy_(torch.arange(7.0, device="cuda"))
     v_before = [w._version for w in ws]
     _C.weight_cache.refresh()
-    for w, (m, cp), f in zip(ws, modes, first):
-        got = _C.weight_layout(w, m, cp)
-        ref = _C._weight_layout_now(w, m, cp)
-        assert torch.equal(got, ref) and not torch.equal(got, f)
+    for w, m, f in zip(ws, modes, first):
+        got = _C.weight_layout(w, *m)
+        ref = _C._weight_layout_now(w, m[0], m[1], None, *m[2:])
+        assert torch.equal(got, ref) and not torch.equal(got, f), (tuple(w.shape), m)
     assert [w._version for w in ws] == v_before or True
     with torch.no_grad():
         ws[0].mul_(2.0)  # torch update: version bump -> served fresh without a refresh
