@@ -66,7 +66,7 @@ __device__ __forceinline__ Corner corners(const UpGeom& g, int b, int Y, int X) 
 }
 
 // interpolated logits of one pixel (K <= 32 classes, bf16 low-res map); returns log-sum-exp
-template <int K8>
+template <int K8, bool LSE = true>
 __device__ __forceinline__ float interp_logits(const uint16_t* __restrict__ lg, const Corner& c, int K, float (&z)[K8 * 8]) {
     float m = -3.0e38f;
 #pragma unroll
@@ -84,6 +84,7 @@ __device__ __forceinline__ float interp_logits(const uint16_t* __restrict__ lg, 
             if (v * 8 + q < K) m = fmaxf(m, val);
         }
     }
+    if (!LSE) return m;
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < K8 * 8; ++k)
@@ -92,11 +93,19 @@ __device__ __forceinline__ float interp_logits(const uint16_t* __restrict__ lg, 
 }
 
 // Phase 2 of the backward tile kernels, separable: rows first (sum over the tile's x with the horizontal bilinear weight
-// of every footprint column), then columns.  res: [TY*TX][KK] residuals in LDS; rowsum: [TY][MAXC][KK] scratch in LDS.
+// of every footprint column), then columns.  res: [KK][TY][RP] residuals in LDS; rowsum: [TY][MAXC][KK] scratch in LDS.
 constexpr int MAXC = 8, MAXR = 6;  // footprint bound of a 32x16 tile for scale >= 4 (checked on the host)
-constexpr int RP = TX + 1;         // pitch of a residual row in LDS: res[(k*TY + yy)*RP + xx] (conflict-free for the phase-1
-                                   // writes, lanes along xx, and for the row pass, lanes along yy and k)
+constexpr int RP = TX + 4;         // pitch of a residual row in LDS: res[(k*TY + yy)*RP + xx].  36 words: rows are 16-byte aligned
+                                   // (the row pass reads them as float4) and eight consecutive rows start in eight different bank
+                                   // quads, so those reads -- lanes along yy -- are conflict-free
 __device__ __forceinline__ int res_idx(int k, int yy, int xx) { return (k * TY + yy) * RP + xx; }
+// rowsum[yy][cxi][k] with odd pitches: the column pass reads it with lanes along k (consecutive banks), the row pass writes it
+// with lanes along yy (stride YP, odd -> 16 different banks).  (The [k][yy][cxi] layout this replaces put all 24 lanes of a
+// column-pass read on ONE bank: SQ_LDS_BANK_CONFLICT was 52 % of the LDS cycles of upce_bwd, profiles/r02_upce_pmc.txt.)
+template <int KK> struct ScatterLds {
+    static constexpr int KKP = KK | 1, YP = MAXC * KKP + 1;
+    static constexpr int FLOATS = KK * TY * RP + TY * YP;   // res + rowsum
+};
 
 template <int KK>
 __device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int Y0, int K, const float* res, float* rowsum,
@@ -130,16 +139,32 @@ __device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int
         wys[o] = wgt;
     }
     __syncthreads();
-    // rows: rowsum[k][yy][cxi] = sum_xx wxs[xx][cxi] * res[k][yy][xx]      (lanes: yy fastest, then k)
+    // rows: rowsum[yy][cxi][k] = sum_xx wxs[xx][cxi] * res[k][yy][xx]      (lanes: yy fastest, then k)
+    using L = ScatterLds<KK>;
+    constexpr bool UNI = (TY * KK) % 64 == 0;   // cxi is the same for a whole wave: its 32 weights travel through ONE LDS read per
+                                                // lane and v_readlane (scalar operands of the FMAs) instead of 32 broadcast reads
     for (int o = threadIdx.x; o < TY * KK * nc; o += TPB) {
         const int yy = o % TY, k = (o / TY) % KK, cxi = o / (TY * KK);
         float acc = 0.f;
-        if (k < K && yy < ny) {
-            const float* rr = res + res_idx(k, yy, 0);
+        const float* rr = res + res_idx(k, yy, 0);
+        if (UNI) {
+            const float wl = wxs[(threadIdx.x & 31) * MAXC + cxi];
+            float wv[TX];
+#pragma unroll
+            for (int xx = 0; xx < TX; ++xx) wv[xx] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), xx));
+            if (k < K) {   // (rows k >= K of res are not written by every caller)
+#pragma unroll
+                for (int q = 0; q < TX / 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(rr + 4 * q);   // rows beyond ny / columns beyond nx hold zeros
+                    acc = fmaf(wv[4 * q], v.x, acc); acc = fmaf(wv[4 * q + 1], v.y, acc);   // (the order of the scalar loop)
+                    acc = fmaf(wv[4 * q + 2], v.z, acc); acc = fmaf(wv[4 * q + 3], v.w, acc);
+                }
+            }
+        } else if (k < K && yy < ny) {
 #pragma unroll 8
             for (int xx = 0; xx < TX; ++xx) acc += wxs[xx * MAXC + cxi] * rr[xx];   // columns beyond nx carry weight 0
         }
-        rowsum[(k * TY + yy) * MAXC + cxi] = acc;
+        rowsum[yy * L::YP + cxi * L::KKP + k] = acc;
     }
     __syncthreads();
     for (int o = threadIdx.x; o < nr * nc * KK; o += TPB) {
@@ -147,7 +172,7 @@ __device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int
         if (k >= K) continue;
         float acc = 0.f;
 #pragma unroll
-        for (int yy = 0; yy < TY; ++yy) acc += wys[yy * MAXR + cyi] * rowsum[(k * TY + yy) * MAXC + cxi];
+        for (int yy = 0; yy < TY; ++yy) acc += wys[yy * MAXR + cyi] * rowsum[yy * L::YP + cxi * L::KKP + k];
         if (acc != 0.f) atomicAdd(out + (((long)b * g.h + ly0 + cyi) * g.w + lx0 + cxi) * out_stride + k, acc);
     }
 }
@@ -236,33 +261,65 @@ template <int K8>
 __global__ __launch_bounds__(TPB) void upce_bwd(const uint16_t* __restrict__ lg, UpGeom g, int K, int Kp, const long* __restrict__ labels,
                                                 const float* __restrict__ weights, int ignore, const float* __restrict__ ce_map,
                                                 const float* __restrict__ sel, const float* __restrict__ gout, float* dlg) {
-    extern __shared__ float res[];  // [K8*8][TY][RP] residuals g*(p_k - onehot)
+    extern __shared__ __attribute__((aligned(16))) float res[];  // [K8*8][TY][RP] residuals g*(p_k - onehot), then rowsum
     constexpr int KK = K8 * 8;
     const int X0 = (blockIdx.x + g.bx0) * TX, Y0 = (blockIdx.y + g.by0) * TY, b = blockIdx.z;
     const float tau = sel[0], tie_w = sel[1], scale = sel[2] * gout[0];
-    // ---- phase 1: residual vectors of the tile's pixels
-    for (int t = threadIdx.x; t < TX * TY; t += TPB) {
+    // ---- phase 1: residual vectors of the tile's pixels.  A thread owns TWO pixels (rows yy and yy + 8 of column xx): their
+    // scalars are loaded first, then -- under ONE wave-uniform branch, so that the twelve 16-byte corner loads of both pixels
+    // sit in one basic block and are in flight together (2 waves per SIMD are all the LDS footprint leaves for hiding them) --
+    // the interpolated soft-max of both
+    static_assert(TX * TY == 2 * TPB, "two pixels per thread");
+    float gpx[2];
+    int lab[2], Xc[2], Yc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = threadIdx.x + u * TPB;
         const int X = X0 + (t % TX), Y = Y0 + (t / TX);
-        float z[KK];
-        float gpx = 0.f;
-        long lab = ignore;
-        float lse = 0.f;
+        gpx[u] = 0.f;
+        lab[u] = -1;
+        Xc[u] = min(X, g.W - 1); Yc[u] = min(Y, g.H - 1);
         if (X < g.W && Y < g.H) {
             const long p = ((long)b * g.H + Y) * g.W + X;
-            lab = labels[p];
+            const long l = labels[p];
             const float ce = ce_map[p];
             const float sw = ce > tau ? 1.f : (ce == tau ? tie_w : 0.f);
-            if (lab != ignore && sw != 0.f) {
-                gpx = sw * scale * (weights ? weights[p] : 1.f);
-                const Corner c = corners(g, b, Y, X);
-                lse = interp_logits<K8>(lg, c, K, z);
-            }
+            if (l != ignore && sw != 0.f) { gpx[u] = sw * scale * (weights ? weights[p] : 1.f); lab[u] = (int)l; }
+        }
+    }
+    if (__any(gpx[0] != 0.f || gpx[1] != 0.f)) {
+        float z[2][KK], inv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const Corner c = corners(g, b, Yc[u], Xc[u]);
+            (void)interp_logits<K8, false>(lg, c, K, z[u]);
         }
 #pragma unroll
-        for (int k = 0; k < KK; ++k) {
-            float r = 0.f;
-            if (gpx != 0.f && k < K) r = gpx * (__expf(z[k] - lse) - (k == (int)lab ? 1.f : 0.f));
-            res[res_idx(k, t / TX, t % TX)] = r;
+        for (int u = 0; u < 2; ++u) {   // soft-max as exp(z - max) / sum: one exponential per class (not a second one against the lse)
+            float m = -3.0e38f;
+#pragma unroll
+            for (int k = 0; k < KK; ++k)
+                if (k < K) m = fmaxf(m, z[u][k]);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KK; ++k) {
+                z[u][k] = k < K ? __expf(z[u][k] - m) : 0.f;
+                sum += z[u][k];
+            }
+            inv[u] = gpx[u] / sum;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = threadIdx.x + u * TPB;
+#pragma unroll
+            for (int k = 0; k < KK; ++k) res[res_idx(k, t / TX, t % TX)] = k < K ? fmaf(z[u][k], inv[u], k == lab[u] ? -gpx[u] : 0.f) : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = threadIdx.x + u * TPB;
+#pragma unroll
+            for (int k = 0; k < KK; ++k) res[res_idx(k, t / TX, t % TX)] = 0.f;
         }
     }
     __syncthreads();
@@ -340,7 +397,7 @@ __global__ __launch_bounds__(SUMT) void sum4_kernel(const float* partials, int n
 
 // gout = {d/d loss_center, d/d loss_offset}; sums = output of sum4_kernel
 __global__ __launch_bounds__(TPB) void ins_bwd(InsMaps m, const float* __restrict__ sums, const float* __restrict__ gout, float* dco) {
-    __shared__ float res[4 * TY * RP + 4 * TY * MAXC];
+    __shared__ __attribute__((aligned(16))) float res[ScatterLds<4>::FLOATS];
     const int X0 = (blockIdx.x + m.gc.bx0) * TX, Y0 = (blockIdx.y + m.gc.by0) * TY, b = blockIdx.z;
     const UpGeom& g = m.gc;  // centre and offset maps share the geometry
     const float sc = sums[2] > 0.f ? gout[0] / sums[2] : 0.f, so = sums[3] > 0.f ? gout[1] / sums[3] : 0.f;
@@ -382,7 +439,7 @@ __global__ __launch_bounds__(TPB) void up1_fwd(const float* __restrict__ lr, UpG
 }
 
 __global__ __launch_bounds__(TPB) void up1_bwd(const float* __restrict__ dfull, UpGeom g, float* dlr) {
-    __shared__ float res[TY * RP + TY * MAXC];
+    __shared__ __attribute__((aligned(16))) float res[ScatterLds<1>::FLOATS];
     const int X0 = (blockIdx.x + g.bx0) * TX, Y0 = (blockIdx.y + g.by0) * TY, b = blockIdx.z;
     for (int t = threadIdx.x; t < TX * TY; t += TPB) {
         const int X = X0 + (t % TX), Y = Y0 + (t / TX);
@@ -548,7 +605,13 @@ int MGN_SYM(mgn_upce_bwd)(const void* logits_bf16, long sb, long sh, long sw, in
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* lg = (const uint16_t*)logits_bf16;
     const int k8 = (K + 7) / 8;
-    const size_t lds = sizeof(float) * (TY * RP + TY * MAXC) * k8 * 8;
+    const size_t lds = sizeof(float) * (k8 == 1 ? ScatterLds<8>::FLOATS : k8 == 2 ? ScatterLds<16>::FLOATS : k8 == 3 ? ScatterLds<24>::FLOATS : ScatterLds<32>::FLOATS);
+    static bool attr = false;
+    if (!attr) {   // more than 64 KB of dynamic LDS for 17..32 classes
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upce_bwd<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ScatterLds<24>::FLOATS));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upce_bwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ScatterLds<32>::FLOATS));
+        attr = true;
+    }
     serial_scatter(grid, [&](dim3 gr, int bx0, int by0) {
         UpGeom gg = g;
         gg.bx0 = bx0; gg.by0 = by0;
