@@ -135,52 +135,71 @@ __global__ __launch_bounds__(256) void maxpool_bwd(const uint16_t* __restrict__ 
 // ---- fused with the activated batch norm of the stem --------------------------------------------------------------------
 __device__ __forceinline__ uint32_t f2bf_rne(float f) { return mgn_f2h(f); }
 
+// A thread owns one 8-channel vector of TWO adjacent output pixels: their windows share the middle input column, so 15 instead of
+// 18 vectors are loaded per pair -- all of them up front (282 -> 270 us at 8 x 512 x 1024 x 64; an XCD-banded block order on
+// top of it measured neutral, so the re-read of the shared input row is not what bounds it) -- and the activation is evaluated once per loaded value.  Scan order and
+// the strict comparison are those of the separate kernels (first maximum in (kh, kw) order wins).
 __global__ __launch_bounds__(256) void abn_maxpool_fwd(const uint16_t* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ offset, int leaky, float slope,
                                                        uint16_t* __restrict__ y, uint8_t* __restrict__ idx, int N, int IH, int IW, int C,
                                                        int OH, int OW) {
-    const int cv = C / 8;
+    const int cv = C / 8, OWP = (OW + 1) / 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)N * OH * OW * cv) return;
+    if (i >= (long)N * OH * OWP * cv) return;
     const int c8 = (int)(i % cv);
     long r = i / cv;
-    const int ow = (int)(r % OW); r /= OW;
+    const int ow0 = (int)(r % OWP) * 2; r /= OWP;
     const int oh = (int)(r % OH);
     const int n = (int)(r / OH);
-    float sc[8], of[8], best[8];
-    uint16_t bits[8];
-    uint8_t arg[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { sc[k] = scale[c8 * 8 + k]; of[k] = offset[c8 * 8 + k]; best[k] = -3.4e38f; bits[k] = MGN_H16_LOWEST; arg[k] = 0; }
+    uint4 v[3][5];
+    bool ok[3][5];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int ih = oh * 2 - 1 + kh;
-        if (ih < 0 || ih >= IH) continue;
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int iw = ow * 2 - 1 + kw;
-            if (iw < 0 || iw >= IW) continue;
-            const uint4 v = *reinterpret_cast<const uint4*>(x + (((long)n * IH + ih) * IW + iw) * C + c8 * 8);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (int j = 0; j < 5; ++j) {
+            const int iw = ow0 * 2 - 1 + j;
+            ok[kh][j] = ih >= 0 && ih < IH && iw >= 0 && iw < IW;
+            v[kh][j] = ok[kh][j] ? *reinterpret_cast<const uint4*>(x + (((long)n * IH + ih) * IW + iw) * C + c8 * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    float sc[8], of[8], best[2][8];
+    uint8_t arg[2][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = scale[c8 * 8 + k]; of[k] = offset[c8 * 8 + k];
+        best[0][k] = best[1][k] = -3.4e38f; arg[0][k] = arg[1][k] = 0;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (!ok[kh][j]) continue;
+            const uint32_t w[4] = {v[kh][j].x, v[kh][j].y, v[kh][j].z, v[kh][j].w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float z = fmaf(bf2f((uint16_t)(w[k >> 1] >> ((k & 1) * 16))), sc[k], of[k]);   // iabn_apply's arithmetic
                 if (leaky) z = z > 0.f ? z : z * slope;
-                const uint16_t b = (uint16_t)f2bf_rne(z);
-                const float f = bf2f(b);
-                if (f > best[k]) { best[k] = f; bits[k] = b; arg[k] = (uint8_t)(kh * 3 + kw); }
+                const float f = bf2f((uint16_t)f2bf_rne(z));
+                // column j is tap kw = j of the left pixel (j <= 2) and tap kw = j - 2 of the right one (j >= 2)
+                if (j <= 2 && f > best[0][k]) { best[0][k] = f; arg[0][k] = (uint8_t)(kh * 3 + j); }
+                if (j >= 2 && f > best[1][k]) { best[1][k] = f; arg[1][k] = (uint8_t)(kh * 3 + j - 2); }
             }
         }
     }
-    uint4 o;
-    o.x = bits[0] | ((uint32_t)bits[1] << 16); o.y = bits[2] | ((uint32_t)bits[3] << 16);
-    o.z = bits[4] | ((uint32_t)bits[5] << 16); o.w = bits[6] | ((uint32_t)bits[7] << 16);
-    const long op = (((long)n * OH + oh) * OW + ow) * C + c8 * 8;
-    *reinterpret_cast<uint4*>(y + op) = o;
-    uint2 a;
-    a.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((uint32_t)arg[3] << 24);
-    a.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((uint32_t)arg[7] << 24);
-    *reinterpret_cast<uint2*>(idx + op) = a;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (ow0 + u >= OW) break;
+        uint4 o;
+        o.x = mgn_pack2(best[u][0], best[u][1]); o.y = mgn_pack2(best[u][2], best[u][3]);   // (exact: the maxima are 16-bit values)
+        o.z = mgn_pack2(best[u][4], best[u][5]); o.w = mgn_pack2(best[u][6], best[u][7]);
+        const long op = (((long)n * OH + oh) * OW + ow0 + u) * C + c8 * 8;
+        *reinterpret_cast<uint4*>(y + op) = o;
+        uint2 a;
+        a.x = arg[u][0] | (arg[u][1] << 8) | (arg[u][2] << 16) | ((uint32_t)arg[u][3] << 24);
+        a.y = arg[u][4] | (arg[u][5] << 8) | (arg[u][6] << 16) | ((uint32_t)arg[u][7] << 24);
+        *reinterpret_cast<uint2*>(idx + op) = a;
+    }
 }
 
 struct AbnBwd {
@@ -279,7 +298,7 @@ int MGN_SYM(mgn_abn_maxpool_fwd)(const void* x_bf16, const float* scale, const f
     if (!x_bf16 || !scale || !offset || !y_bf16 || !argmax || N < 1 || IH < 1 || IW < 1 || C < 8 || C % 8) return MGN_EINVAL;
     if (activation != 0 && activation != 1) return MGN_EINVAL;
     const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
-    const long n = (long)N * OH * OW * (C / 8);
+    const long n = (long)N * OH * ((OW + 1) / 2) * (C / 8);   // a thread per 8-channel vector of two adjacent output pixels
     hipLaunchKernelGGL(abn_maxpool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16, scale,
                        offset, activation, slope, (uint16_t*)y_bf16, argmax, N, IH, IW, C, OH, OW);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
