@@ -1,6 +1,11 @@
 """[HIP] Adam + full-model gradient-norm clipping on the flat buckets of GradReducer (mgnet_amd/csrc/optim.hip).
 Same update rule as torch.optim.Adam behind FullModelGradientClippingOptimizer (tools/train_net.py:129-148); a
-torch.optim.Optimizer subclass so that the LR scheduler and `param_groups` work unchanged."""
+torch.optim.Optimizer subclass so that the LR scheduler and `param_groups` work unchanged.
+
+Deviation from torch.optim.Adam: a parameter that received NO gradient in a step is not skipped -- GradReducer.finish zero-fills
+its gradient, so its moments decay and it moves by lr * m / (sqrt(v) + eps) -- and there is one step count for the whole model.
+Every registered parameter of MGNet receives a gradient in every configuration (heads that are switched off are not built), so the
+trajectories agree; `load_state_dict` rejects a state whose per-parameter step counts differ."""
 import numpy as np
 import torch
 
@@ -114,7 +119,10 @@ class FusedAdam(torch.optim.Optimizer):
                     self._v[k][o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
                     steps.add(int(float(st["step"])))
                 idx += 1
-        assert len(steps) <= 1, "per-parameter step counts differ: not a full-model Adam state"
+        if len(steps) > 1:
+            raise ValueError(f"optimizer state with different per-parameter step counts {sorted(steps)}: torch.optim.Adam skips parameters "
+                             "without a gradient and counts steps per parameter; this optimizer keeps ONE step count for the flat buffers "
+                             "(every parameter of the model receives a gradient in every MGNet configuration) and cannot resume such a state")
         self._t = steps.pop() if steps else 0
 
     def loss_scale(self):
