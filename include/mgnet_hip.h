@@ -269,18 +269,24 @@ int mgn_weight_layout_batch(const void* table_dev, int n_entries, long total_blo
  *                  upsampled on the fly; out4 = {sum w(c-t)^2 / sum w, sum w|o*s-t| / sum w, sum w_c, sum w_o};
  *                  backward dco [B,h,w,4] fp32 (zero-initialised) = {d centre_lr, d offset_lr[0], d offset_lr[1], 0}.
  * Low-res maps: bf16 (logits/offset) with channel stride 1 and element strides (sb, sh, sw) multiples of 8.
+ * The three backward entry points (mgn_upce_bwd, mgn_ins_loss_bwd, mgn_upsample1_bwd) compute the bilinear ADJOINT per 32x16
+ * pixel tile.  footprints == NULL: the tiles add their low-res footprints with float atomics (the destination must be
+ * zero-initialised; sums are order-dependent in the last bits).  footprints != NULL (mgn_adjoint_footprint_floats floats; channels =
+ * K | 3 | 1): every tile stores its footprint into its own slot and a second kernel sums, per low-res element, the slots
+ * that cover it in a fixed order -- bit-reproducible, the destination need not be initialised.
  * ---------------------------------------------------------------------------------------------- */
 int mgn_upce_partials(int B, int H, int W);
+int mgn_adjoint_footprint_floats(int B, int h, int w, int H, int W, int channels, size_t* floats);
 /* single-channel fp32 bilinear (align_corners=True) upsampling [B,1,h,w] -> [B,1,H,W] and its adjoint (dlr zero-initialised);
  * replaces F.interpolate at mg_net.py:804-807 (depth head, x8/x16/x32). The adjoint needs an upsampling factor >= 7. */
 int mgn_upsample1_fwd(const float* lr, int B, int h, int w, int H, int W, float* out, void* stream);
-int mgn_upsample1_bwd(const float* dfull, int B, int h, int w, int H, int W, float* dlr_zeroed, void* stream);
+int mgn_upsample1_bwd(const float* dfull, int B, int h, int w, int H, int W, float* dlr_zeroed, float* footprints, void* stream);
 int mgn_upce_fwd(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K,
                  const long* labels, const float* weights, int ignore, float thr, float* ce_map, float* partials,
                  float* sums3, void* stream);
 int mgn_upce_bwd(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K, int Kp,
                  const long* labels, const float* weights, int ignore, const float* ce_map, const float* sel3,
-                 const float* gout, float* dlogits, void* stream);
+                 const float* gout, float* dlogits, float* footprints, void* stream);
 /* OhemCE / DeepLabCE selection on the device (replaces the full torch.sort of loss.py:67-81 and its host-side branch):
  * from the per-pixel loss map and sums3 of mgn_upce_fwd -> sel3 = {tau, tie_weight, scale} for mgn_upce_bwd and the loss.
  * count(ce > thr) > n_sel: mean of {ce > thr}; otherwise (or force_topk: DeepLabCE hard-pixel mining) the mean of the n_sel
@@ -293,7 +299,8 @@ int mgn_ins_loss_fwd(const float* center_lr, long csb, long csh, long csw, const
                      const float* ow, float oscale, float* partials, float* out4, void* stream);
 int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh,
                      long osw, int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot,
-                     const float* ow, float oscale, const float* out4, const float* gout2, float* dco, void* stream);
+                     const float* ow, float oscale, const float* out4, const float* gout2, float* dco, float* footprints,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Network input assembly -- replaces mg_net.py:250-264 (`.float()/255`, mean/std normalisation of image, image_prev,
@@ -585,13 +592,13 @@ int mgn_upce_fwd_f16(const void* logits_h16, long sb, long sh, long sw, int B, i
     void* stream);
 int mgn_upce_bwd_f16(const void* logits_h16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K,
     int Kp, const long* labels, const float* weights, int ignore, const float* ce_map, const float* sel3, const
-    float* gout, float* dlogits, void* stream);
+    float* gout, float* dlogits, float* footprints, void* stream);
 int mgn_ins_loss_fwd_f16(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_h16, long osb,
     long osh, long osw, int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot, const
     float* ow, float oscale, float* partials, float* out4, void* stream);
 int mgn_ins_loss_bwd_f16(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_h16, long osb,
     long osh, long osw, int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot, const
-    float* ow, float oscale, const float* out4, const float* gout2, float* dco, void* stream);
+    float* ow, float oscale, const float* out4, const float* gout2, float* dco, float* footprints, void* stream);
 int mgn_prep_input_f16(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
     const float* pixel_std3, void* out_h16, int Cp, void* stream);
 int mgn_iabn_stats_f16(const void* x, int dtype, long M, int C, float* stats /*[3][C]: count, mean, M2*/, void*

@@ -16,7 +16,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
            "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv_win_patch_rows", "mgn_conv_stem7", "mgn_conv_stem7_blocks", "mgn_iabn_coeffs_from_partials", "mgn_iabn_partials_reduce", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
-           "mgn_upce_partials", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
+           "mgn_upce_partials", "mgn_adjoint_footprint_floats", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
            "mgn_nearest_bwd", "mgn_concat2", "mgn_split2", "mgn_vec_linear_fwd", "mgn_vec_linear_bwd_workspace_bytes", "mgn_vec_linear_bwd",
@@ -118,13 +118,14 @@ def lib():
         L.mgn_weight_layout_batch.argtypes = [vp, ci, cl, vp]
         L.mgn_upce_partials.argtypes = [ci, ci, ci]
         L.mgn_upce_fwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp, vp]
-        L.mgn_upce_bwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
+        L.mgn_upce_bwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp]
+        L.mgn_adjoint_footprint_floats.argtypes = [ci] * 6 + [vp]
         L.mgn_ohem_select_workspace_bytes.argtypes = [cl, ctypes.POINTER(sz)]
         L.mgn_ohem_select.argtypes = [vp, cl, vp, cf, cl, ci, vp, vp, vp, sz, vp]
         L.mgn_ins_loss_fwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp]
-        L.mgn_ins_loss_bwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
+        L.mgn_ins_loss_bwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp]
         L.mgn_upsample1_fwd.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
-        L.mgn_upsample1_bwd.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
+        L.mgn_upsample1_bwd.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp]
         L.mgn_maxpool3x3s2_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
         L.mgn_maxpool3x3s2_bwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
         L.mgn_add_relu_fwd.argtypes = [vp, vp, vp, cl, vp]
@@ -891,13 +892,24 @@ def ohem_select(ce, sums, thr, n_sel, force_topk):
     return out[:3], out[3]
 
 
+def _adjoint_dst(shape, dev, B, h, w, H, W, channels):
+    """destination + footprint table of the tile-wise bilinear adjoints (csrc/headloss.hip).  Default: the reproducible two-kernel
+    form (every tile stores its footprint, a gather sums them in a fixed order: uninitialised destination); MGN_ADJOINT_ATOMICS=1:
+    float atomics into a zeroed destination (order-dependent last bits; MGN_SERIAL_SCATTER=1 orders them, one tile per launch)."""
+    if os.environ.get("MGN_ADJOINT_ATOMICS") or os.environ.get("MGN_SERIAL_SCATTER"):
+        return torch.zeros(shape, dtype=torch.float32, device=dev), None
+    n = ctypes.c_size_t(0)
+    check(lib().mgn_adjoint_footprint_floats(B, h, w, H, W, channels, ctypes.byref(n)), "mgn_adjoint_footprint_floats")
+    return torch.empty(shape, dtype=torch.float32, device=dev), torch.empty(n.value, dtype=torch.float32, device=dev)
+
+
 def upce_bwd(lr, labels, weights, H, W, ignore, ce, sel3, gout, Kp):
     B, K, h, w = lr.shape
     sb, sh, sw = _lr_strides(lr)
-    dlg = torch.zeros((B, h, w, Kp), dtype=torch.float32, device=lr.device)
+    dlg, foot = _adjoint_dst((B, h, w, Kp), lr.device, B, h, w, H, W, K)
     check(_fn("mgn_upce_bwd", lr)(lr.data_ptr(), sb, sh, sw, B, h, w, H, W, K, Kp, labels.data_ptr(),
                              None if weights is None else weights.data_ptr(), ignore, ce.data_ptr(), sel3.data_ptr(),
-                             gout.data_ptr(), dlg.data_ptr(), _stream()), "mgn_upce_bwd")
+                             gout.data_ptr(), dlg.data_ptr(), None if foot is None else foot.data_ptr(), _stream()), "mgn_upce_bwd")
     return dlg
 
 
@@ -914,10 +926,11 @@ def ins_loss_fwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale):
 
 def ins_loss_bwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale, out4, gout2):
     B, _, h, w = center_lr.shape
-    dco = torch.zeros((B, h, w, 4), dtype=torch.float32, device=ct.device)
+    dco, foot = _adjoint_dst((B, h, w, 4), ct.device, B, h, w, H, W, 3)
     cs, os_ = _lr_strides(center_lr), _lr_strides(offset_lr)
     check(_fn("mgn_ins_loss_bwd", offset_lr)(center_lr.data_ptr(), *cs, offset_lr.data_ptr(), *os_, B, h, w, H, W, ct.data_ptr(), cw.data_ptr(),
-                                 ot.data_ptr(), ow.data_ptr(), oscale, out4.data_ptr(), gout2.data_ptr(), dco.data_ptr(), _stream()),
+                                 ot.data_ptr(), ow.data_ptr(), oscale, out4.data_ptr(), gout2.data_ptr(), dco.data_ptr(),
+                                 None if foot is None else foot.data_ptr(), _stream()),
           "mgn_ins_loss_bwd")
     return dco
 
@@ -931,8 +944,9 @@ def upsample1_fwd(lr, H, W):
 
 def upsample1_bwd(dfull, h, w):
     B, _, H, W = dfull.shape
-    dlr = torch.zeros((B, 1, h, w), dtype=torch.float32, device=dfull.device)
-    check(lib().mgn_upsample1_bwd(dfull.data_ptr(), B, h, w, H, W, dlr.data_ptr(), _stream()), "mgn_upsample1_bwd")
+    dlr, foot = _adjoint_dst((B, 1, h, w), dfull.device, B, h, w, H, W, 1)
+    check(lib().mgn_upsample1_bwd(dfull.data_ptr(), B, h, w, H, W, dlr.data_ptr(), None if foot is None else foot.data_ptr(), _stream()),
+          "mgn_upsample1_bwd")
     return dlr
 
 

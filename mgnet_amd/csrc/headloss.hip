@@ -31,6 +31,8 @@ constexpr int TX = 32, TY = 16;      // backward pixel tile
 struct UpGeom {
     int B, h, w, H, W;
     int bx0, by0;      // tile offset of this launch (0 unless MGN_SERIAL_SCATTER: one tile per launch, see serial_scatter())
+    float* foot;       // footprint table [B][tiles y][tiles x][fr][fc][KK] of the backward tile kernels, or null (float atomics)
+    int fr, fc;        // footprint bound of this geometry (rows, columns)
     long sb, sh, sw;   // element strides of the low-res map (channel stride 1)
     float ry, rx;      // (h-1)/(H-1), (w-1)/(W-1)   (align_corners=True)
 };
@@ -167,6 +169,22 @@ __device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int
         rowsum[yy * L::YP + cxi * L::KKP + k] = acc;
     }
     __syncthreads();
+    if (g.foot) {
+        // reproducible form: the tile's footprint goes to its own slot of the table with plain stores (zeros outside nr x nc and
+        // for k >= K); adjoint_gather() then sums, per low-res element, the slots that cover it in a FIXED order
+        const size_t ti = ((size_t)b * ((g.H + TY - 1) / TY) + Y0 / TY) * ((g.W + TX - 1) / TX) + X0 / TX;
+        float* slot = g.foot + ti * g.fr * g.fc * K;   // [fr][fc][K]
+        for (int o = threadIdx.x; o < g.fr * g.fc * K; o += TPB) {
+            const int k = o % K, cxi = (o / K) % g.fc, cyi = o / (K * g.fc);
+            float acc = 0.f;
+            if (cxi < nc && cyi < nr) {
+#pragma unroll
+                for (int yy = 0; yy < TY; ++yy) acc += wys[yy * MAXR + cyi] * rowsum[yy * L::YP + cxi * L::KKP + k];
+            }
+            slot[o] = acc;
+        }
+        return;
+    }
     for (int o = threadIdx.x; o < nr * nc * KK; o += TPB) {
         const int k = o % KK, cxi = (o / KK) % nc, cyi = o / (KK * nc);
         if (k >= K) continue;
@@ -175,6 +193,40 @@ __device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int
         for (int yy = 0; yy < TY; ++yy) acc += wys[yy * MAXR + cyi] * rowsum[yy * L::YP + cxi * L::KKP + k];
         if (acc != 0.f) atomicAdd(out + (((long)b * g.h + ly0 + cyi) * g.w + lx0 + cxi) * out_stride + k, acc);
     }
+}
+
+// Second half of the reproducible adjoint: out[b, y, x, k] = sum over the tiles whose footprint covers (y, x), tile rows then tile
+// columns ascending, of their table entries.  The footprint origin of a tile is recomputed with scatter_tile's own expressions.
+// A thread per (b, y, x, k < out_stride); channels k >= K (padding of the destination) are zero.
+__global__ __launch_bounds__(TPB) void adjoint_gather(UpGeom g, int KK, float* __restrict__ out, int out_stride) {   // KK = table channels (K)
+    const long i = (long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= (long)g.B * g.h * g.w * out_stride) return;
+    const int k = (int)(i % out_stride);
+    long r = i / out_stride;
+    const int x = (int)(r % g.w); r /= g.w;
+    const int y = (int)(r % g.h);
+    const int b = (int)(r / g.h);
+    float acc = 0.f;
+    if (k < KK) {
+        const int tny = (g.H + TY - 1) / TY, tnx = (g.W + TX - 1) / TX;
+        // candidate tiles: those whose pixel rows / columns map near y / x (a generous bracket, membership is tested exactly)
+        int ty0 = 0, ty1 = tny - 1, tx0 = 0, tx1 = tnx - 1;
+        if (g.ry > 0.f) { ty0 = max(0, (int)((y - 1) / g.ry) / TY - 1); ty1 = min(tny - 1, (int)((y + 1) / g.ry) / TY + 1); }
+        if (g.rx > 0.f) { tx0 = max(0, (int)((x - 1) / g.rx) / TX - 1); tx1 = min(tnx - 1, (int)((x + 1) / g.rx) / TX + 1); }
+        for (int ty = ty0; ty <= ty1; ++ty) {
+            const int Y0 = ty * TY, Yl = min(Y0 + TY, g.H) - 1;
+            const int ly0 = min((int)(Y0 * g.ry), g.h - 1), ly1 = min(min((int)(Yl * g.ry), g.h - 1) + 1, g.h - 1);
+            if (y < ly0 || y > ly1 || y - ly0 >= g.fr) continue;
+            for (int tx = tx0; tx <= tx1; ++tx) {
+                const int X0 = tx * TX, Xl = min(X0 + TX, g.W) - 1;
+                const int lx0 = min((int)(X0 * g.rx), g.w - 1), lx1 = min(min((int)(Xl * g.rx), g.w - 1) + 1, g.w - 1);
+                if (x < lx0 || x > lx1 || x - lx0 >= g.fc) continue;
+                const size_t ti = ((size_t)b * tny + ty) * tnx + tx;
+                acc += g.foot[(ti * g.fr * g.fc + (size_t)(y - ly0) * g.fc + (x - lx0)) * KK + k];
+            }
+        }
+    }
+    out[i] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -547,10 +599,10 @@ __global__ void ohem_final(const float* sums3, float thr, long n_sel, const Ohem
     }
 }
 
-// The backward kernels add the low-resolution footprints of neighbouring pixel tiles with float atomics: the sum of the <= 4
-// contributions to a border pixel depends on the arrival order in its last bit (the only run-to-run variation of the training
-// step; the reference's F.interpolate backward uses atomics too).  MGN_SERIAL_SCATTER=1 (debugging / reproducibility checks,
-// slow) launches one tile per launch in a fixed order instead: bit-reproducible.
+// Atomic form of the backward kernels (footprints == NULL): the low-resolution footprints of neighbouring pixel tiles are added
+// with float atomics, so the sum of the <= 4 contributions to a border pixel depends on the arrival order in its last bit (the
+// reference's F.interpolate backward does the same).  MGN_SERIAL_SCATTER=1 (debugging, slow) launches one tile per launch in a
+// fixed order.  The default path of the product is the footprint table + adjoint_gather (bit-reproducible).
 template <typename F>
 inline void serial_scatter(dim3 grid, F&& launch) {   // launch(grid, bx0, by0)
     if (!getenv("MGN_SERIAL_SCATTER")) { launch(grid, 0, 0); return; }
@@ -560,12 +612,43 @@ inline void serial_scatter(dim3 grid, F&& launch) {   // launch(grid, bx0, by0)
 
 inline int geom_ok(int B, int h, int w, int H, int W) { return B >= 1 && h >= 2 && w >= 2 && H >= h && W >= w; }
 
+// exact footprint bound of this geometry: the largest low-res extent of any TX x TY tile, with scatter_tile's own (float) expressions
+inline void footprint_bound(int h, int w, int H, int W, int* fr, int* fc) {
+    const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    int r = 1, c = 1;
+    for (int Y0 = 0; Y0 < H; Y0 += TY) {
+        const int Yl = (Y0 + TY < H ? Y0 + TY : H) - 1;
+        int l0 = (int)(Y0 * ry), l1 = (int)(Yl * ry);
+        l0 = l0 < h - 1 ? l0 : h - 1; l1 = l1 < h - 1 ? l1 : h - 1; l1 = l1 + 1 < h - 1 ? l1 + 1 : h - 1;
+        r = l1 - l0 + 1 > r ? l1 - l0 + 1 : r;
+    }
+    for (int X0 = 0; X0 < W; X0 += TX) {
+        const int Xl = (X0 + TX < W ? X0 + TX : W) - 1;
+        int l0 = (int)(X0 * rx), l1 = (int)(Xl * rx);
+        l0 = l0 < w - 1 ? l0 : w - 1; l1 = l1 < w - 1 ? l1 : w - 1; l1 = l1 + 1 < w - 1 ? l1 + 1 : w - 1;
+        c = l1 - l0 + 1 > c ? l1 - l0 + 1 : c;
+    }
+    *fr = r < MAXR ? r : MAXR; *fc = c < MAXC ? c : MAXC;
+}
+inline size_t footprint_floats(int B, int h, int w, int H, int W, int KK) {
+    int fr, fc;
+    footprint_bound(h, w, H, W, &fr, &fc);
+    return (size_t)B * ((H + TY - 1) / TY) * ((W + TX - 1) / TX) * fr * fc * KK;
+}
+
 inline UpGeom make_geom(int B, int h, int w, int H, int W, long sb, long sh, long sw) {
     UpGeom g;
     g.B = B; g.h = h; g.w = w; g.H = H; g.W = W; g.sb = sb; g.sh = sh; g.sw = sw; g.bx0 = g.by0 = 0;
+    g.foot = nullptr;
+    footprint_bound(h, w, H, W, &g.fr, &g.fc);
     g.ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     g.rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     return g;
+}
+
+inline void launch_gather(const UpGeom& g, int KK, float* out, int out_stride, hipStream_t s) {
+    const long n = (long)g.B * g.h * g.w * out_stride;
+    hipLaunchKernelGGL(adjoint_gather, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, g, KK, out, out_stride);
 }
 
 }  // namespace
@@ -596,11 +679,12 @@ int MGN_SYM(mgn_upce_fwd)(const void* logits_bf16, long sb, long sh, long sw, in
 
 int MGN_SYM(mgn_upce_bwd)(const void* logits_bf16, long sb, long sh, long sw, int B, int h, int w, int H, int W, int K, int Kp,
                  const long* labels, const float* weights, int ignore, const float* ce_map, const float* sel3, const float* gout,
-                 float* dlogits, void* stream) {
+                 float* dlogits, float* footprints, void* stream) {
     if (!logits_bf16 || !labels || !ce_map || !sel3 || !gout || !dlogits || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
     if (K < 1 || K > 32 || Kp < K || sw % 8 != 0 || sh % 8 != 0 || sb % 8 != 0) return MGN_ENOTSUP;
     if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
-    const UpGeom g = make_geom(B, h, w, H, W, sb, sh, sw);
+    UpGeom g = make_geom(B, h, w, H, W, sb, sh, sw);
+    g.foot = footprints;
     const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* lg = (const uint16_t*)logits_bf16;
@@ -622,6 +706,7 @@ int MGN_SYM(mgn_upce_bwd)(const void* logits_bf16, long sb, long sh, long sw, in
             default: hipLaunchKernelGGL(upce_bwd<4>, gr, dim3(TPB), lds, s, lg, gg, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
         }
     });
+    if (footprints) launch_gather(g, K, dlogits, Kp, s);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -671,12 +756,13 @@ int MGN_SYM(mgn_ins_loss_fwd)(const float* center_lr, long csb, long csh, long c
 
 int MGN_SYM(mgn_ins_loss_bwd)(const float* center_lr, long csb, long csh, long csw, const void* offset_lr_bf16, long osb, long osh, long osw,
                      int B, int h, int w, int H, int W, const float* ct, const float* cw, const float* ot, const float* ow,
-                     float oscale, const float* out4, const float* gout2, float* dco, void* stream) {
+                     float oscale, const float* out4, const float* gout2, float* dco, float* footprints, void* stream) {
     if (!center_lr || !offset_lr_bf16 || !ct || !cw || !ot || !ow || !out4 || !gout2 || !dco || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
     if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
     InsMaps m;
     m.center = nullptr; m.center_f = center_lr; m.offset = (const uint16_t*)offset_lr_bf16;
     m.gc = make_geom(B, h, w, H, W, csb, csh, csw);
+    m.gc.foot = footprints;
     m.go = make_geom(B, h, w, H, W, osb, osh, osw);
     m.ct = ct; m.cw = cw; m.ot = ot; m.ow = ow; m.oscale = oscale;
     const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
@@ -685,6 +771,7 @@ int MGN_SYM(mgn_ins_loss_bwd)(const float* center_lr, long csb, long csh, long c
         mm.gc.bx0 = bx0; mm.gc.by0 = by0;
         hipLaunchKernelGGL(ins_bwd, gr, dim3(TPB), 0, (hipStream_t)stream, mm, out4, gout2, dco);
     });
+    if (footprints) launch_gather(m.gc, 3, dco, 4, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -698,16 +785,27 @@ int mgn_upsample1_fwd(const float* lr, int B, int h, int w, int H, int W, float*
 #endif
 
 #ifndef MGN_F16
-int mgn_upsample1_bwd(const float* dfull, int B, int h, int w, int H, int W, float* dlr_zeroed, void* stream) {
+int mgn_upsample1_bwd(const float* dfull, int B, int h, int w, int H, int W, float* dlr_zeroed, float* footprints, void* stream) {
     if (!dfull || !dlr_zeroed || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
     if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
-    const UpGeom g = make_geom(B, h, w, H, W, (long)h * w, w, 1);
+    UpGeom g = make_geom(B, h, w, H, W, (long)h * w, w, 1);
+    g.foot = footprints;
     serial_scatter(dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B), [&](dim3 gr, int bx0, int by0) {
         UpGeom gg = g;
         gg.bx0 = bx0; gg.by0 = by0;
         hipLaunchKernelGGL(up1_bwd, gr, dim3(TPB), 0, (hipStream_t)stream, dfull, gg, dlr_zeroed);
     });
+    if (footprints) launch_gather(g, 1, dlr_zeroed, 1, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+/* floats of the footprint table of the reproducible backward of mgn_upce_bwd (channels = K), mgn_ins_loss_bwd (3) and
+ * mgn_upsample1_bwd (1) for this geometry */
+int mgn_adjoint_footprint_floats(int B, int h, int w, int H, int W, int channels, size_t* floats) {
+    if (!floats || !geom_ok(B, h, w, H, W) || channels < 1) return MGN_EINVAL;
+    if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
+    *floats = footprint_floats(B, h, w, H, W, channels);
+    return MGN_OK;
 }
 #endif
 

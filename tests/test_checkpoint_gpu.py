@@ -8,10 +8,9 @@ pytestmark = pytest.mark.gpu
 
 
 def test_resume_reproduces_the_trajectory(tmp_path, monkeypatch):
-    # bf16 HIP path with the float atomics of the bilinear-adjoint kernels ordered (MGN_SERIAL_SCATTER): the step
-    # is then bit-reproducible, so the resumed trajectory has to be THE trajectory (the fp32 torch-staging convolutions this test used
-    # before are not reproducible run to run, and a 2e-3 tolerance failed about once in ten runs)
-    monkeypatch.setenv("MGN_SERIAL_SCATTER", "1")
+    # the bf16 HIP step is bit-reproducible (no order-dependent arithmetic), so the resumed trajectory has to be
+    # THE trajectory (the fp32 torch-staging convolutions this test used before are not reproducible run to run, and a 2e-3
+    # tolerance failed about once in ten runs)
     from mgnet_amd.data import synthetic_batch
     from mgnet_amd.engine import Trainer
     from mgnet_amd.solver.fused_adam import FusedAdam

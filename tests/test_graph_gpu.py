@@ -8,13 +8,6 @@ from test_network_cpu import small_model
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _ordered_atomics(monkeypatch):
-    """the float atomics of the bilinear-adjoint kernels are the step's only run-to-run variation; ordered, the
-    eager and the replayed trajectories can be compared without that noise"""
-    monkeypatch.setenv("MGN_SERIAL_SCATTER", "1")
-
-
 def _trainer(seed, amp=True):
     from mgnet_amd.engine import Trainer
     cfg, m = small_model(with_depth=True, seed=seed)

@@ -134,3 +134,38 @@ def test_depth_upsample_fwd_bwd(cfg):
     (y * gy.cuda()).sum().backward()
     assert torch.allclose(y.cpu(), yr, atol=1e-6, rtol=1e-6)
     assert torch.allclose(x.grad.cpu(), xr.grad, atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", [(2, 19, 16, 24, 8), (1, 7, 9, 13, 8), (3, 32, 5, 6, 16), (2, 19, 33, 17, 8)])
+def test_bilinear_adjoint_is_reproducible_and_equals_the_atomic_form(cfg, monkeypatch):
+    """The tile-wise bilinear adjoints (semantic / instance / depth heads) in their default form -- every tile stores its footprint,
+    a gather sums them in a fixed order into an UNINITIALISED destination -- give the same bits on every run and agree with the
+    float-atomic form (MGN_ADJOINT_ATOMICS=1) to summation-order noise, on ragged geometries (partial tiles, tiny low-res maps)."""
+    from mgnet_amd import _C
+
+    B, K, h, w, sc = cfg
+    H, W = h * sc - 3, w * sc - 5            # not a multiple of the 32 x 16 tile, align_corners geometry
+    torch.manual_seed(sum(cfg))
+    Kc = (K + 7) // 8 * 8
+    lr = torch.randn(B, Kc, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)[:, :K]
+    labels = torch.randint(0, K, (B, H, W), device="cuda")
+    labels[torch.rand(B, H, W, device="cuda") < 0.1] = 255
+    weights = torch.rand(B, H, W, device="cuda") + 0.5
+    ce, sums = _C.upce_fwd(lr, labels, weights, H, W, 255, 0.3)
+    sel, _ = _C.ohem_select(ce, sums, 0.3, max(1, B * H * W // 16), False)
+    sel = sel.float().contiguous()
+    g = torch.ones(1, device="cuda")
+    dfull = torch.randn(B, 1, H, W, device="cuda")
+
+    def run():
+        torch.empty(64 << 20, device="cuda").fill_(float("nan"))   # poison the allocator's free blocks: nothing may rely on zeros
+        return _C.upce_bwd(lr, labels, weights, H, W, 255, ce, sel, g, Kc).clone(), _C.upsample1_bwd(dfull, h, w).clone()
+
+    a1, b1 = run()
+    a2, b2 = run()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    assert torch.isfinite(a1).all() and torch.isfinite(b1).all() and float(a1[..., K:].abs().max() if Kc > K else 0.0) == 0.0
+    monkeypatch.setenv("MGN_ADJOINT_ATOMICS", "1")
+    a3, b3 = run()
+    assert float((a1 - a3).abs().max()) <= 2e-6 * float(a3.abs().max()) + 1e-12
+    assert float((b1 - b3).abs().max()) <= 2e-6 * float(b3.abs().max()) + 1e-12

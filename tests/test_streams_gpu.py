@@ -1,8 +1,8 @@
 """GPU: the side streams of MGNet.forward (pose network | backbone, then the three heads with their losses on three streams; the
 autograd engine replays each node on the stream of its forward; engine/reducer.py packs buckets whose gradients come from several
-streams) must not change a single bit of the training trajectory.  The only run-to-run variation of the step are the float
-atomics of the bilinear-adjoint kernels (csrc/headloss.hip scatter_tile); MGN_SERIAL_SCATTER=1 orders them, which makes the
-comparison exact."""
+streams) must not change a single bit of the training trajectory.  The step has no order-dependent arithmetic (the bilinear-adjoint
+kernels of csrc/headloss.hip sum their tile footprints in a fixed order; their float-atomic form is MGN_ADJOINT_ATOMICS=1), so
+the comparison is exact."""
 import os
 
 import pytest
@@ -38,8 +38,7 @@ def _trajectory(streams, steps, B, H, W):
     return torch.stack(losses).cpu(), [p.detach().clone().cpu() for p in model.parameters()], used
 
 
-def test_side_streams_do_not_change_the_trajectory(monkeypatch):
-    monkeypatch.setenv("MGN_SERIAL_SCATTER", "1")
+def test_side_streams_do_not_change_the_trajectory():
     try:
         l0, p0, used0 = _trajectory("0", 4, 2, 128, 256)
         l1, p1, used1 = _trajectory("1", 4, 2, 128, 256)
