@@ -269,14 +269,15 @@ int mgn_weight_layout_batch(const void* table_dev, int n_entries, long total_blo
  *                  upsampled on the fly; out4 = {sum w(c-t)^2 / sum w, sum w|o*s-t| / sum w, sum w_c, sum w_o};
  *                  backward dco [B,h,w,4] fp32 (zero-initialised) = {d centre_lr, d offset_lr[0], d offset_lr[1], 0}.
  * Low-res maps: bf16 (logits/offset) with channel stride 1 and element strides (sb, sh, sw) multiples of 8.
- * The three backward entry points (mgn_upce_bwd, mgn_ins_loss_bwd, mgn_upsample1_bwd) compute the bilinear ADJOINT per 32x16
- * pixel tile.  footprints == NULL: the tiles add their low-res footprints with float atomics (the destination must be
+ * The three backward entry points (mgn_upce_bwd, mgn_ins_loss_bwd, mgn_upsample1_bwd) compute the bilinear ADJOINT per pixel
+ * tile (32 x 8 for mgn_upce_bwd, 32 x 16 for the others).  footprints == NULL: the tiles add their low-res footprints with float atomics (the destination must be
  * zero-initialised; sums are order-dependent in the last bits).  footprints != NULL (mgn_adjoint_footprint_floats floats; channels =
  * K | 3 | 1): every tile stores its footprint into its own slot and a second kernel sums, per low-res element, the slots
  * that cover it in a fixed order -- bit-reproducible, the destination need not be initialised.
  * ---------------------------------------------------------------------------------------------- */
 int mgn_upce_partials(int B, int H, int W);
-int mgn_adjoint_footprint_floats(int B, int h, int w, int H, int W, int channels, size_t* floats);
+int mgn_adjoint_footprint_floats(int which /* 0: mgn_upce_bwd, 1: mgn_ins_loss_bwd, 2: mgn_upsample1_bwd */, int B, int h, int w, int H,
+                                 int W, int channels, size_t* floats);
 /* single-channel fp32 bilinear (align_corners=True) upsampling [B,1,h,w] -> [B,1,H,W] and its adjoint (dlr zero-initialised);
  * replaces F.interpolate at mg_net.py:804-807 (depth head, x8/x16/x32). The adjoint needs an upsampling factor >= 7. */
 int mgn_upsample1_fwd(const float* lr, int B, int h, int w, int H, int W, float* out, void* stream);

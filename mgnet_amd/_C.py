@@ -119,7 +119,7 @@ def lib():
         L.mgn_upce_partials.argtypes = [ci, ci, ci]
         L.mgn_upce_fwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp, vp]
         L.mgn_upce_bwd.argtypes = [vp, cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp]
-        L.mgn_adjoint_footprint_floats.argtypes = [ci] * 6 + [vp]
+        L.mgn_adjoint_footprint_floats.argtypes = [ci] * 7 + [vp]
         L.mgn_ohem_select_workspace_bytes.argtypes = [cl, ctypes.POINTER(sz)]
         L.mgn_ohem_select.argtypes = [vp, cl, vp, cf, cl, ci, vp, vp, vp, sz, vp]
         L.mgn_ins_loss_fwd.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp]
@@ -892,21 +892,21 @@ def ohem_select(ce, sums, thr, n_sel, force_topk):
     return out[:3], out[3]
 
 
-def _adjoint_dst(shape, dev, B, h, w, H, W, channels):
+def _adjoint_dst(which, shape, dev, B, h, w, H, W, channels):
     """destination + footprint table of the tile-wise bilinear adjoints (csrc/headloss.hip).  Default: the reproducible two-kernel
     form (every tile stores its footprint, a gather sums them in a fixed order: uninitialised destination); MGN_ADJOINT_ATOMICS=1:
     float atomics into a zeroed destination (order-dependent last bits; MGN_SERIAL_SCATTER=1 orders them, one tile per launch)."""
     if os.environ.get("MGN_ADJOINT_ATOMICS") or os.environ.get("MGN_SERIAL_SCATTER"):
         return torch.zeros(shape, dtype=torch.float32, device=dev), None
     n = ctypes.c_size_t(0)
-    check(lib().mgn_adjoint_footprint_floats(B, h, w, H, W, channels, ctypes.byref(n)), "mgn_adjoint_footprint_floats")
+    check(lib().mgn_adjoint_footprint_floats(which, B, h, w, H, W, channels, ctypes.byref(n)), "mgn_adjoint_footprint_floats")
     return torch.empty(shape, dtype=torch.float32, device=dev), torch.empty(n.value, dtype=torch.float32, device=dev)
 
 
 def upce_bwd(lr, labels, weights, H, W, ignore, ce, sel3, gout, Kp):
     B, K, h, w = lr.shape
     sb, sh, sw = _lr_strides(lr)
-    dlg, foot = _adjoint_dst((B, h, w, Kp), lr.device, B, h, w, H, W, K)
+    dlg, foot = _adjoint_dst(0, (B, h, w, Kp), lr.device, B, h, w, H, W, K)
     check(_fn("mgn_upce_bwd", lr)(lr.data_ptr(), sb, sh, sw, B, h, w, H, W, K, Kp, labels.data_ptr(),
                              None if weights is None else weights.data_ptr(), ignore, ce.data_ptr(), sel3.data_ptr(),
                              gout.data_ptr(), dlg.data_ptr(), None if foot is None else foot.data_ptr(), _stream()), "mgn_upce_bwd")
@@ -926,7 +926,7 @@ def ins_loss_fwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale):
 
 def ins_loss_bwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale, out4, gout2):
     B, _, h, w = center_lr.shape
-    dco, foot = _adjoint_dst((B, h, w, 4), ct.device, B, h, w, H, W, 3)
+    dco, foot = _adjoint_dst(1, (B, h, w, 4), ct.device, B, h, w, H, W, 3)
     cs, os_ = _lr_strides(center_lr), _lr_strides(offset_lr)
     check(_fn("mgn_ins_loss_bwd", offset_lr)(center_lr.data_ptr(), *cs, offset_lr.data_ptr(), *os_, B, h, w, H, W, ct.data_ptr(), cw.data_ptr(),
                                  ot.data_ptr(), ow.data_ptr(), oscale, out4.data_ptr(), gout2.data_ptr(), dco.data_ptr(),
@@ -944,7 +944,7 @@ def upsample1_fwd(lr, H, W):
 
 def upsample1_bwd(dfull, h, w):
     B, _, H, W = dfull.shape
-    dlr, foot = _adjoint_dst((B, 1, h, w), dfull.device, B, h, w, H, W, 1)
+    dlr, foot = _adjoint_dst(2, (B, 1, h, w), dfull.device, B, h, w, H, W, 1)
     check(lib().mgn_upsample1_bwd(dfull.data_ptr(), B, h, w, H, W, dlr.data_ptr(), None if foot is None else foot.data_ptr(), _stream()),
           "mgn_upsample1_bwd")
     return dlr

@@ -26,13 +26,17 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr int TX = 32, TY = 16;      // backward pixel tile
+constexpr int TX = 32;               // backward pixel tile: TX x TYT, TYT = 8 for the semantic head (34 KB of LDS per block: four blocks per
+                                     // CU hide the corner-load latency; 16 rows ran at two) and 16 for the 1..3-channel adjoints
+constexpr int TYU = 8, TYS = 16;
 
 struct UpGeom {
     int B, h, w, H, W;
     int bx0, by0;      // tile offset of this launch (0 unless MGN_SERIAL_SCATTER: one tile per launch, see serial_scatter())
     float* foot;       // footprint table [B][tiles y][tiles x][fr][fc][KK] of the backward tile kernels, or null (float atomics)
     int fr, fc;        // footprint bound of this geometry (rows, columns)
+    int ty;            // tile height of the kernel that fills the table
+    int kt;            // channels per table entry
     long sb, sh, sw;   // element strides of the low-res map (channel stride 1)
     float ry, rx;      // (h-1)/(H-1), (w-1)/(W-1)   (align_corners=True)
 };
@@ -100,16 +104,16 @@ constexpr int MAXC = 8, MAXR = 6;  // footprint bound of a 32x16 tile for scale 
 constexpr int RP = TX + 4;         // pitch of a residual row in LDS: res[(k*TY + yy)*RP + xx].  36 words: rows are 16-byte aligned
                                    // (the row pass reads them as float4) and eight consecutive rows start in eight different bank
                                    // quads, so those reads -- lanes along yy -- are conflict-free
-__device__ __forceinline__ int res_idx(int k, int yy, int xx) { return (k * TY + yy) * RP + xx; }
+template <int TY> __device__ __forceinline__ int res_idx(int k, int yy, int xx) { return (k * TY + yy) * RP + xx; }
 // rowsum[yy][cxi][k] with odd pitches: the column pass reads it with lanes along k (consecutive banks), the row pass writes it
 // with lanes along yy (stride YP, odd -> 16 different banks).  (The [k][yy][cxi] layout this replaces put all 24 lanes of a
 // column-pass read on ONE bank: SQ_LDS_BANK_CONFLICT was 52 % of the LDS cycles of upce_bwd, profiles/r02_upce_pmc.txt.)
-template <int KK> struct ScatterLds {
+template <int KK, int TY> struct ScatterLds {
     static constexpr int KKP = KK | 1, YP = MAXC * KKP + 1;
     static constexpr int FLOATS = KK * TY * RP + TY * YP;   // res + rowsum
 };
 
-template <int KK>
+template <int KK, int TY>
 __device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int Y0, int K, const float* res, float* rowsum,
                                              float* out, int out_stride) {
     __shared__ float wxs[TX * MAXC], wys[TY * MAXR];   // bilinear weight of tile column xx (row yy) on footprint column cxi (row cyi)
@@ -142,13 +146,13 @@ __device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int
     }
     __syncthreads();
     // rows: rowsum[yy][cxi][k] = sum_xx wxs[xx][cxi] * res[k][yy][xx]      (lanes: yy fastest, then k)
-    using L = ScatterLds<KK>;
+    using L = ScatterLds<KK, TY>;
     constexpr bool UNI = (TY * KK) % 64 == 0;   // cxi is the same for a whole wave: its 32 weights travel through ONE LDS read per
                                                 // lane and v_readlane (scalar operands of the FMAs) instead of 32 broadcast reads
     for (int o = threadIdx.x; o < TY * KK * nc; o += TPB) {
         const int yy = o % TY, k = (o / TY) % KK, cxi = o / (TY * KK);
         float acc = 0.f;
-        const float* rr = res + res_idx(k, yy, 0);
+        const float* rr = res + res_idx<TY>(k, yy, 0);
         if (UNI) {
             const float wl = wxs[(threadIdx.x & 31) * MAXC + cxi];
             float wv[TX];
@@ -173,11 +177,12 @@ __device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int
         // reproducible form: the tile's footprint goes to its own slot of the table with plain stores (zeros outside nr x nc and
         // for k >= K); adjoint_gather() then sums, per low-res element, the slots that cover it in a FIXED order
         const size_t ti = ((size_t)b * ((g.H + TY - 1) / TY) + Y0 / TY) * ((g.W + TX - 1) / TX) + X0 / TX;
-        float* slot = g.foot + ti * g.fr * g.fc * K;   // [fr][fc][K]
-        for (int o = threadIdx.x; o < g.fr * g.fc * K; o += TPB) {
-            const int k = o % K, cxi = (o / K) % g.fc, cyi = o / (K * g.fc);
+        const int KT = g.kt;                              // table channels: K rounded up to a multiple of 4 (1 for one channel)
+        float* slot = g.foot + ti * g.fr * g.fc * KT;     // [fr][fc][KT]
+        for (int o = threadIdx.x; o < g.fr * g.fc * KT; o += TPB) {
+            const int k = o % KT, cxi = (o / KT) % g.fc, cyi = o / (KT * g.fc);
             float acc = 0.f;
-            if (cxi < nc && cyi < nr) {
+            if (k < K && cxi < nc && cyi < nr) {
 #pragma unroll
                 for (int yy = 0; yy < TY; ++yy) acc += wys[yy * MAXR + cyi] * rowsum[yy * L::YP + cxi * L::KKP + k];
             }
@@ -195,38 +200,66 @@ __device__ __forceinline__ void scatter_tile(const UpGeom& g, int b, int X0, int
     }
 }
 
-// Second half of the reproducible adjoint: out[b, y, x, k] = sum over the tiles whose footprint covers (y, x), tile rows then tile
+// Second half of the reproducible adjoint: out[b, y, x, :] = sum over the tiles whose footprint covers (y, x), tile rows then tile
 // columns ascending, of their table entries.  The footprint origin of a tile is recomputed with scatter_tile's own expressions.
-// A thread per (b, y, x, k < out_stride); channels k >= K (padding of the destination) are zero.
-__global__ __launch_bounds__(TPB) void adjoint_gather(UpGeom g, int KK, float* __restrict__ out, int out_stride) {   // KK = table channels (K)
+// A thread per low-res pixel (the search for the covering tiles is done once, not per channel); the table keeps KT = 4 * KV channels
+// per entry (K rounded up: 16-byte loads); destination channels >= KT are zero.  KV = 0: single-channel tables, scalar.
+template <int KV>
+__global__ __launch_bounds__(TPB) void adjoint_gather(UpGeom g, float* __restrict__ out, int out_stride) {
+    constexpr int KT = KV ? 4 * KV : 1;
     const long i = (long)blockIdx.x * TPB + threadIdx.x;
-    if (i >= (long)g.B * g.h * g.w * out_stride) return;
-    const int k = (int)(i % out_stride);
-    long r = i / out_stride;
+    if (i >= (long)g.B * g.h * g.w) return;
+    long r = i;
     const int x = (int)(r % g.w); r /= g.w;
     const int y = (int)(r % g.h);
     const int b = (int)(r / g.h);
-    float acc = 0.f;
-    if (k < KK) {
-        const int tny = (g.H + TY - 1) / TY, tnx = (g.W + TX - 1) / TX;
-        // candidate tiles: those whose pixel rows / columns map near y / x (a generous bracket, membership is tested exactly)
-        int ty0 = 0, ty1 = tny - 1, tx0 = 0, tx1 = tnx - 1;
-        if (g.ry > 0.f) { ty0 = max(0, (int)((y - 1) / g.ry) / TY - 1); ty1 = min(tny - 1, (int)((y + 1) / g.ry) / TY + 1); }
-        if (g.rx > 0.f) { tx0 = max(0, (int)((x - 1) / g.rx) / TX - 1); tx1 = min(tnx - 1, (int)((x + 1) / g.rx) / TX + 1); }
-        for (int ty = ty0; ty <= ty1; ++ty) {
-            const int Y0 = ty * TY, Yl = min(Y0 + TY, g.H) - 1;
-            const int ly0 = min((int)(Y0 * g.ry), g.h - 1), ly1 = min(min((int)(Yl * g.ry), g.h - 1) + 1, g.h - 1);
-            if (y < ly0 || y > ly1 || y - ly0 >= g.fr) continue;
-            for (int tx = tx0; tx <= tx1; ++tx) {
-                const int X0 = tx * TX, Xl = min(X0 + TX, g.W) - 1;
-                const int lx0 = min((int)(X0 * g.rx), g.w - 1), lx1 = min(min((int)(Xl * g.rx), g.w - 1) + 1, g.w - 1);
-                if (x < lx0 || x > lx1 || x - lx0 >= g.fc) continue;
-                const size_t ti = ((size_t)b * tny + ty) * tnx + tx;
-                acc += g.foot[(ti * g.fr * g.fc + (size_t)(y - ly0) * g.fc + (x - lx0)) * KK + k];
+    float acc[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) acc[k] = 0.f;
+    const int TY = g.ty, tny = (g.H + TY - 1) / TY, tnx = (g.W + TX - 1) / TX;
+    // candidate tiles: those whose pixel rows / columns map near y / x (a generous bracket, membership is tested exactly)
+    int ty0 = 0, ty1 = tny - 1, tx0 = 0, tx1 = tnx - 1;
+    if (g.ry > 0.f) { ty0 = max(0, (int)((y - 1) / g.ry) / TY - 1); ty1 = min(tny - 1, (int)((y + 1) / g.ry) / TY + 1); }
+    if (g.rx > 0.f) { tx0 = max(0, (int)((x - 1) / g.rx) / TX - 1); tx1 = min(tnx - 1, (int)((x + 1) / g.rx) / TX + 1); }
+    for (int ty = ty0; ty <= ty1; ++ty) {
+        const int Y0 = ty * TY, Yl = min(Y0 + TY, g.H) - 1;
+        const int ly0 = min((int)(Y0 * g.ry), g.h - 1), ly1 = min(min((int)(Yl * g.ry), g.h - 1) + 1, g.h - 1);
+        if (y < ly0 || y > ly1 || y - ly0 >= g.fr) continue;
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            const int X0 = tx * TX, Xl = min(X0 + TX, g.W) - 1;
+            const int lx0 = min((int)(X0 * g.rx), g.w - 1), lx1 = min(min((int)(Xl * g.rx), g.w - 1) + 1, g.w - 1);
+            if (x < lx0 || x > lx1 || x - lx0 >= g.fc) continue;
+            const size_t ti = ((size_t)b * tny + ty) * tnx + tx;
+            const float* e = g.foot + (ti * g.fr * g.fc + (size_t)(y - ly0) * g.fc + (x - lx0)) * KT;
+            if (KV) {
+#pragma unroll
+                for (int v = 0; v < (KV ? KV : 1); ++v) {
+                    const float4 q = *reinterpret_cast<const float4*>(e + 4 * v);
+                    acc[4 * v] += q.x; acc[4 * v + 1] += q.y; acc[4 * v + 2] += q.z; acc[4 * v + 3] += q.w;
+                }
+            } else {
+                acc[0] += e[0];
             }
         }
     }
-    out[i] = acc;
+    float* o = out + i * out_stride;
+    if (KV && out_stride % 4 == 0) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {   // (out_stride <= 32)
+            if (4 * v >= out_stride) break;
+            const float4 q = v < KV ? make_float4(acc[4 * (v < KV ? v : 0)], acc[4 * (v < KV ? v : 0) + 1], acc[4 * (v < KV ? v : 0) + 2], acc[4 * (v < KV ? v : 0) + 3])
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(o + 4 * v) = q;
+        }
+    } else {
+        for (int k = 0; k < out_stride; ++k) {
+            float v = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk)
+                if (kk == k) v = acc[kk];
+            o[k] = v;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -314,18 +347,19 @@ __global__ __launch_bounds__(TPB) void upce_bwd(const uint16_t* __restrict__ lg,
                                                 const float* __restrict__ weights, int ignore, const float* __restrict__ ce_map,
                                                 const float* __restrict__ sel, const float* __restrict__ gout, float* dlg) {
     extern __shared__ __attribute__((aligned(16))) float res[];  // [K8*8][TY][RP] residuals g*(p_k - onehot), then rowsum
-    constexpr int KK = K8 * 8;
+    constexpr int KK = K8 * 8, TY = TYU;
     const int X0 = (blockIdx.x + g.bx0) * TX, Y0 = (blockIdx.y + g.by0) * TY, b = blockIdx.z;
     const float tau = sel[0], tie_w = sel[1], scale = sel[2] * gout[0];
     // ---- phase 1: residual vectors of the tile's pixels.  A thread owns TWO pixels (rows yy and yy + 8 of column xx): their
     // scalars are loaded first, then -- under ONE wave-uniform branch, so that the twelve 16-byte corner loads of both pixels
     // sit in one basic block and are in flight together (2 waves per SIMD are all the LDS footprint leaves for hiding them) --
     // the interpolated soft-max of both
-    static_assert(TX * TY == 2 * TPB, "two pixels per thread");
-    float gpx[2];
-    int lab[2], Xc[2], Yc[2];
+    constexpr int NPX = TX * TY / TPB;   // pixels per thread
+    static_assert(TX * TY % TPB == 0, "whole pixels per thread");
+    float gpx[NPX];
+    int lab[NPX], Xc[NPX], Yc[NPX];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NPX; ++u) {
         const int t = threadIdx.x + u * TPB;
         const int X = X0 + (t % TX), Y = Y0 + (t / TX);
         gpx[u] = 0.f;
@@ -339,15 +373,18 @@ __global__ __launch_bounds__(TPB) void upce_bwd(const uint16_t* __restrict__ lg,
             if (l != ignore && sw != 0.f) { gpx[u] = sw * scale * (weights ? weights[p] : 1.f); lab[u] = (int)l; }
         }
     }
-    if (__any(gpx[0] != 0.f || gpx[1] != 0.f)) {
-        float z[2][KK], inv[2];
+    bool any_px = false;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NPX; ++u) any_px = any_px || gpx[u] != 0.f;
+    if (__any(any_px)) {
+        float z[NPX][KK], inv[NPX];
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
             const Corner c = corners(g, b, Yc[u], Xc[u]);
             (void)interp_logits<K8, false>(lg, c, K, z[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {   // soft-max as exp(z - max) / sum: one exponential per class (not a second one against the lse)
+        for (int u = 0; u < NPX; ++u) {   // soft-max as exp(z - max) / sum: one exponential per class (not a second one against the lse)
             float m = -3.0e38f;
 #pragma unroll
             for (int k = 0; k < KK; ++k)
@@ -361,22 +398,22 @@ __global__ __launch_bounds__(TPB) void upce_bwd(const uint16_t* __restrict__ lg,
             inv[u] = gpx[u] / sum;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NPX; ++u) {
             const int t = threadIdx.x + u * TPB;
 #pragma unroll
-            for (int k = 0; k < KK; ++k) res[res_idx(k, t / TX, t % TX)] = k < K ? fmaf(z[u][k], inv[u], k == lab[u] ? -gpx[u] : 0.f) : 0.f;
+            for (int k = 0; k < KK; ++k) res[res_idx<TY>(k, t / TX, t % TX)] = k < K ? fmaf(z[u][k], inv[u], k == lab[u] ? -gpx[u] : 0.f) : 0.f;
         }
     } else {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NPX; ++u) {
             const int t = threadIdx.x + u * TPB;
 #pragma unroll
-            for (int k = 0; k < KK; ++k) res[res_idx(k, t / TX, t % TX)] = 0.f;
+            for (int k = 0; k < KK; ++k) res[res_idx<TY>(k, t / TX, t % TX)] = 0.f;
         }
     }
     __syncthreads();
     // ---- phase 2: separable bilinear adjoint of the tile into its low-res footprint
-    scatter_tile<KK>(g, b, X0, Y0, K, res, res + KK * TY * RP, dlg, Kp);
+    scatter_tile<KK, TY>(g, b, X0, Y0, K, res, res + KK * TY * RP, dlg, Kp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -449,7 +486,8 @@ __global__ __launch_bounds__(SUMT) void sum4_kernel(const float* partials, int n
 
 // gout = {d/d loss_center, d/d loss_offset}; sums = output of sum4_kernel
 __global__ __launch_bounds__(TPB) void ins_bwd(InsMaps m, const float* __restrict__ sums, const float* __restrict__ gout, float* dco) {
-    __shared__ __attribute__((aligned(16))) float res[ScatterLds<4>::FLOATS];
+    constexpr int TY = TYS;
+    __shared__ __attribute__((aligned(16))) float res[ScatterLds<4, TY>::FLOATS];
     const int X0 = (blockIdx.x + m.gc.bx0) * TX, Y0 = (blockIdx.y + m.gc.by0) * TY, b = blockIdx.z;
     const UpGeom& g = m.gc;  // centre and offset maps share the geometry
     const float sc = sums[2] > 0.f ? gout[0] / sums[2] : 0.f, so = sums[3] > 0.f ? gout[1] / sums[3] : 0.f;
@@ -467,14 +505,15 @@ __global__ __launch_bounds__(TPB) void ins_bwd(InsMaps m, const float* __restric
             r1 = wo * (float)((d0 > 0.f) - (d0 < 0.f));
             r2 = wo * (float)((d1 > 0.f) - (d1 < 0.f));
         }
-        res[res_idx(0, t / TX, t % TX)] = r0; res[res_idx(1, t / TX, t % TX)] = r1; res[res_idx(2, t / TX, t % TX)] = r2;
+        res[res_idx<TY>(0, t / TX, t % TX)] = r0; res[res_idx<TY>(1, t / TX, t % TX)] = r1; res[res_idx<TY>(2, t / TX, t % TX)] = r2;
     }
     __syncthreads();
-    scatter_tile<4>(g, b, X0, Y0, 3, res, res + 4 * TY * RP, dco, 4);
+    scatter_tile<4, TY>(g, b, X0, Y0, 3, res, res + 4 * TY * RP, dco, 4);
 }
 
-// a 32x16 pixel tile must fall into at most MAXC x MAXR low-res cells
+// a 32 x 16 pixel tile (the tallest) must fall into at most MAXC x MAXR low-res cells
 inline bool footprint_ok(int h, int w, int H, int W) {
+    constexpr int TY = TYS;
     const double rx = W > 1 ? (double)(w - 1) / (W - 1) : 0.0, ry = H > 1 ? (double)(h - 1) / (H - 1) : 0.0;
     return (TX - 1) * rx + 3 <= MAXC && (TY - 1) * ry + 3 <= MAXR;
 }
@@ -491,14 +530,15 @@ __global__ __launch_bounds__(TPB) void up1_fwd(const float* __restrict__ lr, UpG
 }
 
 __global__ __launch_bounds__(TPB) void up1_bwd(const float* __restrict__ dfull, UpGeom g, float* dlr) {
-    __shared__ __attribute__((aligned(16))) float res[ScatterLds<1>::FLOATS];
+    constexpr int TY = TYS;
+    __shared__ __attribute__((aligned(16))) float res[ScatterLds<1, TY>::FLOATS];
     const int X0 = (blockIdx.x + g.bx0) * TX, Y0 = (blockIdx.y + g.by0) * TY, b = blockIdx.z;
     for (int t = threadIdx.x; t < TX * TY; t += TPB) {
         const int X = X0 + (t % TX), Y = Y0 + (t / TX);
-        res[res_idx(0, t / TX, t % TX)] = (X < g.W && Y < g.H) ? dfull[((long)b * g.H + Y) * g.W + X] : 0.f;
+        res[res_idx<TY>(0, t / TX, t % TX)] = (X < g.W && Y < g.H) ? dfull[((long)b * g.H + Y) * g.W + X] : 0.f;
     }
     __syncthreads();
-    scatter_tile<1>(g, b, X0, Y0, 1, res, res + TY * RP, dlr, 1);
+    scatter_tile<1, TY>(g, b, X0, Y0, 1, res, res + TY * RP, dlr, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -613,7 +653,7 @@ inline void serial_scatter(dim3 grid, F&& launch) {   // launch(grid, bx0, by0)
 inline int geom_ok(int B, int h, int w, int H, int W) { return B >= 1 && h >= 2 && w >= 2 && H >= h && W >= w; }
 
 // exact footprint bound of this geometry: the largest low-res extent of any TX x TY tile, with scatter_tile's own (float) expressions
-inline void footprint_bound(int h, int w, int H, int W, int* fr, int* fc) {
+inline void footprint_bound(int h, int w, int H, int W, int TY, int* fr, int* fc) {
     const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     int r = 1, c = 1;
     for (int Y0 = 0; Y0 < H; Y0 += TY) {
@@ -630,25 +670,38 @@ inline void footprint_bound(int h, int w, int H, int W, int* fr, int* fc) {
     }
     *fr = r < MAXR ? r : MAXR; *fc = c < MAXC ? c : MAXC;
 }
-inline size_t footprint_floats(int B, int h, int w, int H, int W, int KK) {
+inline size_t footprint_floats(int B, int h, int w, int H, int W, int KK, int TY) {
     int fr, fc;
-    footprint_bound(h, w, H, W, &fr, &fc);
+    footprint_bound(h, w, H, W, TY, &fr, &fc);
     return (size_t)B * ((H + TY - 1) / TY) * ((W + TX - 1) / TX) * fr * fc * KK;
 }
 
-inline UpGeom make_geom(int B, int h, int w, int H, int W, long sb, long sh, long sw) {
+inline UpGeom make_geom(int B, int h, int w, int H, int W, long sb, long sh, long sw, int TY = TYS) {
     UpGeom g;
     g.B = B; g.h = h; g.w = w; g.H = H; g.W = W; g.sb = sb; g.sh = sh; g.sw = sw; g.bx0 = g.by0 = 0;
-    g.foot = nullptr;
-    footprint_bound(h, w, H, W, &g.fr, &g.fc);
+    g.foot = nullptr; g.ty = TY; g.kt = 1;
+    footprint_bound(h, w, H, W, TY, &g.fr, &g.fc);
     g.ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     g.rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     return g;
 }
 
-inline void launch_gather(const UpGeom& g, int KK, float* out, int out_stride, hipStream_t s) {
-    const long n = (long)g.B * g.h * g.w * out_stride;
-    hipLaunchKernelGGL(adjoint_gather, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, g, KK, out, out_stride);
+inline int table_channels(int K) { return K == 1 ? 1 : (K + 3) / 4 * 4; }
+
+inline void launch_gather(const UpGeom& g, float* out, int out_stride, hipStream_t s) {
+    const long n = (long)g.B * g.h * g.w;
+    const dim3 grid((unsigned)((n + TPB - 1) / TPB)), blk(TPB);
+    switch (g.kt / 4) {
+        case 0: hipLaunchKernelGGL(adjoint_gather<0>, grid, blk, 0, s, g, out, out_stride); break;
+        case 1: hipLaunchKernelGGL(adjoint_gather<1>, grid, blk, 0, s, g, out, out_stride); break;
+        case 2: hipLaunchKernelGGL(adjoint_gather<2>, grid, blk, 0, s, g, out, out_stride); break;
+        case 3: hipLaunchKernelGGL(adjoint_gather<3>, grid, blk, 0, s, g, out, out_stride); break;
+        case 4: hipLaunchKernelGGL(adjoint_gather<4>, grid, blk, 0, s, g, out, out_stride); break;
+        case 5: hipLaunchKernelGGL(adjoint_gather<5>, grid, blk, 0, s, g, out, out_stride); break;
+        case 6: hipLaunchKernelGGL(adjoint_gather<6>, grid, blk, 0, s, g, out, out_stride); break;
+        case 7: hipLaunchKernelGGL(adjoint_gather<7>, grid, blk, 0, s, g, out, out_stride); break;
+        default: hipLaunchKernelGGL(adjoint_gather<8>, grid, blk, 0, s, g, out, out_stride); break;
+    }
 }
 
 }  // namespace
@@ -683,17 +736,17 @@ int MGN_SYM(mgn_upce_bwd)(const void* logits_bf16, long sb, long sh, long sw, in
     if (!logits_bf16 || !labels || !ce_map || !sel3 || !gout || !dlogits || !geom_ok(B, h, w, H, W)) return MGN_EINVAL;
     if (K < 1 || K > 32 || Kp < K || sw % 8 != 0 || sh % 8 != 0 || sb % 8 != 0) return MGN_ENOTSUP;
     if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
-    UpGeom g = make_geom(B, h, w, H, W, sb, sh, sw);
-    g.foot = footprints;
-    const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
+    UpGeom g = make_geom(B, h, w, H, W, sb, sh, sw, TYU);
+    g.foot = footprints; g.kt = table_channels(K);
+    const dim3 grid((W + TX - 1) / TX, (H + TYU - 1) / TYU, B);
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* lg = (const uint16_t*)logits_bf16;
     const int k8 = (K + 7) / 8;
-    const size_t lds = sizeof(float) * (k8 == 1 ? ScatterLds<8>::FLOATS : k8 == 2 ? ScatterLds<16>::FLOATS : k8 == 3 ? ScatterLds<24>::FLOATS : ScatterLds<32>::FLOATS);
+    const size_t lds = sizeof(float) * (k8 == 1 ? ScatterLds<8, TYU>::FLOATS : k8 == 2 ? ScatterLds<16, TYU>::FLOATS : k8 == 3 ? ScatterLds<24, TYU>::FLOATS : ScatterLds<32, TYU>::FLOATS);
     static bool attr = false;
     if (!attr) {   // more than 64 KB of dynamic LDS for 17..32 classes
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upce_bwd<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ScatterLds<24>::FLOATS));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upce_bwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ScatterLds<32>::FLOATS));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upce_bwd<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ScatterLds<24, TYU>::FLOATS));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upce_bwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ScatterLds<32, TYU>::FLOATS));
         attr = true;
     }
     serial_scatter(grid, [&](dim3 gr, int bx0, int by0) {
@@ -706,7 +759,7 @@ int MGN_SYM(mgn_upce_bwd)(const void* logits_bf16, long sb, long sh, long sw, in
             default: hipLaunchKernelGGL(upce_bwd<4>, gr, dim3(TPB), lds, s, lg, gg, K, Kp, labels, weights, ignore, ce_map, sel3, gout, dlogits); break;
         }
     });
-    if (footprints) launch_gather(g, K, dlogits, Kp, s);
+    if (footprints) launch_gather(g, dlogits, Kp, s);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -762,16 +815,16 @@ int MGN_SYM(mgn_ins_loss_bwd)(const float* center_lr, long csb, long csh, long c
     InsMaps m;
     m.center = nullptr; m.center_f = center_lr; m.offset = (const uint16_t*)offset_lr_bf16;
     m.gc = make_geom(B, h, w, H, W, csb, csh, csw);
-    m.gc.foot = footprints;
+    m.gc.foot = footprints; m.gc.kt = table_channels(3);
     m.go = make_geom(B, h, w, H, W, osb, osh, osw);
     m.ct = ct; m.cw = cw; m.ot = ot; m.ow = ow; m.oscale = oscale;
-    const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
+    const dim3 grid((W + TX - 1) / TX, (H + TYS - 1) / TYS, B);
     serial_scatter(grid, [&](dim3 gr, int bx0, int by0) {
         InsMaps mm = m;
         mm.gc.bx0 = bx0; mm.gc.by0 = by0;
         hipLaunchKernelGGL(ins_bwd, gr, dim3(TPB), 0, (hipStream_t)stream, mm, out4, gout2, dco);
     });
-    if (footprints) launch_gather(m.gc, 3, dco, 4, (hipStream_t)stream);
+    if (footprints) launch_gather(m.gc, dco, 4, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
@@ -790,21 +843,21 @@ int mgn_upsample1_bwd(const float* dfull, int B, int h, int w, int H, int W, flo
     if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
     UpGeom g = make_geom(B, h, w, H, W, (long)h * w, w, 1);
     g.foot = footprints;
-    serial_scatter(dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B), [&](dim3 gr, int bx0, int by0) {
+    serial_scatter(dim3((W + TX - 1) / TX, (H + TYS - 1) / TYS, B), [&](dim3 gr, int bx0, int by0) {
         UpGeom gg = g;
         gg.bx0 = bx0; gg.by0 = by0;
         hipLaunchKernelGGL(up1_bwd, gr, dim3(TPB), 0, (hipStream_t)stream, dfull, gg, dlr_zeroed);
     });
-    if (footprints) launch_gather(g, 1, dlr_zeroed, 1, (hipStream_t)stream);
+    if (footprints) launch_gather(g, dlr_zeroed, 1, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-/* floats of the footprint table of the reproducible backward of mgn_upce_bwd (channels = K), mgn_ins_loss_bwd (3) and
- * mgn_upsample1_bwd (1) for this geometry */
-int mgn_adjoint_footprint_floats(int B, int h, int w, int H, int W, int channels, size_t* floats) {
-    if (!floats || !geom_ok(B, h, w, H, W) || channels < 1) return MGN_EINVAL;
+/* floats of the footprint table of the reproducible backward of which = 0: mgn_upce_bwd (channels = K), 1: mgn_ins_loss_bwd (3),
+ * 2: mgn_upsample1_bwd (1) for this geometry (the kernels use different tile heights) */
+int mgn_adjoint_footprint_floats(int which, int B, int h, int w, int H, int W, int channels, size_t* floats) {
+    if (!floats || !geom_ok(B, h, w, H, W) || channels < 1 || which < 0 || which > 2) return MGN_EINVAL;
     if (!footprint_ok(h, w, H, W)) return MGN_ENOTSUP;
-    *floats = footprint_floats(B, h, w, H, W, channels);
+    *floats = footprint_floats(B, h, w, H, W, table_channels(channels), which == 0 ? TYU : TYS);
     return MGN_OK;
 }
 #endif
