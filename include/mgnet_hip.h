@@ -500,6 +500,9 @@ int mgn_vec_linear_bwd(const float* dout, const float* out, const float* in, con
  *   mgn_concat2 / mgn_split2            : torch.cat([a, b], dim=1) (layers.py:316) and the split of its gradient
  * ---------------------------------------------------------------------------------------------- */
 int mgn_add_relu_fwd(const void* a, const void* b, void* y, long n_elems, void* stream);
+/* y = a + b (+ c) on 16-bit tensors, fp32 sum, one rounding: the gradient of a tensor consumed by three branches (the backbone
+ * features feed the semantic, instance and depth heads, mg_net.py:290-311) in one pass; c may be NULL */
+int mgn_sum3(const void* a, const void* b, const void* c, void* y, long n_elems, void* stream);
 /* BasicBlock tail (res_net.py:62-79) with the second InPlaceABNSync(identity) folded in:
  * y = relu(bf16(scale[c] * x + offset[c]) + shortcut), x [M,C] bf16 = conv2 output (kept for the backward), C % 8 == 0. */
 int mgn_abn_add_relu_fwd(const void* x, const float* scale, const float* offset, const void* shortcut, void* y, long M, int C,
@@ -569,6 +572,7 @@ int mgn_conv3x3_win_f16(const void* in, const void* w, void* out, int N, int H, 
 int mgn_conv_wgrad_partial_f16(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
     int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
 int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);
+int mgn_sum3_f16(const void* a, const void* b, const void* c, void* y, long n_elems, void* stream);
 int mgn_abn_add_relu_fwd_f16(const void* x, const float* scale, const float* offset, const void* shortcut, void* y,
     long M, int C, void* stream);
 int mgn_relu_mask_bwd_f16(const void* dy, const void* y, void* dx, long n_elems, void* stream);

@@ -48,6 +48,25 @@ __global__ __launch_bounds__(TPB) void add_relu_fwd(const uint4* __restrict__ a,
         y[i] = pack8(va);
     }
 }
+// sum of the gradients of a tensor consumed by three branches (the backbone features feed the three heads): one pass, one rounding
+// (autograd's own accumulation is two passes with an intermediate 16-bit tensor); c may be null
+__global__ __launch_bounds__(TPB) void sum3_h16(const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ c,
+                                                uint4* __restrict__ y, long nvec) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+        float va[8], vb[8], vc[8];
+        unpack8(a[i], va);
+        unpack8(b[i], vb);
+        if (c) {
+            unpack8(c[i], vc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) va[k] = (va[k] + vb[k]) + vc[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) va[k] += vb[k];
+        }
+        y[i] = pack8(va);
+    }
+}
 // residual-block tail with the second norm folded in: y = relu(bf16(scale[c] * x + offset[c]) + b)  -- the value the separate
 // in-place norm + add_relu_fwd produce, without writing the normalised map (x, the conv output, is kept for the backward)
 __global__ __launch_bounds__(TPB) void abn_add_relu_fwd(const uint4* __restrict__ x, const float* __restrict__ scale,
@@ -244,6 +263,12 @@ extern "C" {
 int MGN_SYM(mgn_add_relu_fwd)(const void* a, const void* b, void* y, long n_elems, void* stream) {
     if (!a || !b || !y || n_elems < 8 || n_elems % 8) return MGN_EINVAL;
     hipLaunchKernelGGL(add_relu_fwd, dim3(blocks_for(n_elems / 8)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b, (uint4*)y, n_elems / 8);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int MGN_SYM(mgn_sum3)(const void* a, const void* b, const void* c, void* y, long n_elems, void* stream) {
+    if (!a || !b || !y || n_elems < 8 || n_elems % 8) return MGN_EINVAL;
+    hipLaunchKernelGGL(sum3_h16, dim3(blocks_for(n_elems / 8)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b, (const uint4*)c,
+                       (uint4*)y, n_elems / 8);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 int MGN_SYM(mgn_abn_add_relu_fwd)(const void* x, const float* scale, const float* offset, const void* b, void* y, long M, int C, void* stream) {

@@ -248,19 +248,25 @@ class MGNet(nn.Module):
         # the three heads and their losses: semantic on the current stream, instance on side stream 0 (after the pose network),
         # depth on side stream 1 (its loss reads the poses of stream 0)
         losses = {}
+        f_sem = f_ins = f_dep = features
+        if self.with_panoptic and self.with_depth:
+            # every feature map feeds all three heads: three aliases whose gradients one kernel sums (ops.fanout3)
+            from . import ops
+            fan = {k: ops.fanout3(v) for k, v in features.items()}
+            f_sem, f_ins, f_dep = ({k: t[j] for k, t in fan.items()} for j in range(3))
         if side:
-            handover(main, side[0], features, targets)
-            handover(main, side[1], features, targets)
+            handover(main, side[0], f_ins, targets)
+            handover(main, side[1], f_dep, targets)
         if self.with_panoptic:
-            outputs["sem_seg"] = self.sem_seg_head(features)
+            outputs["sem_seg"] = self.sem_seg_head(f_sem)
             losses.update(self.sem_seg_head.losses(outputs, targets))
             with on(0):
-                outputs["center"], outputs["offset"] = self.ins_embed_head(features)
+                outputs["center"], outputs["offset"] = self.ins_embed_head(f_ins)
                 l_ins = self.ins_embed_head.losses(outputs, targets)
             losses.update(l_ins)
         if self.with_depth:
             with on(1):
-                outputs["depth"] = self.depth_head(features)
+                outputs["depth"] = self.depth_head(f_dep)
                 if side:
                     handover(side[0], side[1], outputs.get("poses"))
                 l_depth = self.depth_head.losses(outputs, targets)

@@ -356,6 +356,35 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=Fals
     return (y, x) if with_skip else y
 
 
+class _FanoutFn(torch.autograd.Function):
+    """x -> (x, x, x) for a tensor three branches consume (the backbone features and the three heads, mg_net.py:290-311): the backward
+    sums the three gradients in ONE pass ([HIP] csrc/eltwise.hip sum3) instead of autograd's two accumulation passes."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        from .. import _C
+        gs = [g for g in (g0, g1, g2) if g is not None]
+        if len(gs) <= 1:
+            return gs[0] if gs else None
+        same = all(g.dtype == gs[0].dtype and g.shape == gs[0].shape and g.stride() == gs[0].stride() for g in gs)
+        if same and gs[0].is_cuda and gs[0].dtype in _C.H16 and gs[0].numel() % 8 == 0 and \
+                (gs[0].is_contiguous() or gs[0].is_contiguous(memory_format=torch.channels_last)):
+            return _C.sum3(*gs)
+        out = gs[0] + gs[1]
+        return out + gs[2] if len(gs) == 3 else out
+
+
+def fanout3(x):
+    """three aliases of x whose gradients are summed by one kernel"""
+    if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled() and not os.environ.get("MGN_NO_FANOUT"):
+        return _FanoutFn.apply(x)
+    return x, x, x
+
+
 class _MaxPoolFn(torch.autograd.Function):
     """[HIP] csrc/pool.hip"""
 

@@ -96,3 +96,29 @@ def test_u8_frames_to_f32_is_exactly_float_div_255():
     # unsupported layouts fall back (None): not a multiple of 16 bytes, non-contiguous
     assert _C.u8_frames_to_f32([torch.zeros(3, 5, 7, dtype=torch.uint8, device="cuda")], 255.0) is None
     assert _C.u8_frames_to_f32([frames[0].transpose(1, 2)], 255.0) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fanout3_sums_the_three_gradients_in_one_pass(dtype):
+    """ops.fanout3 (backbone features -> three heads): three aliases in the forward; the backward is a + b + c in fp32 with one rounding
+    (csrc/eltwise.hip sum3), also with one branch unused (two gradients) and for a layout the kernel does not take (fallback)."""
+    from mgnet_amd import _C
+    from mgnet_amd.modeling import ops
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 64, 12, 20, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    a, b, c = ops.fanout3(x)
+    assert a.data_ptr() == x.data_ptr() and torch.equal(a, x) and torch.equal(c, x)
+    g = [torch.randn_like(x) for _ in range(3)]
+    (a.float() * g[0].float()).sum().backward(retain_graph=True)
+    assert torch.equal(x.grad, g[0])                                                     # one gradient: passed through
+    x.grad = None
+    ((a.float() * g[0].float()).sum() + (b.float() * g[1].float()).sum() + (c.float() * g[2].float()).sum()).backward()
+    ref = ((g[0].float() + g[1].float()) + g[2].float()).to(dtype)
+    assert torch.equal(x.grad, ref)
+    assert torch.equal(_C.sum3(g[0], g[1]), (g[0].float() + g[1].float()).to(dtype))
+    # a shape the 16-byte kernel does not take (numel % 8 != 0): torch fallback, same value up to the intermediate rounding
+    y = torch.randn(1, 3, 5, 7, device="cuda").to(dtype).requires_grad_(True)
+    u, v, w = ops.fanout3(y)
+    (u.float().sum() + 2 * v.float().sum() + 3 * w.float().sum()).backward()
+    assert torch.allclose(y.grad.float(), torch.full_like(y, 6.0).float())
