@@ -171,7 +171,7 @@ def full_step_bench(args, world, rank, dev):
     # Execution mode of the timed steps: "eager" (default) = the launches of a step issued from Python, with the independent
     # branches of MGNet.forward on side streams (pose network | backbone, three heads: concurrent short kernels, hidden dispatch
     # latency); "graph" (--graph on, one rank only) = the whole step captured once in a hipGraph on ONE stream and replayed.
-    # Measured: eager + side streams 32.3 ms, graph 35.8 ms (capturing the side-stream branches crashes hipGraph on ROCm 7.0).
+    # Measured (end of round 2): eager + side streams 30.2 ms, graph 32.5 ms (capturing the side-stream branches crashes hipGraph on ROCm 7.0).
     use_graph = args.graph == "on" and world == 1
     mode = "eager"
     for _ in range(max(args.warmup, 3) if use_graph else args.warmup):
