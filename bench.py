@@ -23,8 +23,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
-FWD_BYTES_PER_PX = 49 + 12     # march kernel: reads 3 inv + 9 image floats + mask, writes 3 grad floats
+FWD_BYTES_PER_PX = 49 + 12     # march kernel on the reference's fp32 frames: reads 3 inv + 9 image floats + mask, writes 3 grad floats
 BWD_BYTES_PER_PX = 37 + 12     # streaming backward: 3 inv + 3 img + mask + 3 g (read) ; 3 d_inv (write)
+FWD_BYTES_PER_PX_U8 = 25 + 12  # ... on uint8 RGBX frames (frame_layout 2, what the training step uses): 3 inv floats + 3 packed pixels + mask
+BWD_BYTES_PER_PX_U8 = 29 + 12
+
+
+def reproj_roofline(kern_ms, npx, u8, traffic, extra=None):
+    """roofline object of reproj_march<true>.  `achieved` counts the ALGORITHMIC bytes of the kernel that ran -- with uint8 RGBX frames
+    that is 37 B/px, not the 61 B/px of the reference's fp32 tensors; the 61 B/px equivalent (comparable with the
+    round-1/2 lines, which ran the fp32 layout) is reported next to it."""
+    bpp = FWD_BYTES_PER_PX_U8 if u8 else FWD_BYTES_PER_PX
+    achieved = bpp * npx / (kern_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": "reproj_march<true, %s> (fused reprojection loss + photometric gradient)" % ("uint8 RGBX frames" if u8 else "fp32 planar frames"),
+         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+         "traffic": traffic, "bytes_per_px": bpp, "bytes_per_launch": bpp * npx, "avg_launch_ms": round(kern_ms, 4),
+         "achieved_at_61_B_per_px": round(FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9, 1),
+         "frac_at_61_B_per_px": round(FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "limiter": "VALU issue + vector-memory instruction rate, not HBM (DESIGN.md 2.4: counted)"}
+    r.update(extra or {})
+    return r
 
 
 def synth_batch(B, H, W, seed, device):
@@ -248,12 +266,12 @@ def full_step_bench(args, world, rank, dev):
     if rank == 0:
         kern_ms = float(np.median(ev.elapsed_ms()))
         npx = B * H * W
-        achieved = FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9
+        u8_frames = model._orig_frames_u8(batch) is not None     # the layout MGNet.forward hands to the loss for this batch
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if (tj.get("B"), tj.get("H"), tj.get("W")) == (B, H, W):
+            if (tj.get("B"), tj.get("H"), tj.get("W")) == (B, H, W) and bool(tj.get("u8_frames", False)) == u8_frames:
                 traffic = tj.get("hbm_bytes_per_launch")
         img_s = world * B * args.steps / dt
         # forward conv FLOPs per image scale with the pixel count; training ~ 3x forward
@@ -270,18 +288,15 @@ def full_step_bench(args, world, rank, dev):
                        "frames_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
                        "parallelism": f"dp{world}", "step_execution": mode + (" (one hipGraph replay per step, one stream)" if mode == "graph" else
                                                   " (launches issued from Python; side streams for the independent branches: " +
-                                                  ("on" if getattr(model, "_streams", None) else "off") + ")"),
+                                                  ("on" if model._side_streams() is not None else "off") + ")"),
                        "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2),
                        "host_issue_ms_per_step_unloaded": None if host_unloaded is None else round(host_unloaded, 2), "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
                        "losses": {k: round(float(v.detach()), 5) for k, v in last.items()},
                        "torch_staging_ops": sorted(__import__("mgnet_amd.modeling.ops", fromlist=["x"]).STAGING_USED)},
-            "roofline": {"bound": "hbm", "kernel": "reproj_march<true> (fused reprojection loss + photometric gradient)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_launch": FWD_BYTES_PER_PX * npx, "avg_launch_ms": round(kern_ms, 4),
-                         "timed_with": "hipEvent pairs around the kernel on its launch stream, " +
-                                       (f"{args.steps} eager steps run right after the graph-replayed timed region" if mode == "graph"
-                                        else "inside the timed steps")},
+            "roofline": reproj_roofline(kern_ms, npx, u8_frames, traffic, {
+                "timed_with": "hipEvent pairs around the kernel on its launch stream, " +
+                              (f"{args.steps} eager steps run right after the graph-replayed timed region" if mode == "graph"
+                               else "inside the timed steps")}),
         }
         if dist_info is not None:
             line["config"]["distributed"] = dist_info
@@ -358,6 +373,12 @@ def main():
             t = torch.zeros((B, 4, H, W), device=dev).contiguous(memory_format=torch.channels_last)
             t[:, :3] = d[k]
             d[k] = t
+    u8_frames = bool(os.environ.get("MGN_REPROJ_U8"))
+    if u8_frames:   # diagnostic: all three frames as uint8 RGBX ([B,H,W,4] in memory), the layout the training step uses
+        for k in ("img", "prev", "nxt"):
+            t = torch.zeros((B, 4, H, W), device=dev, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+            t[:, :3] = (d[k] * 255).round().to(torch.uint8)
+            d[k] = t
     inv = [x.requires_grad_(not args.fwd_only) for x in d["inv"]]
     poses = d["poses"].requires_grad_(not args.fwd_only)
     nsteps = args.warmup + args.steps
@@ -401,12 +422,11 @@ def main():
         ms = ev.elapsed_ms()
         kern_ms = float(np.mean(ms))
         npx = B * H * W
-        achieved = FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("B") == B and tj.get("H") == H and tj.get("W") == W:
+            if tj.get("B") == B and tj.get("H") == H and tj.get("W") == W and bool(tj.get("u8_frames", False)) == u8_frames:
                 traffic = tj.get("hbm_bytes_per_launch")
         line = {
             "metric": "training img/s at 1024x2048 Cityscapes, 1/2/4/8 MI355X; reprojection-loss HBM GB/s",
@@ -418,10 +438,7 @@ def main():
                                    f"{B} frames/GPU of {H}x{W}, 3 scales, 2 context frames",
                        "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"dp{world}",
                        "loss_photometric": float(last[0]), "loss_smoothness": float(last[1])},
-            "roofline": {"bound": "hbm", "kernel": "reproj_march<true> (fused loss + photometric gradient)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_launch": FWD_BYTES_PER_PX * npx, "avg_launch_ms": round(kern_ms, 4)},
+            "roofline": reproj_roofline(kern_ms, npx, u8_frames, traffic),
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(H, W)

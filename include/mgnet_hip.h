@@ -29,6 +29,11 @@ extern "C" {
 
 #define MGN_MAX_SCALES 4
 
+/* mgn_reproj_cfg.frame_layout */
+#define MGN_FRAMES_PLANAR_F32 0
+#define MGN_FRAMES_CTX_RGBX_F32 1
+#define MGN_FRAMES_RGBX_U8 2
+
 /* library identification: "mgnet_hip <version> gfx950" */
 const char* mgn_version(void);
 
@@ -44,7 +49,7 @@ const char* mgn_version(void);
  *
  * Inputs
  *   inv_depth[n_scales] : [B,1,H,W] fp32 each (all scales already at full resolution, mg_net.py:804-807)
- *   img, prev, next     : [B,3,H,W] fp32 in [0,1]   (image_orig, image_prev_orig, image_next_orig)
+ *   img, prev, next     : [B,3,H,W] fp32 in [0,1]   (image_orig, image_prev_orig, image_next_orig); other layouts: cfg.frame_layout
  *   mask                : [B,1,H,W] uint8 (torch.bool storage) or NULL = all ones (loss.py:236-237)
  *   cam                 : camera matrices, fp32; `cam_stride` floats between images and `cam_ld` floats between
  *                         rows, so that camera_matrix[B,4,4] (cam_stride=16, cam_ld=4) is consumed in place
@@ -72,9 +77,14 @@ typedef struct {
     int photometric_reduce_op;/* 0 = "min" (only supported value), 1 = "mean" */
     int padding_mode;         /* 0 = "zeros" (only supported value), 1 = "border", 2 = "reflection" */
     int rows_per_wave;        /* 0 = choose automatically; else rows each wavefront owns (>=4) */
-    int ctx_interleaved;      /* 0: prev / next are [B,3,H,W] planes like the reference's tensors; 1: [B,H,W,4] RGBx (a 4-channel
-                                 channels_last tensor, 4th channel ignored; mgn_u8_frames_to_f32_nhwc4 produces it): one 16-byte
-                                 gather per bilinear corner instead of three 4-byte ones, same results */
+    int frame_layout;         /* MGN_FRAMES_*: how img / prev / next are laid out (same results for all three):
+                                 0 PLANAR_F32   fp32 [B,3,H,W] planes, the reference's tensors (mg_net.py:320-335 `uint8.float() / 255`)
+                                 1 CTX_RGBX_F32 prev / next fp32 [B,H,W,4] RGBx (a 4-channel channels_last tensor, 4th channel
+                                                ignored; mgn_u8_frames_to_f32_nhwc4 produces it), img planar: one 16-byte gather
+                                                per bilinear corner instead of three 4-byte ones
+                                 2 RGBX_U8      img, prev, next uint8 [B,H,W,4] RGBX (mgn_u8_frames_to_rgbx produces it from the
+                                                [3,H,W] uint8 frames the step receives): one 4-byte gather per corner, 4 B/px per
+                                                frame; the kernels convert with the exactly rounded byte / 255 */
     void* prof_begin;         /* optional hipEvent_t recorded on `stream` right before the dominant kernel */
     void* prof_end;           /* optional hipEvent_t recorded right after it (bench.py's roofline leg); NULL = off */
 } mgn_reproj_cfg;
@@ -82,7 +92,7 @@ typedef struct {
 int mgn_reproj_workspace_bytes(const mgn_reproj_cfg* cfg, size_t* bytes);
 
 int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg,
-                        const float* const* inv_depth, const float* img, const float* prev, const float* next,
+                        const float* const* inv_depth, const void* img, const void* prev, const void* next,
                         const uint8_t* mask, const float* cam, int cam_stride, int cam_ld, const float* pose,
                         int want_grad, float* losses, float* d_pose, float* const* g_inv, float* dbg_minmap,
                         void* workspace, size_t workspace_bytes, void* stream);
@@ -91,7 +101,7 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg,
  * g_inv[i] (written by the forward with want_grad=1 and the SAME workspace) is overwritten with
  * d(grad_losses . losses)/d inv_depth[i].  d_pose_out[B,2,6] = grad_losses[0] * d_pose. */
 int mgn_reproj_loss_bwd(const mgn_reproj_cfg* cfg,
-                        const float* const* inv_depth, const float* img, const uint8_t* mask,
+                        const float* const* inv_depth, const void* img, const uint8_t* mask,
                         const float* grad_losses, const float* d_pose, float* const* g_inv, float* d_pose_out,
                         const void* workspace, size_t workspace_bytes, void* stream);
 
@@ -319,8 +329,13 @@ int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int
  * (16-byte aligned) to n_per_frame bytes each (n_per_frame % 16 == 0); out: [n_frames, n_per_frame] fp32.  IEEE division. */
 int mgn_u8_frames_to_f32(const void* const* frames_u8, int n_frames, long n_per_frame, float divisor, float* out, void* stream);
 /* the same conversion of n_frames [3,H,W] uint8 frames (hw = H*W, a multiple of 4) into ONE pixel-interleaved RGBx batch
- * [n_frames][H][W][4] fp32 (4th channel 0): the context-frame layout of mgn_reproj_cfg.ctx_interleaved */
+ * [n_frames][H][W][4] fp32 (4th channel 0): the context-frame layout MGN_FRAMES_CTX_RGBX_F32 of mgn_reproj_cfg.frame_layout */
 int mgn_u8_frames_to_f32_nhwc4(const void* const* frames_u8, int n_frames, long hw, float divisor, float* out, void* stream);
+/* n_frames (<= 48: three frame sets of a batch of 16) [3,H,W] uint8 frames (4-byte aligned, hw = H*W a multiple of 4) -> ONE
+ * pixel-interleaved uint8 batch [n_frames][H][W][4] (R,G,B,0): the layout MGN_FRAMES_RGBX_U8 of the reprojection loss.  The un-jittered
+ * frames of the photometric loss (mg_net.py:320-335) stay bytes until the loss kernel converts them in registers: 7 B/px of traffic
+ * here instead of the 15 B/px of mgn_u8_frames_to_f32, and 4 B/px per frame in the loss instead of 12. */
+int mgn_u8_frames_to_rgbx(const void* const* frames_u8, int n_frames, long hw, void* out_u8, void* stream);
 
 /* The stem's activated batch norm folded into the pooling (BasicStem, res_net.py:82-110: conv -> InPlaceABNSync -> max_pool):
  * forward pools y = act(scale * x + offset) evaluated on the fly (bf16-rounded like mgn_iabn_apply stores it; the

@@ -23,7 +23,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
            "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_instance_post_workspace_bytes", "mgn_instance_post", "mgn_instance_masks", "mgn_pseudo_label_ids", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
            "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd",
-           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4",
+           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4", "mgn_u8_frames_to_rgbx",
            "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
            "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd"]
 SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
@@ -56,7 +56,7 @@ class ReprojCfg(ctypes.Structure):
                 ("ssim_loss_weight", ctypes.c_float), ("photometric_loss_weight", ctypes.c_float),
                 ("smoothing_loss_weight", ctypes.c_float), ("automask_loss", ctypes.c_int),
                 ("photometric_reduce_op", ctypes.c_int), ("padding_mode", ctypes.c_int), ("rows_per_wave", ctypes.c_int),
-                ("ctx_interleaved", ctypes.c_int), ("prof_begin", ctypes.c_void_p), ("prof_end", ctypes.c_void_p)]
+                ("frame_layout", ctypes.c_int), ("prof_begin", ctypes.c_void_p), ("prof_end", ctypes.c_void_p)]
 
 
 _lib = None
@@ -144,6 +144,7 @@ def lib():
         L.mgn_prep_input.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
         L.mgn_u8_frames_to_f32.argtypes = [vp, ci, cl, cf, vp, vp]
         L.mgn_u8_frames_to_f32_nhwc4.argtypes = [vp, ci, cl, cf, vp, vp]
+        L.mgn_u8_frames_to_rgbx.argtypes = [vp, ci, cl, vp, vp]
         L.mgn_iabn_bwd_reduce_x.argtypes = [vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, ci, cf, vp, vp, vp, sz, vp]
         L.mgn_iabn_bwd_apply_x.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp]
         L.mgn_abn_add_relu_fwd.argtypes = [vp, vp, vp, vp, vp, cl, ci, vp]
@@ -255,15 +256,22 @@ def reproj_loss_fwd(cfg, inv, img, prev, nxt, mask, cam, pose, want_grad=True, w
     """-> dict(losses[2], d_pose[B,2,6], g_inv[list], workspace, minmap)   (all device tensors, stream-ordered)"""
     dev = img.device
     inv = [_dev_f32(t, f"inv_depth[{i}]") for i, t in enumerate(inv)]
-    for n_, t in (("img", img), ("camera_matrix", cam), ("pose", pose)):
+    for n_, t in (("camera_matrix", cam), ("pose", pose)):
         _dev_f32(t, n_)
-    # context frames: [B,3,H,W] planes like the reference's tensors, or -- both -- pixel-interleaved RGBx: a [B,4,H,W] channels_last
-    # tensor ([B,H,W,4] in memory, 4th channel ignored): one 16-byte gather per bilinear corner instead of three 4-byte ones
-    ilv = all(t.dim() == 4 and t.shape[1] == 4 and t.is_contiguous(memory_format=torch.channels_last) for t in (prev, nxt))
-    for n_, t in (("prev", prev), ("next", nxt)):
-        if not (t.is_cuda and t.dtype == torch.float32 and (ilv or (t.shape[1] == 3 and t.is_contiguous()))):
-            raise ValueError(f"{n_}: expected a float32 GPU tensor, [B,3,H,W] contiguous or (both context frames) [B,4,H,W] channels_last")
-    cfg.ctx_interleaved = int(ilv)
+    # frame layouts (mgn_reproj_cfg.frame_layout): [B,3,H,W] fp32 planes like the reference's tensors; or both context frames
+    # pixel-interleaved fp32 RGBx (a [B,4,H,W] channels_last tensor = [B,H,W,4] in memory, 4th channel ignored); or ALL THREE frames
+    # as uint8 RGBX ([B,4,H,W] uint8 channels_last, what u8_frames_to_rgbx makes of the uint8 frames the step receives)
+    nhwc4 = lambda t: t.dim() == 4 and t.shape[1] == 4 and t.is_cuda and t.is_contiguous(memory_format=torch.channels_last)
+    if all(nhwc4(t) and t.dtype == torch.uint8 for t in (img, prev, nxt)):
+        cfg.frame_layout = 2
+    else:
+        _dev_f32(img, "img")
+        ilv = all(nhwc4(t) for t in (prev, nxt))
+        for n_, t in (("prev", prev), ("next", nxt)):
+            if not (t.is_cuda and t.dtype == torch.float32 and (ilv or (t.shape[1] == 3 and t.is_contiguous()))):
+                raise ValueError(f"{n_}: expected a float32 GPU tensor, [B,3,H,W] contiguous or (both context frames) [B,4,H,W] channels_last; "
+                                 "or img, prev and next all uint8 [B,4,H,W] channels_last")
+        cfg.frame_layout = int(ilv)
     if mask is not None:
         if mask.dtype not in (torch.bool, torch.uint8) or not mask.is_contiguous() or not mask.is_cuda:
             raise ValueError("reprojection_mask: expected a contiguous bool/uint8 GPU tensor")
@@ -471,6 +479,20 @@ def u8_frames_to_f32_rgbx(frames, divisor):
     out = torch.empty((len(frames), 4, H, W), dtype=torch.float32, device=f0.device, memory_format=torch.channels_last)
     ptrs = (ctypes.c_void_p * len(frames))(*[t.data_ptr() for t in frames])
     check(lib().mgn_u8_frames_to_f32_nhwc4(ptrs, len(frames), H * W, float(divisor), out.data_ptr(), _stream()), "mgn_u8_frames_to_f32_nhwc4")
+    return out
+
+
+def u8_frames_to_rgbx(frames):
+    """list of n <= 48 [3,H,W] uint8 CUDA frames -> [n,4,H,W] uint8 channels_last batch ([n,H,W,4] in memory: R,G,B,0), one launch; None if
+    unsupported.  The frame layout MGN_FRAMES_RGBX_U8 of the reprojection loss."""
+    f0 = frames[0]
+    if (len(frames) > 48 or f0.dim() != 3 or f0.shape[0] != 3 or (f0.shape[1] * f0.shape[2]) % 4
+            or any(t.dtype != torch.uint8 or not t.is_cuda or t.shape != f0.shape or not t.is_contiguous() or t.data_ptr() % 4 for t in frames)):
+        return None
+    H, W = f0.shape[1:]
+    out = torch.empty((len(frames), 4, H, W), dtype=torch.uint8, device=f0.device, memory_format=torch.channels_last)
+    ptrs = (ctypes.c_void_p * len(frames))(*[t.data_ptr() for t in frames])
+    check(lib().mgn_u8_frames_to_rgbx(ptrs, len(frames), H * W, out.data_ptr(), _stream()), "mgn_u8_frames_to_rgbx")
     return out
 
 

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void u8_frames_to_f32(U8Frames fr, long n16, f
 }
 
 // the same conversion into a pixel-interleaved RGBx batch [B][H][W][4] (4th channel 0): the layout the reprojection kernel gathers
-// with one 16-byte load per bilinear corner (mgn_reproj_cfg.ctx_interleaved); each thread converts 4 consecutive pixels
+// with one 16-byte load per bilinear corner (mgn_reproj_cfg.frame_layout = MGN_FRAMES_CTX_RGBX_F32); each thread converts 4 consecutive pixels
 __global__ __launch_bounds__(256) void u8_frames_to_f32_nhwc4(U8Frames fr, long hw4, float divisor, float* __restrict__ out) {
     const uint8_t* src = fr.f[blockIdx.y];
     float4* dst = reinterpret_cast<float4*>(out) + (long)blockIdx.y * hw4 * 4;
@@ -72,9 +72,40 @@ __global__ __launch_bounds__(256) void u8_frames_to_f32_nhwc4(U8Frames fr, long 
     }
 }
 
+// uint8 planes -> packed uint8 RGBX pixels (the frames stay bytes; the reprojection kernels convert in registers): each thread packs 4
+// consecutive pixels from three dword loads into one 16-byte store
+struct U8Frames48 { const uint8_t* f[48]; };
+__global__ __launch_bounds__(256) void u8_frames_to_rgbx(U8Frames48 fr, long hw4, uint4* __restrict__ out) {
+    const uint8_t* src = fr.f[blockIdx.y];
+    uint4* dst = out + (long)blockIdx.y * hw4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw4; i += (long)gridDim.x * 256) {
+        const uint32_t r = reinterpret_cast<const uint32_t*>(src)[i], g = reinterpret_cast<const uint32_t*>(src + hw4 * 4)[i],
+                       b = reinterpret_cast<const uint32_t*>(src + hw4 * 8)[i];
+        uint32_t px[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            px[k] = ((r >> (8 * k)) & 255u) | (((g >> (8 * k)) & 255u) << 8) | (((b >> (8 * k)) & 255u) << 16);
+        dst[i] = make_uint4(px[0], px[1], px[2], px[3]);
+    }
+}
+
 }  // namespace
 
 #ifndef MGN_F16
+extern "C" int mgn_u8_frames_to_rgbx(const void* const* frames_u8, int n_frames, long hw, void* out_u8, void* stream) {
+    if (!frames_u8 || n_frames < 1 || n_frames > 48 || hw < 4 || hw % 4 || !out_u8 || ((uintptr_t)out_u8 & 15)) return MGN_EINVAL;
+    U8Frames48 fr;
+    for (int i = 0; i < 48; ++i) {
+        fr.f[i] = i < n_frames ? (const uint8_t*)frames_u8[i] : nullptr;
+        if (i < n_frames && (!fr.f[i] || ((uintptr_t)fr.f[i] & 3))) return MGN_EINVAL;
+    }
+    const long hw4 = hw / 4;
+    long bx = (hw4 + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(u8_frames_to_rgbx, dim3((unsigned)bx, (unsigned)n_frames), dim3(256), 0, (hipStream_t)stream, fr, hw4, (uint4*)out_u8);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
 extern "C" int mgn_u8_frames_to_f32_nhwc4(const void* const* frames_u8, int n_frames, long hw, float divisor, float* out, void* stream) {
     if (!frames_u8 || n_frames < 1 || n_frames > 16 || hw < 4 || hw % 4 || !(divisor != 0.f) || !out) return MGN_EINVAL;
     U8Frames fr;

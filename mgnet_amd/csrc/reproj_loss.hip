@@ -55,9 +55,9 @@ struct Stats {         // per (image, scale), written by finalize, read by the b
 struct Params {
     const float* inv[MGN_MAX_SCALES];
     float* ginv[MGN_MAX_SCALES];
-    const float* img;
-    const float* prev;
-    const float* nxt;
+    const void* img;      // frames: fp32 planes / fp32 RGBx / uint8 RGBX according to the kernel's FMT
+    const void* prev;
+    const void* nxt;
     const uint8_t* mask;
     const CamConst* cam;
     float* partials;
@@ -173,8 +173,36 @@ __device__ __forceinline__ float bload(rsrc_t r, int voff_bytes, int soff_bytes)
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
 }
 
+// Frame formats (mgn_reproj_cfg.frame_layout):
+//   0  the reference's tensors: target and context frames [B,3,H,W] fp32 planes
+//   1  context frames pixel-interleaved fp32 RGBx [B,H,W,4] (target planar): one 16-byte gather per bilinear corner
+//   2  all three frames as the uint8 RGBX [B,H,W,4] the step receives them in (mg_net.py:320-335 computes `uint8.float() / 255` on the
+//      way in): ONE dword per pixel -- a bilinear corner is one 4-byte gather instead of three, a target / context row one coalesced
+//      dword load instead of three, 4 B/px of HBM traffic per frame instead of 12 -- converted in registers.
+constexpr int FMT_PLANAR = 0, FMT_RGBX_F32 = 1, FMT_RGBX_U8 = 2;
+
+// byte k of a packed RGBX pixel -> byte / 255 exactly as the reference's fp32 division rounds it, for every one of the 256 values
+// (tests/test_reproj_gpu.py checks all of them): v_cvt_f32_ubyte<k>, then the quotient as a two-term product with 1/255 split into
+// fp32 high and low parts -- b * hi alone is 1 ulp off for 126 of the 256 values, fma(b, hi, b * lo) for none.
+template <int K>
+__device__ __forceinline__ float u8unit(uint32_t w) {
+    constexpr float HI = (float)(1.0 / 255.0);
+    constexpr float LO = (float)(1.0 / 255.0 - (double)HI);
+    const float b = (float)((w >> (8 * K)) & 255u);
+    return fmaf(b, HI, b * LO);
+}
+__device__ __forceinline__ void u8unit3(uint32_t w, float out[3]) {
+    out[0] = u8unit<0>(w); out[1] = u8unit<1>(w); out[2] = u8unit<2>(w);
+}
+
+template <int FMT>
 struct Gather {       // the 12 corner values of one sample position (3 channel planes) and its fractional offsets
     float v[3][4];   // [channel][00, 10, 01, 11]
+    float tx, ty;
+};
+template <>
+struct Gather<FMT_RGBX_U8> {   // the four corners as packed pixels: 4 registers carried across the row instead of 12
+    uint32_t w[4];   // [00, 10, 01, 11]
     float tx, ty;
 };
 // first half: corner addresses and the 12 loads (nothing waits for them here)
@@ -182,8 +210,9 @@ struct Gather {       // the 12 corner values of one sample position (3 channel 
 // ONE 16-byte load per corner through one resource instead of three dword loads through three plane resources -- the same 12
 // values, a third of the vector-memory instructions (the kernel's second limiter after VALU issue).  (The compiler
 // narrows the 16-byte load to buffer_load_dwordx3 since only three elements are used; the 16-byte pixel keeps every load aligned.)
-template <bool ILV>
-__device__ __forceinline__ void bilinear3_issue(const rsrc_t (&plane)[3], int W, int H, float ix, float iy, Gather& g) {
+template <int FMT>
+__device__ __forceinline__ void bilinear3_issue(const rsrc_t (&plane)[3], int W, int H, float ix, float iy, Gather<FMT>& g) {
+    constexpr bool ILV = FMT == FMT_RGBX_F32;
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     g.tx = ix - fx0;
     g.ty = iy - fy0;
@@ -195,7 +224,12 @@ __device__ __forceinline__ void bilinear3_issue(const rsrc_t (&plane)[3], int W,
     const int o00 = (yi * W + xi) * PX;
     const int a00 = x0ok ? o00 : OUT, a10 = x1ok ? o00 + PX : OUT;
     const int a01 = x0ok ? o00 + PX * W : OUT, a11 = x1ok ? o00 + PX * W + PX : OUT;
-    if (ILV) {
+    if constexpr (FMT == FMT_RGBX_U8) {
+        g.w[0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(plane[0], a00, 0, 0);
+        g.w[1] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(plane[0], a10, 0, 0);
+        g.w[2] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(plane[0], a01, 0, 0);
+        g.w[3] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(plane[0], a11, 0, 0);
+    } else if constexpr (ILV) {
         // (the result goes through a float vector and .x/.y/.z: indexing an unsigned ext-vector of this builtin's result and
         //  bit-casting the element is miscompiled by this toolchain into ONE dword load splatted over the elements)
         typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -207,24 +241,34 @@ __device__ __forceinline__ void bilinear3_issue(const rsrc_t (&plane)[3], int W,
         g.v[0][1] = c10.x; g.v[1][1] = c10.y; g.v[2][1] = c10.z;
         g.v[0][2] = c01.x; g.v[1][2] = c01.y; g.v[2][2] = c01.z;
         g.v[0][3] = c11.x; g.v[1][3] = c11.y; g.v[2][3] = c11.z;
-        return;
-    }
+    } else {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        g.v[c][0] = bload(plane[c], a00, 0);
-        g.v[c][1] = bload(plane[c], a10, 0);
-        g.v[c][2] = bload(plane[c], a01, 0);
-        g.v[c][3] = bload(plane[c], a11, 0);
+        for (int c = 0; c < 3; ++c) {
+            g.v[c][0] = bload(plane[c], a00, 0);
+            g.v[c][1] = bload(plane[c], a10, 0);
+            g.v[c][2] = bload(plane[c], a01, 0);
+            g.v[c][3] = bload(plane[c], a11, 0);
+        }
     }
 }
 // second half: blend
-template <bool GRAD>
-__device__ __forceinline__ void bilinear3_finish(const Gather& g, float out[3], float ex[3], float ey[3]) {
+template <bool GRAD, int FMT>
+__device__ __forceinline__ void bilinear3_finish(const Gather<FMT>& g, float out[3], float ex[3], float ey[3]) {
     const float tx = g.tx, ty = g.ty, sx = 1.f - tx, sy = 1.f - ty;
     const float w00 = sx * sy, w10 = tx * sy, w01 = sx * ty, w11 = tx * ty;
+    float cv[4][3];
+    if constexpr (FMT == FMT_RGBX_U8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u8unit3(g.w[k], cv[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cv[k][c] = g.v[c][k];
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float v00 = g.v[c][0], v10 = g.v[c][1], v01 = g.v[c][2], v11 = g.v[c][3];
+        const float v00 = cv[0][c], v10 = cv[1][c], v01 = cv[2][c], v11 = cv[3][c];
         out[c] = v00 * w00 + v10 * w10 + v01 * w01 + v11 * w11;
         if (GRAD) {
             ex[c] = (v10 - v00) * sy + (v11 - v01) * ty;
@@ -296,8 +340,9 @@ __device__ __forceinline__ void row_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool GRAD, bool ILV = false>
+template <bool GRAD, int FMT = FMT_PLANAR>
 __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params p) {
+    constexpr bool ILV = FMT == FMT_RGBX_F32, U8 = FMT == FMT_RGBX_U8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int lane = threadIdx.x & (WAVE - 1);
@@ -329,14 +374,16 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
     const int r0 = seg * p.RH;
     const int rend = min(r0 + p.RH, H);
     const float fu = (float)ucol;
-    const float* imgb = p.img + (size_t)b * 3 * HWp;
+    const float* imgb = (const float*)p.img + (size_t)b * 3 * HWp;            // (planar fp32 target)
+    const uint32_t* img32 = (const uint32_t*)p.img + (size_t)b * HWp;          // (U8: one packed pixel per dword)
     const float ssim_w = p.ssim_w;
     const float l1_w3 = (1.f - ssim_w) * (1.f / 3.f), ssim_w3 = ssim_w * (1.f / 3.f);
     float* share = smem + (size_t)p.n * RING * NSTATE * WAVE + lane;  // [2][NSHARE][WAVE]
 
     if (wave == 0) {
         // =========================================== image wave ===========================================
-        const float* refb[2] = {p.prev + (size_t)b * (ILV ? 4 : 3) * HWp, p.nxt + (size_t)b * (ILV ? 4 : 3) * HWp};
+        const float* refb[2] = {(const float*)p.prev + (size_t)b * (ILV ? 4 : 3) * HWp, (const float*)p.nxt + (size_t)b * (ILV ? 4 : 3) * HWp};
+        const uint32_t* ref32[2] = {(const uint32_t*)p.prev + (size_t)b * HWp, (const uint32_t*)p.nxt + (size_t)b * HWp};
         const uint8_t* maskb = p.mask ? p.mask + (size_t)b * HWp : nullptr;
         float y1[3] = {0.f, 0.f, 0.f}, y2[3] = {0.f, 0.f, 0.f}, rf1[2][3], rf2[2][3];
 #pragma unroll
@@ -350,11 +397,18 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 const int vrow = reflect_clamp(s + 1, H);
                 const int off = vrow * W + ucol;
                 float y0[3], rf0[2][3];
+                if constexpr (U8) {   // three coalesced dword loads per row instead of nine
+                    const uint32_t wy = img32[off], w0 = ref32[0][off], w1 = ref32[1][off];
+                    u8unit3(wy, y0);
+                    u8unit3(w0, rf0[0]);
+                    u8unit3(w1, rf0[1]);
+                } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    y0[c] = imgb[c * HWp + off];
-                    rf0[0][c] = ILV ? refb[0][off * 4 + c] : refb[0][c * HWp + off];
-                    rf0[1][c] = ILV ? refb[1][off * 4 + c] : refb[1][c * HWp + off];
+                    for (int c = 0; c < 3; ++c) {
+                        y0[c] = imgb[c * HWp + off];
+                        rf0[0][c] = ILV ? refb[0][off * 4 + c] : refb[0][c * HWp + off];
+                        rf0[1][c] = ILV ? refb[1][off * 4 + c] : refb[1][c * HWp + off];
+                    }
                 }
                 const bool m0 = maskb ? (maskb[off] != 0) : true;
                 if (s >= r0 - 1) {
@@ -437,10 +491,12 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
             col1[j][k] = cam.M[j][k * 3 + 1];
             kt[j][k] = cam.Kt[j][k];
         }
-    const float* refb[2] = {p.prev + (size_t)b * (ILV ? 4 : 3) * HWp, p.nxt + (size_t)b * (ILV ? 4 : 3) * HWp};
-    // (ILV: one resource over the whole interleaved frame, 16 bytes per pixel; the other two entries are unused)
+    // (U8: a frame is HWp dwords = what one fp32 plane is, so the pointer arithmetic below is in dwords for every format)
+    const float* refb[2] = {(const float*)p.prev + (size_t)b * (ILV ? 4 : (U8 ? 1 : 3)) * HWp,
+                            (const float*)p.nxt + (size_t)b * (ILV ? 4 : (U8 ? 1 : 3)) * HWp};
+    // (ILV / U8: one resource over the whole interleaved frame, 16 / 4 bytes per pixel; the other two entries are unused)
     const uint32_t pbytes = ILV ? 16u * HWp : 4u * HWp;
-    const int pstep = ILV ? 0 : HWp;
+    const int pstep = (ILV || U8) ? 0 : HWp;
     const rsrc_t plane[2][3] = {{make_rsrc(refb[0], pbytes), make_rsrc(refb[0] + pstep, pbytes), make_rsrc(refb[0] + 2 * pstep, pbytes)},
                                 {make_rsrc(refb[1], pbytes), make_rsrc(refb[1] + pstep, pbytes), make_rsrc(refb[1] + 2 * pstep, pbytes)}};
     // weights realising the adjoint of F.pad(reflect): a border pixel's adjoint window is seen twice by its neighbour
@@ -475,8 +531,9 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
     // through the row barrier) alternated instead of overlapping -- with the loads removed the kernel takes 1.4 ms, with
     // them 2.5.  Now iteration t blends the corners of row t (issued one iteration earlier, carried in registers), then
     // issues the loads of row t+1, and the SSIM / adjoint stages run while those are in flight.
-    Gather gth[2];
+    Gather<FMT> gth[2];
     float y_pre[3] = {0.f, 0.f, 0.f};
+    uint32_t y_pre32 = 0u;
     float inv_pre = invb[reflect_clamp(r0 - 2, H) * W + ucol];   // inverse depth of row t+1, loaded one iteration ahead
     float inv_cur = 0.f;                                         // ... of row t
     for (int t = r0 - 3; t <= rend + 1; ++t) {
@@ -488,7 +545,7 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float ex[3], ey[3];
-                bilinear3_finish<GRAD>(gth[j], xw0[j], ex, ey);
+                bilinear3_finish<GRAD, FMT>(gth[j], xw0[j], ex, ey);
                 if (GRAD) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
@@ -497,8 +554,12 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                     }
                 }
             }
+            if constexpr (U8) {
+                u8unit3(y_pre32, y0);
+            } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) y0[c] = y_pre[c];
+                for (int c = 0; c < 3; ++c) y0[c] = y_pre[c];
+            }
         }
         const float inv0 = inv_cur;
         // ------------------------------ stage R, first half: geometry and loads of row t+1 ------------------------------
@@ -517,7 +578,7 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 const bool zf = z >= 1e-5f;             // camera.py:172 clamp(min=1e-5)
                 const float rz = frcp(fmaxf(z, 1e-5f));
                 const float ix = X * rz, iy = Y * rz;   // == ((Xn+1)/2)(W-1) of grid_sample
-                bilinear3_issue<ILV>(plane[j], W, H, ix, iy, gth[j]);
+                bilinear3_issue<FMT>(plane[j], W, H, ix, iy, gth[j]);
                 if (GRAD) {
                     st[(j * 9 + 6) * WAVE] = zf ? rz : -rz;  // rz > 0: the sign carries the clamp flag
                     st[(j * 9 + 7) * WAVE] = ix;
@@ -525,8 +586,12 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 }
             }
             if (GRAD) st[18 * WAVE] = (inv_n >= 1e-6f) ? d : -d;  // d > 0: the sign carries "inverse depth not clamped"
+            if constexpr (U8) {
+                y_pre32 = img32[off];
+            } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) y_pre[c] = imgb[c * HWp + off];
+                for (int c = 0; c < 3; ++c) y_pre[c] = imgb[c * HWp + off];
+            }
             inv_cur = inv_n;
         }
         if (t >= r0 - 2 && active) {  // wave-uniform
@@ -799,7 +864,7 @@ __global__ void reproj_fin2(const double* persum, const CamConst* cam, const flo
 struct BwdParams {
     const float* inv[MGN_MAX_SCALES];
     float* ginv[MGN_MAX_SCALES];
-    const float* img;
+    const void* img;      // fp32 planes [B,3,H,W], or (U8 kernels) uint8 RGBX [B,H,W,4]
     const uint8_t* mask;
     const float* grad_losses;
     const FinHdr* hdr;
@@ -809,6 +874,7 @@ struct BwdParams {
     int B, H, W, n;
 };
 
+template <bool U8>
 __global__ __launch_bounds__(256) void reproj_bwd(BwdParams p) {
     const int W = p.W, H = p.H, HWp = H * W;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -818,17 +884,27 @@ __global__ __launch_bounds__(256) void reproj_bwd(BwdParams p) {
         for (int k = threadIdx.x; k < p.B * 12; k += blockDim.x) p.d_pose_out[k] = p.grad_losses[0] * p.d_pose[k];
     if (u >= W) return;
     const int off = v * W + u;
-    const float* im = p.img + (size_t)b * 3 * HWp;
+    const float* im = (const float*)p.img + (size_t)b * 3 * HWp;
+    const uint32_t* im32 = (const uint32_t*)p.img + (size_t)b * HWp;
     const uint8_t* mk = p.mask ? p.mask + (size_t)b * HWp : nullptr;
     const bool hasR = u + 1 < W, hasL = u > 0, hasD = v + 1 < H, hasU = v > 0;
     float gR = 0.f, gL = 0.f, gD = 0.f, gU = 0.f;  // image gradient magnitudes towards right/left/down/up
+    if constexpr (U8) {
+        float ctr[3], o[3];
+        u8unit3(im32[off], ctr);
+        if (hasR) { u8unit3(im32[off + 1], o); gR = fabsf(ctr[0] - o[0]) + fabsf(ctr[1] - o[1]) + fabsf(ctr[2] - o[2]); }
+        if (hasL) { u8unit3(im32[off - 1], o); gL = fabsf(o[0] - ctr[0]) + fabsf(o[1] - ctr[1]) + fabsf(o[2] - ctr[2]); }
+        if (hasD) { u8unit3(im32[off + W], o); gD = fabsf(ctr[0] - o[0]) + fabsf(ctr[1] - o[1]) + fabsf(ctr[2] - o[2]); }
+        if (hasU) { u8unit3(im32[off - W], o); gU = fabsf(o[0] - ctr[0]) + fabsf(o[1] - ctr[1]) + fabsf(o[2] - ctr[2]); }
+    } else {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float ctr = im[c * HWp + off];
-        if (hasR) gR += fabsf(ctr - im[c * HWp + off + 1]);
-        if (hasL) gL += fabsf(im[c * HWp + off - 1] - ctr);
-        if (hasD) gD += fabsf(ctr - im[c * HWp + off + W]);
-        if (hasU) gU += fabsf(im[c * HWp + off - W] - ctr);
+        for (int c = 0; c < 3; ++c) {
+            const float ctr = im[c * HWp + off];
+            if (hasR) gR += fabsf(ctr - im[c * HWp + off + 1]);
+            if (hasL) gL += fabsf(im[c * HWp + off - 1] - ctr);
+            if (hasD) gD += fabsf(ctr - im[c * HWp + off + W]);
+            if (hasU) gU += fabsf(im[c * HWp + off - W] - ctr);
+        }
     }
     const bool mC = mk ? mk[off] != 0 : true;
     const bool mL = hasL && (mk ? mk[off - 1] != 0 : true);
@@ -855,6 +931,7 @@ __global__ __launch_bounds__(256) void reproj_bwd(BwdParams p) {
 }
 
 // Same computation, 4 pixels per thread with 16-byte loads/stores (W % 4 == 0).
+template <bool U8>
 __global__ __launch_bounds__(256) void reproj_bwd4(BwdParams p) {
     const int W = p.W, H = p.H, HWp = H * W;
     const int u = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -864,11 +941,49 @@ __global__ __launch_bounds__(256) void reproj_bwd4(BwdParams p) {
         for (int k = threadIdx.x; k < p.B * 12; k += blockDim.x) p.d_pose_out[k] = p.grad_losses[0] * p.d_pose[k];
     if (u >= W) return;
     const int off = v * W + u;
-    const float* im = p.img + (size_t)b * 3 * HWp;
+    const float* im = (const float*)p.img + (size_t)b * 3 * HWp;
+    const uint32_t* im32 = (const uint32_t*)p.img + (size_t)b * HWp;
     const uint8_t* mk = p.mask ? p.mask + (size_t)b * HWp : nullptr;
     const bool hasL = u > 0, hasR4 = u + 4 < W, hasD = v + 1 < H, hasU = v > 0;
     // image gradient magnitudes of the pairs (k-1,k) for k=0..4 along x, and (up,ctr), (ctr,down) per pixel
     float gx[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, gu[4] = {0.f, 0.f, 0.f, 0.f}, gd[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (U8) {   // 4 packed pixels per 16-byte load: 5 loads per thread instead of 15
+        const uint4 c4 = *reinterpret_cast<const uint4*>(im32 + off);
+        const uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
+        float cv[4][3], l[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u8unit3(cw[k], cv[k]);
+        if (hasL) u8unit3(im32[off - 1], l);
+        if (hasR4) u8unit3(im32[off + 4], r);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gx[0] += fabsf(l[c] - cv[0][c]);
+            gx[1] += fabsf(cv[0][c] - cv[1][c]);
+            gx[2] += fabsf(cv[1][c] - cv[2][c]);
+            gx[3] += fabsf(cv[2][c] - cv[3][c]);
+            gx[4] += fabsf(cv[3][c] - r[c]);
+        }
+        if (hasU) {
+            const uint4 u4 = *reinterpret_cast<const uint4*>(im32 + off - W);
+            const uint32_t uw[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float o[3];
+                u8unit3(uw[k], o);
+                gu[k] = fabsf(o[0] - cv[k][0]) + fabsf(o[1] - cv[k][1]) + fabsf(o[2] - cv[k][2]);
+            }
+        }
+        if (hasD) {
+            const uint4 d4 = *reinterpret_cast<const uint4*>(im32 + off + W);
+            const uint32_t dw[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float o[3];
+                u8unit3(dw[k], o);
+                gd[k] = fabsf(cv[k][0] - o[0]) + fabsf(cv[k][1] - o[1]) + fabsf(cv[k][2] - o[2]);
+            }
+        }
+    } else
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* ic = im + c * HWp + off;
@@ -975,6 +1090,7 @@ int make_layout(const mgn_reproj_cfg* c, Layout* L) {
 
 int check_options(const mgn_reproj_cfg* c) {
     if (c->automask_loss != 1 || c->photometric_reduce_op != 0 || c->padding_mode != 0) return MGN_ENOTSUP;
+    if (c->frame_layout < 0 || c->frame_layout > MGN_FRAMES_RGBX_U8) return MGN_EINVAL;
     if (!(c->ssim_loss_weight > 0.f)) return MGN_ENOTSUP;  // ssim_w == 0 makes the reference return a 3-channel L1 map
     return MGN_OK;
 }
@@ -994,8 +1110,8 @@ int mgn_reproj_workspace_bytes(const mgn_reproj_cfg* cfg, size_t* bytes) {
     return MGN_OK;
 }
 
-int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth, const float* img, const float* prev,
-                        const float* next, const uint8_t* mask, const float* cam, int cam_stride, int cam_ld,
+int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth, const void* img, const void* prev,
+                        const void* next, const uint8_t* mask, const float* cam, int cam_stride, int cam_ld,
                         const float* pose, int want_grad, float* losses, float* d_pose, float* const* g_inv,
                         float* dbg_minmap, void* workspace, size_t workspace_bytes, void* stream_) {
     Layout L;
@@ -1029,12 +1145,15 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
                        (CamConst*)(ws + L.off_cam));
     if (cfg->prof_begin) (void)hipEventRecord((hipEvent_t)cfg->prof_begin, stream);
     const dim3 mgrid(L.nblocks), mblock(WAVE * (cfg->n_scales + 1));
-    if (cfg->ctx_interleaved) {   // prev / next are [B][H][W][4] (4-channel channels_last, 4th channel unused)
-        if (want_grad) hipLaunchKernelGGL((reproj_march<true, true>), mgrid, mblock, L.lds_bytes, stream, p);
-        else hipLaunchKernelGGL((reproj_march<false, true>), mgrid, mblock, L.lds_bytes, stream, p);
+    if (cfg->frame_layout == MGN_FRAMES_RGBX_U8) {          // img / prev / next are uint8 [B][H][W][4]
+        if (want_grad) hipLaunchKernelGGL((reproj_march<true, FMT_RGBX_U8>), mgrid, mblock, L.lds_bytes, stream, p);
+        else hipLaunchKernelGGL((reproj_march<false, FMT_RGBX_U8>), mgrid, mblock, L.lds_bytes, stream, p);
+    } else if (cfg->frame_layout == MGN_FRAMES_CTX_RGBX_F32) {   // prev / next are fp32 [B][H][W][4] (4th channel unused)
+        if (want_grad) hipLaunchKernelGGL((reproj_march<true, FMT_RGBX_F32>), mgrid, mblock, L.lds_bytes, stream, p);
+        else hipLaunchKernelGGL((reproj_march<false, FMT_RGBX_F32>), mgrid, mblock, L.lds_bytes, stream, p);
     } else {
-        if (want_grad) hipLaunchKernelGGL((reproj_march<true, false>), mgrid, mblock, L.lds_bytes, stream, p);
-        else hipLaunchKernelGGL((reproj_march<false, false>), mgrid, mblock, L.lds_bytes, stream, p);
+        if (want_grad) hipLaunchKernelGGL((reproj_march<true, FMT_PLANAR>), mgrid, mblock, L.lds_bytes, stream, p);
+        else hipLaunchKernelGGL((reproj_march<false, FMT_PLANAR>), mgrid, mblock, L.lds_bytes, stream, p);
     }
     if (cfg->prof_end) (void)hipEventRecord((hipEvent_t)cfg->prof_end, stream);
     hipLaunchKernelGGL(reproj_fin1, dim3(cfg->B, cfg->n_scales), dim3(256), 0, stream, (const float*)(ws + L.off_partials),
@@ -1046,7 +1165,7 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
-int mgn_reproj_loss_bwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth, const float* img, const uint8_t* mask,
+int mgn_reproj_loss_bwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth, const void* img, const uint8_t* mask,
                         const float* grad_losses, const float* d_pose, float* const* g_inv, float* d_pose_out,
                         const void* workspace, size_t workspace_bytes, void* stream_) {
     Layout L;
@@ -1071,10 +1190,12 @@ int mgn_reproj_loss_bwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
     const bool vec4 = (cfg->W % 4 == 0) && (((uintptr_t)img | (uintptr_t)mask) % 16 == 0);
     bool aligned = vec4;
     for (int i = 0; i < cfg->n_scales; ++i) aligned = aligned && (((uintptr_t)inv_depth[i] | (uintptr_t)g_inv[i]) % 16 == 0);
-    if (aligned)
-        hipLaunchKernelGGL(reproj_bwd4, dim3((cfg->W / 4 + 255) / 256, cfg->H, cfg->B), dim3(256), 0, (hipStream_t)stream_, p);
-    else
-        hipLaunchKernelGGL(reproj_bwd, dim3((cfg->W + 255) / 256, cfg->H, cfg->B), dim3(256), 0, (hipStream_t)stream_, p);
+    const bool u8 = cfg->frame_layout == MGN_FRAMES_RGBX_U8;
+    const dim3 g4((cfg->W / 4 + 255) / 256, cfg->H, cfg->B), g1((cfg->W + 255) / 256, cfg->H, cfg->B);
+    if (aligned && u8) hipLaunchKernelGGL(reproj_bwd4<true>, g4, dim3(256), 0, (hipStream_t)stream_, p);
+    else if (aligned) hipLaunchKernelGGL(reproj_bwd4<false>, g4, dim3(256), 0, (hipStream_t)stream_, p);
+    else if (u8) hipLaunchKernelGGL(reproj_bwd<true>, g1, dim3(256), 0, (hipStream_t)stream_, p);
+    else hipLaunchKernelGGL(reproj_bwd<false>, g1, dim3(256), 0, (hipStream_t)stream_, p);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

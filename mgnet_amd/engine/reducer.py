@@ -2,7 +2,8 @@
 "gloo" in the CPU tests).  Replaces detectron2's `create_ddp_model` -> torch DDP.
 
 * parameters are packed, in REVERSE registration order (= roughly the order in which backward produces gradients:
-  heads -> decoders -> res5 .. stem), into flat fp32 buckets; `param.grad` are views into the bucket, so there is no
+  heads -> decoders -> res5 .. stem; `ready_order` moves the pose network, whose backward is issued last, to the end),
+  into flat fp32 buckets; `param.grad` are views into the bucket, so there is no
   gather/scatter copy around the collective.  With `flatten_params=True` the parameters themselves (and later the Adam
   moments) live in flat buffers of the same layout, which is what the fused clip+Adam kernels consume.
 * a post-accumulate-grad hook counts a bucket's ready gradients and launches ONE asynchronous all-reduce per bucket as
@@ -17,15 +18,27 @@ import torch
 import torch.distributed as dist
 
 
+def ready_order(model, params):
+    """`params` in the order in which the backward of an MGNet step hands their gradients over: reverse registration order,
+    except for the pose network -- its forward is issued FIRST (lowest autograd sequence numbers, mg_net.py:262-265), so the
+    engine replays its backward LAST, after the backbone's.  With plain reverse order the first bucket (log_vars + pose_net)
+    completes at the very end of backward and every other bucket's all-reduce queues up behind it: no overlap."""
+    pose = getattr(model, "pose_net", None)
+    late = {id(p) for p in pose.parameters()} if pose is not None else set()
+    rev = list(reversed(list(params)))
+    return [p for p in rev if id(p) not in late] + [p for p in rev if id(p) in late]
+
+
 class GradReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, align=1, flatten_params=False, average=True):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, align=1, flatten_params=False, average=True, ordered=False):
+        """ordered: `params` is already in gradient-ready order (see `ready_order`); otherwise reverse registration order"""
         self.group, self.align, self.average = group, align, average
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         params = [p for p in params if p.requires_grad]
         self.buckets = []          # dict(flat_g, flat_p, params, offsets, pending, n)
         self._bucket_of = {}
         cur, cur_bytes = [], 0
-        for p in reversed(params):
+        for p in (params if ordered else reversed(params)):
             nb = self._padded(p.numel()) * 4
             if cur and cur_bytes + nb > bucket_bytes:
                 self._seal(cur, flatten_params)
@@ -37,6 +50,7 @@ class GradReducer:
         self._handles = []
         self._next = 0             # buckets are reduced in index order on every rank (collectives must be issued in the same order)
         self.collectives = 0       # all-reduce calls issued so far (bench.py reports it)
+        self.cross_stream_waits = 0  # all-reduces that had to wait for a packing copy issued on another stream
         self.enabled = True        # False: skip the exchange (bench.py's "step without all-reduce" leg)
         if self.world > 1 and flatten_params:
             # DDP broadcasts rank 0's parameters at construction; same here, on the flat buffers
@@ -75,11 +89,19 @@ class GradReducer:
         if self.buckets and self.buckets[0]["flat_g"].is_cuda:
             _C.WGRAD_LAZY[0] = bool(on)
 
+    def abort(self):
+        """a backward raised: drop the deferred weight-gradient entries it registered (keyed by address, see _C.WGRAD_PENDING)"""
+        from .. import _C
+        _C.WGRAD_PENDING.clear()
+
     def zero_grad(self):
         """Gradients are not zeroed: `.grad` is dropped, so autograd hands over each freshly computed gradient without an
         accumulate kernel per parameter; `_hook` packs a bucket's gradients into its flat buffer with one multi-tensor
         copy when the bucket is complete (parameters that got no gradient are zero-filled in `finish`)."""
         self._next = 0
+        if self.buckets and self.buckets[0]["flat_g"].is_cuda:
+            from .. import _C
+            _C.WGRAD_PENDING.clear()   # leftovers of a backward that raised: stale addresses must never match a later gradient
         for b in self.buckets:
             b["pending"] = b["n"]
             b["seen"] = set()
@@ -134,6 +156,15 @@ class GradReducer:
                 v.zero_()
             p.grad = v
         b["packed"] = True
+        if b["flat_g"].is_cuda and not torch.cuda.is_current_stream_capturing():
+            # the all-reduce of this bucket may be issued later, from the hook of a lower-index bucket on ANOTHER stream
+            # (ProcessGroupNCCL orders its stream only behind the stream that is current at the call): the event orders it
+            # behind this packing copy
+            ev = b.get("packed_ev")
+            if ev is None:
+                ev = b["packed_ev"] = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(b["flat_g"].device))
+            b["packed_on"] = torch.cuda.current_stream(b["flat_g"].device)
 
     def _hook(self, p):
         b = self._bucket_of[p]
@@ -159,6 +190,11 @@ class GradReducer:
                     return
                 self._pack(b)   # unused parameters this iteration: zero-filled, still reduced to stay in lock step
             if self.world > 1 and self.enabled:
+                if b["flat_g"].is_cuda and b.get("packed_ev") is not None:
+                    cur = torch.cuda.current_stream(b["flat_g"].device)
+                    if b.get("packed_on") != cur:
+                        cur.wait_event(b["packed_ev"])
+                        self.cross_stream_waits += 1
                 self._handles.append(dist.all_reduce(b["flat_g"], group=self.group, async_op=True))
                 self.collectives += 1
             self._next += 1

@@ -8,7 +8,7 @@ import torch
 
 from ..events import EventStorage
 from ..solver import build_lr_scheduler, build_optimizer
-from .reducer import GradReducer
+from .reducer import GradReducer, ready_order
 
 
 class Trainer:
@@ -19,12 +19,14 @@ class Trainer:
             from .. import _C
             from ..solver import get_mgnet_optimizer_params
             groups = get_mgnet_optimizer_params(model, cfg.SOLVER.BASE_LR, head_lr_factor=cfg.SOLVER.HEAD_LR_FACTOR)
-            self.reducer = GradReducer([p for g in groups for p in (g["params"] if isinstance(g["params"], list) else [g["params"]])],
-                                       bucket_bytes, align=_C.optim_chunk(), flatten_params=True, average=False)
+            plist = [p for g in groups for p in (g["params"] if isinstance(g["params"], list) else [g["params"]])]
+            self.reducer = GradReducer(ready_order(model, plist), bucket_bytes, align=_C.optim_chunk(), flatten_params=True,
+                                       average=False, ordered=True)
             self.optimizer = build_optimizer(cfg, model, reducer=self.reducer)
         else:
             self.optimizer = build_optimizer(cfg, model)
-            self.reducer = GradReducer([p for g in self.optimizer.param_groups for p in g["params"]], bucket_bytes)
+            self.reducer = GradReducer(ready_order(model, [p for g in self.optimizer.param_groups for p in g["params"]]), bucket_bytes,
+                                       ordered=True)
         self.scheduler = build_lr_scheduler(cfg, self.optimizer)
         self.storage = EventStorage()
         self.iter = 0
@@ -65,14 +67,16 @@ class Trainer:
         # (the captured step stays on ONE stream: capturing the side-stream branches of MGNet.forward crashes hipGraph
         #  instantiation on ROCm 7.0; the eager step with side streams is the faster of the two)
         self.model._no_side_streams = True
-        with torch.cuda.graph(graph):
-            self.reducer.zero_grad()
-            with self.storage:
-                loss_dict = self.model(batched_inputs)
-                self._backward(loss_dict)
-            self.reducer.finish()
-            self.optimizer.launch_step()
-        self.model._no_side_streams = False
+        try:
+            with torch.cuda.graph(graph):
+                self.reducer.zero_grad()
+                with self.storage:
+                    loss_dict = self.model(batched_inputs)
+                    self._backward(loss_dict)
+                self.reducer.finish()
+                self.optimizer.launch_step()
+        finally:   # (a failed capture must not leave the eager step without its side streams)
+            self.model._no_side_streams = False
         self._graph, self._graph_losses = graph, loss_dict
         return graph
 
@@ -94,6 +98,9 @@ class Trainer:
         self.reducer.lazy_wgrad(not os.environ.get("MGN_NO_LAZY_WGRAD") and not getattr(self.model, "_no_side_streams", False))
         try:
             (losses if scale is None else losses * scale).backward()
+        except BaseException:
+            self.reducer.abort()
+            raise
         finally:
             self.reducer.lazy_wgrad(False)
 

@@ -103,6 +103,9 @@ class MultiViewPhotometricLoss(nn.Module):
     predictions = {"depth": [inv_depth_i [B,1,H,W]], "poses": [B,2,6]}
     targets     = {"image_orig", "image_prev_orig", "image_next_orig": [B,3,H,W] in [0,1],
                    "camera_matrix": [B,4,4] (or [B,3,3]), optional "reprojection_mask": [B,1,H,W] bool}
+                  The three frames may also arrive as the BYTES they were before mg_net.py:320-335 divided them by 255: uint8
+                  [B,4,H,W] channels_last tensors (RGBX pixels, `_C.u8_frames_to_rgbx`); the kernels then convert in registers with
+                  the exactly rounded byte / 255 -- same losses and gradients, a third of the gather instructions and of the bytes.
     returns     {"loss_photometric", "loss_smoothness"}  (already multiplied by their weights, loss.py:151-154)
     """
 
@@ -142,13 +145,19 @@ class MultiViewPhotometricLoss(nn.Module):
         if mask is not None:
             mask = mask.contiguous()
         f32 = lambda t: t.float().contiguous()
-        # context frames may arrive pixel-interleaved ([B,4,H,W] channels_last, 4th channel unused; MGNet.forward produces them
-        # straight from the uint8 frames): the kernel then gathers 16 bytes per bilinear corner instead of 3 x 4
-        rgbx = lambda t: t.dim() == 4 and t.shape[1] == 4 and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(memory_format=torch.channels_last)
+        # frames may arrive pixel-interleaved ([B,4,H,W] channels_last, 4th channel unused; MGNet.forward produces them straight from
+        # the uint8 frames): all three as uint8 RGBX (one 4-byte gather per bilinear corner), or the context frames as fp32 RGBx (16)
+        nhwc4 = lambda t, dt: t.dim() == 4 and t.shape[1] == 4 and t.is_cuda and t.dtype == dt and t.is_contiguous(memory_format=torch.channels_last)
         prev, nxt = targets["image_prev_orig"], targets["image_next_orig"]
-        if not (rgbx(prev) and rgbx(nxt)):
-            prev, nxt = f32(prev[:, :3]), f32(nxt[:, :3])
-        losses = _ReprojLossFn.apply(cfg, f32(img), prev, nxt,
+        if all(nhwc4(t, torch.uint8) for t in (img, prev, nxt)):
+            pass
+        else:
+            if any(t.dtype == torch.uint8 for t in (img, prev, nxt)):
+                raise ValueError("uint8 frames: image_orig, image_prev_orig and image_next_orig must ALL be uint8 [B,4,H,W] channels_last (RGBX)")
+            img = f32(img)
+            if not (nhwc4(prev, torch.float32) and nhwc4(nxt, torch.float32)):
+                prev, nxt = f32(prev[:, :3]), f32(nxt[:, :3])
+        losses = _ReprojLossFn.apply(cfg, img, prev, nxt,
                                      mask, f32(targets["camera_matrix"]), pose_results.float(),
                                      *[x.float() for x in inv_depths])
         return {"loss_photometric": losses[0], "loss_smoothness": losses[1]}

@@ -136,6 +136,25 @@ class MGNet(nn.Module):
         # (true division of the uint8 batch promotes to fp32 inside ONE kernel: same values as .float() / scale)
         return t if scale is None else (t / scale if not t.is_floating_point() else t.float() / scale)
 
+    def _orig_frames_u8(self, batched_inputs):
+        """The un-jittered frames of the photometric loss (mg_net.py:320-335: `uint8.float() / 255`, no mean / std) as ONE uint8 RGBX
+        batch made by one launch; the loss kernels divide by 255 in registers (exactly rounded, so the values are the reference's).
+        None when the frames are not uint8 CUDA tensors of a size that needs no padding (then the fp32 path assembles them);
+        MGN_FRAMES_F32=1 forces the fp32 path."""
+        keys = ("image_orig", "image_prev_orig", "image_next_orig")
+        f0 = batched_inputs[0].get("image_orig")
+        d = self.size_divisibility
+        if (f0 is None or not f0.is_cuda or f0.dtype != torch.uint8 or os.environ.get("MGN_FRAMES_F32") or os.environ.get("MGN_RGBX")
+                or (d > 1 and (f0.shape[-2] % d or f0.shape[-1] % d)) or 3 * len(batched_inputs) > 48):
+            return None
+        from .. import _C
+        frames = [x[k] for k in keys for x in batched_inputs]
+        out = _C.u8_frames_to_rgbx(frames)
+        if out is None:
+            return None
+        B = len(batched_inputs)
+        return {k: out[j * B:(j + 1) * B] for j, k in enumerate(keys)}
+
     def _to_device_async(self, t, slot=None):
         """Small host tensor -> device without stalling the host (see _C.PinnedStager)."""
         if t.device == self.device or self.device.type != "cuda":
@@ -237,10 +256,13 @@ class MGNet(nn.Module):
                 "offset_weights": self._stack(batched_inputs, "offset_weights"),
             })
         if self.with_depth:
+            orig = self._orig_frames_u8(batched_inputs)
+            if orig is None:
+                orig = {"image_orig": self._stack(batched_inputs, "image_orig", 255.0),  # NOT mean/std normalised (:320-335)
+                        "image_prev_orig": self._stack(batched_inputs, "image_prev_orig", 255.0, rgbx=True),
+                        "image_next_orig": self._stack(batched_inputs, "image_next_orig", 255.0, rgbx=True)}
+            targets.update(orig)
             targets.update({
-                "image_orig": self._stack(batched_inputs, "image_orig", 255.0),  # NOT mean/std normalised (:320-335)
-                "image_prev_orig": self._stack(batched_inputs, "image_prev_orig", 255.0, rgbx=True),
-                "image_next_orig": self._stack(batched_inputs, "image_next_orig", 255.0, rgbx=True),
                 "camera_matrix": self._to_device_async(torch.stack([x["camera_matrix"] for x in batched_inputs], 0), "camera_matrix"),
                 "reprojection_mask": self._stack(batched_inputs, "reprojection_mask").unsqueeze(1),
             })

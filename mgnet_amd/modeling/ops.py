@@ -1,7 +1,8 @@
-"""Functional ops of the network path.  Each op has exactly ONE implementation at a time: the hand-written HIP
-kernel behind the C-ABI once it exists (marked [HIP]), otherwise a torch GPU op used as staging while the row is
-being ported (marked [torch-staging]; listed as not-yet-HIP in DESIGN.md section 7).  There is no CPU fallback and the
-oracle is never used here."""
+"""Functional ops of the network path.  CUDA tensors have ONE implementation per op: the hand-written HIP kernel behind the
+C-ABI (marked [HIP]); the few ops without a kernel are torch GPU ops marked [torch-staging] and a
+convolution without a kernel (fp32 activations) raises unless MGNET_ALLOW_TORCH_STAGING=1.  CPU tensors (the host-logic tests
+of `-m "not gpu"`: config / registry / state-dict / gloo reducer plumbing) run torch restatements of `iabn` and `conv2d`; they
+are never taken for a CUDA tensor and the oracle is never used here."""
 import os
 
 import torch

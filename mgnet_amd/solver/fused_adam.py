@@ -92,11 +92,20 @@ class FusedAdam(torch.optim.Optimizer):
     def state_dict(self):
         sd = super().state_dict()   # param_groups with integer ids in group order
         where, state, idx = self._slices(), {}, 0
+        steps = self._t
+        if self.scaler is not None:
+            # fp16: the DEVICE counts the optimizer steps actually taken (a step with inf gradients is skipped and halves the
+            # scale); Adam's bias corrections continue from that count, so it is what a resume needs -- together with the scale
+            # and its growth tracker (detectron2's AMPTrainer checkpoints `grad_scaler` the same way)
+            sc = [float(v) for v in self.scaler.tolist()]
+            sd["grad_scaler"] = {"scale": sc[0], "growth_tracker": int(sc[1]), "steps_taken": int(sc[2]),
+                                 "growth_interval": self.growth_interval, "host_steps": int(self._t)}
+            steps = int(sc[2])
         for g in self.param_groups:
             for p in g["params"]:
                 k, o = where[p]
                 if self._t:
-                    state[idx] = {"step": torch.tensor(float(self._t)),
+                    state[idx] = {"step": torch.tensor(float(steps)),
                                   "exp_avg": self._m[k][o:o + p.numel()].view(p.shape).clone(),
                                   "exp_avg_sq": self._v[k][o:o + p.numel()].view(p.shape).clone()}
                 idx += 1
@@ -124,6 +133,13 @@ class FusedAdam(torch.optim.Optimizer):
                              "without a gradient and counts steps per parameter; this optimizer keeps ONE step count for the flat buffers "
                              "(every parameter of the model receives a gradient in every MGNet configuration) and cannot resume such a state")
         self._t = steps.pop() if steps else 0
+        if self.scaler is not None:
+            gs = sd.get("grad_scaler")
+            if gs is not None:      # our own fp16 checkpoint: scale, growth tracker and the device-side step count
+                self.scaler.copy_(torch.tensor([float(gs["scale"]), float(gs["growth_tracker"]), float(gs["steps_taken"])]))
+                self._t = int(gs.get("host_steps", self._t))
+            else:                   # a torch.optim.Adam state (reference checkpoint): continue the bias corrections from its step
+                self.scaler[2] = float(self._t)
 
     def loss_scale(self):
         """device scalar S the loss must be multiplied with before backward (None: no loss scaling)"""

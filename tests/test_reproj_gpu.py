@@ -39,7 +39,8 @@ def run_hip(c, g=(1.0, 1.0), rows_per_wave=0, want_grad=True, want_minmap=False)
     return out
 
 
-def grad_close(got, ref, name, rtol=2e-3, frac_tol=5e-4, agg_tol=1e-3):
+def grad_close(got, ref, name, rtol=2e-3, frac_tol=1e-4, agg_tol=1e-4):
+    # (round 3: 5-10x what the GPU runs measure -- aggregate 2..40e-6 between two fp32 evaluations, off-fraction 0 -- instead of 100x)
     scale = np.abs(ref).max() + 1e-30
     if scale < 1e-10:  # degenerate (identity pose, identical frames): round-off noise in the reference too
         assert np.abs(got).max() < 1e-7, (name, np.abs(got).max())
@@ -257,7 +258,7 @@ def test_interleaved_context_frames_are_bit_identical(name):
         prev, nxt = (_rgbx(d["prev"]), _rgbx(d["nxt"])) if il else (d["prev"], d["nxt"])
         cfg = _C.make_reproj_cfg(B, H, W, len(d["inv"]))
         fwd = _C.reproj_loss_fwd(cfg, d["inv"], d["img"], prev, nxt, d.get("mask"), d["K"], d["poses"], want_grad=True)
-        assert cfg.ctx_interleaved == int(il)
+        assert cfg.frame_layout == int(il)
         g, dp = _C.reproj_loss_bwd(cfg, d["inv"], d["img"], d.get("mask"), torch.ones(2, device="cuda"), fwd)
         outs.append((fwd["losses"].clone(), dp.clone(), [x.clone() for x in g]))
     (l0, p0, g0), (l1, p1, g1) = outs
@@ -274,6 +275,84 @@ def test_u8_frames_to_rgbx():
     # (IEEE division like the reference's CPU arithmetic and mgn_u8_frames_to_f32; torch's GPU kernel multiplies by the reciprocal)
     assert torch.equal(out[:, :3].cpu(), torch.stack([f.cpu() for f in frames]).float() / 255.0) and float(out[:, 3].abs().max()) == 0.0
     assert torch.equal(out[:, :3], _C.u8_frames_to_f32(frames, 255.0))
+
+
+def _rgbx_u8(t_u8):
+    """[B,3,H,W] uint8 -> [B,4,H,W] uint8 channels_last with a junk 4th byte (the kernels must ignore it)"""
+    B, _, H, W = t_u8.shape
+    out = torch.full((B, 4, H, W), 201, dtype=torch.uint8, device=t_u8.device).contiguous(memory_format=torch.channels_last)
+    out[:, :3] = t_u8
+    return out
+
+
+@pytest.mark.parametrize("name", ["rand_small", "oob_clamp", "no_mask_odd", "smooth"])
+def test_uint8_rgbx_frames_are_bit_identical(name):
+    """All three frames handed over as the uint8 RGBX pixels they were before mg_net.py:320-335 divided them by 255 (frame_layout 2: one
+    4-byte gather per bilinear corner, conversion in registers) give the same BITS as the planar fp32 tensors `uint8.float() / 255` (IEEE
+    division on the CPU): losses, pose gradient, every inverse-depth gradient -- which also pins the in-register byte / 255 as exactly
+    rounded for the byte values that occur (every one of the 256: checked below), forward, automask and smoothness paths alike."""
+    from mgnet_amd import _C
+
+    c = golden_case_inputs(name)
+    d = _dev(c)
+    B, _, H, W = c["img"].shape
+    g = torch.Generator().manual_seed(3)
+    u8 = [torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8) for _ in range(3)]
+    u8[1][:, :, : H // 2] = u8[0][:, :, : H // 2]       # static upper half: automask ties / exact zeros as in a real sequence
+    assert all(len(torch.unique(t)) == 256 for t in u8)
+    f32 = [(t.float() / 255.0).cuda() for t in u8]      # CPU: true IEEE division, what the reference computes
+    px = [_rgbx_u8(t.cuda()) for t in u8]
+    outs = []
+    for frames in (f32, px):
+        cfg = _C.make_reproj_cfg(B, H, W, len(d["inv"]))
+        fwd = _C.reproj_loss_fwd(cfg, d["inv"], frames[0], frames[1], frames[2], d.get("mask"), d["K"], d["poses"], want_grad=True, want_minmap=True)
+        assert cfg.frame_layout == (2 if frames is px else 0)
+        gi, dp = _C.reproj_loss_bwd(cfg, d["inv"], frames[0], d.get("mask"), torch.tensor([0.7, 1.3], device="cuda"), fwd)
+        outs.append((fwd["losses"].clone(), dp.clone(), [x.clone() for x in gi], fwd["minmap"].clone()))
+    (l0, p0, g0, m0), (l1, p1, g1, m1) = outs
+    assert torch.equal(m0, m1), float((m0 - m1).abs().max())
+    assert torch.equal(l0, l1) and torch.equal(p0, p1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+
+def test_uint8_rgbx_odd_width_and_module_path():
+    """W % 4 != 0 takes the scalar backward kernel; the nn.Module accepts the uint8 RGBX frames under the reference's target keys and mixed
+    formats are refused."""
+    from mgnet_amd.modeling import MultiViewPhotometricLoss
+
+    B, H, W = 2, 37, 75
+    g = torch.Generator().manual_seed(5)
+    u8 = [torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8) for _ in range(3)]
+    K = torch.eye(4).repeat(B, 1, 1)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = 0.58 * W, 1.92 * H, 0.5 * W, 0.5 * H
+    inv0 = [torch.rand(B, 1, H, W, generator=g) * 1.9 + 0.05 for _ in range(3)]
+    poses0 = 0.01 * torch.randn(B, 2, 6, generator=g)
+    mask = torch.rand(B, 1, H, W, generator=g) > 0.1
+    crit = MultiViewPhotometricLoss(0.85, 1.0, 0.001, True, "min", "zeros")
+    res = []
+    for as_u8 in (False, True):
+        inv = [t.cuda().requires_grad_(True) for t in inv0]
+        poses = poses0.cuda().requires_grad_(True)
+        fr = [_rgbx_u8(t.cuda()) for t in u8] if as_u8 else [(t.float() / 255.0).cuda() for t in u8]
+        out = crit({"depth": inv, "poses": poses}, {"image_orig": fr[0], "image_prev_orig": fr[1], "image_next_orig": fr[2],
+                                                     "camera_matrix": K.cuda(), "reprojection_mask": mask.cuda()})
+        (out["loss_photometric"] + 3.0 * out["loss_smoothness"]).backward()
+        res.append([out["loss_photometric"].detach(), out["loss_smoothness"].detach(), poses.grad] + [t.grad for t in inv])
+    assert all(torch.equal(a, b) for a, b in zip(*res))
+    with pytest.raises(ValueError):
+        crit({"depth": inv, "poses": poses}, {"image_orig": (u8[0].float() / 255).cuda(), "image_prev_orig": _rgbx_u8(u8[1].cuda()),
+                                               "image_next_orig": _rgbx_u8(u8[2].cuda()), "camera_matrix": K.cuda()})
+
+
+def test_u8_frames_to_rgbx_pack():
+    """mgn_u8_frames_to_rgbx: [3,H,W] uint8 planes -> [n,H,W,4] packed pixels (R,G,B,0), up to 48 frames in one launch"""
+    from mgnet_amd import _C
+
+    g = torch.Generator().manual_seed(1)
+    frames = [torch.randint(0, 256, (3, 20, 36), generator=g, dtype=torch.uint8).cuda() for _ in range(24)]
+    out = _C.u8_frames_to_rgbx(frames)
+    assert out.shape == (24, 4, 20, 36) and out.dtype == torch.uint8 and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out[:, :3], torch.stack(frames)) and int(out[:, 3].max()) == 0
+    assert _C.u8_frames_to_rgbx([f[:, :, :35] for f in frames]) is None      # H*W % 4 != 0 / non-contiguous: the caller takes the fp32 path
 
 
 def _grad_err(got, ref64):
@@ -299,10 +378,10 @@ def test_gradient_error_against_fp64_is_what_fp32_costs(name, capsys):
         fh, ah = _grad_err(hip["d_inv"][i], o64["d_inv"][i])
         fr, ar = _grad_err(out[f"dphot_dinv{i}"], o64["d_inv"][i])
         rows.append((i, fh, ah, fr, ar))
-        assert fh <= 2.0 * fr + 2e-3 and ah <= 2.0 * ar + 2e-3, (name, i, "HIP", fh, ah, "reference fp32", fr, ar)
+        assert fh <= 2.0 * fr + 2e-4 and ah <= 2.0 * ar + 2e-4, (name, i, "HIP", fh, ah, "reference fp32", fr, ar)
     ph, pr = np.abs(hip["d_pose"] - o64["d_poses"]).max(), np.abs(out["dphot_dposes"] - o64["d_poses"]).max()
     ps = np.abs(o64["d_poses"]).max()
-    assert ph <= 2.0 * pr + 2e-3 * ps, (name, "pose", ph, pr, ps)
+    assert ph <= 2.0 * pr + 2e-4 * ps, (name, "pose", ph, pr, ps)
     with capsys.disabled():
         for i, fh, ah, fr, ar in rows:
             print(f"\n[reproj grad vs fp64] {name} scale {i}: HIP off-fraction {fh:.2e} aggregate {ah:.2e} | reference fp32 {fr:.2e} {ar:.2e}", end="")

@@ -52,14 +52,15 @@ def summarize(root):
     known_r, known_w = 4.0 * px, 12.0 * px
     fr, fw = known_r / avg[("calib", "FETCH_SIZE")], known_w / avg[("calib", "WRITE_SIZE")]
     rd, wr = avg[("reproj", "FETCH_SIZE")] * fr, avg[("reproj", "WRITE_SIZE")] * fw
-    out = {"B": B, "H": H, "W": W, "kernel": "reproj_march<true>", "hbm_bytes_per_launch": int(round(rd + wr)),
+    u8 = not os.environ.get("MGN_FRAMES_F32")   # (round 3: the training step hands the frames over as uint8 RGBX: 37 B/px algorithmic)
+    out = {"B": B, "H": H, "W": W, "u8_frames": u8, "kernel": "reproj_march<true>", "hbm_bytes_per_launch": int(round(rd + wr)),
            "read_bytes_per_launch": int(round(rd)), "write_bytes_per_launch": int(round(wr)),
            "raw_counters_bytes": {"FETCH_SIZE": int(avg[("reproj", "FETCH_SIZE")]), "WRITE_SIZE": int(avg[("reproj", "WRITE_SIZE")])},
            "calibration": {"kernel": "reconstruct_kernel<false> on [8,1,1024,2048] fp32 (dword loads / stores, one per lane)",
                            "known_read_bytes": int(known_r), "known_write_bytes": int(known_w),
                            "FETCH_SIZE_bytes": int(avg[("calib", "FETCH_SIZE")]), "WRITE_SIZE_bytes": int(avg[("calib", "WRITE_SIZE")]),
                            "factor_read": round(fr, 4), "factor_write": round(fw, 4)},
-           "algorithmic_bytes_per_launch": 61 * px,
+           "algorithmic_bytes_per_launch": (37 if u8 else 61) * px,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of tools/measure_traffic.py run (tools/pmc_traffic2.sh); "
                    "counters of the reprojection kernel multiplied by the factors that make the same counters of a dword stream "
                    "of known size (same process, same pass) equal to its byte count"}
