@@ -337,6 +337,54 @@ int mgn_u8_frames_to_f32_nhwc4(const void* const* frames_u8, int n_frames, long 
  * here instead of the 15 B/px of mgn_u8_frames_to_f32, and 4 B/px per frame in the loss instead of 12. */
 int mgn_u8_frames_to_rgbx(const void* const* frames_u8, int n_frames, long hw, void* out_u8, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Multi-scale + flip inference: the per-pass tensor algebra of mg_net.py:427-520 `forward_multi_scale_flip`.
+ *
+ * mgn_msc_input: `x = F.interpolate(norm_images, scale_factor=scale, bilinear, align_corners=True)` (+ `torch.flip(x, dims=(3,))`,
+ *   mg_net.py:451-455) written as the network input: norm_nchw [N,3,H,W] fp32 -> out [N,h,w,8] bf16 (out_f16 = 0) or fp16 (1),
+ *   channels-last, channels 3..7 zero (the stem kernels' layout, like mgn_prep_input); h, w = floor(H * scale), floor(W * scale).
+ * mgn_msc_accumulate: one head output of one pass added to its running average (mg_net.py:462-512):
+ *   lr      low-resolution head output [N,C,h,w] with element strides sn, sc, sh, sw; dtype 0 = fp32, 1 = bf16, 2 = fp16; C <= 32
+ *   acc     [N,C,H,W] fp32 contiguous: the running sum; first != 0: written, not added to (no zero fill needed)
+ *   mode    0  softmax over C of the upsampled logits       (sem_seg, :464-470)
+ *           1  the upsampled map itself                     (center, :471-476)
+ *           2  (upsampled * stride) / scale, channel 1 (x) negated when flip   (offset, :477-493)
+ *           3  1 / max(upsampled, 1e-6)                     (depth = inv2depth, :499-507)
+ *   flip    the pass ran on the mirrored frame: output column x takes the upsampled map's column W-1-x (:487-490)
+ *   divide  > 0 on the last pass: acc = (acc + v) / divide  (the averages of :514-520, rounded like sum / n)
+ *   Upsampling = F.interpolate(bilinear, align_corners=True) from [h,w] to [H,W].
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_msc_input(const float* norm_nchw, int N, int H, int W, int h, int w, int flip, int out_f16, void* out_nhwc8, void* stream);
+int mgn_msc_accumulate(const void* lr, int dtype, long sn, long sc, long sh, long sw, int N, int C, int h, int w, int H, int W, int mode,
+                       int flip, int first, float stride, float scale, float divide, float* acc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Uncertainty weighting of the task losses (mg_net.py:360-372), all tasks in one launch:
+ *     weighted[k] = tau_k * exp(-log_vars[k]) * raw_losses[k][0] + 0.5 * log_vars[k],  tau_k = 1 if bit k of tau_one_mask else 0.5
+ *     uncertainty[k] = exp(log_vars[k])                      (the "<loss>_uncertainty" scalar of the event storage, :369)
+ * raw_losses / grads: HOST arrays of n (<= MGN_MAX_TASKS) DEVICE pointers to fp32 scalars (the loss kernels' outputs where they lie;
+ * a null grads[k] = that output was not used).  Backward: d_raw[k] = tau_k exp(-lv_k) g_k, d_log_vars[k] = (0.5 - tau_k exp(-lv_k)
+ * raw_k) g_k for k < n and 0 for n <= k < n_log_vars.
+ * ---------------------------------------------------------------------------------------------- */
+#define MGN_MAX_TASKS 8
+int mgn_uncertainty_fwd(const float* const* raw_losses, int n, const float* log_vars, unsigned tau_one_mask, float* weighted, float* uncertainty,
+                        void* stream);
+int mgn_uncertainty_bwd(const float* const* raw_losses, const float* const* grads, int n, int n_log_vars, const float* log_vars,
+                        unsigned tau_one_mask, float* d_raw, float* d_log_vars, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tails of the prediction heads: between a 1x1 predictor (output channels padded to P = 32, channels-last, 16-bit) and its loss.
+ * mgn_head_act_fwd: y[B,C,h,w] fp32 = f(x_padded[B,h,w,P][..., :C].float()); kind 0: identity, 1: sigmoid (centre heat map,
+ *   mg_net.py:694), 2: sigmoid / 0.5 (inverse depth, :819-823).
+ * mgn_head_act_bwd: dx_padded[B,h,w,P] 16-bit = f'(.) * gscale * g for channels < C, ZERO for the padding channels (what the
+ *   predictor's data / weight gradient kernels consume); g is fp32 with element strides sb / sc / sp per image / channel / pixel
+ *   (an NCHW map: C*h*w, h*w, 1; an NHWC table of the loss kernels with pitch Kp: h*w*Kp, 1, Kp); y = the forward's output (kind != 0).
+ * Replaces per head and step: .float(), sigmoid, / 0.5 and their autograd twins + the zero-fill and strided copy of the channel slice.
+ * ---------------------------------------------------------------------------------------------- */
+int mgn_head_act_fwd(const void* x_padded, int B, int h, int w, int P, int C, int kind, int is_f16, float* y, void* stream);
+int mgn_head_act_bwd(const float* g, long sb, long sc, long sp, const float* y, int B, int h, int w, int P, int C, int kind, int is_f16,
+                     float gscale, void* dx_padded, void* stream);
+
 /* The stem's activated batch norm folded into the pooling (BasicStem, res_net.py:82-110: conv -> InPlaceABNSync -> max_pool):
  * forward pools y = act(scale * x + offset) evaluated on the fly (bf16-rounded like mgn_iabn_apply stores it; the
  * normalised map is never written), backward = mgn_iabn_bwd_reduce on (pooled, d pooled) for the channel sums, then
@@ -510,7 +558,7 @@ int mgn_vec_linear_bwd(const float* dout, const float* out, const float* in, con
  *                                         average pool (scale = 1/HW) and the d/d attention reduction; deterministic
  *   mgn_bcast_rows                      : dx[n,r,c] = g[n,c] * scale (adjoint of the pool)
  *   mgn_scale_channels                  : y = x * s[n,c] (mode 0, layers.py:262-267) | x * (1 + s[n,c]) (mode 1, :315-322)
- *                                         [+ add[n,c]]
+ *                                         [+ add[n,c]] [+ addt[n,r,c]]
  *   mgn_nearest_fwd / _bwd              : F.interpolate(mode="nearest") (layers.py:90, :217) and its adjoint
  *   mgn_concat2 / mgn_split2            : torch.cat([a, b], dim=1) (layers.py:316) and the split of its gradient
  * ---------------------------------------------------------------------------------------------- */
@@ -527,7 +575,8 @@ int mgn_colsum(const void* x, const void* x2 /*nullable*/, int N, long HW, int C
                size_t workspace_bytes /* >= N*64*C*4 */, void* stream);
 int mgn_bcast_rows(const float* g, int N, long HW, int C, float scale, void* dx, void* stream);
 int mgn_scale_channels(const void* x, const float* s, int N, long HW, int C, int mode, const float* add /* nullable:
-                       y += add[n,c] (the pooled branch of the attention backward) */, void* y, void* stream);
+                       y += add[n,c] (the pooled branch of the attention backward) */, const void* addt /* nullable: y += addt[n,r,c], a
+                       16-bit tensor of x's shape: `arm(x) + last` of the decoder, layers.py:87, in the same pass */, void* y, void* stream);
 int mgn_nearest_fwd(const void* x, int N, int h, int w, int H, int W, int C, void* y, void* stream);
 int mgn_nearest_bwd(const void* dy, int N, int h, int w, int H, int W, int C, void* dx, void* stream);
 int mgn_concat2(const void* a, const void* b, long rows, int Ca, int Cb, void* y, void* stream);
@@ -595,7 +644,7 @@ int mgn_colsum_f16(const void* x, const void* x2 /*nullable*/, int N, long HW, i
     float* workspace, size_t workspace_bytes /* >= N*64*C*4 */, void* stream);
 int mgn_bcast_rows_f16(const float* g, int N, long HW, int C, float scale, void* dx, void* stream);
 int mgn_scale_channels_f16(const void* x, const float* s, int N, long HW, int C, int mode, const float* add /*
-    nullable: y += add[n,c] (the pooled branch of the attention backward) */, void* y, void* stream);
+    nullable: y += add[n,c] (the pooled branch of the attention backward) */, const void* addt /* nullable */, void* y, void* stream);
 int mgn_nearest_fwd_f16(const void* x, int N, int h, int w, int H, int W, int C, void* y, void* stream);
 int mgn_nearest_bwd_f16(const void* dy, int N, int h, int w, int H, int W, int C, void* dx, void* stream);
 int mgn_abn_maxpool_fwd_f16(const void* x_h16, const float* scale, const float* offset, int activation, float slope,

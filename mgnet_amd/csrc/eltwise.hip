@@ -163,8 +163,10 @@ __global__ __launch_bounds__(TPB) void bcast_rows(const float* __restrict__ g, l
 }
 
 // y = x * s[n, c]            (mode 0)      y = x + x * s[n, c] = x * (1 + s)   (mode 1)
+// (+ add[n, c], + addt[n, r, c]: a full tensor of x's shape -- the decoder's `arm(x) + last`, layers.py:87 -- fp32 sum, one rounding)
 __global__ __launch_bounds__(TPB) void scale_channels(const uint4* __restrict__ x, const float* __restrict__ s, long HW, int C, int mode,
-                                                      const float* __restrict__ add, uint4* __restrict__ y, long nvec) {
+                                                      const float* __restrict__ add, const uint4* __restrict__ addt, uint4* __restrict__ y,
+                                                      long nvec) {
     const int cv = C / 8;
     const float base = mode ? 1.f : 0.f;
     for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
@@ -180,6 +182,12 @@ __global__ __launch_bounds__(TPB) void scale_channels(const uint4* __restrict__ 
             const float4* ap = reinterpret_cast<const float4*>(add + n * C + c8 * 8);
             const float4 a0 = ap[0], a1 = ap[1];
             av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+        }
+        if (addt) {
+            float tv[8];
+            unpack8(addt[i], tv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) av[k] += tv[k];
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], base + sv[k], av[k]);
@@ -304,10 +312,11 @@ int MGN_SYM(mgn_bcast_rows)(const float* g, int N, long HW, int C, float scale, 
     hipLaunchKernelGGL(bcast_rows, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, g, HW, C, scale, (uint4*)dx, nvec);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
-int MGN_SYM(mgn_scale_channels)(const void* x, const float* s, int N, long HW, int C, int mode, const float* add, void* y, void* stream) {
+int MGN_SYM(mgn_scale_channels)(const void* x, const float* s, int N, long HW, int C, int mode, const float* add, const void* addt, void* y,
+                                void* stream) {
     if (!x || !s || !y || N < 1 || HW < 1 || !c_ok(C) || mode < 0 || mode > 1) return MGN_EINVAL;
     const long nvec = (long)N * HW * (C / 8);
-    hipLaunchKernelGGL(scale_channels, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)x, s, HW, C, mode, add, (uint4*)y, nvec);
+    hipLaunchKernelGGL(scale_channels, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)x, s, HW, C, mode, add, (const uint4*)addt, (uint4*)y, nvec);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 int MGN_SYM(mgn_nearest_fwd)(const void* x, int N, int h, int w, int H, int W, int C, void* y, void* stream) {

@@ -1,0 +1,162 @@
+// mscflip.hip -- multi-scale + flip inference for MI355X (gfx950).
+//
+// Replaces the per-pass tensor algebra of mgnet/modeling/mg_net.py:427-520 `forward_multi_scale_flip`: 7 scales x 2 flips = 14
+// passes, each of which rescales the normalised frame (bilinear, align_corners=True), flips it, runs the network, and then -- at FULL
+// output resolution, for 20 + 1 + 2 + 1 channels -- upsamples the stride-8 head outputs, soft-maxes / rescales / inverts them, flips
+// them back and adds them to running averages.  In the reference that is ~12 ATen passes over [N,20,H,W] fp32 per network pass.
+// Here: ONE kernel per head output and pass that reads the low-resolution map (L2-resident), evaluates upsample -> soft-max |
+// offset scaling | 1 / depth -> un-flip in registers and does the read-modify-write of the accumulator: 8 B per output element and
+// pass, the HBM floor of a running sum held in fp32.  HBM-bound streaming work, no LDS, no MFMA.
+//
+//   msc_input       normalised fp32 frame [N,3,H,W] -> rescaled (+ flipped) network input [N,h,w,8] 16-bit channels-last, channels
+//                   3..7 zero (the stem kernels' packed layout, like csrc/prep.hip)
+//   msc_accumulate  acc[N,C,H,W] (+)= f(upsample(lr[N,C,h,w]))   f = soft-max over C | identity | (v * stride) / scale with the x
+//                   offset negated on flipped passes | 1 / max(v, 1e-6);   the last pass also divides by the number of passes
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mgnet_hip.h"
+
+namespace {
+
+constexpr int MSC_MAX_C = 32;
+
+__device__ __forceinline__ float ld_any(const void* p, long i, int dt) {
+    if (dt == 0) return ((const float*)p)[i];
+    const uint16_t h = ((const uint16_t*)p)[i];
+    if (dt == 1) return __uint_as_float((uint32_t)h << 16);            // bf16
+    return (float)__builtin_bit_cast(_Float16, h);                      // fp16
+}
+
+// torch's upsample_bilinear2d, align_corners=True: source index = dst * (in - 1) / (out - 1) in fp32, floor, lambda
+struct Axis { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Axis axis(int dst, float scale, int in) {
+    const float s = scale * (float)dst;
+    Axis a;
+    a.i0 = min((int)s, in - 1);
+    a.i1 = a.i0 + (a.i0 < in - 1 ? 1 : 0);
+    a.l1 = s - (float)a.i0;
+    a.l0 = 1.f - a.l1;
+    return a;
+}
+
+struct AccParams {
+    const void* lr;
+    float* acc;
+    long sn, sc, sh, sw;   // element strides of lr[N,C,h,w]
+    int N, C, h, w, H, W;
+    int dtype, mode, flip, first;
+    float stride, scale, divide;   // mode 2: (v * stride) / scale; divide > 0: acc = (acc + v) / divide (the last pass)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void msc_accumulate(AccParams p) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), n = blockIdx.z;
+    if (x >= p.W || y >= p.H) return;
+    // r = flip(upsample(net(flip(frame)))): the value at output column x is the upsampled map at column W-1-x
+    const int xs = p.flip ? p.W - 1 - x : x;
+    const float sy = p.H > 1 ? (float)(p.h - 1) / (float)(p.H - 1) : 0.f, sx = p.W > 1 ? (float)(p.w - 1) / (float)(p.W - 1) : 0.f;
+    const Axis ay = axis(y, sy, p.h), ax = axis(xs, sx, p.w);
+    const long b00 = n * p.sn + ay.i0 * p.sh + ax.i0 * p.sw, b01 = n * p.sn + ay.i0 * p.sh + ax.i1 * p.sw;
+    const long b10 = n * p.sn + ay.i1 * p.sh + ax.i0 * p.sw, b11 = n * p.sn + ay.i1 * p.sh + ax.i1 * p.sw;
+    float v[MSC_MAX_C];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < MSC_MAX_C; ++c) {
+        if (c < p.C) {
+            const float v00 = ld_any(p.lr, b00 + c * p.sc, p.dtype), v01 = ld_any(p.lr, b01 + c * p.sc, p.dtype);
+            const float v10 = ld_any(p.lr, b10 + c * p.sc, p.dtype), v11 = ld_any(p.lr, b11 + c * p.sc, p.dtype);
+            v[c] = ay.l0 * (ax.l0 * v00 + ax.l1 * v01) + ay.l1 * (ax.l0 * v10 + ax.l1 * v11);
+            mx = fmaxf(mx, v[c]);
+        }
+    }
+    if (MODE == 0) {   // F.softmax(r, 1)
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < MSC_MAX_C; ++c)
+            if (c < p.C) { v[c] = expf(v[c] - mx); sum += v[c]; }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int c = 0; c < MSC_MAX_C; ++c)
+            if (c < p.C) v[c] *= inv;
+    } else if (MODE == 2) {   // offsets: * stride / scale; x component (channel 1) mirrored on flipped passes
+#pragma unroll
+        for (int c = 0; c < MSC_MAX_C; ++c)
+            if (c < p.C) {
+                v[c] = (v[c] * p.stride) / p.scale;
+                if (p.flip && c == 1) v[c] = -v[c];
+            }
+    } else if (MODE == 3) {   // inv2depth (depth.py:15)
+#pragma unroll
+        for (int c = 0; c < MSC_MAX_C; ++c)
+            if (c < p.C) v[c] = 1.f / fmaxf(v[c], 1e-6f);
+    }
+    const long plane = (long)p.H * p.W;
+    float* a = p.acc + ((long)n * p.C) * plane + (long)y * p.W + x;
+#pragma unroll
+    for (int c = 0; c < MSC_MAX_C; ++c)
+        if (c < p.C) {
+            float o = p.first ? v[c] : a[c * plane] + v[c];
+            if (p.divide > 0.f) o = o / p.divide;
+            a[c * plane] = o;
+        }
+}
+
+struct InParams {
+    const float* src;   // [N,3,H,W] fp32
+    uint16_t* dst;      // [N,h,w,8] 16-bit
+    int N, H, W, h, w, flip, f16;
+};
+
+__global__ __launch_bounds__(256) void msc_input(InParams p) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), n = blockIdx.z;
+    if (x >= p.w || y >= p.h) return;
+    const int xs = p.flip ? p.w - 1 - x : x;   // torch.flip of the rescaled frame
+    const float sy = p.h > 1 ? (float)(p.H - 1) / (float)(p.h - 1) : 0.f, sx = p.w > 1 ? (float)(p.W - 1) / (float)(p.w - 1) : 0.f;
+    const Axis ay = axis(y, sy, p.H), ax = axis(xs, sx, p.W);
+    uint32_t o[4] = {0u, 0u, 0u, 0u};
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* s = p.src + ((long)n * 3 + c) * p.H * p.W;
+        const float v00 = s[(long)ay.i0 * p.W + ax.i0], v01 = s[(long)ay.i0 * p.W + ax.i1];
+        const float v10 = s[(long)ay.i1 * p.W + ax.i0], v11 = s[(long)ay.i1 * p.W + ax.i1];
+        v[c] = ay.l0 * (ax.l0 * v00 + ax.l1 * v01) + ay.l1 * (ax.l0 * v10 + ax.l1 * v11);
+    }
+    uint16_t hv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        hv[c] = p.f16 ? __builtin_bit_cast(uint16_t, (_Float16)v[c]) : __builtin_bit_cast(uint16_t, (__bf16)v[c]);
+    o[0] = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+    o[1] = (uint32_t)hv[2];
+    reinterpret_cast<uint4*>(p.dst)[((long)n * p.h + y) * p.w + x] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mgn_msc_input(const float* norm_nchw, int N, int H, int W, int h, int w, int flip, int out_f16, void* out_nhwc8, void* stream) {
+    if (!norm_nchw || !out_nhwc8 || N < 1 || H < 1 || W < 1 || h < 1 || w < 1 || ((uintptr_t)out_nhwc8 & 15)) return MGN_EINVAL;
+    InParams p{norm_nchw, (uint16_t*)out_nhwc8, N, H, W, h, w, flip ? 1 : 0, out_f16 ? 1 : 0};
+    hipLaunchKernelGGL(msc_input, dim3((w + 63) / 64, (h + 3) / 4, N), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_msc_accumulate(const void* lr, int dtype, long sn, long sc, long sh, long sw, int N, int C, int h, int w, int H, int W, int mode,
+                       int flip, int first, float stride, float scale, float divide, float* acc, void* stream) {
+    if (!lr || !acc || N < 1 || C < 1 || C > MSC_MAX_C || h < 1 || w < 1 || H < 1 || W < 1) return MGN_EINVAL;
+    if (dtype < 0 || dtype > 2 || mode < 0 || mode > 3 || (mode == 2 && !(scale > 0.f))) return MGN_EINVAL;
+    AccParams p{lr, acc, sn, sc, sh, sw, N, C, h, w, H, W, dtype, mode, flip ? 1 : 0, first ? 1 : 0, stride, scale, divide};
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, N), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(msc_accumulate<0>, grid, block, 0, s, p); break;
+        case 1: hipLaunchKernelGGL(msc_accumulate<1>, grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL(msc_accumulate<2>, grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL(msc_accumulate<3>, grid, block, 0, s, p); break;
+    }
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+}  // extern "C"

@@ -273,7 +273,6 @@ class MGNet(nn.Module):
         f_sem = f_ins = f_dep = features
         if self.with_panoptic and self.with_depth:
             # every feature map feeds all three heads: three aliases whose gradients one kernel sums (ops.fanout3)
-            from . import ops
             fan = {k: ops.fanout3(v) for k, v in features.items()}
             f_sem, f_ins, f_dep = ({k: t[j] for k, t in fan.items()} for j in range(3))
         if side:
@@ -298,21 +297,14 @@ class MGNet(nn.Module):
             handover(side[1], main, losses)
 
         if self.with_uncertainty:  # mg_net.py:360-372 -- same scalar names, but no .item() host syncs inside forward
-            # evaluated for all tasks at once (a handful of launches instead of ~20 scalar kernels per task):
             #   loss_k <- tau_k * exp(-log_vars[k]) * loss_k + 0.5 * log_vars[k],  tau = 1 for loss_sem_seg, else 0.5
+            # for all tasks at once: [HIP] one launch forward, one backward (ops.uncertainty_weighting)
             storage = get_event_storage()
-            keys = list(losses.keys())
-            raw = torch.stack([losses[k].float().reshape(()) for k in keys])
-            lv = self.log_vars[:len(keys)]
-            tau = torch.tensor([1.0 if k == "loss_sem_seg" else 0.5 for k in keys], dtype=raw.dtype).to(raw.device, non_blocking=True) \
-                if not hasattr(self, "_tau") or self._tau[0] != keys else self._tau[1]
-            self._tau = (keys, tau)
-            weighted = tau * torch.exp(-lv) * raw + 0.5 * lv
-            unc = torch.exp(lv.detach())
-            for idx, key in enumerate(keys):
-                storage.put_scalar(key + "_raw", raw[idx].detach())
-                storage.put_scalar(key + "_uncertainty", unc[idx])
-                losses[key] = weighted[idx]
+            weighted, raw, unc = ops.uncertainty_weighting(losses, self.log_vars)
+            for key in list(losses):
+                storage.put_scalar(key + "_raw", raw[key])
+                storage.put_scalar(key + "_uncertainty", unc[key])
+                losses[key] = weighted[key]
         return losses
 
 
@@ -329,10 +321,14 @@ def _as_net_input(self, x):
 def forward_multi_scale_flip(self, norm_images, scales=None, flip=True):
     """mg_net.py:427-520: average the raw predictions over rescaled (bilinear, align_corners=True) and horizontally
     flipped copies of the normalised frames; softmax probabilities for sem_seg, offsets rescaled by stride / scale and
-    their x component negated for the flipped pass."""
-    import torch.nn.functional as F
+    their x component negated for the flipped pass.
+    CUDA + 16-bit trunk: [HIP] csrc/mscflip.hip -- one launch builds each pass's network input, one launch per head output folds
+    upsample -> softmax | offset scaling | 1 / depth -> un-flip -> running sum (the last pass divides); no full-resolution torch op."""
     scales = [0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0] if scales is None else scales
     n_flip = 2 if flip else 1
+    if norm_images.is_cuda and self.amp_dtype in (torch.bfloat16, torch.float16):
+        return _msc_flip_hip(self, norm_images.float().contiguous(), scales, n_flip)
+    import torch.nn.functional as F
     up = lambda t, stride, scale: F.interpolate(t.float(), scale_factor=stride / scale, mode="bilinear", align_corners=True)
     avg = {"sem_seg": None, "center": None, "offset": None, "depth": None}
 
@@ -361,6 +357,42 @@ def forward_multi_scale_flip(self, norm_images, scales=None, flip=True):
                 add("depth", torch.flip(d, dims=(3,)) if f else d)
     n = n_flip * len(scales)
     return {k: (v / n if v is not None else None) for k, v in avg.items()}
+
+
+def _msc_flip_hip(self, norm, scales, n_flip):
+    """the device path of forward_multi_scale_flip (see there)"""
+    import math
+
+    from .. import _C
+    N, _, H, W = norm.shape
+    n = n_flip * len(scales)
+    acc = {}
+
+    def fold(key, lr, mode, stride, scale, f, k):
+        # output size of F.interpolate(lr, scale_factor=stride / scale) (floor of size * factor, evaluated in double like torch)
+        oh, ow = int(math.floor(lr.shape[2] * (stride / scale))), int(math.floor(lr.shape[3] * (stride / scale)))
+        if key not in acc:
+            acc[key] = torch.empty((N, lr.shape[1], oh, ow), dtype=torch.float32, device=norm.device)
+        if tuple(acc[key].shape[2:]) != (oh, ow):   # (the reference's `average + r` would raise the same way)
+            raise RuntimeError(f"multi-scale inference: pass at scale {scale} yields {(oh, ow)} for '{key}', the running average is {tuple(acc[key].shape[2:])}")
+        _C.msc_accumulate(acc[key], lr, mode, f, k == 0, stride=float(stride), scale=float(scale), divide=float(n) if k == n - 1 else 0.0)
+
+    k = 0
+    for scale in scales:
+        h, w = int(math.floor(H * scale)), int(math.floor(W * scale))
+        for f in range(n_flip):
+            x = _C.msc_input(norm, h, w, f, self.amp_dtype)
+            features = self.backbone(x)
+            features["global_context"] = self.global_context(features[self.bb_features[-1]])
+            if self.with_panoptic:
+                fold("sem_seg", self.sem_seg_head.layers(features), "softmax", self.sem_seg_head.common_stride, scale, f, k)
+                center, offset = self.ins_embed_head.layers(features)
+                fold("center", center, "plain", self.ins_embed_head.common_stride, scale, f, k)
+                fold("offset", offset, "offset", self.ins_embed_head.common_stride, scale, f, k)
+            if self.with_depth:
+                fold("depth", self.depth_head.layers(features)[0], "inv2depth", self.depth_head.common_stride, scale, f, k)
+            k += 1
+    return {key: acc.get(key) for key in ("sem_seg", "center", "offset", "depth")}
 
 
 MGNet._as_net_input = _as_net_input
@@ -444,14 +476,14 @@ class MGNetSemSegHead(MGNetDecoder):  # mg_net.py:523-610
 
     def forward(self, features):
         from .. import _C
-        y = self.layers(features)
-        if self.training and _C.upce_supported(y):   # the loss kernel interpolates the low-res logits on the fly
+        y = self.layers(features, keep_pad=self.training)   # (training: the channel-padded predictor output, read in place)
+        if self.training and _C.upce_supported(ops.real_channels(y)):   # the loss kernel interpolates the low-res logits on the fly
             return ops.LazyUpsample(y, self.common_stride)
-        return ops.upsample_bilinear(y, self.common_stride)
+        return ops.upsample_bilinear(ops.real_channels(y), self.common_stride)
 
-    def layers(self, features):
+    def layers(self, features, keep_pad=False):
         y, _ = super().forward(features)
-        return self.head(y)
+        return self.head(y, keep_pad=keep_pad)
 
     def losses(self, predictions, targets):
         if self.loss_type == "cross_entropy":  # nn.CrossEntropyLoss(mean, ignore_index): mean over non-ignored pixels
@@ -481,17 +513,17 @@ class MGNetInsEmbedHead(MGNetDecoder):  # mg_net.py:621-715
         return ret
 
     def forward(self, features):
-        center, offset = self.layers(features)
+        center, offset = self.layers(features, keep_pad=self.training)
         lc = ops.LazyUpsample(center, self.common_stride)
         lo = ops.LazyUpsample(offset, self.common_stride, mult=float(self.common_stride))  # pixel offsets (:682-694)
         if self.training and ops.ins_losses_supported(lc, lo):
             return lc, lo
         return lc.materialize(), lo.materialize()
 
-    def layers(self, features):
+    def layers(self, features, keep_pad=False):
         y, _ = super().forward(features)
-        center = torch.sigmoid(self.center_head(y).float())  # mg_net.py:694 (sigmoid_ before the upsample)
-        return center, self.offset_head(y)
+        center = ops.head_activation(self.center_head(y, keep_pad=keep_pad), "sigmoid")  # mg_net.py:694 (sigmoid_ before the upsample)
+        return center, self.offset_head(y, keep_pad=keep_pad)
 
     def losses(self, predictions, targets):
         """[torch-staging] weighted MSE / L1 (mg_net.py:697-715) without the two `.sum() > 0` host syncs:
@@ -543,7 +575,7 @@ class MGNetSelfSupervisedDepthHead(MGNetDecoder):  # mg_net.py:726-829
         y, msc = super().forward(features)
         feats = [y, msc[1], msc[0]] if self.training and self.msc_loss else [y]
         # sigmoid / 0.5 -> inverse depth in (0, 2) (mg_net.py:819-823)
-        return [torch.sigmoid(head(f).float()) / 0.5 for head, f in zip(self.heads, feats)]
+        return [ops.head_activation(head(f, keep_pad=self.training), "sigmoid2") for head, f in zip(self.heads, feats)]
 
     def losses(self, predictions, targets):  # fp32 by contract (custom_fwd(cast_inputs=float32), mg_net.py:827)
         return self.loss(predictions, targets)

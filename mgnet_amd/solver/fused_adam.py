@@ -23,9 +23,15 @@ class FusedAdam(torch.optim.Optimizer):
         self._t = 0
         self._m = [torch.zeros_like(b["flat_g"]) for b in reducer.buckets]
         self._v = [torch.zeros_like(b["flat_g"]) for b in reducer.buckets]
-        self._lr_dev = [torch.zeros(b["flat_g"].numel() // self.chunk, device=dev) for b in reducer.buckets]
-        self._wd_dev = [torch.zeros(b["flat_g"].numel() // self.chunk, device=dev) for b in reducer.buckets]
-        self._hyper = torch.ones(2, device=dev)   # [1/(1-b1^t), 1/sqrt(1-b2^t)] of the current step
+        # ONE static device table for everything the host computes per step: [lr per chunk | weight decay per chunk] of every bucket,
+        # then the two bias corrections -- one pinned staging copy + one device copy per step instead of three per bucket
+        nch = [b["flat_g"].numel() // self.chunk for b in reducer.buckets]
+        self._tab = torch.zeros(2 * sum(nch) + 2, device=dev)
+        offs = np.concatenate([[0], np.cumsum(nch)])
+        self._lr_dev = [self._tab[offs[k]:offs[k + 1]] for k in range(len(nch))]
+        self._wd_dev = [self._tab[sum(nch) + offs[k]:sum(nch) + offs[k + 1]] for k in range(len(nch))]
+        self._hyper = self._tab[2 * sum(nch):]    # [1/(1-b1^t), 1/sqrt(1-b2^t)] of the current step
+        self._hyper.fill_(1.0)
         self._stager = _C.PinnedStager()
         self._partials = torch.zeros(1024 * len(reducer.buckets), device=dev)
         self._coef = torch.zeros(4, device=dev)    # clip coefficient (/ loss scale), gradient norm, found_inf
@@ -43,16 +49,15 @@ class FusedAdam(torch.optim.Optimizer):
         staged through pinned memory, stream-ordered, no host stall.  Separate from the launches so that a captured step
         (hipGraph) only needs this small upload before each replay."""
         g0 = self.param_groups[0]
-        for k, b in enumerate(self.reducer.buckets):
-            lr = np.repeat(np.array([self._group_of[p]["lr"] for p in b["params"]], np.float32), self._reps[k])
-            wd = np.repeat(np.array([self._group_of[p]["weight_decay"] or 0.0 for p in b["params"]], np.float32), self._reps[k])
-            tab = self._stager.stage(torch.from_numpy(np.stack([lr, wd])), self._lr_dev[k].device, slot=k)   # (event-guarded pinned ring)
-            self._lr_dev[k].copy_(tab[0])
-            self._wd_dev[k].copy_(tab[1])
+        lr = [np.repeat(np.array([self._group_of[p]["lr"] for p in b["params"]], np.float32), self._reps[k]) for k, b in enumerate(self.reducer.buckets)]
+        wd = [np.repeat(np.array([self._group_of[p]["weight_decay"] or 0.0 for p in b["params"]], np.float32), self._reps[k])
+              for k, b in enumerate(self.reducer.buckets)]
+        hy = np.ones(2, np.float32)
         if self.scaler is None:   # (with loss scaling the device counts the steps taken: a step with inf gradients is skipped)
             bc1, bc2 = 1.0 - g0["betas"][0] ** self._t, 1.0 - g0["betas"][1] ** self._t
-            hy = self._stager.stage(torch.tensor([1.0 / bc1, 1.0 / np.sqrt(bc2)], dtype=torch.float32), self._hyper.device, slot="hyper")
-            self._hyper.copy_(hy)
+            hy = np.array([1.0 / bc1, 1.0 / np.sqrt(bc2)], np.float32)
+        host = torch.from_numpy(np.concatenate(lr + wd + [hy]))
+        self._tab.copy_(self._stager.stage(host, self._tab.device, slot="tables"))   # (event-guarded pinned ring)
 
     def prepare_step(self):
         """host part of a step (step count, tables); `launch_step` is the device part"""

@@ -1,0 +1,102 @@
+"""GPU: the kernels of multi-scale + flip inference (csrc/mscflip.hip) against the torch formulation of
+mg_net.py:427-520 -- F.interpolate(bilinear, align_corners=True), softmax, offset scaling, inv2depth, torch.flip, running sums."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_pass(lr, mode, flip, stride, scale):
+    up = F.interpolate(lr.float(), scale_factor=stride / scale, mode="bilinear", align_corners=True)
+    if mode == "softmax":
+        v = torch.softmax(up, 1)
+    elif mode == "offset":
+        v = up * stride / scale
+    elif mode == "inv2depth":
+        v = 1.0 / up.clamp(min=1e-6)
+    else:
+        v = up
+    if flip:
+        v = torch.flip(v, dims=(3,))
+        if mode == "offset":
+            v[:, 1] *= -1
+    return v
+
+
+@pytest.mark.parametrize("mode,C,dtype", [("softmax", 20, torch.bfloat16), ("softmax", 19, torch.float16), ("plain", 1, torch.float32),
+                                          ("offset", 2, torch.bfloat16), ("inv2depth", 1, torch.float32)])
+def test_accumulate_matches_torch_over_all_passes(mode, C, dtype):
+    """the seven scales x two flips of the reference's default schedule, on head outputs of the sizes those passes produce (ragged:
+    H=104, W=200 -> stride-8 maps of 6x12 ... 26x50), strided like the predictors' channel-padded outputs"""
+    from mgnet_amd import _C
+    torch.manual_seed(0)
+    N, H, W, stride = 2, 104, 200, 8
+    scales = [0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0]
+    acc = torch.empty(N, C, H, W, device="cuda")
+    ref = None
+    n = 2 * len(scales)
+    k = 0
+    for scale in scales:
+        h, w = int(math.floor(H * scale)) // stride, int(math.floor(W * scale)) // stride
+        for f in range(2):
+            pad = torch.randn(N, 32, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+            lr = pad[:, :C] if dtype != torch.float32 else (torch.rand(N, C, h, w, device="cuda") * 2 - (0.0 if mode == "inv2depth" else 1.0))
+            if tuple(F.interpolate(lr.float(), scale_factor=stride / scale, mode="bilinear", align_corners=True).shape[2:]) != (H, W):
+                pytest.skip("schedule does not map back to (H, W) for this size")
+            _C.msc_accumulate(acc, lr, mode, f, k == 0, stride=float(stride), scale=float(scale), divide=float(n) if k == n - 1 else 0.0)
+            v = _ref_pass(lr, mode, f, stride, scale)
+            ref = v if ref is None else ref + v
+            k += 1
+    ref = ref / n
+    tol = 2e-5 if mode != "inv2depth" else 2e-4
+    err = ((acc - ref).abs() / (ref.abs() + (1e-3 if mode != "inv2depth" else 1.0))).max()
+    assert float(err) < tol, (mode, float(err))
+    if mode == "softmax":
+        assert torch.allclose(acc.sum(1), torch.ones(N, H, W, device="cuda"), atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_input_rescale_flip_matches_torch(dtype):
+    from mgnet_amd import _C
+    torch.manual_seed(1)
+    N, H, W = 2, 70, 122
+    norm = torch.randn(N, 3, H, W, device="cuda")
+    for scale in (0.5, 0.75, 1.0, 1.25, 2.0):
+        x = F.interpolate(norm, scale_factor=scale, mode="bilinear", align_corners=True)
+        h, w = x.shape[2:]
+        assert (h, w) == (int(math.floor(H * scale)), int(math.floor(W * scale)))
+        for f in (0, 1):
+            want = torch.flip(x, dims=(3,)) if f else x
+            got = _C.msc_input(norm, h, w, f, dtype)
+            assert got.shape == (N, 8, h, w) and got.is_contiguous(memory_format=torch.channels_last)
+            assert float(got[:, 3:].abs().max()) == 0.0
+            # same fp32 interpolation up to contraction order, then ONE rounding to 16 bits: at most one 16-bit ulp apart, rarely
+            d = (got[:, :3].float() - want.to(dtype).float()).abs()
+            ulp = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * want.abs().clamp(min=2.0 ** -14)
+            assert bool((d <= ulp * 1.01).all()) and float((d > 0).float().mean()) < 2e-2, (scale, f, float(d.max()))
+
+
+def test_hip_path_matches_torch_formulation_end_to_end():
+    """forward_multi_scale_flip on the bf16 HIP trunk: device path (mscflip.hip) vs the torch formulation driving the SAME network"""
+    from test_model_golden import GM, _model
+    m = _model("cuda", True).eval()
+    img = GM.eval_image().cuda()
+    with torch.no_grad():
+        x = ((img[None].float() / 255.0) - m.pixel_mean) / m.pixel_std
+        got = m.forward_multi_scale_flip(x, scales=[0.5, 1.0, 1.5], flip=True)
+        amp, m.amp_dtype = m.amp_dtype, None
+        try:     # torch formulation: force it by hiding the 16-bit trunk from the dispatcher, then feed the same 16-bit inputs
+            m._as_net_input = lambda t, _amp=amp: torch.nn.functional.pad(t, (0, 0, 0, 0, 0, 5)).to(_amp).contiguous(memory_format=torch.channels_last)
+            want = m.forward_multi_scale_flip(x, scales=[0.5, 1.0, 1.5], flip=True)
+        finally:
+            m.amp_dtype = amp
+            del m._as_net_input
+    for k in ("sem_seg", "center", "offset"):
+        a, b = got[k].float(), want[k].float()
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-4, (k, float((a - b).abs().max()), float(b.abs().max()))
+    a, b = 1.0 / got["depth"], 1.0 / want["depth"]
+    assert float((a - b).abs().max()) < 0.05

@@ -25,7 +25,10 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     for _ in range(2):
         trainer.run_step(batch)
     torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.self_device_time_total > 0]
+rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12) if e.key.startswith("aten::") and e.self_device_time_total > 0]
 rows.sort(key=lambda e: -e.self_device_time_total)
-for e in rows[:40]:
-    print(f"{e.self_device_time_total / 2e3:8.3f} ms/step  {e.count // 2:4d} calls  {e.key:28s} {str(e.input_shapes)[:150]}")
+tot = sum(e.self_device_time_total for e in rows) / 2e3
+print(f"# torch (aten) ops with device time in one training step: {tot:.3f} ms/step, {sum(e.count for e in rows) // 2} calls/step")
+for e in rows[:int(os.environ.get("TOP", "80"))]:
+    where = [f.split("/")[-1] for f in (e.stack or []) if "mgnet_amd" in f or "bench" in f][:3]
+    print(f"{e.self_device_time_total / 2e3:8.3f} ms/step  {e.count / 2:5.1f} calls  {e.key:26s} {str(e.input_shapes)[:90]:90s} {' <- '.join(where)}")
