@@ -1,0 +1,451 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MGNet training hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no torch.distributed environment the process
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (before anything touches the GPU) and
+exits with its code; under a launcher (RANK/WORLD_SIZE set) it is one rank.  A step = one full MGNet training step
+(2x ResNet-18 + 3 decoders/heads forward + backward, five losses incl. the photometric reprojection loss, gradient
+all-reduce, clip, Adam) over one per-GPU batch of synthetic Cityscapes-shaped input that is already resident in HBM.
+Rank 0 prints ONE JSON line; `config.workload` says exactly what is timed.  `--loss-only` / `--fwd-only` are diagnostics
+that time the reprojection loss alone (not the benchmark).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
+FWD_BYTES_PER_PX = 49 + 12     # march kernel on the reference's fp32 frames: reads 3 inv + 9 image floats + mask, writes 3 grad floats
+BWD_BYTES_PER_PX = 37 + 12     # streaming backward: 3 inv + 3 img + mask + 3 g (read) ; 3 d_inv (write)
+FWD_BYTES_PER_PX_U8 = 25 + 12  # ... on uint8 RGBX frames (frame_layout 2, what the training step uses): 3 inv floats + 3 packed pixels + mask
+BWD_BYTES_PER_PX_U8 = 29 + 12
+
+
+def reproj_roofline(kern_ms, npx, u8, traffic, extra=None):
+    """roofline object of reproj_march<true>.  `achieved` counts the ALGORITHMIC bytes of the kernel that ran -- with uint8 RGBX frames
+    that is 37 B/px, not the 61 B/px of the reference's fp32 tensors; the 61 B/px equivalent (comparable with the
+    round-1/2 lines, which ran the fp32 layout) is reported next to it."""
+    bpp = FWD_BYTES_PER_PX_U8 if u8 else FWD_BYTES_PER_PX
+    achieved = bpp * npx / (kern_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": "reproj_march<true, %s> (fused reprojection loss + photometric gradient)" % ("uint8 RGBX frames" if u8 else "fp32 planar frames"),
+         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+         "traffic": traffic, "bytes_per_px": bpp, "bytes_per_launch": bpp * npx, "avg_launch_ms": round(kern_ms, 4),
+         "achieved_at_61_B_per_px": round(FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9, 1),
+         "frac_at_61_B_per_px": round(FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "limiter": "VALU issue + vector-memory instruction rate, not HBM (DESIGN.md 2.4: counted)"}
+    r.update(extra or {})
+    return r
+
+
+def synth_batch(B, H, W, seed, device):
+    """SURVEY.md 8(d) synthetic inputs, built on the GPU with torch (plumbing)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                            torch.arange(W + 16, device=device, dtype=torch.float32), indexing="ij")
+    img = torch.zeros(B, 3, H, W + 16, device=device)
+    for _ in range(8):
+        f = torch.rand(B, 3, 2, device=device, generator=g) * 0.2 + 0.005
+        ph = torch.rand(B, 3, 1, 1, device=device, generator=g) * 6.283
+        img += torch.sin(f[..., 0, None, None] * xx + f[..., 1, None, None] * yy + ph)
+    img = (img - img.amin((2, 3), keepdim=True)) / (img.amax((2, 3), keepdim=True) - img.amin((2, 3), keepdim=True))
+    img = (0.95 * img + 0.05 * torch.rand(img.shape, device=device, generator=g)).clamp(0, 1)
+    img = (img * 255).round() / 255  # uint8 frames / 255 like mg_net.py:320-335
+    cur = img[..., 8:8 + W].contiguous()
+    prev = torch.roll(img[..., 5:5 + W], 1, 2).contiguous()    # shifted by (+3,+1) px
+    nxt = torch.roll(img[..., 11:11 + W], -1, 2).contiguous()  # shifted by (-3,-1) px
+    inv = []
+    for s in (8, 16, 32):  # the heads predict at /8,/16,/32 and upsample bilinearly (mg_net.py:804-807)
+        lo = torch.rand(B, 1, H // s, W // s, device=device, generator=g) * 1.9 + 0.05
+        inv.append(torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=True).contiguous())
+    poses = 0.01 * torch.randn(B, 2, 6, device=device, generator=g)
+    mask = torch.rand(B, 1, H, W, device=device, generator=g) < 0.9
+    K = torch.eye(4, device=device).repeat(B, 1, 1)
+    sx, sy = W / 2048.0, H / 1024.0  # camera_utils.py:15-21 scale_intrinsics of the Cityscapes camera
+    K[:, 0, 0], K[:, 1, 1] = 2262.52 * sx, 2265.30 * sy
+    K[:, 0, 2], K[:, 1, 2] = (1096.98 + 0.5) * sx - 0.5, (513.137 + 0.5) * sy - 0.5
+    return dict(inv=inv, img=cur, prev=prev, nxt=nxt, poses=poses, mask=mask, K=K)
+
+
+class HipEvents:
+    """Raw hipEvent_t pair handed to the C-ABI (cfg.prof_begin/prof_end) so that the dominant kernel is timed on
+    the stream it is launched on."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.pairs = []
+        for _ in range(n):
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
+            self.pairs.append((a, b))
+
+    def elapsed_ms(self):
+        out = []
+        for a, b in self.pairs:
+            ms = ctypes.c_float()
+            assert self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+            out.append(ms.value)
+        return out
+
+
+def cpu_baseline(H, W, state_dict=None, cfg=None):
+    """CPU baseline on a bounded sample (ONE frame of the workload), `kind: "port"`:
+    with a state_dict: the full training step (network forward + five losses + backward) of oracle/network_oracle.py
+    (plain-torch fp32 restatement of the reference network + the pinned C oracle of the reprojection loss);
+    without: only the reprojection loss (used by --loss-only)."""
+    import oracle
+
+    oracle.build()
+    if state_dict is not None:
+        from mgnet_amd.data import synthetic_batch
+        from oracle import network_oracle as NO
+
+        torch.manual_seed(0)
+        nb = 2  # F.batch_norm refuses a single value per channel (the 1x1-spatial GCM / attention layers need B >= 2)
+        batch = synthetic_batch(nb, H, W, "cpu", seed=99)
+        sd = {k: v.detach().float().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in state_dict.items()}
+        t0 = time.time()
+        losses = NO.mgnet_losses(sd, batch, pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD,
+                                 ohem_n_min=min(cfg.MODEL.SEM_SEG_HEAD.OHEM_N_MIN, H * W // 4 - 1))
+        sum(losses.values()).backward()
+        dt = time.time() - t0
+        return {"value": round(nb / dt, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{nb} frames {H}x{W}: full MGNet training step fwd+bwd (no optimizer), oracle/network_oracle.py "
+                          f"(torch fp32 CPU, {torch.get_num_threads()} threads) + oracle/reproj_oracle.c, {dt:.1f} s"}
+    rs = np.random.RandomState(0)
+    B = 1
+    inv = [rs.uniform(0.05, 1.95, (B, 1, H, W)).astype(np.float32) for _ in range(3)]
+    img, prev, nxt = [rs.uniform(0, 1, (B, 3, H, W)).astype(np.float32) for _ in range(3)]
+    poses = (0.01 * rs.randn(B, 2, 6)).astype(np.float32)
+    mask = rs.uniform(size=(B, 1, H, W)) > 0.1
+    K = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = 2262.52, 2265.30, 1096.98, 513.137
+    t0 = time.time()
+    oracle.reproj_loss(inv, img, prev, nxt, mask, K, poses)
+    dt = time.time() - t0
+    return {"value": round(B / dt, 4), "unit": "img/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"1 frame {H}x{W}, reprojection loss fwd+bwd, oracle/reproj_oracle.c fp32 OpenMP, {dt:.1f} s"}
+
+
+def conv_roofline(dev, B):
+    """Second roofline object (informative): the convolution kernel that takes the largest share of the step -- the 3x3
+    256->256 head/refine layers at 1/8 resolution (conv3x3_win16, csrc/conv_win.hip) -- timed live with events on the launch stream."""
+    from mgnet_amd import _C
+    x = torch.randn(B, 256, 128, 256, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(256, 256, 3, 3, device=dev) * 0.02)
+    wl = _C.weight_layout(w, 0)
+    for _ in range(3):
+        _C.conv_igemm(x, wl, (128, 256), None, 1, 1)
+    n = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        _C.conv_igemm(x, wl, (128, 256), None, 1, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * B * 128 * 256 * 256 * 256 * 9
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv3x3_win16 (windowed 3x3, 256->256 channels, 8x128x256 pixels: the layer shape with the largest share of the step)",
+            "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+            "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
+
+
+def full_step_bench(args, world, rank, dev):
+    """The benchmark: one full MGNet training step (SURVEY 3.1 hot loop) per per-GPU batch of synthetic frames."""
+    from mgnet_amd import add_mgnet_config, get_cfg
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.engine import Trainer
+    from mgnet_amd.registry import build_model
+
+    B, H, W = args.batch, args.height, args.width
+    cfg = get_cfg()
+    add_mgnet_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "bench-c4-cityscapes-videosequence.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", str(dev), "SOLVER.IMS_PER_BATCH", B * world,
+                         "MODEL.SEM_SEG_HEAD.OHEM_N_MIN", min(524287, B * H * W // 4 - 1),
+                         "SOLVER.AMP.DTYPE", {"bf16": "bfloat16", "fp16": "float16"}[args.dtype]])
+    torch.manual_seed(0)  # identical initial weights on every rank (DDP broadcasts rank 0's; same seed is equivalent)
+    model = build_model(cfg)
+    trainer = Trainer(cfg, model)
+    batch = synthetic_batch(B, H, W, dev, seed=1234 + rank)
+    ev = HipEvents(args.steps)
+    depth_loss = model.depth_head.loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    # Execution mode of the timed steps: "eager" (default) = the launches of a step issued from Python, with the independent
+    # branches of MGNet.forward on side streams (pose network | backbone, three heads: concurrent short kernels, hidden dispatch
+    # latency); "graph" (--graph on, one rank only) = the whole step captured once in a hipGraph on ONE stream and replayed.
+    # Measured (end of round 2): eager + side streams 30.2 ms, graph 32.5 ms (capturing the side-stream branches crashes hipGraph on ROCm 7.0).
+    use_graph = args.graph == "on" and world == 1
+    mode = "eager"
+    for _ in range(max(args.warmup, 3) if use_graph else args.warmup):
+        trainer.run_step(batch)
+    if use_graph:
+        try:
+            trainer.capture_step(batch)
+            for _ in range(2):
+                trainer.replay_step()
+            mode = "graph"
+        except Exception as e:  # noqa: BLE001 -- report and fall back to the eager step rather than lose the measurement
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr, flush=True)
+    fence()
+    t0 = time.perf_counter()
+    if mode == "graph":
+        for k in range(args.steps):
+            last = trainer.replay_step()
+    else:
+        for k in range(args.steps):
+            depth_loss.prof_events = ev.pairs[k]
+            last = trainer.run_step(batch)
+    t_issue = time.perf_counter() - t0   # host time to issue the K steps (no sync inside a step): ~dt means launch-bound
+    fence()
+    dt = time.perf_counter() - t0
+    if mode == "graph":
+        # events recorded by graph nodes cannot be read back with hipEventElapsedTime, so the dominant kernel is timed with
+        # event pairs on its launch stream in eager steps of the same workload run right after the timed region
+        for k in range(args.steps):
+            depth_loss.prof_events = ev.pairs[k]
+            trainer.run_step(batch)
+        fence()
+    # What the host needs to ISSUE a step, measured where the GPU cannot back-pressure the launch queue: the same model and launch
+    # sequence on two 512x1024 frames (an eighth of the device work, the same host work).  `host_issue_ms_per_step` above is the
+    # wall time of the launch loop at the benchmark size, which mostly waits for queue slots once the GPU is the bottleneck.
+    host_unloaded = None
+    if rank == 0 and world == 1 and mode == "eager" and not args.no_host_probe:
+        try:
+            small = synthetic_batch(2, 512, 1024, dev, seed=7)
+            for _ in range(2):
+                trainer.run_step(small)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for _ in range(5):
+                trainer.run_step(small)
+            host_unloaded = (time.perf_counter() - th) / 5 * 1e3
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- informative only
+            print(f"[bench] unloaded host-issue measurement skipped ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+    dist_info = None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+        # what the exchange costs: a few more steps WITHOUT the gradient all-reduce (measurement only, after the timed region;
+        # the ranks' weights drift apart from here on, nothing is timed afterwards)
+        from mgnet_amd.modeling import ops as _ops
+        n_ar, n_bn = trainer.reducer.collectives, _ops.SYNCBN_COLLECTIVES[0]
+        trainer.run_step(batch)
+        n_ar, n_bn = trainer.reducer.collectives - n_ar, _ops.SYNCBN_COLLECTIVES[0] - n_bn
+        trainer.reducer.enabled = False
+        n_extra = max(3, min(10, args.steps))
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n_extra):
+            trainer.run_step(batch)
+        fence()
+        t_no = torch.tensor([(time.perf_counter() - t1) / n_extra], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t_no, op=torch.distributed.ReduceOp.MAX)
+        dist_info = {"backend": torch.distributed.get_backend(), "rccl_world_size": torch.distributed.get_world_size(),
+                     "grad_allreduce_calls_per_step": n_ar, "grad_bytes_per_step": trainer.reducer.grad_bytes(),
+                     "syncbn_collectives_per_step": n_bn,
+                     "ms_per_step_without_grad_allreduce": round(float(t_no.item()) * 1e3, 3),
+                     "exposed_grad_allreduce_ms_per_step": round(dt / args.steps * 1e3 - float(t_no.item()) * 1e3, 3)}
+    if rank == 0:
+        kern_ms = float(np.median(ev.elapsed_ms()))
+        npx = B * H * W
+        u8_frames = model._orig_frames_u8(batch) is not None     # the layout MGNet.forward hands to the loss for this batch
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if (tj.get("B"), tj.get("H"), tj.get("W")) == (B, H, W) and bool(tj.get("u8_frames", False)) == u8_frames:
+                traffic = tj.get("hbm_bytes_per_launch")
+        img_s = world * B * args.steps / dt
+        # forward conv FLOPs per image scale with the pixel count; training ~ 3x forward
+        gflop_fwd = 560.2 * (H * W) / (1024 * 2048)
+        line = {
+            "metric": "training img/s at 1024x2048 Cityscapes, 1/2/4/8 MI355X; reprojection-loss HBM GB/s",
+            "value": round(img_s, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"MGNet-Cityscapes-VideoSequence recipe (BASELINE {'C5: fp16 + dynamic loss scaling' if args.dtype == 'fp16' else 'C4/C5'}): full multi-task training step "
+                                   f"(2x ResNet-18 + 3 decoders/heads fwd+bwd, OHEM CE, centre/offset, photometric "
+                                   f"reprojection + smoothness, uncertainty weighting, grad all-reduce, clip, Adam), "
+                                   f"{B} frames/GPU of {H}x{W}",
+                       "frames_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
+                       "parallelism": f"dp{world}", "step_execution": mode + (" (one hipGraph replay per step, one stream)" if mode == "graph" else
+                                                  " (launches issued from Python; side streams for the independent branches: " +
+                                                  ("on" if model._side_streams() is not None else "off") + ")"),
+                       "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2),
+                       "host_issue_ms_per_step_unloaded": None if host_unloaded is None else round(host_unloaded, 2), "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
+                       "losses": {k: round(float(v.detach()), 5) for k, v in last.items()},
+                       "torch_staging_ops": sorted(__import__("mgnet_amd.modeling.ops", fromlist=["x"]).STAGING_USED)},
+            "roofline": reproj_roofline(kern_ms, npx, u8_frames, traffic, {
+                "timed_with": "hipEvent pairs around the kernel on its launch stream, " +
+                              (f"{args.steps} eager steps run right after the graph-replayed timed region" if mode == "graph"
+                               else "inside the timed steps")}),
+        }
+        if dist_info is not None:
+            line["config"]["distributed"] = dist_info
+        line["roofline_mfma"] = conv_roofline(dev, B)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(H, W, model.state_dict(), cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()   # rank 0 may still be timing the informative conv roofline: leave together
+        torch.distributed.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run the N ranks as a child job (one process per GPU over RCCL) and
+    return its exit code.  Called before any HIP call of this process; the parent never initialises the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU (C4/C5: 8)")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-probe", action="store_true", help="skip the small-batch steps that time the unloaded launch loop (profiling runs)")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="16-bit activation format of the trunk: bf16 (default) or the reference's AMP format fp16 with dynamic loss "
+                         "scaling (BASELINE C5)")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="on: replay the captured step as a hipGraph (1 GPU, one stream); auto/off: issue every launch from Python "
+                         "with the independent branches on side streams (the faster mode)")
+    ap.add_argument("--fwd-only", action="store_true", help="diagnostic: loss only (no gradient); NOT the benchmark")
+    ap.add_argument("--loss-only", action="store_true",
+                    help="diagnostic: time only the reprojection loss fwd+bwd (round-1 v2 workload); NOT the benchmark")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))   # nothing has touched the GPU in this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # one rank per GPU.  (MGNET_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than ranks --
+    # ranks then share devices, which RCCL refuses; a functional check only, never a measurement)
+    backend = os.environ.get("MGNET_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
+    torch.cuda.set_device(local)          # before the process group: RCCL binds the communicator to the current device
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+
+    from mgnet_amd import _C
+    from mgnet_amd.modeling.loss import _ReprojLossFn
+
+    B, H, W = args.batch, args.height, args.width
+    if not (args.loss_only or args.fwd_only):
+        return full_step_bench(args, world, rank, dev)
+    d = synth_batch(B, H, W, 1234 + rank, dev)
+    if os.environ.get("MGN_REPROJ_RGBX"):   # diagnostic: context frames pixel-interleaved ([B,H,W,4] in memory, 4th channel unused)
+        for k in ("prev", "nxt"):
+            t = torch.zeros((B, 4, H, W), device=dev).contiguous(memory_format=torch.channels_last)
+            t[:, :3] = d[k]
+            d[k] = t
+    u8_frames = bool(os.environ.get("MGN_REPROJ_U8"))
+    if u8_frames:   # diagnostic: all three frames as uint8 RGBX ([B,H,W,4] in memory), the layout the training step uses
+        for k in ("img", "prev", "nxt"):
+            t = torch.zeros((B, 4, H, W), device=dev, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+            t[:, :3] = (d[k] * 255).round().to(torch.uint8)
+            d[k] = t
+    inv = [x.requires_grad_(not args.fwd_only) for x in d["inv"]]
+    poses = d["poses"].requires_grad_(not args.fwd_only)
+    nsteps = args.warmup + args.steps
+    ev = HipEvents(args.steps)
+    cfgs = [_C.make_reproj_cfg(B, H, W, 3) for _ in range(nsteps)]
+    for k in range(args.steps):
+        cfgs[args.warmup + k].prof_begin, cfgs[args.warmup + k].prof_end = ev.pairs[k]
+    w = torch.ones(2, device=dev)
+
+    def step(k):
+        # data-parallel: each rank owns its B frames; the loss has no cross-rank term (per-rank means)
+        losses = _ReprojLossFn.apply(cfgs[k], d["img"], d["prev"], d["nxt"], d["mask"], d["K"], poses, *inv)
+        if args.fwd_only:
+            return losses
+        (losses * w).sum().backward()
+        for x in inv:
+            x.grad = None
+        poses.grad = None
+        return losses
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        last = step(args.warmup + k)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms = ev.elapsed_ms()
+        kern_ms = float(np.mean(ms))
+        npx = B * H * W
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("B") == B and tj.get("H") == H and tj.get("W") == W and bool(tj.get("u8_frames", False)) == u8_frames:
+                traffic = tj.get("hbm_bytes_per_launch")
+        line = {
+            "metric": "training img/s at 1024x2048 Cityscapes, 1/2/4/8 MI355X; reprojection-loss HBM GB/s",
+            "value": round(world * B * args.steps / dt, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"MGNet-Cityscapes-VideoSequence (C4/C5 shape): photometric reprojection loss "
+                                   f"fwd+bwd only (SURVEY 8a group G; network rows N not in the step yet), "
+                                   f"{B} frames/GPU of {H}x{W}, 3 scales, 2 context frames",
+                       "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"dp{world}",
+                       "loss_photometric": float(last[0]), "loss_smoothness": float(last[1])},
+            "roofline": reproj_roofline(kern_ms, npx, u8_frames, traffic),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(H, W)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,6 @@
 import ctypes
 import os
 
-import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,7 +23,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
            "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_instance_post_workspace_bytes", "mgn_instance_post", "mgn_instance_masks", "mgn_pseudo_label_ids", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
            "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd",
-           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4", "mgn_u8_frames_to_rgbx", "mgn_msc_input", "mgn_msc_accumulate", "mgn_uncertainty_fwd", "mgn_uncertainty_bwd", "mgn_head_act_fwd", "mgn_head_act_bwd",
+           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4", "mgn_u8_frames_to_rgbx",
            "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
            "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd"]
 SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
@@ -134,7 +133,7 @@ def lib():
         L.mgn_relu_mask_bwd.argtypes = [vp, vp, vp, cl, vp]
         L.mgn_colsum.argtypes = [vp, vp, ci, cl, ci, cf, vp, vp, sz, vp]
         L.mgn_bcast_rows.argtypes = [vp, ci, cl, ci, cf, vp, vp]
-        L.mgn_scale_channels.argtypes = [vp, vp, ci, cl, ci, ci, vp, vp, vp, vp]
+        L.mgn_scale_channels.argtypes = [vp, vp, ci, cl, ci, ci, vp, vp, vp]
         L.mgn_vec_linear_fwd.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp]
         L.mgn_vec_linear_bwd_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(sz)]
         L.mgn_vec_linear_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, sz, vp]
@@ -146,12 +145,6 @@ def lib():
         L.mgn_u8_frames_to_f32.argtypes = [vp, ci, cl, cf, vp, vp]
         L.mgn_u8_frames_to_f32_nhwc4.argtypes = [vp, ci, cl, cf, vp, vp]
         L.mgn_u8_frames_to_rgbx.argtypes = [vp, ci, cl, vp, vp]
-        L.mgn_uncertainty_fwd.argtypes = [vp, ci, vp, ctypes.c_uint, vp, vp, vp]
-        L.mgn_uncertainty_bwd.argtypes = [vp, vp, ci, ci, vp, ctypes.c_uint, vp, vp, vp]
-        L.mgn_head_act_fwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
-        L.mgn_head_act_bwd.argtypes = [vp, cl, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp]
-        L.mgn_msc_input.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
-        L.mgn_msc_accumulate.argtypes = [vp, ci, cl, cl, cl, cl] + [ci] * 9 + [cf, cf, cf, vp, vp]
         L.mgn_iabn_bwd_reduce_x.argtypes = [vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, ci, cf, vp, vp, vp, sz, vp]
         L.mgn_iabn_bwd_apply_x.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp]
         L.mgn_abn_add_relu_fwd.argtypes = [vp, vp, vp, vp, vp, cl, ci, vp]
@@ -181,9 +174,6 @@ def lib():
     return _lib
 
 
-_NP_OK = (torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8, torch.int16, torch.bool)
-
-
 class PinnedStager:
     """Host -> device copies of small per-step tensors without stalling the host: a copy from pageable memory is
     stream-ordered AND blocks the host until every kernel queued before it has run.  Staged through a ring of pinned
@@ -205,16 +195,7 @@ class PinnedStager:
         ring["turn"] = (i + 1) % self.depth
         if ring["evs"][i] is not None:
             ring["evs"][i].synchronize()
-        # plain memcpy through numpy views: a torch CPU copy_ of more than 32 K elements goes through the intra-op thread pool,
-        # whose workers then spin-wait on every core for the next ~200 ms and starve this (launch-issuing) thread -- measured: the
-        # single 60 K-float optimizer table made the whole step 10-15 ms slower and erratic
-        if src.dtype in _NP_OK and src.is_contiguous() and not src.requires_grad:
-            views = ring.get("np")
-            if views is None:
-                views = ring["np"] = [b.numpy() for b in ring["bufs"]]
-            np.copyto(views[i], src.numpy())
-        else:
-            ring["bufs"][i].copy_(src)
+        ring["bufs"][i].copy_(src)
         out = ring["bufs"][i].to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -513,84 +494,6 @@ def u8_frames_to_rgbx(frames):
     ptrs = (ctypes.c_void_p * len(frames))(*[t.data_ptr() for t in frames])
     check(lib().mgn_u8_frames_to_rgbx(ptrs, len(frames), H * W, out.data_ptr(), _stream()), "mgn_u8_frames_to_rgbx")
     return out
-
-
-_HEAD_ACT = {"none": 0, "sigmoid": 1, "sigmoid2": 2}
-
-
-def head_act_fwd(xp, C, kind):
-    """xp: padded predictor output [B,P,h,w] 16-bit channels_last -> fp32 [B,C,h,w] = act(xp[:, :C])   (mgn_head_act_fwd)"""
-    B, P, h, w = xp.shape
-    assert xp.is_cuda and xp.dtype in H16 and xp.is_contiguous(memory_format=torch.channels_last) and C <= P
-    y = torch.empty((B, C, h, w), dtype=torch.float32, device=xp.device)
-    check(lib().mgn_head_act_fwd(xp.data_ptr(), B, h, w, P, C, _HEAD_ACT[kind], int(xp.dtype == torch.float16), y.data_ptr(), _stream()), "mgn_head_act_fwd")
-    return y
-
-
-def head_act_bwd(g, y, shape, C, kind, dtype, gscale=1.0, g_strides=None):
-    """g: fp32 gradient wrt act(x)[:, :C] ([B,C,h,w]-indexable through element strides (sb, sc, sp)) -> gradient wrt the padded predictor
-    output, [B,P,h,w] `dtype` channels_last with zero padding channels   (mgn_head_act_bwd)"""
-    B, P, h, w = shape
-    if g_strides is None:
-        assert g.shape == (B, C, h, w) and g.stride(3) * w == g.stride(2)
-        g_strides = (g.stride(0), g.stride(1), g.stride(3))
-    dx = torch.empty((B, P, h, w), dtype=dtype, device=g.device, memory_format=torch.channels_last)
-    check(lib().mgn_head_act_bwd(_dev_f32_any(g).data_ptr(), g_strides[0], g_strides[1], g_strides[2], None if y is None else y.data_ptr(), B, h, w, P, C,
-                                 _HEAD_ACT[kind], int(dtype == torch.float16), float(gscale), dx.data_ptr(), _stream()), "mgn_head_act_bwd")
-    return dx
-
-
-def _dev_f32_any(t):
-    if not (t.is_cuda and t.dtype == torch.float32):
-        raise ValueError(f"expected a float32 GPU tensor, got {t.dtype} {t.device}")
-    return t
-
-
-def uncertainty_fwd(raws, log_vars, tau_mask):
-    """raws: list of n fp32 device scalars -> (weighted [n], uncertainty [n])   (mgn_uncertainty_fwd)"""
-    n = len(raws)
-    out = torch.empty((2, n), dtype=torch.float32, device=log_vars.device)
-    ptrs = (ctypes.c_void_p * n)(*[_dev_f32(t, "raw loss").data_ptr() for t in raws])
-    check(lib().mgn_uncertainty_fwd(ptrs, n, _dev_f32(log_vars, "log_vars").data_ptr(), tau_mask, out[0].data_ptr(), out[1].data_ptr(), _stream()),
-          "mgn_uncertainty_fwd")
-    return out[0], out[1]
-
-
-def uncertainty_bwd(raws, grads, log_vars, tau_mask):
-    """-> (d_raw [n], d_log_vars [len(log_vars)])"""
-    n = len(raws)
-    d_raw = torch.empty(n, dtype=torch.float32, device=log_vars.device)
-    d_lv = torch.empty(log_vars.numel(), dtype=torch.float32, device=log_vars.device)
-    rp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in raws])
-    gp = (ctypes.c_void_p * n)(*[None if g is None else _dev_f32(g, "grad").data_ptr() for g in grads])
-    check(lib().mgn_uncertainty_bwd(rp, gp, n, log_vars.numel(), log_vars.data_ptr(), tau_mask, d_raw.data_ptr(), d_lv.data_ptr(), _stream()),
-          "mgn_uncertainty_bwd")
-    return d_raw, d_lv
-
-
-_MSC_MODE = {"softmax": 0, "plain": 1, "offset": 2, "inv2depth": 3}
-_MSC_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
-
-
-def msc_input(norm, h, w, flip, dtype):
-    """[N,3,H,W] fp32 normalised frames -> bilinear(align_corners) rescale to (h, w) (+ horizontal flip) as the network input
-    [N,8,h,w] `dtype` channels_last (channels 3..7 zero): one launch instead of interpolate + flip + pad + cast + layout change"""
-    N, C, H, W = norm.shape
-    assert C == 3 and norm.dtype == torch.float32 and norm.is_cuda and norm.is_contiguous() and dtype in H16
-    out = torch.empty((N, 8, h, w), dtype=dtype, device=norm.device, memory_format=torch.channels_last)
-    check(lib().mgn_msc_input(norm.data_ptr(), N, H, W, h, w, int(bool(flip)), int(dtype == torch.float16), out.data_ptr(), _stream()), "mgn_msc_input")
-    return out
-
-
-def msc_accumulate(acc, lr, mode, flip, first, stride=1.0, scale=1.0, divide=0.0):
-    """acc[N,C,H,W] fp32 (+)= f(bilinear upsample of lr[N,C,h,w]) for one pass of multi-scale + flip inference (mgn_msc_accumulate)"""
-    N, C, h, w = lr.shape
-    assert acc.is_cuda and acc.dtype == torch.float32 and acc.is_contiguous() and acc.shape[:2] == (N, C) and lr.dtype in _MSC_DT and C <= 32
-    H, W = acc.shape[2:]
-    check(lib().mgn_msc_accumulate(lr.data_ptr(), _MSC_DT[lr.dtype], lr.stride(0), lr.stride(1), lr.stride(2), lr.stride(3), N, C, h, w, H, W,
-                                   _MSC_MODE[mode], int(bool(flip)), int(bool(first)), float(stride), float(scale), float(divide),
-                                   acc.data_ptr(), _stream()), "mgn_msc_accumulate")
-    return acc
 
 
 def prep_input(frames_u8, mean3, std3, Cp, dtype=torch.bfloat16):
@@ -1147,15 +1050,6 @@ def colsum(x, x2, scale):
     return out
 
 
-def colsum_all(x):
-    """[C] fp32 = sum over N, H, W of a 16-bit channels_last tensor (mgn_colsum with the batch folded into the rows)"""
-    N, C, H, W = x.shape
-    out = torch.empty((1, C), dtype=torch.float32, device=x.device)
-    ws = torch.empty(64 * C, dtype=torch.float32, device=x.device)
-    check(_fn("mgn_colsum", x)(x.data_ptr(), None, 1, N * H * W, C, 1.0, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()), "mgn_colsum")
-    return out[0]
-
-
 def bcast_rows(g, shape, scale, dtype=torch.bfloat16):
     N, C, H, W = shape
     dx = torch.empty(shape, dtype=dtype, device=g.device, memory_format=torch.channels_last)
@@ -1163,13 +1057,11 @@ def bcast_rows(g, shape, scale, dtype=torch.bfloat16):
     return dx
 
 
-def scale_channels(x, s, mode, add=None, addt=None):
-    """x * s[n,c] (mode 0) | x * (1 + s[n,c]) (mode 1)  [+ add[n,c]]  [+ addt: a 16-bit tensor of x's shape and layout]"""
+def scale_channels(x, s, mode, add=None):
     N, C, H, W = x.shape
     y = _cl_like(x)
-    assert addt is None or (addt.shape == x.shape and addt.dtype == x.dtype and addt.is_contiguous(memory_format=torch.channels_last))
-    check(_fn("mgn_scale_channels", x)(x.data_ptr(), s.data_ptr(), N, H * W, C, mode, None if add is None else add.data_ptr(),
-                                   None if addt is None else addt.data_ptr(), y.data_ptr(), _stream()), "mgn_scale_channels")
+    check(_fn("mgn_scale_channels", x)(x.data_ptr(), s.data_ptr(), N, H * W, C, mode, None if add is None else add.data_ptr(), y.data_ptr(),
+                                   _stream()), "mgn_scale_channels")
     return y
 
 

@@ -1,0 +1,362 @@
+// conv_win.hip -- 3x3 / stride 1 / pad 1 convolutions with >= 128 output channels as a WINDOWED implicit GEMM (gfx950).
+//
+// Replaces, for the 128/256/512-channel layers of mgnet/modeling/res_net.py:28-60 (BasicBlock conv1/conv2 of res3..res5) and
+// layers.py:53-72,110-118,201-210,283-311 (decoder / head 3x3 convs), the generic implicit GEMM of conv.hip.  Same contract as
+// mgn_conv_igemm (NHWC 16-bit activations, weights [Cout][3][3][Cin], fp32 accumulation, optional 16-bit residual); the data
+// gradient of those layers is this kernel on the flipped / transposed weights.
+//
+// Why: the implicit GEMM gathers the A operand once per TAP (every input pixel travels L2 -> LDS nine times) and the
+// global -> LDS fill rate of a CU (~12 B/clk) bounds it at ~36 % MFMA utilisation for a 256 x 256 tile, ~25 % for the 128-channel
+// layers.  Here a block owns a 2-D PATCH of PH x 32 output pixels and keeps the (PH+2) x 34 input window
+// of one 32-channel chunk in LDS for all nine taps: a tap is an address offset into the window, so A is fetched ~1.2x instead
+// of 9x.  With A nearly free the tile is tall and narrow -- 512 pixels x 128 output channels -- which halves the weight bytes
+// per flop as well: 8 KB of weights + 4.4 KB of window per k-step (512 x 128 x 32 MACs) instead of 32 KB.
+//
+//   block : 8 waves = 4 (pixel rows) x 2 (64 output channels); wave tile (PH/4 rows x 32 px) x 64 co = PH/4 x 2 MFMA tiles
+//           (v_mfma_f32_32x32x16, operands swapped: D rows = output channels, so a lane holds 4 consecutive channels of a pixel)
+//   k loop: channel chunk outer (32 channels), tap inner; one barrier per k-step
+//   LDS   : window [2 buffers][640 px][64 B] (pixel-major, 16-byte slots XOR-swizzled by (px >> 2) & 3: every fragment read is
+//           conflict-free for ANY tap shift), weights [8 stages][128 co][64 B]; everything arrives by LDS-DMA
+//           (buffer_load_dwordx4 ... lds, zero padding from the buffer bounds check), the next chunk's window is fetched while the
+//           nine taps of the current one run; counted vmcnt waits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "mgnet_hip.h"
+
+namespace {
+
+#include "h16.h"
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct WinParams {
+    const uint16_t* in;        // [N, H, W, Cin]
+    const uint16_t* w;         // [Cout, 3, 3, Cin]
+    uint16_t* out;             // [N, H, W, Cout]
+    const uint16_t* residual;  // [N, H, W, Cout] added before rounding, or null
+    int N, H, W, Cin, Cout;
+    float* stat_part;          // [N*py*px][Cout][2] per-patch sums of (r - shift), (r - shift)^2 of the rounded outputs, or null
+    const float* stat_shift;   // [Cout] or null (= 0)
+    int py, px;                // patches per image (rows, columns)
+    int xcd;                   // 1: deal contiguous bands of patches to the XCDs
+};
+
+constexpr int PW = 32, WW = PW + 2;
+constexpr int WIN_PIECES = 40;                 // 1-KB DMA pieces of 16 pixels x 64 B: 5 per wave (612 of the 640 pixels are real)
+constexpr int WIN_BYTES = WIN_PIECES * 1024;
+constexpr int WST_BYTES = 128 * 64;            // one weight stage: 128 output channels x 32 input channels
+constexpr int NWST = 8;                        // weight stages (power of two)
+constexpr int PD = 6;                          // W(s + PD) is issued at k-step s (PD + 1 <= NWST)
+constexpr int WIN_LDS = 2 * WIN_BYTES + NWST * WST_BYTES + 1024;   // + one scratch KB for the dummy loads
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ int xcd_tile(int b, int nb) {   // block b -> XCD b % 8; XCD k works on a contiguous band of tiles
+    const int k = b & 7, j = b >> 3, q = nb >> 3, r = nb & 7;
+    return k * q + (k < r ? k : r) + j;
+}
+
+// PH = 16: patch 16 x 32 (4 rows per wave); PH = 8: patch 8 x 32 (2 rows per wave) for layers with few pixels
+template <int PH>
+__device__ __forceinline__ void conv_win_body(const WinParams& p) {
+    constexpr int RPW = PH / 4;               // pixel rows (= MFMA tiles) per wave
+    constexpr int WPX = (PH + 2) * WW;        // real window pixels
+    constexpr int NWP = (WPX + 127) / 128;    // window pieces per wave and chunk (5 for PH = 16, 3 for PH = 8)
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    unsigned char* const winb = wsm;
+    unsigned char* const wst = wsm + 2 * WIN_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int patch = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x, bn = blockIdx.y;
+    const int ppi = p.py * p.px;
+    const int n = patch / ppi, prem = patch - n * ppi, pyi = prem / p.px, pxi = prem - pyi * p.px;
+    const int y0 = pyi * PH, x0 = pxi * PW;
+
+    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.H * p.W * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * 9 * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, w_bytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    // window pieces of this wave: piece q = wave + 8 i covers window pixels 16 q .. 16 q + 15 (lane >> 2), 16-byte slot lane & 3
+    int wvoff[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int pp = (wave + 8 * i) * 16 + (lane >> 2);
+        const int sseg = (lane & 3) ^ ((pp >> 2) & 3);    // source segment that lands in slot lane & 3
+        const int wy = pp / WW, wx = pp - wy * WW;
+        const int iy = y0 - 1 + wy, ix = x0 - 1 + wx;
+        const bool ok = pp < WPX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        wvoff[i] = ok ? (((n * p.H + iy) * p.W + ix) * p.Cin + sseg * 8) * 2 : OOB;
+    }
+    int wbase;
+    {
+        const int row = wave * 16 + (lane >> 2);
+        const int sseg = (lane & 3) ^ ((row >> 2) & 3);
+        wbase = ((bn * 128 + row) * 9 * p.Cin + sseg * 8) * 2;
+    }
+    const int nch = p.Cin / 32, ksteps = nch * 9;
+    auto issue_w = [&](int c, int t, int stage) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(wst + stage * WST_BYTES + wave * 1024), 16, wbase, (t * p.Cin + c * 32) * 2, 0, 0);
+    };
+    auto issue_win = [&](int c, int i, int buf) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(winb + buf * WIN_BYTES + (wave + 8 * i) * 1024), 16, wvoff[i], c * 64, 0, 0);
+    };
+
+    // fragment byte offsets (kk = 0; kk = 1 flips bit 5): A from the window at (row 4*wm*RPW/4.. + dy, column l31 + kw)
+    int aoff[RPW + 2][3];
+#pragma unroll
+    for (int dy = 0; dy < RPW + 2; ++dy)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int pp = (wm * RPW + dy) * WW + l31 + kw;
+            aoff[dy][kw] = pp * 64 + ((hi ^ ((pp >> 2) & 3)) << 4);
+        }
+    int boff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wn * 64 + j * 32 + l31;
+        boff[j] = row * 64 + ((hi ^ ((row >> 2) & 3)) << 4);
+    }
+
+    f32x16 acc[RPW][2];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // Pipeline.  Every k-step issues exactly TWO LDS-DMA loads per wave, in the order [window piece of the next chunk | dummy]
+    // [W(s + PD) | dummy]; a dummy is an out-of-range load (no memory request, zeros into a scratch KB), which keeps the number
+    // of loads younger than any given one a compile-time constant.  Barriers stand at the even taps of a chunk (5 per 9 k-steps:
+    // with a barrier per step both waves of a SIMD sit in the same bubble); the wait before the barrier of step s is for
+    // W(s + 2), issued at step s + 2 - PD (younger: 2 (PD - 3) loads): the two steps up to the next barrier read W(s), W(s + 1)
+    // and -- the first half (kk = 0) of the NEXT step's fragments is fetched from LDS while the second half of a step's MFMAs
+    // run -- W(s + 2).  Ring hazards: step s writes the stage of step s + PD - NWST = s - 2 and, at taps 0 .. NWP-1, the window
+    // buffer last read in the previous chunk; a barrier separates both from their last readers (tap 0 always has one).
+    auto issue_dummy = [&]() {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(wsm + WIN_LDS - 1024), 16, OOB, 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) issue_win(0, i, 0);
+#pragma unroll
+    for (int k = 0; k < PD; ++k) {   // what steps -PD .. -1 would have issued (ksteps >= 9 > PD)
+        issue_dummy();
+        issue_w(0, k, k);
+    }
+    wait_vmcnt<2 * (PD - 3)>();
+    __builtin_amdgcn_s_barrier();
+
+    auto load_frags = [&](const unsigned char* win, const unsigned char* ws, int kh, int kw, int kk, h16x8 (&a)[RPW], h16x8 (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) a[i] = *reinterpret_cast<const h16x8*>(win + (aoff[i + kh][kw] ^ (kk << 5)));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const h16x8*>(ws + (boff[j] ^ (kk << 5)));
+    };
+    auto mma = [&](const h16x8 (&a)[RPW], const h16x8 (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = MGN_MFMA_32x32x16(b[j], a[i], acc[i][j]);
+    };
+
+    h16x8 a0[RPW], b0[2], a1[RPW], b1[2];
+    load_frags(winb, wst, 0, 0, 0, a0, b0);
+    int stage = 0;   // stage of k-step s = s % NWST
+    auto chunk = [&](int c, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const unsigned char* win = winb + (c & 1) * WIN_BYTES;
+        const unsigned char* win_next = winb + ((c + 1) & 1) * WIN_BYTES;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t % 2 == 0) {   // one barrier per TWO k-steps (taps 0|1, 2|3, 4|5, 6|7, 8): see the pipeline comment
+                wait_vmcnt<2 * (PD - 3)>();
+                __builtin_amdgcn_s_barrier();
+            }
+            if (!LAST && t < NWP) issue_win(c + 1, t, (c + 1) & 1);
+            else issue_dummy();
+            if (!LAST || t + PD <= 8) {
+                const int tn = t + PD >= 9 ? t + PD - 9 : t + PD, cn = t + PD >= 9 ? c + 1 : c;
+                if (LAST || cn < nch) issue_w(cn, tn, (stage + PD) & (NWST - 1));
+                else issue_dummy();
+            } else {
+                issue_dummy();
+            }
+            const int kh = t / 3, kw = t - kh * 3;
+            const unsigned char* ws = wst + stage * WST_BYTES;
+            const unsigned char* ws_next = wst + ((stage + 1) & (NWST - 1)) * WST_BYTES;
+            // (sched_barrier: keep the two fragment sets in separate registers and each batch of LDS reads a full batch of MFMAs
+            //  ahead of its use -- left alone, the scheduler re-serialises read -> wait -> MFMA to save registers)
+            load_frags(win, ws, kh, kw, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < 8) load_frags(win, ws_next, (t + 1) / 3, (t + 1) % 3, 0, a0, b0);
+            else if (!LAST) load_frags(win_next, ws_next, 0, 0, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage = (stage + 1) & (NWST - 1);
+        }
+    };
+    for (int c = 0; c + 1 < nch; ++c) chunk(c, std::false_type{});
+    chunk(nch - 1, std::true_type{});
+    wait_vmcnt<0>();   // (the dummies of the last steps still write their zeros: nothing may land after the block has ended)
+
+    // D = W-rows x pixels: column = lane & 31 -> pixel of the row, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel
+    const int ox = x0 + l31;
+    // optional per-channel statistics of the ROUNDED output (what the following InPlaceABNSync normalises with): a lane sums
+    // (r - shift) and (r - shift)^2 of its 32 channels over its RPW pixels; see the reduction below the stores
+    const bool stats = p.stat_part != nullptr;
+    float s1[2][4][4], s2[2][4][4], sh[2][4][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (stats && p.stat_shift) t = *reinterpret_cast<const float4*>(p.stat_shift + bn * 128 + wn * 64 + j * 32 + 8 * q + 4 * hi);
+            sh[j][q][0] = t.x; sh[j][q][1] = t.y; sh[j][q][2] = t.z; sh[j][q][3] = t.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s1[j][q][e] = s2[j][q][e] = 0.f;
+        }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int oy = y0 + wm * RPW + i;
+        if (oy >= p.H) break;   // wave-uniform
+        const bool ok = ox < p.W;
+        const size_t m = ((size_t)n * p.H + oy) * p.W + (ok ? ox : 0);
+        uint16_t* opix = p.out + m * p.Cout + bn * 128 + wn * 64;
+        if (p.residual) {
+            if (!ok) continue;
+            const uint16_t* rpix = p.residual + m * p.Cout + bn * 128 + wn * 64;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = j * 32 + 8 * q + 4 * hi;
+                    const uint2 r = *reinterpret_cast<const uint2*>(rpix + co);
+                    const float v0 = acc[i][j][q * 4 + 0] + mgn_lo2f(r.x), v1 = acc[i][j][q * 4 + 1] + mgn_hi2f(r.x);
+                    const float v2 = acc[i][j][q * 4 + 2] + mgn_lo2f(r.y), v3 = acc[i][j][q * 4 + 3] + mgn_hi2f(r.y);
+                    *reinterpret_cast<uint2*>(opix + co) = make_uint2(mgn_pack2(v0, v1), mgn_pack2(v2, v3));
+                }
+        } else {
+            // v_permlane32_swap exchanges the 4-channel groups of lane l and lane l + 32: every lane then owns 8 consecutive
+            // channels of its pixel (16-byte stores, half the store instructions)
+            const float msk = ok ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    uint32_t pk[2][2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int q = 2 * qp + u;
+                        pk[u][0] = mgn_pack2(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1]);
+                        pk[u][1] = mgn_pack2(acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+                        if (stats) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const float d0 = (mgn_lo2f(pk[u][h]) - sh[j][q][2 * h]) * msk, d1 = (mgn_hi2f(pk[u][h]) - sh[j][q][2 * h + 1]) * msk;
+                                s1[j][q][2 * h] += d0; s2[j][q][2 * h] = fmaf(d0, d0, s2[j][q][2 * h]);
+                                s1[j][q][2 * h + 1] += d1; s2[j][q][2 * h + 1] = fmaf(d1, d1, s2[j][q][2 * h + 1]);
+                            }
+                        }
+                    }
+                    const auto w0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                    const auto w1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                    if (ok) *reinterpret_cast<uint4*>(opix + j * 32 + 16 * qp + 8 * hi) = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+                }
+        }
+    }
+    if (stats) {
+        // 16-lane butterflies (DPP: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror): every lane of a 16-lane row
+        // then holds the row's sum; lanes 0 / 16 / 32 / 48 park it in LDS (rows 0,1 = channels 4*hi.., two pixel halves), and
+        // after a block barrier 256 threads add the 8 parts (4 pixel waves x 2 rows) of one (channel, moment) each in a fixed
+        // order and store the block's partial row: stat_part[patch][Cout][2].  The window memory is free by then.
+        auto row_sum = [](float v) {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+            return v;
+        };
+        float* red = reinterpret_cast<float*>(wsm);   // [wm 4][row 2][128 channels][2]
+        __syncthreads();                               // every wave has left the k loop: the window buffers are dead
+        const int rw = (lane >> 4) & 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = row_sum(s1[j][q][e]), b = row_sum(s2[j][q][e]);
+                    if ((lane & 15) == 0) {
+                        const int ch = wn * 64 + j * 32 + 8 * q + 4 * hi + e;
+                        *reinterpret_cast<float2*>(red + ((wm * 2 + rw) * 128 + ch) * 2) = make_float2(a, b);
+                    }
+                }
+        __syncthreads();
+        if (tid < 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 256 + tid];
+            p.stat_part[((size_t)patch * p.Cout + bn * 128) * 2 + tid] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void conv3x3_win16(WinParams p) { conv_win_body<16>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_win8(WinParams p) { conv_win_body<8>(p); }
+
+}  // namespace
+
+extern "C" {
+
+#ifndef MGN_F16
+/* patch height the dispatcher uses for this layer: 16-row patches when they fill the chip, 8-row patches for the low-resolution
+ * layers, 0 = not a layer for this kernel (MGN_CONV_WIN = "0" | "8" | "16" overrides: tests, A/B runs) */
+int mgn_conv_win_patch_rows(int N, int OH, int OW, int Cin, int Cout) {
+    if (N < 1 || OH < 1 || OW < 1 || Cin < 32 || Cin % 32 != 0 || Cin == 64 || Cout < 128 || Cout % 128 != 0) return 0;
+    if ((size_t)N * OH * OW * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fffffffu) return 0;
+    const char* ewin = getenv("MGN_CONV_WIN");
+    if (ewin) {
+        const int pr = atoi(ewin);
+        return pr == 8 || pr == 16 ? pr : 0;
+    }
+    const long pc = (long)N * ((OW + 31) / 32) * (Cout / 128);
+    return pc * ((OH + 15) / 16) >= 200 ? 16 : (pc * ((OH + 7) / 8) >= 64 ? 8 : 0);
+}
+#endif
+
+int MGN_SYM(mgn_conv3x3_win)(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
+                             int patch_rows, float* stat_partials, const float* stat_shift, void* stream) {
+    if (!in || !w || !out || N < 1 || H < 1 || W < 1) return MGN_EINVAL;
+    if (Cin < 32 || Cin % 32 != 0 || Cout < 128 || Cout % 128 != 0) return MGN_ENOTSUP;
+    if ((size_t)N * H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fffffffu) return MGN_ENOTSUP;   // 32-bit byte offsets
+    if (patch_rows != 8 && patch_rows != 16) return MGN_EINVAL;
+    WinParams p;
+    p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = (uint16_t*)out; p.residual = (const uint16_t*)residual;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.stat_part = stat_partials; p.stat_shift = stat_shift;
+    if (stat_partials && residual) return MGN_ENOTSUP;
+    p.py = (H + patch_rows - 1) / patch_rows; p.px = (W + PW - 1) / PW;
+    const long npatch = (long)N * p.py * p.px;
+    if (npatch > 0x7fffffffL) return MGN_EINVAL;
+    p.xcd = (npatch >= 16 && !getenv("MGN_CONV_NOXCD")) ? 1 : 0;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_win16), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_win8), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+        attr = true;
+    }
+    const dim3 grid((unsigned)npatch, (unsigned)(Cout / 128));
+    if (patch_rows == 16) hipLaunchKernelGGL(conv3x3_win16, grid, dim3(512), WIN_LDS, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv3x3_win8, grid, dim3(512), WIN_LDS, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,338 @@
+// eltwise.hip -- the element-wise / broadcast / pooling glue of the MGNet blocks on channels-last bf16 activations.
+//
+// Replaces the torch ops at (reference file:line)
+//   res_net.py:77-78        out = out + shortcut ; F.relu_(out)                          -> add_relu (+ backward mask)
+//   layers.py:170-184       FastGlobalAvgPool2d (mean over H*W)                          -> gap (two-stage column mean) + backward
+//   layers.py:90, :217      F.interpolate(mode="nearest") (decoder x2, GCM 1x1 -> h x w) -> nearest upsampling + adjoint
+//   layers.py:262-267       fm * sigmoid-attention  (AttentionRefinementModule)          -> scale_channels (mode 0)
+//   layers.py:315-322       fm + fm * attention     (FeatureFusionModule)                -> scale_channels (mode 1)
+//   layers.py:316           torch.cat([fsp, fcp], dim=1)                                 -> concat2 + split backward
+// All kernels stream 16 bytes per lane; x is [N, H*W, C] with C % 8 == 0.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mgnet_hip.h"
+#include "h16.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ void unpack8(const uint4& r, float (&v)[8]) {   // 8 activations of this TU's 16-bit format (h16.h)
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[2 * k] = mgn_lo2f(w[k]);
+        v[2 * k + 1] = mgn_hi2f(w[k]);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    uint4 r;
+    r.x = mgn_pack2(v[0], v[1]); r.y = mgn_pack2(v[2], v[3]);
+    r.z = mgn_pack2(v[4], v[5]); r.w = mgn_pack2(v[6], v[7]);
+    return r;
+}
+inline unsigned blocks_for(long nvec) {
+    long b = (nvec + TPB - 1) / TPB;
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// y = relu(a + b)
+__global__ __launch_bounds__(TPB) void add_relu_fwd(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ y, long nvec) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+        float va[8], vb[8];
+        unpack8(a[i], va);
+        unpack8(b[i], vb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) va[k] = fmaxf(va[k] + vb[k], 0.f);
+        y[i] = pack8(va);
+    }
+}
+// sum of the gradients of a tensor consumed by three branches (the backbone features feed the three heads): one pass, one rounding
+// (autograd's own accumulation is two passes with an intermediate 16-bit tensor); c may be null
+__global__ __launch_bounds__(TPB) void sum3_h16(const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ c,
+                                                uint4* __restrict__ y, long nvec) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+        float va[8], vb[8], vc[8];
+        unpack8(a[i], va);
+        unpack8(b[i], vb);
+        if (c) {
+            unpack8(c[i], vc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) va[k] = (va[k] + vb[k]) + vc[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) va[k] += vb[k];
+        }
+        y[i] = pack8(va);
+    }
+}
+// residual-block tail with the second norm folded in: y = relu(bf16(scale[c] * x + offset[c]) + b)  -- the value the separate
+// in-place norm + add_relu_fwd produce, without writing the normalised map (x, the conv output, is kept for the backward)
+__global__ __launch_bounds__(TPB) void abn_add_relu_fwd(const uint4* __restrict__ x, const float* __restrict__ scale,
+                                                        const float* __restrict__ offset, const uint4* __restrict__ b, uint4* __restrict__ y,
+                                                        long nvec, int cv) {
+    const long i0 = (long)blockIdx.x * TPB + threadIdx.x, stride = (long)gridDim.x * TPB;   // stride % cv == 0 (host)
+    const int c0 = (int)(i0 % cv) * 8;
+    float sc[8], of[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; of[k] = offset[c0 + k]; }
+    for (long i = i0; i < nvec; i += stride) {
+        float va[8], vb[8];
+        unpack8(x[i], va);
+        unpack8(b[i], vb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) va[k] = fmaf(va[k], sc[k], of[k]);
+        unpack8(pack8(va), va);   // the bf16 rounding of the stored normalised value
+#pragma unroll
+        for (int k = 0; k < 8; ++k) va[k] = fmaxf(va[k] + vb[k], 0.f);
+        y[i] = pack8(va);
+    }
+}
+// dx = dy where y > 0 (the same tensor is the gradient of both summands)
+__global__ __launch_bounds__(TPB) void relu_mask_bwd(const uint4* __restrict__ dy, const uint4* __restrict__ y, uint4* __restrict__ dx, long nvec) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+        float g[8], v[8];
+        unpack8(dy[i], g);
+        unpack8(y[i], v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = v[k] > 0.f ? g[k] : 0.f;
+        dx[i] = pack8(g);
+    }
+}
+
+// ---- per-image column sums over HW of f(row): partial[n][chunk][C] then final ------------------------------------
+// block = (C/8 column vectors) x (256/(C/8) row lanes); grid = (chunks, N)
+template <bool PRODUCT>
+__global__ __launch_bounds__(TPB) void colsum_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, long HW, int C,
+                                                      float* partial) {
+    __shared__ float sh[TPB * 8];
+    const int cv = C / 8, rl = TPB / cv;
+    const int tx = threadIdx.x % cv, ty = threadIdx.x / cv;
+    const int n = blockIdx.y, chunks = gridDim.x;
+    const long r0 = HW * blockIdx.x / chunks, r1 = HW * (blockIdx.x + 1) / chunks;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    if (ty < rl)
+        for (long r = r0 + ty; r < r1; r += rl) {
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + ((long)n * HW + r) * C + tx * 8), v);
+            if (PRODUCT) {
+                float w[8];
+                unpack8(*reinterpret_cast<const uint4*>(x2 + ((long)n * HW + r) * C + tx * 8), w);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v[k] * w[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v[k];
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[(ty * cv + tx) * 8 + k] = acc[k];
+    __syncthreads();
+    if (ty == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float s = 0.f;
+            for (int y = 0; y < rl; ++y) s += sh[(y * cv + tx) * 8 + k];
+            partial[((long)n * chunks + blockIdx.x) * C + tx * 8 + k] = s;
+        }
+    }
+}
+__global__ void colsum_final(const float* partial, int chunks, int C, int N, float scale, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += partial[((long)n * chunks + k) * C + c];
+    out[i] = s * scale;
+}
+
+// dx[n, r, c] = g[n, c] * scale  (adjoint of the global average pool)
+__global__ __launch_bounds__(TPB) void bcast_rows(const float* __restrict__ g, long HW, int C, float scale, uint4* __restrict__ dx, long nvec) {
+    const int cv = C / 8;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+        const int c8 = (int)(i % cv);
+        const long n = i / cv / HW;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = g[n * C + c8 * 8 + k] * scale;
+        dx[i] = pack8(v);
+    }
+}
+
+// y = x * s[n, c]            (mode 0)      y = x + x * s[n, c] = x * (1 + s)   (mode 1)
+__global__ __launch_bounds__(TPB) void scale_channels(const uint4* __restrict__ x, const float* __restrict__ s, long HW, int C, int mode,
+                                                      const float* __restrict__ add, uint4* __restrict__ y, long nvec) {
+    const int cv = C / 8;
+    const float base = mode ? 1.f : 0.f;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+        const int c8 = (int)(i % cv);
+        const long n = i / cv / HW;
+        float v[8];
+        unpack8(x[i], v);
+        const float4* sp = reinterpret_cast<const float4*>(s + n * C + c8 * 8);
+        const float4 s0 = sp[0], s1 = sp[1];
+        const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        float av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (add) {
+            const float4* ap = reinterpret_cast<const float4*>(add + n * C + c8 * 8);
+            const float4 a0 = ap[0], a1 = ap[1];
+            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], base + sv[k], av[k]);
+        y[i] = pack8(v);
+    }
+}
+
+// nearest-neighbour upsampling (torch: src = floor(dst * in / out)) and its adjoint (sum over the preimage)
+__global__ __launch_bounds__(TPB) void nearest_fwd(const uint16_t* __restrict__ x, int N, int h, int w, int H, int W, int C, uint4* __restrict__ y) {
+    const int cv = C / 8;
+    const long nvec = (long)N * H * W * cv;
+    const float sy = (float)h / H, sx = (float)w / W;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+        const int c8 = (int)(i % cv);
+        long r = i / cv;
+        const int X = (int)(r % W); r /= W;
+        const int Y = (int)(r % H);
+        const int n = (int)(r / H);
+        const int ys = min((int)floorf(Y * sy), h - 1), xs = min((int)floorf(X * sx), w - 1);
+        y[i] = *reinterpret_cast<const uint4*>(x + (((long)n * h + ys) * w + xs) * C + c8 * 8);
+    }
+}
+__global__ __launch_bounds__(TPB) void nearest_bwd(const uint16_t* __restrict__ dy, int N, int h, int w, int H, int W, int C, uint4* __restrict__ dx) {
+    const int cv = C / 8;
+    const long nvec = (long)N * h * w * cv;
+    const float sy = (float)h / H, sx = (float)w / W;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+        const int c8 = (int)(i % cv);
+        long r = i / cv;
+        const int xs = (int)(r % w); r /= w;
+        const int ys = (int)(r % h);
+        const int n = (int)(r / h);
+        // destination rows/cols whose source is (ys, xs): a contiguous range around ys*H/h
+        int Y0 = (int)((long)ys * H / h), X0 = (int)((long)xs * W / w);
+        while (Y0 > 0 && min((int)floorf((Y0 - 1) * sy), h - 1) == ys) --Y0;
+        while (X0 > 0 && min((int)floorf((X0 - 1) * sx), w - 1) == xs) --X0;
+        while (Y0 < H && min((int)floorf(Y0 * sy), h - 1) < ys) ++Y0;
+        while (X0 < W && min((int)floorf(X0 * sx), w - 1) < xs) ++X0;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int Y = Y0; Y < H && min((int)floorf(Y * sy), h - 1) == ys; ++Y)
+            for (int X = X0; X < W && min((int)floorf(X * sx), w - 1) == xs; ++X) {
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4*>(dy + (((long)n * H + Y) * W + X) * C + c8 * 8), v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v[k];
+            }
+        dx[i] = pack8(acc);
+    }
+}
+
+// out[n, r, :] = [a[n, r, :Ca], b[n, r, :Cb]]   and the split of its gradient
+__global__ __launch_bounds__(TPB) void concat2(const uint4* __restrict__ a, const uint4* __restrict__ b, int Ca, int Cb, uint4* __restrict__ y, long rows) {
+    const int va = Ca / 8, vb = Cb / 8, vt = va + vb;
+    const long nvec = rows * vt;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+        const long r = i / vt;
+        const int c = (int)(i % vt);
+        y[i] = c < va ? a[r * va + c] : b[r * vb + (c - va)];
+    }
+}
+__global__ __launch_bounds__(TPB) void split2(const uint4* __restrict__ dy, int Ca, int Cb, uint4* __restrict__ da, uint4* __restrict__ db, long rows) {
+    const int va = Ca / 8, vb = Cb / 8, vt = va + vb;
+    const long nvec = rows * vt;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+        const long r = i / vt;
+        const int c = (int)(i % vt);
+        if (c < va) da[r * va + c] = dy[i];
+        else db[r * vb + (c - va)] = dy[i];
+    }
+}
+
+inline bool c_ok(int C) { return C >= 8 && C % 8 == 0 && C / 8 <= TPB && TPB % (C / 8) == 0; }
+inline int chunks_for(long HW) { long c = HW / 512; return (int)(c < 1 ? 1 : (c > 64 ? 64 : c)); }
+
+}  // namespace
+
+extern "C" {
+
+int MGN_SYM(mgn_add_relu_fwd)(const void* a, const void* b, void* y, long n_elems, void* stream) {
+    if (!a || !b || !y || n_elems < 8 || n_elems % 8) return MGN_EINVAL;
+    hipLaunchKernelGGL(add_relu_fwd, dim3(blocks_for(n_elems / 8)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b, (uint4*)y, n_elems / 8);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int MGN_SYM(mgn_sum3)(const void* a, const void* b, const void* c, void* y, long n_elems, void* stream) {
+    if (!a || !b || !y || n_elems < 8 || n_elems % 8) return MGN_EINVAL;
+    hipLaunchKernelGGL(sum3_h16, dim3(blocks_for(n_elems / 8)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b, (const uint4*)c,
+                       (uint4*)y, n_elems / 8);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int MGN_SYM(mgn_abn_add_relu_fwd)(const void* x, const float* scale, const float* offset, const void* b, void* y, long M, int C, void* stream) {
+    if (!x || !scale || !offset || !b || !y || M < 1 || !c_ok(C)) return MGN_EINVAL;
+    const long nvec = M * C / 8;
+    const int cv = C / 8;
+    // c_ok guarantees TPB % cv == 0: with any block count the grid stride stays a multiple of cv (fixed channels per thread)
+    hipLaunchKernelGGL(abn_add_relu_fwd, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)x, scale, offset, (const uint4*)b,
+                       (uint4*)y, nvec, cv);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int MGN_SYM(mgn_relu_mask_bwd)(const void* dy, const void* y, void* dx, long n_elems, void* stream) {
+    if (!dy || !y || !dx || n_elems < 8 || n_elems % 8) return MGN_EINVAL;
+    hipLaunchKernelGGL(relu_mask_bwd, dim3(blocks_for(n_elems / 8)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)dy, (const uint4*)y, (uint4*)dx, n_elems / 8);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+/* out[n, c] = scale * sum_r x[n, r, c] * (x2 ? x2[n, r, c] : 1);  workspace: N * chunks * C floats (chunks <= 64) */
+int MGN_SYM(mgn_colsum)(const void* x, const void* x2, int N, long HW, int C, float scale, float* out, float* workspace, size_t workspace_bytes,
+               void* stream) {
+    if (!x || !out || !workspace || N < 1 || HW < 1 || !c_ok(C)) return MGN_EINVAL;
+    const int chunks = chunks_for(HW);
+    if (workspace_bytes < sizeof(float) * (size_t)N * chunks * C) return MGN_ENOSPC;
+    hipStream_t s = (hipStream_t)stream;
+    if (x2) hipLaunchKernelGGL(colsum_partial<true>, dim3(chunks, N), dim3(TPB), 0, s, (const uint16_t*)x, (const uint16_t*)x2, HW, C, workspace);
+    else hipLaunchKernelGGL(colsum_partial<false>, dim3(chunks, N), dim3(TPB), 0, s, (const uint16_t*)x, (const uint16_t*)nullptr, HW, C, workspace);
+    hipLaunchKernelGGL(colsum_final, dim3((N * C + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, C, N, scale, out);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int MGN_SYM(mgn_bcast_rows)(const float* g, int N, long HW, int C, float scale, void* dx, void* stream) {
+    if (!g || !dx || N < 1 || HW < 1 || !c_ok(C)) return MGN_EINVAL;
+    const long nvec = (long)N * HW * (C / 8);
+    hipLaunchKernelGGL(bcast_rows, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, g, HW, C, scale, (uint4*)dx, nvec);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int MGN_SYM(mgn_scale_channels)(const void* x, const float* s, int N, long HW, int C, int mode, const float* add, void* y, void* stream) {
+    if (!x || !s || !y || N < 1 || HW < 1 || !c_ok(C) || mode < 0 || mode > 1) return MGN_EINVAL;
+    const long nvec = (long)N * HW * (C / 8);
+    hipLaunchKernelGGL(scale_channels, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)x, s, HW, C, mode, add, (uint4*)y, nvec);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int MGN_SYM(mgn_nearest_fwd)(const void* x, int N, int h, int w, int H, int W, int C, void* y, void* stream) {
+    if (!x || !y || N < 1 || h < 1 || w < 1 || H < h || W < w || !c_ok(C)) return MGN_EINVAL;
+    hipLaunchKernelGGL(nearest_fwd, dim3(blocks_for((long)N * H * W * (C / 8))), dim3(TPB), 0, (hipStream_t)stream, (const uint16_t*)x, N, h, w, H, W, C, (uint4*)y);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int MGN_SYM(mgn_nearest_bwd)(const void* dy, int N, int h, int w, int H, int W, int C, void* dx, void* stream) {
+    if (!dy || !dx || N < 1 || h < 1 || w < 1 || H < h || W < w || !c_ok(C)) return MGN_EINVAL;
+    hipLaunchKernelGGL(nearest_bwd, dim3(blocks_for((long)N * h * w * (C / 8))), dim3(TPB), 0, (hipStream_t)stream, (const uint16_t*)dy, N, h, w, H, W, C, (uint4*)dx);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+#ifndef MGN_F16
+int mgn_concat2(const void* a, const void* b, long rows, int Ca, int Cb, void* y, void* stream) {
+    if (!a || !b || !y || rows < 1 || Ca < 8 || Cb < 8 || Ca % 8 || Cb % 8) return MGN_EINVAL;
+    hipLaunchKernelGGL(concat2, dim3(blocks_for(rows * ((Ca + Cb) / 8))), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b, Ca, Cb, (uint4*)y, rows);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+#endif
+#ifndef MGN_F16
+int mgn_split2(const void* dy, long rows, int Ca, int Cb, void* da, void* db, void* stream) {
+    if (!dy || !da || !db || rows < 1 || Ca < 8 || Cb < 8 || Ca % 8 || Cb % 8) return MGN_EINVAL;
+    hipLaunchKernelGGL(split2, dim3(blocks_for(rows * ((Ca + Cb) / 8))), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)dy, Ca, Cb, (uint4*)da, (uint4*)db, rows);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+#endif
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""Thin training loop reproducing what tools/train_net.py delegates to detectron2 (SURVEY 3.1 hot loop): forward ->
+sum of the loss dict -> backward (bucketed all-reduce overlapped) -> full-model clip -> Adam -> poly LR.
+SOLVER.AMP: bf16 activations by default (no loss scaling needed); SOLVER.AMP.DTYPE "float16" runs the reference's fp16 with
+GradScaler's dynamic loss scaling evaluated on the device (solver/fused_adam.py, csrc/optim.hip: no host synchronisation)."""
+import os
+
+import torch
+
+from ..events import EventStorage
+from ..solver import build_lr_scheduler, build_optimizer
+from .reducer import GradReducer, ready_order
+
+
+class Trainer:
+    def __init__(self, cfg, model, bucket_bytes=32 << 20):
+        self.cfg, self.model = cfg, model
+        on_gpu = next(model.parameters()).is_cuda
+        if on_gpu and cfg.SOLVER.OPTIMIZER == "ADAM":
+            from .. import _C
+            from ..solver import get_mgnet_optimizer_params
+            groups = get_mgnet_optimizer_params(model, cfg.SOLVER.BASE_LR, head_lr_factor=cfg.SOLVER.HEAD_LR_FACTOR)
+            plist = [p for g in groups for p in (g["params"] if isinstance(g["params"], list) else [g["params"]])]
+            self.reducer = GradReducer(ready_order(model, plist), bucket_bytes, align=_C.optim_chunk(), flatten_params=True,
+                                       average=False, ordered=True)
+            self.optimizer = build_optimizer(cfg, model, reducer=self.reducer)
+        else:
+            self.optimizer = build_optimizer(cfg, model)
+            self.reducer = GradReducer(ready_order(model, [p for g in self.optimizer.param_groups for p in g["params"]]), bucket_bytes,
+                                       ordered=True)
+        self.scheduler = build_lr_scheduler(cfg, self.optimizer)
+        self.storage = EventStorage()
+        self.iter = 0
+        from ..checkpoint import Checkpointer
+        self.checkpointer = Checkpointer(model, getattr(cfg, "OUTPUT_DIR", "") or "", optimizer=self.optimizer, scheduler=self.scheduler)
+
+    def resume_or_load(self, resume=True):
+        """detectron2 DefaultTrainer.resume_or_load (tools/train_net.py:234): MODEL.WEIGHTS, or the last checkpoint of
+        OUTPUT_DIR (then training continues after its iteration)."""
+        extra = self.checkpointer.resume_or_load(self.cfg.MODEL.WEIGHTS, resume=resume)
+        if resume and self.checkpointer.has_checkpoint():
+            self.iter = int(extra.get("iteration", -1)) + 1
+        return extra
+
+    def save(self, name=None):
+        return self.checkpointer.save(name or f"model_{self.iter - 1:07d}", iteration=self.iter - 1)
+
+    # ---- whole-step hipGraph -----------------------------------------------------------------------------------------
+    # A step issues ~950 launches from Python (about 30 ms of host time against ~38 ms of GPU time at the C4 shape); none of
+    # them depends on a host value any more (OHEM branch, loss selection, bias corrections and learning rates all live in
+    # device memory), so the step is captured ONCE on a capture stream and replayed: the host then only uploads the
+    # learning-rate tables and calls hipGraphLaunch.
+    def capture_step(self, batched_inputs):
+        """Capture forward + backward + clip + Adam for `batched_inputs` (device tensors that stay alive and are refilled
+        in place by the data pipeline between replays).  Needs a few eager steps before it (lazy workspaces, layout cache,
+        allocator warm-up).  One process per GPU without a gradient exchange only: RCCL work inside a capture is not used."""
+        assert self.reducer.world == 1, "graph replay is used by single-process runs; multi-rank steps stay eager"
+        assert hasattr(self.optimizer, "launch_step"), "graph capture needs the fused optimizer"
+        self.model.train()
+        self._graph_inputs = batched_inputs
+        import gc
+        graph = torch.cuda.CUDAGraph()
+        gc.collect()               # cyclic garbage of earlier steps must not be freed (allocator event queries) inside the capture
+        from .. import _C
+        _C.weight_cache.refresh()  # drop the rows of collected models now: the captured refresh launch keeps this table
+        self._graph_keepalive = [_C.weight_cache.table]
+        torch.cuda.synchronize()
+        # (the captured step stays on ONE stream: capturing the side-stream branches of MGNet.forward crashes hipGraph
+        #  instantiation on ROCm 7.0; the eager step with side streams is the faster of the two)
+        self.model._no_side_streams = True
+        try:
+            with torch.cuda.graph(graph):
+                self.reducer.zero_grad()
+                with self.storage:
+                    loss_dict = self.model(batched_inputs)
+                    self._backward(loss_dict)
+                self.reducer.finish()
+                self.optimizer.launch_step()
+        finally:   # (a failed capture must not leave the eager step without its side streams)
+            self.model._no_side_streams = False
+        self._graph, self._graph_losses = graph, loss_dict
+        return graph
+
+    def replay_step(self):
+        """one training step = upload the per-step tables + replay the captured graph"""
+        self.optimizer.prepare_step()
+        self._graph.replay()
+        self.scheduler.step()
+        self.iter += 1
+        self.storage.step()
+        return self._graph_losses
+
+    def _backward(self, loss_dict):
+        """sum of the loss dict -> backward; with fp16 activations the sum is multiplied by the dynamic loss scale first
+        (GradScaler.scale(losses).backward(), detectron2 AMPTrainer.run_step)"""
+        losses = sum(loss_dict.values())
+        scale = self.optimizer.loss_scale() if hasattr(self.optimizer, "loss_scale") else None
+        # split-K sums of a bucket's convs as one launch (reducer._pack); not under hipGraph capture (the table upload uses events)
+        self.reducer.lazy_wgrad(not os.environ.get("MGN_NO_LAZY_WGRAD") and not getattr(self.model, "_no_side_streams", False))
+        try:
+            (losses if scale is None else losses * scale).backward()
+        except BaseException:
+            self.reducer.abort()
+            raise
+        finally:
+            self.reducer.lazy_wgrad(False)
+
+    def run_step(self, batched_inputs):
+        self.model.train()
+        self.reducer.zero_grad()
+        with self.storage:
+            loss_dict = self.model(batched_inputs)
+            self._backward(loss_dict)
+        self.reducer.finish()
+        self.optimizer.step()
+        self.scheduler.step()
+        self.iter += 1
+        self.storage.step()
+        return loss_dict

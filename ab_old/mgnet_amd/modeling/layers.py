@@ -1,7 +1,5 @@
 """Decoder building blocks of MGNet -- host-side mirror of mgnet/modeling/layers.py (same class names, ctor
 arguments, attribute names => same state-dict keys), computing through mgnet_amd.modeling.ops."""
-import os
-
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -71,13 +69,8 @@ class Conv2d(nn.Conv2d):
 class PlainConv2d(nn.Conv2d):
     """nn.Conv2d whose forward goes through ops.conv2d (predictors, PoseCNN decoder convs)."""
 
-    def forward(self, x, relu=False, keep_pad=False):
-        """relu: `torch.relu_(conv(x))` with the ReLU in the convolution's epilogue (and its mask in the backward) on the GPU path.
-        keep_pad: a few-channel predictor may return its 32-channel-padded output as an ops.PaddedMap (training path: the fused
-        losses / ops.head_activation read it in place and hand back a padded gradient)"""
-        if relu and os.environ.get("MGN_NO_POSERELU"):
-            return torch.relu_(ops.conv2d(x, self.weight, self.bias, self.stride, self.padding))
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu=relu, keep_pad=keep_pad)
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding)
 
 
 def mgnet_xavier_fill(module):  # layers.py:325-328
@@ -122,10 +115,9 @@ class AttentionRefinementModule(nn.Module):  # layers.py:221-267
             mgnet_xavier_fill(self.conv)
             mgnet_xavier_fill(self.channel_attention[1])
 
-    def forward(self, x, addend=None):
-        """addend: a tensor added to the result (`arm(x) + last`, layers.py:87) inside the scaling pass on the GPU path"""
+    def forward(self, x):
         fm = self.conv(x)
-        return ops.channel_attention(fm, self.channel_attention, "arm", addend=addend)
+        return ops.channel_attention(fm, self.channel_attention, "arm")
 
 
 class FeatureFusionModule(nn.Module):  # layers.py:270-322
@@ -169,7 +161,7 @@ class MGNetDecoder(nn.Module):  # layers.py:22-94
         fms = [features[k] for k in self.in_features]
         msc, last = [], features["global_context"]
         for k in range(2):
-            fm = self.arms[k](fms[k], last)   # arm(x) + last
+            fm = self.arms[k](fms[k]) + last
             msc.append(fm)
             last = self.refines[k](ops.upsample_nearest(fm, fms[k + 1].shape[2:]))
         return self.ffm(fms[2], last), msc
@@ -184,8 +176,8 @@ class MGNetHead(nn.Module):  # layers.py:97-127
             mgnet_xavier_fill(self.head)
             mgnet_xavier_fill(self.predictor)
 
-    def forward(self, x, keep_pad=False):
-        return self.predictor(self.head(x), keep_pad=keep_pad)
+    def forward(self, x):
+        return self.predictor(self.head(x))
 
 
 class PoseCNN(nn.Module):  # layers.py:130-167
@@ -202,8 +194,9 @@ class PoseCNN(nn.Module):  # layers.py:130-167
 
     def forward(self, image_list):
         out = self.pose_encoder(image_list)["res5"]
-        out = self.conv1(out, relu=True)   # layers.py:158-163: relu_(conv(x))
-        out = self.conv2(out, relu=True)
-        out = self.conv3(out, relu=True)
-        out = ops.mean_hw(self.conv4(out, keep_pad=self.training), 0.01)   # 0.01 * out.mean(3).mean(2), layers.py:165-167
-        return out.view(out.size(0), self.num_context_images, 6)
+        out = torch.relu_(self.conv1(out))
+        out = torch.relu_(self.conv2(out))
+        out = torch.relu_(self.conv3(out))
+        out = self.conv4(out).float()
+        out = out.mean(3).mean(2)
+        return 0.01 * out.view(out.size(0), self.num_context_images, 6)

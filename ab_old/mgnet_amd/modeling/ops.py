@@ -263,7 +263,7 @@ class _ConvFn(torch.autograd.Function):
     gradient on the bf16 matrix cores.  Master weights stay fp32 OIHW; the kernel layouts are derived per call."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, with_skip=False, cout_pad=0, stats=None, keep_pad=False):
+    def forward(ctx, x, weight, bias, stride, pad, relu, with_skip=False, cout_pad=0, stats=None):
         from .. import _C
 
         N, Cin, IH, IW = x.shape   # Cin of the ACTIVATION (8/16 = channel-padded stem input)
@@ -279,9 +279,7 @@ class _ConvFn(torch.autograd.Function):
                 b = torch.cat([b, b.new_zeros(cout_pad - Cout)])
             out = _C.conv_igemm(xs, _C.weight_layout(weight, 0, 0, cout_pad, dtype=xs.dtype), (OH, OW), b, stride, pad, 1, relu, stats=stats)
         ctx.save_for_backward(xs, weight, out if relu else None)
-        ctx.cfg = (stride, pad, relu, bias is not None, cout_pad, keep_pad)
-        if cout_pad and keep_pad:   # the caller works on the padded map itself (ops.head_activation, the fused losses) and hands back a
-            return out              # padded gradient with zero padding channels: no slice, no zero-fill + strided copy in the backward
+        ctx.cfg = (stride, pad, relu, bias is not None, cout_pad)
         if cout_pad:    # few-class predictors: the kernels work on 32-padded output channels, the caller sees the real ones
             return out[:, :Cout]
         if with_skip:   # second output: the input itself (autograd makes it an alias); its gradient comes back into backward
@@ -293,17 +291,17 @@ class _ConvFn(torch.autograd.Function):
         from .. import _C
 
         xs, weight, out = ctx.saved_tensors
-        stride, pad, relu, has_bias, cout_pad, keep_pad = ctx.cfg
+        stride, pad, relu, has_bias, cout_pad = ctx.cfg
         Cout, Cin, KH, KW = weight.shape
         Cx = xs.shape[1]
         dy = dy.to(xs.dtype)
-        if cout_pad and not keep_pad:    # zero gradient for the padding channels
+        if cout_pad:    # zero gradient for the padding channels
             dyp = torch.zeros((dy.shape[0], cout_pad) + tuple(dy.shape[2:]), dtype=dy.dtype, device=dy.device).contiguous(memory_format=torch.channels_last)
             dyp[:, :Cout] = dy
             dy = dyp
+        if relu:
+            dy = dy * (out > 0)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        if relu:   # [HIP] dy * (out > 0) in one pass (csrc/eltwise.hip relu_mask_bwd)
-            dy = _C.relu_mask_bwd(dy, out) if _C.elt_supported(out) and dy.shape == out.shape else dy * (out > 0)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             assert Cx == Cin, "no data gradient for the channel-padded stem input"
@@ -314,12 +312,11 @@ class _ConvFn(torch.autograd.Function):
             # (lazy: under a gradient reducer the split-K sums of a whole bucket run as one launch, engine/reducer.py)
             dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad, cin_real=Cin, lazy=not cout_pad)[:Cout]
         if has_bias and ctx.needs_input_grad[2]:
-            # [HIP] per-channel sum over N*H*W: the column-sum kernel with the batch folded into the rows (deterministic two-stage sum)
-            db = (_C.colsum_all(dy)[:Cout] if _C.elt_supported(dy) else dy.float().sum((0, 2, 3))[:Cout])
-        return dx, dw, db, None, None, None, None, None, None, None
+            db = dy.float().sum((0, 2, 3))[:Cout]
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=False, stats_for=None, keep_pad=False):
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=False, stats_for=None):
     """Convolution in the activation dtype (bf16 under AMP) from fp32 master weights.
     bf16 CUDA activations with Cin % 32 == 0: [HIP] implicit GEMM (Cout is zero-padded to a multiple of 32 for the
     few-class predictors).  Otherwise (fp32 activations, the 3/9-channel 7x7 stems, CPU tests): [torch-staging].
@@ -332,10 +329,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=Fals
         Cout = weight.shape[0]
         if Cout % 32:
             assert not with_skip
-            # keep_pad: return the 32-padded map (a PaddedMap: tensor + real channel count) for consumers that read it in place
-            keep_pad = bool(keep_pad) and not os.environ.get("MGN_NO_PADTAIL")
-            y = _ConvFn.apply(x, weight, bias, stride, padding, relu, False, (Cout + 31) // 32 * 32, None, keep_pad)
-            return PaddedMap(y, Cout) if keep_pad else y
+            return _ConvFn.apply(x, weight, bias, stride, padding, relu, False, (Cout + 31) // 32 * 32)
         # stats_for: the InPlaceABNSync that consumes the output next; in training the conv kernel then leaves the partial sums of
         # the batch statistics behind (attached to the output, taken by ops.iabn / abn_add_relu / abn_max_pool)
         holder = []
@@ -361,89 +355,6 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=Fals
     y = F.conv2d(x, w, b, stride=stride, padding=padding)
     y = torch.relu_(y) if relu else y
     return (y, x) if with_skip else y
-
-
-class PaddedMap:
-    """a predictor output with its channels padded to a multiple of 32 (`t` [B,P,h,w] 16-bit channels_last, `C` real channels): the
-    convolution kernels' own layout, handed to consumers that read it in place and return a padded gradient.  `real()` is the
-    [B,C,h,w] tensor the reference's module returns."""
-
-    def __init__(self, t, C):
-        self.t, self.C = t, C
-
-    def real(self):
-        return self.t[:, :self.C]
-
-    def tensors(self):
-        return [self.t]
-
-
-def real_channels(x):
-    return x.real() if isinstance(x, PaddedMap) else x
-
-
-class _HeadActFn(torch.autograd.Function):
-    """[HIP] csrc/headact.hip: padded predictor output -> fp32 [B,C,h,w] = x | sigmoid(x) | sigmoid(x) / 0.5, and the gradient back
-    into the padded 16-bit layout (zero padding channels) in one launch each"""
-
-    @staticmethod
-    def forward(ctx, xp, C, kind):
-        from .. import _C
-        y = _C.head_act_fwd(xp, C, kind)
-        ctx.save_for_backward(y if kind != "none" else None)
-        ctx.cfg = (tuple(xp.shape), C, kind, xp.dtype)
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        from .. import _C
-        (y,) = ctx.saved_tensors
-        shape, C, kind, dtype = ctx.cfg
-        g = g.float()
-        if g.stride(3) * g.shape[3] != g.stride(2):
-            g = g.contiguous()
-        return _C.head_act_bwd(g, y, shape, C, kind, dtype), None, None
-
-
-def head_activation(x, kind):
-    """`act(x.float())` of a predictor output, act = none | sigmoid (mg_net.py:694) | sigmoid2 = sigmoid / 0.5 (:822).
-    PaddedMap on the GPU: [HIP] one launch forward, one backward; tensors: torch ops"""
-    if isinstance(x, PaddedMap):
-        return _HeadActFn.apply(x.t, x.C, kind)
-    y = x.float()
-    if kind == "none":
-        return y
-    y = torch.sigmoid(y)
-    return y / 0.5 if kind == "sigmoid2" else y
-
-
-class _MeanHWFn(torch.autograd.Function):
-    """[HIP] scale * mean over H, W of a padded map -> [N, C] fp32 (PoseCNN's `0.01 * out.mean(3).mean(2)`, layers.py:165-167): the column-sum
-    kernels forward, the broadcast kernel backward -- which writes the padded 16-bit gradient the predictor's backward consumes"""
-
-    @staticmethod
-    def forward(ctx, xp, C, scale):
-        from .. import _C
-        N, P, H, W = xp.shape
-        ctx.cfg = (tuple(xp.shape), C, scale / (H * W), xp.dtype)
-        return _C.colsum(xp, None, scale / (H * W))[:, :C].contiguous()
-
-    @staticmethod
-    def backward(ctx, g):
-        from .. import _C
-        shape, C, k, dtype = ctx.cfg
-        gp = g.new_zeros((shape[0], shape[1]))
-        gp[:, :C] = g
-        return _C.bcast_rows(gp, shape, k, dtype), None, None
-
-
-def mean_hw(x, scale=1.0):
-    """scale * x.float().mean((2, 3)) -> [N, C] fp32"""
-    from .. import _C
-    if isinstance(x, PaddedMap) and _C.elt_supported(x.t):
-        return _MeanHWFn.apply(x.t, x.C, float(scale))
-    x = real_channels(x).float()
-    return scale * x.mean(3).mean(2)
 
 
 class _FanoutFn(torch.autograd.Function):
@@ -621,7 +532,7 @@ class _ChannelAttentionFn(torch.autograd.Function):
       kind "ffm": s = sigmoid(W2 relu(W1 p))             params: W1, W2"""
 
     @staticmethod
-    def forward(ctx, x, kind, residual, w1, p2, p3, running_mean, running_var, training, momentum, eps, addend=None):
+    def forward(ctx, x, kind, residual, w1, p2, p3, running_mean, running_var, training, momentum, eps):
         from .. import _C
         N, C, H, W = x.shape
         pooled = _C.colsum(x, None, 1.0 / (H * W))
@@ -634,14 +545,13 @@ class _ChannelAttentionFn(torch.autograd.Function):
             h, _, _ = _C.vec_linear_fwd(pooled, w1c, "relu")
             s, _, _ = _C.vec_linear_fwd(h, w2c, "sigmoid")
             ctx.save_for_backward(x, pooled, s, w1c, w2c, h)
-        ctx.cfg = (kind, residual, eps, tuple(w1.shape), None if p2 is None else tuple(p2.shape), addend is not None)
-        # addend: `arm(x) + last` of the decoder (layers.py:87) folded into the scaling pass (fp32 sum, one rounding)
-        return _C.scale_channels(x, s, 1 if residual else 0, addt=addend)
+        ctx.cfg = (kind, residual, eps, tuple(w1.shape), None if p2 is None else tuple(p2.shape))
+        return _C.scale_channels(x, s, 1 if residual else 0)
 
     @staticmethod
     def backward(ctx, g):
         from .. import _C
-        kind, residual, eps, w1s, p2s, has_addend = ctx.cfg
+        kind, residual, eps, w1s, p2s = ctx.cfg
         g = _cl(g, ctx.saved_tensors[0])
         if kind == "arm":
             x, pooled, s, w1c, bnw, xhat, rstd = ctx.saved_tensors
@@ -656,29 +566,24 @@ class _ChannelAttentionFn(torch.autograd.Function):
             d2, d3 = dW2.view(p2s), None
         N, C, H, W = x.shape
         dx = _C.scale_channels(g, s, 1 if residual else 0, add=dpool)   # dpool already carries the pool's 1/(H*W)
-        return dx, None, None, dW1.view(w1s), d2, d3, None, None, None, None, None, (g if has_addend else None)
+        return dx, None, None, dW1.view(w1s), d2, d3, None, None, None, None, None
 
 
-def channel_attention(x, attention, kind, residual=False, addend=None):
+def channel_attention(x, attention, kind, residual=False):
     """x * s / x + x * s with s = `attention`(x), an nn.Sequential(FastGlobalAvgPool2d, Conv2d(+norm | +ReLU), [conv], Sigmoid)
     of the reference's decoder modules.  bf16 CUDA, one process: [HIP] fused path; otherwise the module itself."""
     from .. import _C
     conv = attention[1]
     fused = _C.elt_supported(x) and x.shape[0] <= 64 and conv.bias is None and not os.environ.get("MGN_NO_ATTN_FUSE")
-    add_ok = addend is not None and not os.environ.get("MGN_NO_ARMADD") and addend.shape == x.shape and addend.dtype == x.dtype and addend.is_contiguous(memory_format=torch.channels_last)
     if kind == "arm":
         bn = conv.norm
         fused = fused and not _dist_active(bn.group) and (bn.training or not torch.is_grad_enabled())
         if fused:
-            y = _ChannelAttentionFn.apply(x, "arm", residual, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                          bn.training, bn.momentum, bn.eps, addend if add_ok else None)
-            return y if (addend is None or add_ok) else y + addend
+            return _ChannelAttentionFn.apply(x, "arm", residual, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                             bn.training, bn.momentum, bn.eps)
     elif fused and attention[2].bias is None:
-        y = _ChannelAttentionFn.apply(x, "ffm", residual, conv.weight, attention[2].weight, None, None, None, True, 0.0, 0.0,
-                                      addend if add_ok else None)
-        return y if (addend is None or add_ok) else y + addend
-    y = scale_channels(x, attention(x), residual=residual)
-    return y if addend is None else y + addend
+        return _ChannelAttentionFn.apply(x, "ffm", residual, conv.weight, attention[2].weight, None, None, None, True, 0.0, 0.0)
+    return scale_channels(x, attention(x), residual=residual)
 
 
 class _CatFn(torch.autograd.Function):
@@ -734,10 +639,7 @@ class LazyUpsample:
     kernels interpolate on the fly.  `materialize()` gives the tensor the reference would have produced."""
 
     def __init__(self, lr, scale, mult=1.0):
-        # lr: the low-resolution map, or a PaddedMap (channel-padded predictor output read in place by the fused loss kernels)
-        self.padded = lr if isinstance(lr, PaddedMap) else None
-        self.lr = lr.real() if self.padded is not None else lr
-        self.scale, self.mult = scale, mult
+        self.lr, self.scale, self.mult = lr, scale, mult
 
     @property
     def shape(self):
@@ -748,7 +650,7 @@ class LazyUpsample:
         return y * self.mult if self.mult != 1.0 else y
 
     def tensors(self):
-        return [self.lr] if self.padded is None else [self.lr, self.padded.t]
+        return [self.lr]
 
 
 def materialize(x):
@@ -759,13 +661,9 @@ class _UpCEFn(torch.autograd.Function):
     """[HIP] mgnet_amd/csrc/headloss.hip: x`scale` upsampling + weighted per-pixel CE + OHEM / top-k / mean selection."""
 
     @staticmethod
-    def forward(ctx, lr, labels, weights, H, W, ignore, mode, thr, n_sel, K=None):
+    def forward(ctx, lr, labels, weights, H, W, ignore, mode, thr, n_sel):
         from .. import _C
 
-        ctx.padded = None
-        if K is not None:      # lr is the channel-padded predictor output [B,P,h,w]: read in place, gradient returned padded
-            ctx.padded = (tuple(lr.shape), lr.dtype)
-            lr = lr[:, :K]
         labels = labels.contiguous()
         weights = None if weights is None else weights.float().contiguous()
         ce, sums = _C.upce_fwd(lr, labels, weights, H, W, ignore, thr if mode == "ohem" else 3.0e38)
@@ -787,13 +685,8 @@ class _UpCEFn(torch.autograd.Function):
         lr, labels, weights, ce, sel = ctx.saved_tensors
         H, W, ignore = ctx.cfg
         K = lr.shape[1]
-        Kp = (K + 7) // 8 * 8
-        dlg = _C.upce_bwd(lr, labels, weights, H, W, ignore, ce, sel, g.float().reshape(1).contiguous(), Kp)
-        if ctx.padded is not None:   # [HIP] fp32 [B,h,w,Kp] table -> padded 16-bit gradient in one launch
-            B, h, w = dlg.shape[:3]
-            dpad = _C.head_act_bwd(dlg, None, ctx.padded[0], K, "none", ctx.padded[1], g_strides=(h * w * Kp, 1, Kp))
-            return dpad, None, None, None, None, None, None, None, None, None
-        return dlg[..., :K].permute(0, 3, 1, 2).to(lr.dtype), None, None, None, None, None, None, None, None, None
+        dlg = _C.upce_bwd(lr, labels, weights, H, W, ignore, ce, sel, g.float().reshape(1).contiguous(), (K + 7) // 8 * 8)
+        return dlg[..., :K].permute(0, 3, 1, 2).to(lr.dtype), None, None, None, None, None, None, None, None
 
 
 def upsampled_ce(lazy, labels, weights, ignore, mode, thr=0.0, n_sel=0):
@@ -805,8 +698,6 @@ def upsampled_ce(lazy, labels, weights, ignore, mode, thr=0.0, n_sel=0):
     if mode != "mean" and n_sel >= labels.numel():
         raise IndexError(f"index {n_sel} is out of bounds for dimension 0 with size {labels.numel()}")
     assert lazy.mult == 1.0 and _C.upce_supported(lr)
-    if lazy.padded is not None:
-        return _UpCEFn.apply(lazy.padded.t, labels, weights, H, W, ignore, mode, float(thr), int(n_sel), lazy.padded.C)
     return _UpCEFn.apply(lr, labels, weights, H, W, ignore, mode, float(thr), int(n_sel))
 
 
@@ -814,13 +705,9 @@ class _InsLossFn(torch.autograd.Function):
     """[HIP] centre (weighted MSE) and offset (weighted L1) losses on the fly-upsampled low-res maps."""
 
     @staticmethod
-    def forward(ctx, center_lr, offset_lr, ct, cw, ot, ow, H, W, oscale, offset_C=None):
+    def forward(ctx, center_lr, offset_lr, ct, cw, ot, ow, H, W, oscale):
         from .. import _C
 
-        ctx.padded = None
-        if offset_C is not None:   # offset_lr is the channel-padded predictor output: read in place, gradient returned padded
-            ctx.padded = (tuple(offset_lr.shape), offset_lr.dtype)
-            offset_lr = offset_lr[:, :offset_C]
         center_lr = center_lr.float().contiguous()
         ct, cw, ot, ow = ct.float().contiguous(), cw.float().contiguous(), ot.float().contiguous(), ow.float().contiguous()
         out4 = _C.ins_loss_fwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale)
@@ -836,12 +723,8 @@ class _InsLossFn(torch.autograd.Function):
         H, W, oscale = ctx.cfg
         dco = _C.ins_loss_bwd(center_lr, offset_lr, H, W, ct, cw, ot, ow, oscale, out4, g.float().contiguous())
         d_center = dco[..., 0].unsqueeze(1)
-        if ctx.padded is not None:
-            B, h, w, Kp = dco.shape
-            d_offset = _C.head_act_bwd(dco[..., 1:], None, ctx.padded[0], 2, "none", ctx.padded[1], g_strides=(h * w * Kp, 1, Kp))
-        else:
-            d_offset = dco[..., 1:3].permute(0, 3, 1, 2).to(offset_lr.dtype)
-        return d_center, d_offset, None, None, None, None, None, None, None, None
+        d_offset = dco[..., 1:3].permute(0, 3, 1, 2).to(offset_lr.dtype)
+        return d_center, d_offset, None, None, None, None, None, None, None
 
 
 def ins_losses_supported(center, offset):
@@ -852,55 +735,5 @@ def ins_losses_supported(center, offset):
 
 def upsampled_ins_losses(center, offset, targets):
     H, W = center.shape[2:]
-    if offset.padded is not None:
-        return _InsLossFn.apply(center.lr, offset.padded.t, targets["center"], targets["center_weights"], targets["offset"],
-                                targets["offset_weights"], H, W, float(offset.mult), offset.padded.C)
     return _InsLossFn.apply(center.lr, offset.lr, targets["center"], targets["center_weights"], targets["offset"],
                             targets["offset_weights"], H, W, float(offset.mult))
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# uncertainty weighting of the task losses (mg_net.py:360-372)
-# ---------------------------------------------------------------------------------------------------------------
-class _UncertaintyFn(torch.autograd.Function):
-    """[HIP] csrc/scalars.hip: weighted_k = tau_k exp(-log_vars[k]) raw_k + 0.5 log_vars[k] for all tasks in one launch; one output per
-    task (views of one buffer), one launch for the backward -- the launches carry the pointers of the loss scalars where they lie."""
-
-    @staticmethod
-    def forward(ctx, log_vars, tau_mask, *raws):
-        from .. import _C
-        raws = [r.detach().float().reshape(()).contiguous() for r in raws]
-        lv = log_vars.detach().contiguous()
-        weighted, unc = _C.uncertainty_fwd(raws, lv, tau_mask)
-        ctx.raws, ctx.lv, ctx.tau_mask = raws, lv, tau_mask
-        ctx.mark_non_differentiable(unc)
-        return (unc,) + tuple(weighted.unbind(0))
-
-    @staticmethod
-    def backward(ctx, _g_unc, *gs):
-        from .. import _C
-        gs = [None if g is None else g.float().reshape(()).contiguous() for g in gs]
-        d_raw, d_lv = _C.uncertainty_bwd(ctx.raws, gs, ctx.lv, ctx.tau_mask)
-        return (d_lv, None) + tuple(d_raw.unbind(0))
-
-
-_TAU_CACHE = {}
-
-
-def uncertainty_weighting(losses, log_vars):
-    """mg_net.py:360-372 for a dict of task losses (in task order): -> (weighted dict, raw dict, uncertainty dict) of device scalars"""
-    keys = list(losses)
-    if log_vars.is_cuda and len(keys) <= 8 and all(v.is_cuda for v in losses.values()) and not os.environ.get("MGN_NO_UNC_FUSE"):
-        mask = sum(1 << i for i, k in enumerate(keys) if k == "loss_sem_seg")
-        out = _UncertaintyFn.apply(log_vars, mask, *[losses[k] for k in keys])
-        unc, weighted = out[0], out[1:]
-        return ({k: weighted[i] for i, k in enumerate(keys)}, {k: losses[k].detach() for k in keys}, {k: unc[i] for i, k in enumerate(keys)})
-    raw = torch.stack([losses[k].float().reshape(()) for k in keys])
-    lv = log_vars[:len(keys)]
-    ck = (tuple(keys), str(raw.device))
-    tau = _TAU_CACHE.get(ck)   # (uploaded once: a copy from pageable host memory stalls the host until the queue has drained)
-    if tau is None:
-        tau = _TAU_CACHE[ck] = torch.tensor([1.0 if k == "loss_sem_seg" else 0.5 for k in keys], dtype=raw.dtype).to(raw.device)
-    weighted = tau * torch.exp(-lv) * raw + 0.5 * lv
-    unc = torch.exp(lv.detach())
-    return ({k: weighted[i] for i, k in enumerate(keys)}, {k: raw[i].detach() for i, k in enumerate(keys)}, {k: unc[i] for i, k in enumerate(keys)})

@@ -30,10 +30,10 @@ def _ref_pass(lr, mode, flip, stride, scale):
                                           ("offset", 2, torch.bfloat16), ("inv2depth", 1, torch.float32)])
 def test_accumulate_matches_torch_over_all_passes(mode, C, dtype):
     """the seven scales x two flips of the reference's default schedule, on head outputs of the sizes those passes produce (ragged:
-    H=104, W=200 -> stride-8 maps of 6x12 ... 26x50), strided like the predictors' channel-padded outputs"""
+    H=96, W=160 -> stride-8 maps of 6x10 ... 24x40), strided like the predictors' channel-padded outputs"""
     from mgnet_amd import _C
     torch.manual_seed(0)
-    N, H, W, stride = 2, 104, 200, 8
+    N, H, W, stride = 2, 96, 160, 8
     scales = [0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0]
     acc = torch.empty(N, C, H, W, device="cuda")
     ref = None
@@ -44,8 +44,7 @@ def test_accumulate_matches_torch_over_all_passes(mode, C, dtype):
         for f in range(2):
             pad = torch.randn(N, 32, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
             lr = pad[:, :C] if dtype != torch.float32 else (torch.rand(N, C, h, w, device="cuda") * 2 - (0.0 if mode == "inv2depth" else 1.0))
-            if tuple(F.interpolate(lr.float(), scale_factor=stride / scale, mode="bilinear", align_corners=True).shape[2:]) != (H, W):
-                pytest.skip("schedule does not map back to (H, W) for this size")
+            assert tuple(F.interpolate(lr.float(), scale_factor=stride / scale, mode="bilinear", align_corners=True).shape[2:]) == (H, W)
             _C.msc_accumulate(acc, lr, mode, f, k == 0, stride=float(stride), scale=float(scale), divide=float(n) if k == n - 1 else 0.0)
             v = _ref_pass(lr, mode, f, stride, scale)
             ref = v if ref is None else ref + v
@@ -75,7 +74,8 @@ def test_input_rescale_flip_matches_torch(dtype):
             assert float(got[:, 3:].abs().max()) == 0.0
             # same fp32 interpolation up to contraction order, then ONE rounding to 16 bits: at most one 16-bit ulp apart, rarely
             d = (got[:, :3].float() - want.to(dtype).float()).abs()
-            ulp = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * want.abs().clamp(min=2.0 ** -14)
+            # (spacing of the 16-bit grid at |x|: between 2^-8 |x| and 2^-7 |x| for bf16, 2^-11 .. 2^-10 for fp16)
+            ulp = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * want.abs().clamp(min=2.0 ** -14)
             assert bool((d <= ulp * 1.01).all()) and float((d > 0).float().mean()) < 2e-2, (scale, f, float(d.max()))
 
 

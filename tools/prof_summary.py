@@ -41,6 +41,20 @@ def main(db, out=None):
         span = max(e for _, e in ev) - ev[0][0]
         lines.append(f"concurrency: span {span/1e6:.2f} ms, at least one kernel running {union/1e6:.2f} ms ({100*union/span:.1f} %), "
                      f"sum of kernel times {tot/1e6:.2f} ms (mean concurrency {tot/union:.2f})")
+    # the largest idle gaps of the steady-state window and the kernels on either side of each (what was the GPU waiting for?)
+    named = c.execute("select start, end, name from kernels order by start").fetchall()
+    if len(named) > 100:
+        named = named[int(len(named) * 0.4):]
+        gaps, last_end, last_name = [], named[0][1], named[0][2]
+        for st, en, nm in named[1:]:
+            if st > last_end:
+                gaps.append((st - last_end, last_name, nm))
+            if en >= last_end:
+                last_end, last_name = en, nm
+        gaps.sort(reverse=True)
+        lines.append("largest idle gaps (us): after kernel -> before kernel")
+        for g, a, b in gaps[:24]:
+            lines.append(f"  {g/1e3:9.1f}  {a[:60]:60s} -> {b[:60]}")
     txt = "\n".join(lines)
     print(txt)
     if out:
