@@ -159,6 +159,57 @@ def conv_roofline(dev, B):
             "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
 
 
+def kernel_census(trainer, batch, steps=2):
+    """Every GPU kernel of `steps` training steps (torch.profiler, AFTER the timed region) by origin: this library's kernels, torch's own
+    (at::native::*: what is left of torch on the path), the runtime's copy / fill kernels, RCCL's."""
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(steps):
+            trainer.run_step(batch)
+        torch.cuda.synchronize()
+    cnt = {"mgn": [0, 0.0], "torch": [0, 0.0], "rocclr_copy_fill": [0, 0.0], "rccl": [0, 0.0]}
+    for e in prof.key_averages():
+        t = float(getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0))
+        if t <= 0 or e.key.startswith(("hip", "Memcpy", "Memset")):
+            continue
+        k = ("torch" if "at::" in e.key else "rocclr_copy_fill" if "__amd_rocclr" in e.key else "rccl" if "nccl" in e.key.lower() else "mgn")
+        cnt[k][0] += e.count
+        cnt[k][1] += t
+    out = {k: {"launches_per_step": round(v[0] / steps, 1)} for k, v in cnt.items()}
+    out["torch"]["ms_per_step"] = round(cnt["torch"][1] / steps / 1e3, 3)   # (kernel durations under the profiler; the library's own are in profiles/)
+    out["total_launches_per_step"] = round(sum(v[0] for v in cnt.values()) / steps, 1)
+    return out
+
+
+def fp16_leg(args, dev, B, H, W, steps=5):
+    """BASELINE C5's dtype on the same workload: fp16 activations + dynamic loss scaling, a few steps after the bf16 measurement (a
+    driver-run number for the reference's AMP format; the headline `value` stays the bf16 run)."""
+    from mgnet_amd import add_mgnet_config, get_cfg
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.engine import Trainer
+    from mgnet_amd.registry import build_model
+    cfg = get_cfg()
+    add_mgnet_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "bench-c4-cityscapes-videosequence.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", str(dev), "SOLVER.IMS_PER_BATCH", B, "MODEL.SEM_SEG_HEAD.OHEM_N_MIN", min(524287, B * H * W // 4 - 1),
+                         "SOLVER.AMP.DTYPE", "float16"])
+    torch.manual_seed(0)
+    trainer = Trainer(cfg, build_model(cfg))
+    batch = synthetic_batch(B, H, W, dev, seed=1234)
+    for _ in range(4):
+        trainer.run_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = trainer.run_step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    sc = [float(v) for v in trainer.optimizer.scaler.tolist()]
+    return {"dtype": "fp16", "ms_per_step": round(dt * 1e3, 3), "value": round(B / dt, 2), "unit": "img/s", "steps": steps,
+            "loss_scale": sc[0], "optimizer_steps_taken": int(sc[2]), "steps_attempted": 4 + steps,
+            "losses_finite": bool(all(torch.isfinite(v.detach()).item() for v in last.values()))}
+
+
 def full_step_bench(args, world, rank, dev):
     """The benchmark: one full MGNet training step (SURVEY 3.1 hot loop) per per-GPU batch of synthetic frames."""
     from mgnet_amd import add_mgnet_config, get_cfg
@@ -264,6 +315,7 @@ def full_step_bench(args, world, rank, dev):
                      "ms_per_step_without_grad_allreduce": round(float(t_no.item()) * 1e3, 3),
                      "exposed_grad_allreduce_ms_per_step": round(dt / args.steps * 1e3 - float(t_no.item()) * 1e3, 3)}
     if rank == 0:
+        state_dict_cpu = None if (args.no_cpu_baseline or world > 1) else {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
         kern_ms = float(np.median(ev.elapsed_ms()))
         npx = B * H * W
         u8_frames = model._orig_frames_u8(batch) is not None     # the layout MGNet.forward hands to the loss for this batch
@@ -300,28 +352,85 @@ def full_step_bench(args, world, rank, dev):
         }
         if dist_info is not None:
             line["config"]["distributed"] = dist_info
+        try:
+            line["config"]["kernels_per_step"] = kernel_census(trainer, batch)
+        except Exception as e:  # noqa: BLE001 -- informative only
+            line["config"]["kernels_per_step"] = f"unavailable ({type(e).__name__}: {e})"
         line["roofline_mfma"] = conv_roofline(dev, B)
+        if world == 1 and args.dtype == "bf16" and not args.no_fp16_leg:
+            try:
+                del trainer, model
+                torch.cuda.empty_cache()
+                line["fp16"] = fp16_leg(args, dev, B, H, W)
+            except Exception as e:  # noqa: BLE001
+                line["fp16"] = {"error": f"{type(e).__name__}: {e}"}
+            model = None
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(H, W, model.state_dict(), cfg)
+            line["cpu_baseline"] = cpu_baseline(H, W, state_dict_cpu, cfg)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()   # rank 0 may still be timing the informative conv roofline: leave together
         torch.distributed.destroy_process_group()
 
 
-def self_launch(n):
+def self_launch(n, timeout_s):
     """`python bench.py --gpus N` without a launcher: run the N ranks as a child job (one process per GPU over RCCL) and
-    return its exit code.  Called before any HIP call of this process; the parent never initialises the GPU."""
+    return its exit code.  Called before any HIP call of this process; the parent never initialises the GPU.  The child runs in its
+    own process group: on a timeout exactly that group is stopped (never a pattern), the tail of its stderr (NCCL_DEBUG=WARN) goes into
+    a JSON failure line, and the exit code is non-zero."""
+    import signal
     import socket
     import subprocess
+    import tempfile
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    with tempfile.TemporaryFile(mode="w+") as err:
+        proc = subprocess.Popen(cmd, env=env, stderr=err, start_new_session=True)
+        try:
+            rc = proc.wait(timeout=timeout_s)
+            why = None
+        except subprocess.TimeoutExpired:
+            why = f"child job exceeded --timeout {timeout_s:.0f} s"
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(proc.pid, sig)      # the session / process group this call created
+                except ProcessLookupError:
+                    break
+                try:
+                    proc.wait(timeout=15)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            rc = 124
+        err.seek(0)
+        tail = err.read()[-6000:]
+        sys.stderr.write(tail)
+        if rc != 0:
+            print(json.dumps({"metric": "training img/s at 1024x2048 Cityscapes, 1/2/4/8 MI355X; reprojection-loss HBM GB/s", "value": None,
+                              "n_gpus": n, "error": why or f"child job exited with code {rc}",
+                              "stderr_tail": [ln for ln in tail.splitlines() if ln.strip()][-25:]}), flush=True)
+        return rc
+
+
+def rank_watchdog(timeout_s):
+    """a rank that is still alive after `timeout_s` (a collective that never completes, a peer that died) leaves with code 3 instead of
+    holding the driver: a daemon timer, no GPU call, no exec"""
+    import threading
+
+    def bail():
+        sys.stderr.write(f"[bench] rank {os.environ.get('RANK', '0')}: --timeout {timeout_s:.0f} s exceeded, exiting\n")
+        sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(timeout_s, bail)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def main():
@@ -340,13 +449,17 @@ def main():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="on: replay the captured step as a hipGraph (1 GPU, one stream); auto/off: issue every launch from Python "
                          "with the independent branches on side streams (the faster mode)")
+    ap.add_argument("--no-fp16-leg", action="store_true", help="skip the 5 fp16 + loss-scaling steps run after the bf16 measurement (N = 1)")
+    ap.add_argument("--timeout", type=float, default=1500.0,
+                    help="seconds after which a rank (and, with --gpus N self-launch, the whole child job) is stopped and the bench exits non-zero")
     ap.add_argument("--fwd-only", action="store_true", help="diagnostic: loss only (no gradient); NOT the benchmark")
     ap.add_argument("--loss-only", action="store_true",
                     help="diagnostic: time only the reprojection loss fwd+bwd (round-1 v2 workload); NOT the benchmark")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
-        sys.exit(self_launch(args.gpus))   # nothing has touched the GPU in this process
+        sys.exit(self_launch(args.gpus, args.timeout))   # nothing has touched the GPU in this process
+    rank_watchdog(args.timeout)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -359,7 +472,8 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+        import datetime
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=min(args.timeout, 600.0)))
 
     from mgnet_amd import _C
     from mgnet_amd.modeling.loss import _ReprojLossFn

@@ -31,6 +31,7 @@ __device__ __forceinline__ float ld_any(const void* p, long i, int dt) {
 // torch's upsample_bilinear2d, align_corners=True: source index = dst * (in - 1) / (out - 1) in fp32, floor, lambda
 struct Axis { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Axis axis(int dst, float scale, int in) {
+#pragma clang fp contract(off)   // (torch rounds the source index before taking its fraction: a fused scale * dst - floor moves lambda by 1 ulp of s)
     const float s = scale * (float)dst;
     Axis a;
     a.i0 = min((int)s, in - 1);

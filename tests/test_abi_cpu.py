@@ -48,3 +48,21 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_integration_md_reproj_cfg_matches_the_header():
+    """INTEGRATION.md section 2(b) shows the ctypes struct a maintainer would write for mgn_reproj_cfg: its field list must be the
+    header's (a missing field only 'worked' while it fell into alignment padding)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "mgnet_hip.h")).read()
+    body = hdr[hdr.index("typedef struct {", hdr.index("Self-supervised photometric reprojection loss")):hdr.index("} mgn_reproj_cfg;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields_h = re.findall(r"(?:int|float|void\s*\*)\s*([A-Za-z_, ]+);", body)
+    fields_h = [f.strip() for grp in fields_h for f in grp.split(",")]
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    cfg = md[md.index("class Cfg(ctypes.Structure):"):md.index("def ptrs(ts):")]
+    fields_md = re.findall(r'\("(\w+)",\s*ctypes', cfg)
+    assert fields_md == fields_h, (fields_md, fields_h)
+    from mgnet_amd import _C
+    assert [f[0] for f in _C.ReprojCfg._fields_] == fields_h
