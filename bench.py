@@ -297,9 +297,11 @@ def full_step_bench(args, world, rank, dev):
         # what the exchange costs: a few more steps WITHOUT the gradient all-reduce (measurement only, after the timed region;
         # the ranks' weights drift apart from here on, nothing is timed afterwards)
         from mgnet_amd.modeling import ops as _ops
-        n_ar, n_bn = trainer.reducer.collectives, _ops.SYNCBN_COLLECTIVES[0]
+        from mgnet_amd.engine import peer as _peer
+        n_ar, n_bn, n_p2p = trainer.reducer.collectives, _ops.SYNCBN_COLLECTIVES[0], _ops.SYNCBN_P2P[0]
         trainer.run_step(batch)
-        n_ar, n_bn = trainer.reducer.collectives - n_ar, _ops.SYNCBN_COLLECTIVES[0] - n_bn
+        n_ar, n_bn, n_p2p = trainer.reducer.collectives - n_ar, _ops.SYNCBN_COLLECTIVES[0] - n_bn, _ops.SYNCBN_P2P[0] - n_p2p
+        p2p_failed = bool(_peer.exchange().failed()) if _peer.exchange() is not None else None
         trainer.reducer.enabled = False
         n_extra = max(3, min(10, args.steps))
         fence()
@@ -311,7 +313,8 @@ def full_step_bench(args, world, rank, dev):
         torch.distributed.all_reduce(t_no, op=torch.distributed.ReduceOp.MAX)
         dist_info = {"backend": torch.distributed.get_backend(), "rccl_world_size": torch.distributed.get_world_size(),
                      "grad_allreduce_calls_per_step": n_ar, "grad_bytes_per_step": trainer.reducer.grad_bytes(),
-                     "syncbn_collectives_per_step": n_bn,
+                     "syncbn_collectives_per_step": n_bn, "syncbn_p2p_exchanges_per_step": n_p2p,
+                     "syncbn_exchange": dict(_peer.report(), wait_timed_out=p2p_failed),
                      "ms_per_step_without_grad_allreduce": round(float(t_no.item()) * 1e3, 3),
                      "exposed_grad_allreduce_ms_per_step": round(dt / args.steps * 1e3 - float(t_no.item()) * 1e3, 3)}
     if rank == 0:
@@ -352,10 +355,11 @@ def full_step_bench(args, world, rank, dev):
         }
         if dist_info is not None:
             line["config"]["distributed"] = dist_info
-        try:
-            line["config"]["kernels_per_step"] = kernel_census(trainer, batch)
-        except Exception as e:  # noqa: BLE001 -- informative only
-            line["config"]["kernels_per_step"] = f"unavailable ({type(e).__name__}: {e})"
+        if world == 1:   # (extra steps on rank 0 alone would wait for the other ranks' SyncBN rows forever)
+            try:
+                line["config"]["kernels_per_step"] = kernel_census(trainer, batch)
+            except Exception as e:  # noqa: BLE001 -- informative only
+                line["config"]["kernels_per_step"] = f"unavailable ({type(e).__name__}: {e})"
         line["roofline_mfma"] = conv_roofline(dev, B)
         if world == 1 and args.dtype == "bf16" and not args.no_fp16_leg:
             try:

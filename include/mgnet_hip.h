@@ -385,6 +385,36 @@ int mgn_head_act_fwd(const void* x_padded, int B, int h, int w, int P, int C, in
 int mgn_head_act_bwd(const float* g, long sb, long sc, long sp, const float* y, int B, int h, int w, int P, int C, int kind, int is_f16,
                      float gscale, void* dx_padded, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Peer-to-peer exchange of the SyncBN statistics between the ranks of ONE node (one process per GPU), csrc/p2p.hip.
+ * Replaces the all_gather (forward: 3*C floats) and all_reduce (backward: 2*C floats) that inplace_abn.InPlaceABNSync issues per
+ * layer (68 sites: res_net.py:35,49,59,103, layers.py:63,71,117,209,242,253,291) -- 136 latency-bound collectives per step -- by one
+ * small kernel each on the compute stream: every rank PUSHES its row into a mailbox in every peer's memory (xGMI is point-to-point),
+ * raises a flag there (release, system scope) and waits for the peers' flags in its own mailbox (acquire).
+ *   mgn_p2p_alloc / _free     this rank's mailbox: fine-grained device memory of mgn_p2p_mailbox_bytes(), zeroed (MGN_ENOTSUP if the
+ *                             runtime refuses such an allocation)
+ *   mgn_p2p_export / _open / _close   64-byte IPC handle of the own mailbox (to be sent to the peers by any means, e.g.
+ *                             torch.distributed.all_gather_object) / mapping of a peer's mailbox into this process
+ *   mgn_p2p_exchange          mailboxes: HOST array of `world` device pointers in rank order (own at [rank]); channel < MGN_P2P_CHANNELS
+ *                             = one per stream that issues exchanges; seq = 1, 2, 3, ... per channel, the same on every rank; payload:
+ *                             n <= MGN_P2P_SLOT_FLOATS fp32; reduce = 0: out[world][n] = every rank's payload (all_gather), 1: out[n] =
+ *                             sum over ranks in rank order (all_reduce; bit-identical on every rank).  payload and out must not overlap.
+ *                             status: device int, set to 1 if a peer did not post within timeout_s (results then undefined).
+ * Every rank must issue the same exchanges in the same order per channel, and exchanges of one channel must be stream-ordered.
+ * ---------------------------------------------------------------------------------------------- */
+#define MGN_P2P_CHANNELS 4
+#define MGN_P2P_SLOT_FLOATS 3072
+#define MGN_P2P_MAX_WORLD 8
+#define MGN_P2P_HANDLE_BYTES 64
+size_t mgn_p2p_mailbox_bytes(void);
+int mgn_p2p_alloc(void** mailbox);
+int mgn_p2p_free(void* mailbox);
+int mgn_p2p_export(void* mailbox, void* handle64);
+int mgn_p2p_open(const void* handle64, void** peer_mailbox);
+int mgn_p2p_close(void* peer_mailbox);
+int mgn_p2p_exchange(void* const* mailboxes, int world, int rank, int channel, unsigned seq, const float* payload, int n, int reduce,
+                     float* out, int* status, float timeout_s, void* stream);
+
 /* The stem's activated batch norm folded into the pooling (BasicStem, res_net.py:82-110: conv -> InPlaceABNSync -> max_pool):
  * forward pools y = act(scale * x + offset) evaluated on the fly (bf16-rounded like mgn_iabn_apply stores it; the
  * normalised map is never written), backward = mgn_iabn_bwd_reduce on (pooled, d pooled) for the channel sums, then

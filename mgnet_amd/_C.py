@@ -25,6 +25,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_instance_post_workspace_bytes", "mgn_instance_post", "mgn_instance_masks", "mgn_pseudo_label_ids", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
            "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd",
            "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4", "mgn_u8_frames_to_rgbx", "mgn_msc_input", "mgn_msc_accumulate", "mgn_uncertainty_fwd", "mgn_uncertainty_bwd", "mgn_head_act_fwd", "mgn_head_act_bwd",
+           "mgn_p2p_mailbox_bytes", "mgn_p2p_alloc", "mgn_p2p_free", "mgn_p2p_export", "mgn_p2p_open", "mgn_p2p_close", "mgn_p2p_exchange",
            "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
            "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd"]
 SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
@@ -150,6 +151,13 @@ def lib():
         L.mgn_uncertainty_bwd.argtypes = [vp, vp, ci, ci, vp, ctypes.c_uint, vp, vp, vp]
         L.mgn_head_act_fwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_head_act_bwd.argtypes = [vp, cl, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp]
+        L.mgn_p2p_mailbox_bytes.argtypes = []
+        L.mgn_p2p_alloc.argtypes = [ctypes.POINTER(vp)]
+        L.mgn_p2p_free.argtypes = [vp]
+        L.mgn_p2p_export.argtypes = [vp, vp]
+        L.mgn_p2p_open.argtypes = [vp, ctypes.POINTER(vp)]
+        L.mgn_p2p_close.argtypes = [vp]
+        L.mgn_p2p_exchange.argtypes = [vp, ci, ci, ci, ctypes.c_uint, vp, ci, ci, vp, vp, cf, vp]
         L.mgn_msc_input.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_msc_accumulate.argtypes = [vp, ci, cl, cl, cl, cl] + [ci] * 9 + [cf, cf, cf, vp, vp]
         L.mgn_iabn_bwd_reduce_x.argtypes = [vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, ci, cf, vp, vp, vp, sz, vp]
@@ -174,6 +182,7 @@ def lib():
         L.mgn_project_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
+        L.mgn_p2p_mailbox_bytes.restype = sz
         for n in F16_TWINS:
             getattr(L, n + "_f16").restype = ci
             getattr(L, n + "_f16").argtypes = getattr(L, n).argtypes

@@ -1,0 +1,201 @@
+"""Peer-to-peer exchange of the SyncBN statistics between the ranks of one node (csrc/p2p.hip): every rank pushes its row into a
+mailbox in each peer's memory over xGMI and waits for the peers' flags -- one small kernel on the compute stream per exchange instead
+of a torch.distributed collective (a Python -> ProcessGroupNCCL -> RCCL round trip with an event hand-shake on either side, 136 times
+per step: two per InPlaceABNSync site, the reference's inplace_abn does the same through torch.distributed).
+
+`enable(group)` (called by Trainer when the job has more than one rank) allocates the mailbox, swaps the IPC handles through the
+process group once, opens the peers' mailboxes and SELF-TESTS the exchange against the process group's own all_gather on random data;
+only a passing test switches ops.py over (`exchange()` returns the object), anything else -- a runtime that refuses fine-grained or IPC
+memory, ranks on different hosts, a wrong or late result -- leaves the torch.distributed path in place.  MGNET_SYNCBN=rccl keeps the
+collectives, =p2p makes a failing self-test an error; default "auto".
+
+Contract with the kernels: every rank issues the same exchanges in the same order per channel; a channel is a stream (the step runs its
+branches on up to three), numbered in order of first use -- which the ranks share because they run the same program."""
+import ctypes
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+
+from .. import _C
+
+_EX = [None]
+_REPORT = {"mode": "torch.distributed", "why": "not enabled"}
+
+
+def exchange():
+    """the active PeerExchange, or None (then ops.py uses torch.distributed)"""
+    return _EX[0]
+
+
+def report():
+    return dict(_REPORT)
+
+
+class PeerExchange:
+    def __init__(self, group, device, timeout_s=20.0):
+        lib = _C.lib()
+        self.group, self.device, self.timeout_s = group, device, float(timeout_s)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if self.world > lib_const("MGN_P2P_MAX_WORLD"):
+            raise RuntimeError(f"world size {self.world} > {lib_const('MGN_P2P_MAX_WORLD')}")
+        own = ctypes.c_void_p()
+        _C.check(lib.mgn_p2p_alloc(ctypes.byref(own)), "mgn_p2p_alloc")
+        self._own = own.value
+        handle = (ctypes.c_ubyte * 64)()
+        _C.check(lib.mgn_p2p_export(self._own, handle), "mgn_p2p_export")
+        mine = (socket.gethostname(), int(torch.cuda.current_device()), bytes(handle))
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=group)
+        if len({h for h, _, _ in everyone}) != 1:
+            raise RuntimeError("ranks on different hosts: the mailbox exchange is intra-node (xGMI)")
+        self._peers = []
+        for r, (_, _, hb) in enumerate(everyone):
+            if r == self.rank:
+                self._peers.append(self._own)
+                continue
+            p = ctypes.c_void_p()
+            buf = (ctypes.c_ubyte * 64).from_buffer_copy(hb)
+            _C.check(lib.mgn_p2p_open(buf, ctypes.byref(p)), "mgn_p2p_open")
+            self._peers.append(p.value)
+        self._arr = (ctypes.c_void_p * self.world)(*self._peers)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self._chan, self._seq = {}, {}
+        self.exchanges = 0
+        dist.barrier(group=group)    # every mailbox is mapped everywhere before anyone posts
+
+    def _channel(self):
+        sid = torch.cuda.current_stream(self.device).cuda_stream
+        c = self._chan.get(sid)
+        if c is None:
+            c = self._chan[sid] = len(self._chan)
+            if c >= lib_const("MGN_P2P_CHANNELS"):
+                raise RuntimeError("more streams issue SyncBN exchanges than the mailbox has channels")
+            self._seq[c] = 0
+        self._seq[c] += 1
+        return c, self._seq[c]
+
+    def _run(self, payload, reduce):
+        payload = payload.contiguous()
+        assert payload.is_cuda and payload.dtype == torch.float32 and payload.numel() <= lib_const("MGN_P2P_SLOT_FLOATS")
+        n = payload.numel()
+        out = torch.empty(tuple(payload.shape) if reduce else (self.world,) + tuple(payload.shape), dtype=torch.float32, device=payload.device)
+        c, seq = self._channel()
+        _C.check(_C.lib().mgn_p2p_exchange(self._arr, self.world, self.rank, c, seq, payload.data_ptr(), n, int(reduce), out.data_ptr(),
+                                           self.status.data_ptr(), self.timeout_s, _C._stream()), "mgn_p2p_exchange")
+        self.exchanges += 1
+        return out
+
+    def all_gather(self, t):
+        """[...] fp32 -> [world, ...]: every rank's tensor, in rank order"""
+        return self._run(t, False)
+
+    def all_reduce(self, t):
+        """sum over ranks in rank order (a NEW tensor; bit-identical on every rank)"""
+        return self._run(t, True)
+
+    def failed(self):
+        """True if a wait ran out of time since the last call (synchronises the device)"""
+        bad = bool(int(self.status.item()))
+        if bad:
+            self.status.zero_()
+        return bad
+
+    def close(self):
+        lib = _C.lib()
+        torch.cuda.synchronize(self.device)
+        for r, p in enumerate(self._peers):
+            if r != self.rank and p:
+                lib.mgn_p2p_close(p)
+        lib.mgn_p2p_free(self._own)
+        self._peers, self._own = [], None
+
+
+_CONST = {"MGN_P2P_MAX_WORLD": 8, "MGN_P2P_CHANNELS": 4, "MGN_P2P_SLOT_FLOATS": 3072}   # include/mgnet_hip.h
+
+
+def lib_const(name):
+    return _CONST[name]
+
+
+def _self_test(ex, rounds=24):
+    """the exchange against the process group's own all_gather on random rows, on two streams (two channels), back to back without host
+    synchronisation in between (so that ring slots are reused while peers lag); agreement on every rank decides"""
+    dev, group = ex.device, ex.group
+    g = torch.Generator(device=dev).manual_seed(1234 + ex.rank)
+    side = torch.cuda.Stream(dev)
+    rows, got = [], []
+    for k in range(rounds):
+        n = (3 * 64, 3 * 256, 2 * 512, 3 * 1024)[k % 4]
+        t = torch.randn(n, device=dev, generator=g)
+        rows.append(t)
+        if k % 3 == 2:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                got.append((ex.all_gather(t), ex.all_reduce(t)))
+            torch.cuda.current_stream(dev).wait_stream(side)
+        else:
+            got.append((ex.all_gather(t), ex.all_reduce(t)))
+    torch.cuda.synchronize(dev)
+    ok = not ex.failed()
+    for t, (ga, rs) in zip(rows, got):
+        ref = [torch.empty_like(t) for _ in range(ex.world)]
+        dist.all_gather(ref, t, group=group)
+        ref = torch.stack(ref)
+        want = ref[0].clone()
+        for r in range(1, ex.world):
+            want += ref[r]
+        ok = ok and torch.equal(ga, ref) and torch.equal(rs, want)
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item() == 1.0)
+
+
+def enable(group=None, device=None):
+    """Switch the SyncBN statistics exchange to the mailbox kernels if the job is multi-rank on CUDA, the runtime provides fine-grained
+    IPC memory and the self-test passes on every rank; returns the PeerExchange or None.  Collective: every rank must call it."""
+    mode = os.environ.get("MGNET_SYNCBN", "auto").lower()
+    if _EX[0] is not None:
+        return _EX[0]
+    if mode == "rccl" or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2 or not torch.cuda.is_available():
+        _REPORT.update(mode="torch.distributed", why="MGNET_SYNCBN=rccl" if mode == "rccl" else "single rank / no CUDA")
+        return None
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    ex, err = None, None
+    try:
+        ex = PeerExchange(group, device)
+    except Exception as e:  # noqa: BLE001 -- any refusal of the runtime means: keep the collectives
+        err = f"{type(e).__name__}: {e}"
+    # (the decision is collective: one rank without a mailbox sends everyone back to torch.distributed)
+    have = torch.tensor([0.0 if ex is None else 1.0], device=device)
+    dist.all_reduce(have, op=dist.ReduceOp.MIN, group=group)
+    ok = bool(have.item() == 1.0)
+    if ok:
+        try:
+            ok = _self_test(ex)
+            err = None if ok else "self-test: results differ from the process group's all_gather or a wait timed out"
+        except Exception as e:  # noqa: BLE001
+            ok, err = False, f"self-test raised {type(e).__name__}: {e}"
+    if not ok:
+        if ex is not None:
+            try:
+                ex.close()
+            except Exception:  # noqa: BLE001
+                pass
+        _REPORT.update(mode="torch.distributed", why=err or "a peer could not set its mailbox up")
+        if mode == "p2p":
+            raise RuntimeError("MGNET_SYNCBN=p2p but the peer-to-peer exchange is not usable: " + _REPORT["why"])
+        return None
+    _EX[0] = ex
+    _REPORT.update(mode="p2p mailbox (csrc/p2p.hip)", why="self-test passed on every rank")
+    return ex
+
+
+def disable():
+    if _EX[0] is not None:
+        try:
+            _EX[0].close()
+        finally:
+            _EX[0] = None
+            _REPORT.update(mode="torch.distributed", why="disabled")

@@ -27,6 +27,10 @@ class Trainer:
             self.optimizer = build_optimizer(cfg, model)
             self.reducer = GradReducer(ready_order(model, [p for g in self.optimizer.param_groups for p in g["params"]]), bucket_bytes,
                                        ordered=True)
+        if on_gpu and self.reducer.world > 1:
+            # SyncBN statistics over the peer-to-peer mailbox kernels where the node allows it (self-tested; else torch.distributed)
+            from . import peer
+            peer.enable()
         self.scheduler = build_lr_scheduler(cfg, self.optimizer)
         self.storage = EventStorage()
         self.iter = 0
@@ -115,4 +119,10 @@ class Trainer:
         self.scheduler.step()
         self.iter += 1
         self.storage.step()
+        if self.reducer.world > 1 and self.iter % 200 == 0:
+            from . import peer
+            ex = peer.exchange()
+            if ex is not None and ex.failed():   # (one device synchronisation every 200 steps)
+                raise RuntimeError("SyncBN mailbox exchange: a peer did not post its statistics in time (a rank died or diverged in its "
+                                   "launch order); set MGNET_SYNCBN=rccl to use torch.distributed collectives")
         return loss_dict

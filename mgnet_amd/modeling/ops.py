@@ -10,7 +10,8 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 STAGING_USED = set()   # names of torch staging ops that actually ran on CUDA tensors (bench.py prints it)
-SYNCBN_COLLECTIVES = [0]   # cross-rank statistics exchanges issued so far (bench.py reports the count per step)
+SYNCBN_COLLECTIVES = [0]   # cross-rank statistics exchanges issued through torch.distributed so far (bench.py reports the count per step)
+SYNCBN_P2P = [0]           # ... through the peer-to-peer mailbox kernels (engine/peer.py)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -40,9 +41,32 @@ def _dist_active(group):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
+def _peer_exchange(t):
+    """the mailbox exchange of engine/peer.py when it is active for CUDA tensors (else None: torch.distributed)"""
+    if not t.is_cuda:
+        return None
+    from ..engine import peer
+    return peer.exchange()
+
+
+def _allreduce_sums(sums, group):
+    """backward sums of a SyncBN layer over the ranks: [HIP] mailbox exchange (a new tensor), or dist.all_reduce in place"""
+    ex = _peer_exchange(sums)
+    if ex is not None:
+        SYNCBN_P2P[0] += 1
+        return ex.all_reduce(sums)
+    SYNCBN_COLLECTIVES[0] += 1
+    dist.all_reduce(sums, group=group)
+    return sums
+
+
 def _gather_stats(stats, world, group):
-    """[world, 3, C] statistics of all ranks.  RCCL: one all_gather_into_tensor (no per-rank output list and its copies);
-    other backends (gloo in the CPU tests): the list form."""
+    """[world, 3, C] statistics of all ranks.  [HIP] mailbox exchange when active; RCCL: one all_gather_into_tensor (no per-rank output
+    list and its copies); other backends (gloo in the CPU tests): the list form."""
+    ex = _peer_exchange(stats)
+    if ex is not None:
+        SYNCBN_P2P[0] += 1
+        return ex.all_gather(stats)
     gathered = torch.empty((world,) + tuple(stats.shape), dtype=stats.dtype, device=stats.device)
     SYNCBN_COLLECTIVES[0] += 1
     if dist.get_backend(group) == "nccl":
@@ -117,8 +141,7 @@ class _IABNFn(torch.autograd.Function):
             raise NotImplementedError("backward through eval-mode InPlaceABNSync is not on the training path")
         sums, d_weight, d_bias = _C.iabn_bwd_reduce(y, dy, M, C, w32, b32, eps, act, slope)
         if world > 1:
-            SYNCBN_COLLECTIVES[0] += 1
-            dist.all_reduce(sums, group=group)
+            sums = _allreduce_sums(sums, group)
         _C.iabn_bwd_apply(y, dy, dx, M, C, w32, b32, coef[2:], sums, total, eps, act, slope)
         return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None, None
 
@@ -158,8 +181,7 @@ class _AbnPoolFn(torch.autograd.Function):
         # equal the sums over the pooled tensors
         sums, d_weight, d_bias = _C.iabn_bwd_reduce(y, dy, y.numel() // C, C, w32, b32, eps, act, slope)
         if world > 1:
-            SYNCBN_COLLECTIVES[0] += 1
-            dist.all_reduce(sums, group=group)
+            sums = _allreduce_sums(sums, group)
         dx = _C.abn_maxpool_bwd(x, dy, arg, coef, w32, b32, sums, total, eps, act, slope)
         return dx, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None, None, None
 
@@ -196,8 +218,7 @@ class _AbnAddReluFn(torch.autograd.Function):
         dm = _C.relu_mask_bwd(_cl(g, y), y)   # gradient of both summands
         sums, d_weight, d_bias = _C.iabn_bwd_reduce_x(x, dm, M, C, w32, b32, coef, eps, 0, 0.01)
         if world > 1:
-            SYNCBN_COLLECTIVES[0] += 1
-            dist.all_reduce(sums, group=group)
+            sums = _allreduce_sums(sums, group)
         dx = torch.empty_like(x)
         _C.iabn_bwd_apply_x(x, dm, dx, M, C, w32, b32, coef, sums, total, eps, 0, 0.01)
         return dx, dm, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None

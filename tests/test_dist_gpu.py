@@ -104,6 +104,94 @@ def test_two_rank_training_keeps_replicas_identical():
     assert all(_spawn(_train).values())
 
 
+# ---- peer-to-peer SyncBN exchange (csrc/p2p.hip, engine/peer.py): two PROCESSES on the one GPU, mailboxes mapped through IPC ----------
+def _p2p_exchange(rank, world):
+    """mailbox all_gather / all_reduce against the process group's collectives: many rounds without host synchronisation (ring slots
+    are reused while the peer lags), three streams (three channels), every payload size the 68 norm sites produce"""
+    from mgnet_amd.engine import peer
+    os.environ["MGNET_SYNCBN"] = "auto"
+    ex = peer.enable()
+    if ex is None:
+        return "unavailable: " + peer.report()["why"]
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(77 + rank)
+    streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    rows, got = [], []
+    for k in range(150):
+        C = (64, 128, 256, 512, 1024)[k % 5]
+        t = torch.randn(3 if k % 2 else 2, C, device=dev, generator=g)
+        rows.append(t)
+        st = streams[(k // 7) % 3]
+        st.wait_stream(streams[0])
+        with torch.cuda.stream(st):
+            if rank == 1 and k % 11 == 0:     # one rank lags: the other runs ahead into the ring
+                torch.cuda._sleep(3_000_000)
+            got.append((ex.all_gather(t), ex.all_reduce(t)))
+        streams[0].wait_stream(st)
+    torch.cuda.synchronize()
+    if ex.failed():
+        return "a wait timed out"
+    for t, (ga, rs) in zip(rows, got):
+        ref = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(ref, t)
+        if not (torch.equal(ga, torch.stack(ref)) and torch.equal(rs, ref[0] + ref[1])):
+            return "mismatch"
+    # latency of one exchange (both ranks time the same 200 exchanges)
+    t = torch.randn(3, 256, device=dev)
+    torch.cuda.synchronize(); dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200):
+        ex.all_gather(t)
+    e1.record()
+    torch.cuda.synchronize()
+    return ("ok", round(e0.elapsed_time(e1) / 200 * 1e3, 1), peer.report()["mode"])
+
+
+def test_p2p_mailbox_exchange_matches_collectives(capsys):
+    out = _spawn(_p2p_exchange)
+    if any(isinstance(v, str) and v.startswith("unavailable") for v in out.values()):
+        pytest.skip(f"fine-grained IPC memory is not available to two processes on this box: {out}")
+    assert all(isinstance(v, tuple) and v[0] == "ok" for v in out.values()), out
+    with capsys.disabled():
+        print(f"\n[p2p exchange] 2 processes on one GPU: {out[0][1]} / {out[1][1]} us per all_gather of 3 x 256 floats ({out[0][2]})", end="")
+
+
+def _train_modes(rank, world):
+    """the same three training steps with the statistics exchanged by the mailbox kernels and by torch.distributed: identical parameters
+    (both combine the rows in rank order), and the mailbox path was really taken"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_network_cpu import small_model
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.engine import Trainer, peer
+    from mgnet_amd.modeling import ops
+    res = {}
+    for mode in ("auto", "rccl"):
+        os.environ["MGNET_SYNCBN"] = mode
+        peer.disable()
+        cfg, m = small_model(with_depth=True, seed=7)
+        m = m.cuda()
+        m.amp_dtype = torch.bfloat16
+        n0 = ops.SYNCBN_P2P[0]
+        tr = Trainer(cfg, m)
+        batch = synthetic_batch(1, 64, 96, "cuda", seed=100 + rank)
+        for _ in range(3):
+            tr.run_step(batch)
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack([p.detach().double().sum() for p in m.parameters()]).cpu(), ops.SYNCBN_P2P[0] - n0, peer.report()["mode"])
+    if res["auto"][1] == 0:
+        return "unavailable: " + str(res["auto"][2])
+    return bool(torch.equal(res["auto"][0], res["rccl"][0]) and res["auto"][1] >= 3 * 100 and res["rccl"][1] == 0)
+
+
+def test_two_rank_training_p2p_syncbn_equals_collectives():
+    out = _spawn(_train_modes)
+    if any(isinstance(v, str) for v in out.values()):
+        pytest.skip(f"peer-to-peer exchange not available on this box: {out}")
+    assert all(v is True for v in out.values()), out
+
+
 def _nccl_gather(rank, world):
     """RCCL code path of the statistics exchange (single rank: the transport is trivial, the call sequence is the real one)."""
     from mgnet_amd.modeling import ops
