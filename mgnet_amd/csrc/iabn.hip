@@ -369,7 +369,9 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restric
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 float z = FROMX ? fmaf(yv[k], sck[k], ofk[k]) : yv[k], dz = gv[k];
-                if (leaky && z < 0.f) { z *= inv_slope; dz *= slope; }
+                // (sign BIT: a negative pre-activation whose 0.01-fold underflows the 16-bit format is stored as -0 and must still
+                //  take the negative branch -- fp16: |z| < 3e-6; `z < 0.f` is false for -0)
+                if (leaky && (__float_as_uint(z) >> 31)) { z *= inv_slope; dz *= slope; }
                 a[k] += dz;
                 b[k] += dz * ((z - bk[k]) * igk[k]);
             }
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_apply(const T* __restrict__ y, c
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float z = FROMX ? fmaf(yv[k], sck[k], ofk[k]) : yv[k], dz = gv[k];
-            if (leaky && z < 0.f) { z *= inv_slope; dz *= slope; }
+            if (leaky && (__float_as_uint(z) >> 31)) { z *= inv_slope; dz *= slope; }   // (sign bit: -0 is negative, see the reduction)
             gv[k] = A[k] * (dz - m1[k]) - (z - bk[k]) * Bc[k];
         }
         Vec<T>::store(dx + i * V, gv);

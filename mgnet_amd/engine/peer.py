@@ -121,7 +121,25 @@ def lib_const(name):
 
 def _self_test(ex, rounds=24):
     """the exchange against the process group's own all_gather on random rows, on two streams (two channels), back to back without host
-    synchronisation in between (so that ring slots are reused while peers lag); agreement on every rank decides"""
+    synchronisation in between (so that ring slots are reused while peers lag); agreement on every rank decides.  Runs with a 2 s wait
+    budget and starts with ONE synchronised exchange, so that a node on which the mailboxes do not work costs seconds, not minutes."""
+    dev, group = ex.device, ex.group
+    budget, ex.timeout_s = ex.timeout_s, 2.0
+    try:
+        probe = torch.full((8,), float(ex.rank + 1), device=dev)
+        got = ex.all_reduce(probe)
+        torch.cuda.synchronize(dev)
+        first_ok = (not ex.failed()) and bool((got == float(ex.world * (ex.world + 1) // 2)).all())
+        flag = torch.tensor([1.0 if first_ok else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if flag.item() != 1.0:
+            return False
+        return _self_test_burst(ex, rounds)
+    finally:
+        ex.timeout_s = budget
+
+
+def _self_test_burst(ex, rounds):
     dev, group = ex.device, ex.group
     g = torch.Generator(device=dev).manual_seed(1234 + ex.rank)
     side = torch.cuda.Stream(dev)

@@ -89,3 +89,28 @@ def test_full_step_fp16_matches_oracle_and_trains():
         assert (steps[i] == steps[i - 1]) == (scales[i] < scales[i - 1]), (steps, scales)
     for p in m.parameters():
         assert bool(torch.isfinite(p).all())
+
+
+def test_fp16_full_size_steps_keep_the_loss_scale():
+    """BASELINE C5 at its own resolution (1024 x 2048, 4 frames): fp16's 65504 range is a real limit for the full-resolution stems, so ten
+    optimizer steps must stay finite, the dynamic loss scale must not collapse (>= 2^8: at most eight back-offs from 2^16) and most steps
+    must be taken."""
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.engine import Trainer
+
+    cfg, m = small_model(with_depth=True, seed=11)
+    m = m.cuda().train()
+    m.amp_dtype = torch.float16
+    tr = Trainer(cfg, m)
+    batch = synthetic_batch(4, 1024, 2048, "cuda", seed=21)
+    tot, scales = [], []
+    for _ in range(10):
+        out = tr.run_step(batch)
+        tot.append(float(sum(v.detach() for v in out.values())))
+        scales.append(float(tr.optimizer.scaler[0]))
+    steps_taken = float(tr.optimizer.scaler[2])
+    assert all(np.isfinite(tot)), tot
+    assert min(scales) >= 2.0 ** 8, scales
+    assert steps_taken >= 6, (steps_taken, scales)
+    for n, p in m.named_parameters():
+        assert bool(torch.isfinite(p).all()), n

@@ -63,10 +63,14 @@ def _check_conv(n, dtype, tol_h, tol_f):
     y = F.conv2d(xd, wd, bd, stride=stride, padding=pad)
     if relu:
         y = torch.relu(y)
+    cout = w.shape[0]
     out = n["outs"][0]
+    if out.shape[1] != cout:     # keep_pad: the node works on the 32-channel-padded map; padding channels are zero in both directions
+        assert float(out[:, cout:].abs().max()) == 0.0 and float(n["gout"][0][:, cout:].abs().max()) == 0.0
+        out = out[:, :cout]
     errs = {"y": _rel(out, y)}
     assert errs["y"] < tol_h, ("conv forward", tuple(w.shape), stride, errs)
-    dy = n["gout"][0]
+    dy = n["gout"][0][:, :cout]
     if relu:   # the recorded output is the rounded activation: its zero pattern is the mask the kernel used
         y = y * 0 + F.conv2d(xd, wd, bd, stride=stride, padding=pad) * (out > 0)
     y.backward(dy.double())
@@ -101,8 +105,11 @@ def _check_norm(n, tol_h, tol_p, tol_dx):
     y = _bn_act(xd, wd, bd, eps, activation, slope)
     sd = None
     if kind == "_AbnAddReluFn":
+        # the fused block tail keeps the rounding points of the separate ops (norm output stored in 16 bits, THEN + shortcut, ReLU):
+        # the ReLU mask is decided on that rounded sum
         sd = shortcut.double().requires_grad_(True)
-        y = torch.relu(y + sd)
+        yq = y + (y.detach().to(x.dtype).double() - y.detach())
+        y = torch.relu(yq + sd)
     elif kind == "_AbnPoolFn":
         # pool the ROUNDED activations like the kernel does (arg-max ties are decided on the stored 16-bit values)
         yq = y + (y.detach().to(x.dtype).double() - y.detach())
@@ -115,11 +122,28 @@ def _check_norm(n, tol_h, tol_p, tol_dx):
     if kind == "_AbnAddReluFn":
         dx, dsc, dw, db = gin[:4]
         errs["dshortcut"] = _rel(dsc, sd.grad)
+        if errs["dshortcut"] >= tol_h:
+            fl = (dsc != 0) != (sd.grad != 0)
+            zpre = (_bn_act(x.double(), w.double(), b.double(), eps, activation, slope) + shortcut.double())
+            print("DIAG", kind, tuple(x.shape), "mask flips", int(fl.sum()), "of", dsc.numel(), "pre-activation at flips", [round(v, 6) for v in zpre[fl].tolist()[:8]],
+                  "y there", out[fl].tolist()[:8], "g there", n["gout"][0][fl].tolist()[:8], "dsc there", dsc[fl].tolist()[:8])
         assert errs["dshortcut"] < tol_h, (kind, tuple(x.shape), errs)
     else:
         dx, dw, db = gin[:3]
-    errs["dx"], errs["dw"], errs["db"] = _rel(dx, xd.grad), _rel(dw, wd.grad), _rel(db, bd.grad)
-    assert errs["dx"] < tol_dx and errs["dw"] < tol_p and errs["db"] < tol_p, (kind, tuple(x.shape), activation, errs)
+    errs["dw"], errs["db"] = _rel(dw, wd.grad), _rel(db, bd.grad)
+    if kind == "_IABNFn" and errs["db"] > 1e-3:
+        yo, g = n["outs"][0].double(), n["gout"][0].double()
+        pre = F.batch_norm(x.double(), None, None, w.double().abs() + eps, b.double(), True, 0.0, eps)
+        mism = (yo < 0) != (pre < 0)
+        dz_k = torch.where(yo < 0, g * slope, g)
+        print("DIAG", kind, tuple(x.shape), "sign(y) != sign(pre):", int(mism.sum()), "of", yo.numel(), "zeros in y:", int((yo == 0).sum()),
+              "|pre| at mismatches", [round(v, 8) for v in pre[mism].abs().tolist()[:6]], "db kernel-mask vs kernel:", _rel(db, dz_k.sum((0, 2, 3))),
+              "sum|dz|/|sum dz| (worst channel)", float((dz_k.abs().sum((0, 2, 3)) / dz_k.sum((0, 2, 3)).abs()).max()),
+              "dy dtype", n["gout"][0].dtype, "max|dy|", float(g.abs().max()), "min nonzero |dy|", float(g.abs()[g != 0].min()))
+    if tol_dx is not None:
+        errs["dx"] = _rel(dx, xd.grad)
+        assert errs["dx"] < tol_dx, (kind, tuple(x.shape), activation, errs)
+    assert errs["dw"] < tol_p and errs["db"] < tol_p, (kind, tuple(x.shape), activation, errs)
     return errs
 
 
@@ -139,12 +163,12 @@ def test_every_conv_and_norm_node_of_a_full_step_matches_fp64(dtype, monkeypatch
     H, W = 128, 192
     batch = synthetic_batch(2, H, W, "cuda", seed=5)
     losses = m(batch)
-    scale = 1.0 if dtype == torch.bfloat16 else 1024.0     # (fp16: a loss scale keeps the small gradients out of the subnormals)
+    scale = 1.0 if dtype == torch.bfloat16 else 4096.0     # (fp16: a loss scale keeps the small gradients out of the subnormals; 65536 overflows the 1x1 global-context norm of this random net)
     (sum(losses.values()) * scale).backward()
     torch.cuda.synchronize()
     kinds = [n["kind"] for n in log]
     # 2 x ResNet-18 (20 convs each) + 3 decoders (5 each) + heads/predictors + pose decoder; 68 norm sites minus the 7 fused attention norms
-    assert kinds.count("_ConvFn") >= 75 and kinds.count("_AbnAddReluFn") == 16 and kinds.count("_AbnPoolFn") == 2 and kinds.count("_IABNFn") >= 35, \
+    assert kinds.count("_ConvFn") >= 70 and kinds.count("_AbnAddReluFn") == 16 and kinds.count("_AbnPoolFn") == 2 and kinds.count("_IABNFn") >= 35, \
         {k: kinds.count(k) for k in set(kinds)}
     ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     seen = {"skip": 0, "cout_pad": 0, "stats": 0, "stem": 0, "bias": 0, "tiny_batch_norms": 0}
@@ -159,7 +183,8 @@ def test_every_conv_and_norm_node_of_a_full_step_matches_fp64(dtype, monkeypatch
             seen["bias"] += n["ins"][2] is not None
         else:
             # the norm's result is one 16-bit rounding away from fp64; its backward re-derives x_hat from that rounded output (the
-            # in-place contract), which costs the data gradient ~2 ulp of a tensor norm and the parameter gradients less (they average)
+            # in-place contract), which costs the data gradient less than one ulp of a tensor norm (measured: 0.5; bound 3) and the parameter
+            # gradients less (they average)
             x = n["ins"][0]
             tiny = x.numel() // x.shape[1] < 8
             seen["tiny_batch_norms"] += tiny
@@ -167,7 +192,7 @@ def test_every_conv_and_norm_node_of_a_full_step_matches_fp64(dtype, monkeypatch
             #  difference of two projections, (1 - var/(var+eps)) of its terms: x_hat re-derived from a rounded output cannot resolve
             #  it, in this stack as in inplace_abn; its forward and parameter gradients are checked, its dx only for finiteness)
             e = _check_norm(n, tol_h=1.2 * ulp, tol_p=(2.0 if not tiny else 64.0) * ulp,
-                            tol_dx=1e30 if tiny else (3.0 if n["kind"] != "_AbnPoolFn" else 8.0) * ulp)
+                            tol_dx=None if tiny else 3.0 * ulp)
             assert all(torch.isfinite(g).all() for g in n["gin"] if torch.is_tensor(g))
         for k, v in e.items():
             worst[(n["kind"], k)] = max(worst.get((n["kind"], k), 0.0), v)

@@ -90,8 +90,8 @@ def test_arm_plus_last_in_one_pass(dtype, monkeypatch):
         y.backward(g)
         res.append((y.detach().float(), x.grad.float(), last.grad.float(), [p.grad.clone().float() for p in arm.parameters()]))
     (y1, dx1, dl1, dp1), (y2, dx2, dl2, dp2) = res
-    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
-    assert float((y1 - y2).abs().max()) <= 1.5 * ulp * float(y2.abs().max())
+    spacing = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10     # upper bound of the 16-bit grid spacing relative to |y|
+    assert float((y1 - y2).abs().max()) <= 1.01 * spacing * float(y2.abs().max())   # one grid step at the largest value
     assert torch.equal(dl1, dl2) and torch.equal(dl1, g.float())
     assert torch.equal(dx1, dx2) and all(torch.equal(a, b) for a, b in zip(dp1, dp2))
 

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_traffic2
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python3 $R/tools/measure_traffic.py run > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python3 $R/tools/measure_traffic.py run > $OUT/write.log 2>&1
+rocprofv3 --kernel-include-regex "reproj_march|reconstruct_kernel" --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python3 $R/tools/measure_traffic.py run > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-include-regex "reproj_march|reconstruct_kernel" --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python3 $R/tools/measure_traffic.py run > $OUT/write.log 2>&1
 python3 $R/tools/measure_traffic.py summarize $OUT | tee $OUT/summary.json
 cp $R/profiles/traffic.json $R/gpurun_out/traffic.json
