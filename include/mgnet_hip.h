@@ -159,6 +159,12 @@ int mgn_iabn_bwd_apply(const void* y, const void* dy, void* dx /*may alias dy*/,
 int mgn_iabn_bwd_reduce_x(const void* x, const void* dy, int dtype, long M, int C, const float* weight, const float* bias,
                           const float* scale, const float* offset, float eps, int activation, float slope, float* sums, float* dwb,
                           void* ws, size_t ws_bytes, void* stream);
+/* block tail relu(norm_identity(x) + shortcut) (res_net.py:62-79): mgn_iabn_bwd_reduce_x with the ReLU mask folded in.  g = gradient of the
+ * tail's output, yrelu = that output (16-bit); writes dm = g * (yrelu > 0) -- the gradient of both summands: the shortcut's gradient and
+ * what mgn_iabn_bwd_apply_x reads -- and reduces it in the same pass (replaces mgn_relu_mask_bwd + the re-read of its result). */
+int mgn_iabn_bwd_reduce_x_relu(const void* x, const void* g, const void* yrelu, void* dm, long M, int C, const float* weight,
+                               const float* bias, const float* scale, const float* offset, float eps, float* sums, float* dwb, void* ws,
+                               size_t ws_bytes, void* stream);
 int mgn_iabn_bwd_apply_x(const void* x, const void* dy, void* dx, int dtype, long M, int C, const float* weight, const float* bias,
                          const float* scale, const float* offset, const float* saved, const float* sums, float total_count, float eps,
                          int activation, float slope, void* stream);
@@ -713,6 +719,8 @@ int mgn_iabn_bwd_reduce_f16(const void* y, const void* dy, int dtype, long M, in
 int mgn_iabn_bwd_reduce_x_f16(const void* x, const void* dy, int dtype, long M, int C, const float* weight, const
     float* bias, const float* scale, const float* offset, float eps, int activation, float slope, float* sums,
     float* dwb, void* ws, size_t ws_bytes, void* stream);
+int mgn_iabn_bwd_reduce_x_relu_f16(const void* x, const void* g, const void* yrelu, void* dm, long M, int C, const float* weight,
+    const float* bias, const float* scale, const float* offset, float eps, float* sums, float* dwb, void* ws, size_t ws_bytes, void* stream);
 int mgn_iabn_bwd_apply_f16(const void* y, const void* dy, void* dx /*may alias dy*/, int dtype, long M, int C, const
     float* weight, const float* bias, const float* saved, const float* sums, float total_count, float eps, int
     activation, float slope, void* stream);

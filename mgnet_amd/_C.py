@@ -24,11 +24,11 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
            "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_instance_post_workspace_bytes", "mgn_instance_post", "mgn_instance_masks", "mgn_pseudo_label_ids", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
            "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd",
-           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4", "mgn_u8_frames_to_rgbx", "mgn_msc_input", "mgn_msc_accumulate", "mgn_uncertainty_fwd", "mgn_uncertainty_bwd", "mgn_head_act_fwd", "mgn_head_act_bwd",
+           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_reduce_x_relu", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4", "mgn_u8_frames_to_rgbx", "mgn_msc_input", "mgn_msc_accumulate", "mgn_uncertainty_fwd", "mgn_uncertainty_bwd", "mgn_head_act_fwd", "mgn_head_act_bwd",
            "mgn_p2p_mailbox_bytes", "mgn_p2p_alloc", "mgn_p2p_free", "mgn_p2p_export", "mgn_p2p_open", "mgn_p2p_close", "mgn_p2p_exchange",
            "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
            "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd"]
-SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
+SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
 DEPTH_MAX_FILTER_IDS = 16
 
 
@@ -63,7 +63,7 @@ class ReprojCfg(ctypes.Structure):
 
 _lib = None
 H16 = (torch.bfloat16, torch.float16)   # the 16-bit activation formats: bf16 entry points, or their _f16 twins (csrc/h16.h)
-F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']
+F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']
 
 
 def _fn(name, t):
@@ -161,6 +161,7 @@ def lib():
         L.mgn_msc_input.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_msc_accumulate.argtypes = [vp, ci, cl, cl, cl, cl] + [ci] * 9 + [cf, cf, cf, vp, vp]
         L.mgn_iabn_bwd_reduce_x.argtypes = [vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, ci, cf, vp, vp, vp, sz, vp]
+        L.mgn_iabn_bwd_reduce_x_relu.argtypes = [vp, vp, vp, vp, cl, ci, vp, vp, vp, vp, cf, vp, vp, vp, sz, vp]
         L.mgn_iabn_bwd_apply_x.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp]
         L.mgn_abn_add_relu_fwd.argtypes = [vp, vp, vp, vp, vp, cl, ci, vp]
         L.mgn_abn_maxpool_fwd.argtypes = [vp, vp, vp, ci, cf, vp, vp, ci, ci, ci, ci, vp]
@@ -416,6 +417,17 @@ def iabn_bwd_reduce_x(x, dy, M, C, weight, bias, coef, eps, activation, slope):
                                       coef[0].data_ptr(), coef[1].data_ptr(), eps, activation, slope, out.data_ptr(),
                                       out[2].data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()), "mgn_iabn_bwd_reduce_x")
     return out[:2], out[2], out[3]
+
+
+def iabn_bwd_reduce_x_relu(x, g, yrelu, M, C, weight, bias, coef, eps):
+    """block tail: dm = g * (yrelu > 0) written AND reduced in one pass (mgn_iabn_bwd_reduce_x_relu) -> (dm, sums[2,C], d_weight, d_bias)"""
+    out = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    dm = _cl_like(yrelu)
+    ws = _iabn_ws(x.device)
+    check(_fn("mgn_iabn_bwd_reduce_x_relu", x)(x.data_ptr(), g.data_ptr(), yrelu.data_ptr(), dm.data_ptr(), M, C, weight.data_ptr(), bias.data_ptr(),
+                                           coef[0].data_ptr(), coef[1].data_ptr(), eps, out.data_ptr(), out[2].data_ptr(), ws.data_ptr(),
+                                           ws.numel() * 4, _stream()), "mgn_iabn_bwd_reduce_x_relu")
+    return dm, out[:2], out[2], out[3]
 
 
 def iabn_bwd_apply_x(x, dy, dx, M, C, weight, bias, coef, sums, total_count, eps, activation, slope):

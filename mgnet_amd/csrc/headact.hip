@@ -37,24 +37,34 @@ __global__ __launch_bounds__(256) void head_act_fwd(const uint16_t* __restrict__
     }
 }
 
-// g: element strides (sb, sc, sp) per batch / channel / pixel; y: the forward's output [B,C,h,w] (kind != 0)
+// g: element strides (sb, sc, sp) per batch / channel / pixel; y: the forward's output [B,C,h,w] (kind != 0).
+// One thread per (pixel, 8-channel group): 16-byte stores, four lanes cover a pixel's 64-byte row (the one-thread-per-pixel form wrote
+// 32 scattered 2-byte values per lane: 126 us for the 20-class map of a 1024 x 2048 batch, 0.26 ms per step over the six heads).
 __global__ __launch_bounds__(256) void head_act_bwd(const float* __restrict__ g, long sb, long sc, long sp, const float* __restrict__ y, int P,
                                                     int C, long npix, long hw, int kind, int f16, float gscale, uint16_t* __restrict__ dx) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int gpp = P / 8;                                   // 8-channel groups per pixel (P is a multiple of 8)
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = t / gpp;
+    const int c0 = (int)(t - i * gpp) * 8;
     if (i >= npix) return;
     const long b = i / hw, r = i % hw;
-    uint16_t* o = dx + i * P;
-    for (int c = 0; c < P; ++c) {
-        float v = 0.f;
-        if (c < C) {
-            v = g[b * sb + c * sc + r * sp] * gscale;
-            if (kind) {
-                const float yv = y[(b * C + c) * hw + r];
-                v *= kind == 1 ? yv * (1.f - yv) : yv * (1.f - 0.5f * yv);   // d (2 s) = 2 s (1 - s) = y (1 - y / 2)
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (c0 < C) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
+            float v = 0.f;
+            if (c < C) {
+                v = g[b * sb + c * sc + r * sp] * gscale;
+                if (kind) {
+                    const float yv = y[(b * C + c) * hw + r];
+                    v *= kind == 1 ? yv * (1.f - yv) : yv * (1.f - 0.5f * yv);   // d (2 s) = 2 s (1 - s) = y (1 - y / 2)
+                }
             }
+            w[k >> 1] |= (uint32_t)f2h(v, f16) << ((k & 1) * 16);
         }
-        o[c] = f2h(v, f16);
     }
+    reinterpret_cast<uint4*>(dx)[t] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 }  // namespace
@@ -73,7 +83,9 @@ int mgn_head_act_bwd(const float* g, long sb, long sc, long sp, const float* y, 
                      float gscale, void* dx_padded, void* stream) {
     if (!g || !dx_padded || B < 1 || h < 1 || w < 1 || C < 1 || C > P || kind < 0 || kind > 2 || (kind && !y)) return MGN_EINVAL;
     const long hw = (long)h * w, npix = B * hw;
-    hipLaunchKernelGGL(head_act_bwd, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, sb, sc, sp, y, P, C, npix, hw,
+    if (P % 8 || ((uintptr_t)dx_padded & 15)) return MGN_EINVAL;
+    const long nthreads = npix * (P / 8);
+    hipLaunchKernelGGL(head_act_bwd, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, sb, sc, sp, y, P, C, npix, hw,
                        kind, is_f16 ? 1 : 0, gscale, (uint16_t*)dx_padded);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }

@@ -50,7 +50,39 @@ struct AccParams {
     float stride, scale, divide;   // mode 2: (v * stride) / scale; divide > 0: acc = (acc + v) / divide (the last pass)
 };
 
-template <int MODE>
+__device__ __forceinline__ float msc_post(float v, int mode, int c, const AccParams& p) {
+    if (mode == 2) {           // offsets: * stride / scale; x component (channel 1) mirrored on flipped passes
+        v = (v * p.stride) / p.scale;
+        if (p.flip && c == 1) v = -v;
+    } else if (mode == 3) {    // inv2depth (depth.py:15)
+        v = 1.f / fmaxf(v, 1e-6f);
+    }
+    return v;
+}
+__device__ __forceinline__ void msc_store(float* a, float v, const AccParams& p) {
+    float o = p.first ? v : *a + v;
+    if (p.divide > 0.f) o = o / p.divide;
+    *a = o;
+}
+__device__ __forceinline__ void unpack8h(const uint4& q, int f16, float (&v)[8]) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (f16) {
+            v[2 * k] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[k] & 0xffffu));
+            v[2 * k + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[k] >> 16));
+        } else {
+            v[2 * k] = __uint_as_float(w[k] << 16);
+            v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+}
+
+// VEC: 16-bit map whose channels are contiguous and padded to a multiple of 8 per pixel (the predictors' channel-padded NHWC outputs):
+// 16-byte loads of 8 channels per corner, every value in a register with a static index (the first version indexed a 32-entry array
+// under a run-time channel count with a run-time format switch per load: 512 registers, 6 016 spilled -- 6.8 ms per pass).
+// !VEC: any strides / fp32: channel by channel; the soft-max then takes two passes over the (L2-resident) low-resolution corners.
+template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void msc_accumulate(AccParams p) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), n = blockIdx.z;
     if (x >= p.W || y >= p.H) return;
@@ -60,47 +92,56 @@ __global__ __launch_bounds__(256) void msc_accumulate(AccParams p) {
     const Axis ay = axis(y, sy, p.h), ax = axis(xs, sx, p.w);
     const long b00 = n * p.sn + ay.i0 * p.sh + ax.i0 * p.sw, b01 = n * p.sn + ay.i0 * p.sh + ax.i1 * p.sw;
     const long b10 = n * p.sn + ay.i1 * p.sh + ax.i0 * p.sw, b11 = n * p.sn + ay.i1 * p.sh + ax.i1 * p.sw;
-    float v[MSC_MAX_C];
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int c = 0; c < MSC_MAX_C; ++c) {
-        if (c < p.C) {
-            const float v00 = ld_any(p.lr, b00 + c * p.sc, p.dtype), v01 = ld_any(p.lr, b01 + c * p.sc, p.dtype);
-            const float v10 = ld_any(p.lr, b10 + c * p.sc, p.dtype), v11 = ld_any(p.lr, b11 + c * p.sc, p.dtype);
-            v[c] = ay.l0 * (ax.l0 * v00 + ax.l1 * v01) + ay.l1 * (ax.l0 * v10 + ax.l1 * v11);
-            mx = fmaxf(mx, v[c]);
-        }
-    }
-    if (MODE == 0) {   // F.softmax(r, 1)
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < MSC_MAX_C; ++c)
-            if (c < p.C) { v[c] = expf(v[c] - mx); sum += v[c]; }
-        const float inv = 1.f / sum;
-#pragma unroll
-        for (int c = 0; c < MSC_MAX_C; ++c)
-            if (c < p.C) v[c] *= inv;
-    } else if (MODE == 2) {   // offsets: * stride / scale; x component (channel 1) mirrored on flipped passes
-#pragma unroll
-        for (int c = 0; c < MSC_MAX_C; ++c)
-            if (c < p.C) {
-                v[c] = (v[c] * p.stride) / p.scale;
-                if (p.flip && c == 1) v[c] = -v[c];
-            }
-    } else if (MODE == 3) {   // inv2depth (depth.py:15)
-#pragma unroll
-        for (int c = 0; c < MSC_MAX_C; ++c)
-            if (c < p.C) v[c] = 1.f / fmaxf(v[c], 1e-6f);
-    }
     const long plane = (long)p.H * p.W;
     float* a = p.acc + ((long)n * p.C) * plane + (long)y * p.W + x;
+    if constexpr (VEC) {
+        const uint16_t* lr = (const uint16_t*)p.lr;
+        const int f16 = p.dtype == 2;
+        float v[MSC_MAX_C];
+        float mx = -3.0e38f;
 #pragma unroll
-    for (int c = 0; c < MSC_MAX_C; ++c)
-        if (c < p.C) {
-            float o = p.first ? v[c] : a[c * plane] + v[c];
-            if (p.divide > 0.f) o = o / p.divide;
-            a[c * plane] = o;
+        for (int k = 0; k < MSC_MAX_C / 8; ++k) {
+            if (k * 8 < p.C) {
+                float c00[8], c01[8], c10[8], c11[8];
+                unpack8h(*reinterpret_cast<const uint4*>(lr + b00 + k * 8), f16, c00);
+                unpack8h(*reinterpret_cast<const uint4*>(lr + b01 + k * 8), f16, c01);
+                unpack8h(*reinterpret_cast<const uint4*>(lr + b10 + k * 8), f16, c10);
+                unpack8h(*reinterpret_cast<const uint4*>(lr + b11 + k * 8), f16, c11);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[k * 8 + j] = ay.l0 * (ax.l0 * c00[j] + ax.l1 * c01[j]) + ay.l1 * (ax.l0 * c10[j] + ax.l1 * c11[j]);
+                    if (k * 8 + j < p.C) mx = fmaxf(mx, v[k * 8 + j]);
+                }
+            }
         }
+        float inv = 1.f;
+        if (MODE == 0) {   // F.softmax(r, 1)
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < MSC_MAX_C; ++c)
+                if (c < p.C) { v[c] = expf(v[c] - mx); sum += v[c]; }
+            inv = 1.f / sum;
+        }
+#pragma unroll
+        for (int c = 0; c < MSC_MAX_C; ++c)
+            if (c < p.C) msc_store(a + c * plane, MODE == 0 ? v[c] * inv : msc_post(v[c], MODE, c, p), p);
+    } else {
+        auto blend = [&](int c) {
+            const float v00 = ld_any(p.lr, b00 + c * p.sc, p.dtype), v01 = ld_any(p.lr, b01 + c * p.sc, p.dtype);
+            const float v10 = ld_any(p.lr, b10 + c * p.sc, p.dtype), v11 = ld_any(p.lr, b11 + c * p.sc, p.dtype);
+            return ay.l0 * (ax.l0 * v00 + ax.l1 * v01) + ay.l1 * (ax.l0 * v10 + ax.l1 * v11);
+        };
+        if (MODE == 0) {
+            float mx = -3.0e38f;
+            for (int c = 0; c < p.C; ++c) mx = fmaxf(mx, blend(c));
+            float sum = 0.f;
+            for (int c = 0; c < p.C; ++c) sum += expf(blend(c) - mx);
+            const float inv = 1.f / sum;
+            for (int c = 0; c < p.C; ++c) msc_store(a + c * plane, expf(blend(c) - mx) * inv, p);
+        } else {
+            for (int c = 0; c < p.C; ++c) msc_store(a + c * plane, msc_post(blend(c), MODE, c, p), p);
+        }
+    }
 }
 
 struct InParams {
@@ -151,12 +192,17 @@ int mgn_msc_accumulate(const void* lr, int dtype, long sn, long sc, long sh, lon
     AccParams p{lr, acc, sn, sc, sh, sw, N, C, h, w, H, W, dtype, mode, flip ? 1 : 0, first ? 1 : 0, stride, scale, divide};
     const dim3 grid((W + 63) / 64, (H + 3) / 4, N), block(256);
     hipStream_t s = (hipStream_t)stream;
+    // vector path: 16-bit, channels contiguous, every pixel row 16-byte aligned and padded to a multiple of 8 channels
+    const bool vec = dtype != 0 && sc == 1 && sn % 8 == 0 && sh % 8 == 0 && sw % 8 == 0 && sw >= (C + 7) / 8 * 8 && ((uintptr_t)lr & 15) == 0;
+#define MGN_MSC(M) do { if (vec) hipLaunchKernelGGL((msc_accumulate<M, true>), grid, block, 0, s, p); \
+                        else hipLaunchKernelGGL((msc_accumulate<M, false>), grid, block, 0, s, p); } while (0)
     switch (mode) {
-        case 0: hipLaunchKernelGGL(msc_accumulate<0>, grid, block, 0, s, p); break;
-        case 1: hipLaunchKernelGGL(msc_accumulate<1>, grid, block, 0, s, p); break;
-        case 2: hipLaunchKernelGGL(msc_accumulate<2>, grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL(msc_accumulate<3>, grid, block, 0, s, p); break;
+        case 0: MGN_MSC(0); break;
+        case 1: MGN_MSC(1); break;
+        case 2: MGN_MSC(2); break;
+        default: MGN_MSC(3); break;
     }
+#undef MGN_MSC
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

@@ -184,7 +184,12 @@ class MGNetHead(nn.Module):  # layers.py:97-127
             mgnet_xavier_fill(self.head)
             mgnet_xavier_fill(self.predictor)
 
-    def forward(self, x, keep_pad=False):
+    def forward(self, x, keep_pad=False, with_skip=False):
+        """with_skip: also return the input as an alias for a second consumer (the instance head feeds two MGNetHeads from one decoder
+        output): its gradient is then added inside this head's data-gradient kernel instead of by an accumulation pass"""
+        if with_skip:
+            h, skip = self.head(x, with_skip=True)
+            return self.predictor(h, keep_pad=keep_pad), skip
         return self.predictor(self.head(x), keep_pad=keep_pad)
 
 

@@ -522,7 +522,8 @@ class MGNetInsEmbedHead(MGNetDecoder):  # mg_net.py:621-715
 
     def layers(self, features, keep_pad=False):
         y, _ = super().forward(features)
-        center = ops.head_activation(self.center_head(y, keep_pad=keep_pad), "sigmoid")  # mg_net.py:694 (sigmoid_ before the upsample)
+        c, y = self.center_head(y, keep_pad=keep_pad, with_skip=True)   # (y: alias whose gradient joins center_head's data gradient)
+        center = ops.head_activation(c, "sigmoid")  # mg_net.py:694 (sigmoid_ before the upsample)
         return center, self.offset_head(y, keep_pad=keep_pad)
 
     def losses(self, predictions, targets):

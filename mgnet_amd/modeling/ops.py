@@ -215,8 +215,13 @@ class _AbnAddReluFn(torch.autograd.Function):
         M, C, eps, group, world, training, total, wdtype = ctx.cfg
         if not training:
             raise NotImplementedError("backward through eval-mode InPlaceABNSync is not on the training path")
-        dm = _C.relu_mask_bwd(_cl(g, y), y)   # gradient of both summands
-        sums, d_weight, d_bias = _C.iabn_bwd_reduce_x(x, dm, M, C, w32, b32, coef, eps, 0, 0.01)
+        g = _cl(g, y)
+        if x.dtype in _C.H16 and not os.environ.get("MGN_NO_TAILMASK_FUSE"):
+            # [HIP] ReLU mask + reduction in one pass: dm = g * (y > 0) is written (gradient of both summands) while it is reduced
+            dm, sums, d_weight, d_bias = _C.iabn_bwd_reduce_x_relu(x, g, y, M, C, w32, b32, coef, eps)
+        else:
+            dm = _C.relu_mask_bwd(g, y)   # gradient of both summands
+            sums, d_weight, d_bias = _C.iabn_bwd_reduce_x(x, dm, M, C, w32, b32, coef, eps, 0, 0.01)
         if world > 1:
             sums = _allreduce_sums(sums, group)
         dx = torch.empty_like(x)
