@@ -10,7 +10,8 @@
   soon as it is complete, so the collective overlaps with the rest of backward
 * xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound, ~2*(N-1)/N*bytes/153 GB/s
   (1.4 ms for the 123.8 MB of MGNet at N=8); 32 MB buckets keep each call far above the latency floor while leaving
-  >= 4 calls to pipeline behind backward
+  >= 4 calls to pipeline behind backward; the LAST buckets of the ready order are 16 MB and 4 MB: their all-reduce has
+  nothing left to hide behind, so the exposed tail is one small call
 * gradients are averaged (sum, then 1/world) like DDP -- by `finish()` or, when `average=False`, by the consumer
   (the fused optimizer folds 1/world into its clipping pass)
 """
@@ -37,16 +38,24 @@ class GradReducer:
         params = [p for p in params if p.requires_grad]
         self.buckets = []          # dict(flat_g, flat_p, params, offsets, pending, n)
         self._bucket_of = {}
-        cur, cur_bytes = [], 0
-        for p in (params if ordered else reversed(params)):
+        # Bucket sizes: 32 MB keeps each call far above the latency floor -- except at the END of the ready order: the all-reduce of the
+        # last bucket cannot overlap with anything (backward is over), so the tail is made small: ... 32, 32, 16, 4 MB.  Built from the
+        # end backwards, then reversed.
+        seq = list(params if ordered else reversed(params))
+        caps = [min(bucket_bytes, 4 << 20), min(bucket_bytes, 16 << 20)]
+        groups, cur, cur_bytes = [], [], 0
+        for p in reversed(seq):
             nb = self._padded(p.numel()) * 4
-            if cur and cur_bytes + nb > bucket_bytes:
-                self._seal(cur, flatten_params)
+            cap = caps[len(groups)] if len(groups) < len(caps) else bucket_bytes
+            if cur and cur_bytes + nb > cap:
+                groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nb
         if cur:
-            self._seal(cur, flatten_params)
+            groups.append(cur)
+        for g in reversed(groups):
+            self._seal(list(reversed(g)), flatten_params)
         self._handles = []
         self._next = 0             # buckets are reduced in index order on every rank (collectives must be issued in the same order)
         self.collectives = 0       # all-reduce calls issued so far (bench.py reports it)

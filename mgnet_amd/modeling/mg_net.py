@@ -278,20 +278,32 @@ class MGNet(nn.Module):
         if side:
             handover(main, side[0], f_ins, targets)
             handover(main, side[1], f_dep, targets)
-        if self.with_panoptic:
-            outputs["sem_seg"] = self.sem_seg_head(f_sem)
-            losses.update(self.sem_seg_head.losses(outputs, targets))
-            with on(0):
-                outputs["center"], outputs["offset"] = self.ins_embed_head(f_ins)
-                l_ins = self.ins_embed_head.losses(outputs, targets)
-            losses.update(l_ins)
-        if self.with_depth:
+        # Issue order (the host issues ~100 launches per head one after the other): the depth head FIRST -- its reprojection kernel is
+        # the longest kernel of the forward and VALU-bound, so it should start while the other heads' MFMA-bound convolutions still have
+        # work to overlap with, not after them (MGN_HEAD_ORDER=sem_first: the order of rounds 1-2).  The loss dictionary keeps the
+        # reference's order (mg_net.py:290-358: sem_seg, center, offset, photometric, smoothness) -- the uncertainty weights are indexed by it.
+        l_sem, l_ins, l_depth = {}, {}, {}
+        depth_first = self.with_depth and os.environ.get("MGN_HEAD_ORDER", "depth_first") != "sem_first"
+
+        def run_depth():
             with on(1):
                 outputs["depth"] = self.depth_head(f_dep)
                 if side:
                     handover(side[0], side[1], outputs.get("poses"))
-                l_depth = self.depth_head.losses(outputs, targets)
-            losses.update(l_depth)
+                l_depth.update(self.depth_head.losses(outputs, targets))
+
+        if depth_first:
+            run_depth()
+        if self.with_panoptic:
+            with on(0):
+                outputs["center"], outputs["offset"] = self.ins_embed_head(f_ins)
+                l_ins.update(self.ins_embed_head.losses(outputs, targets))
+            outputs["sem_seg"] = self.sem_seg_head(f_sem)
+            l_sem.update(self.sem_seg_head.losses(outputs, targets))
+        if self.with_depth and not depth_first:
+            run_depth()
+        for part in (l_sem, l_ins, l_depth):
+            losses.update(part)
         if side:
             handover(side[0], main, losses)
             handover(side[1], main, losses)
