@@ -64,6 +64,8 @@ struct Params {
     float* dbg;
     int B, H, W, n, RH, nseg, nstrips;
     float ssim_w;
+    int automask;     // loss.py:139-144: the un-warped context frames compete in the per-pixel min (reference default: 1)
+    int reduce_mean;  // loss.py:242-243 photometric_reduce_op "mean": mean over the warped maps instead of their min (automask must be 0)
 };
 
 // bound_ctrl=1: lanes without a source read 0, so no "old" operand has to be materialised (saves a v_mov per shift)
@@ -631,12 +633,16 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 const float pu0 = sh[SH_PU * WAVE], pu1 = sh[(SH_PU + 1) * WAVE];
                 const float wxm = sh[SH_WX * WAVE], wym = sh[SH_WY * WAVE];
                 const bool live = sh[SH_LIVE * WAVE] != 0.f;
-                // loss.py:241-246: min over [warp_prev, unwarp_prev, warp_next, unwarp_next]; first index wins ties
+                // loss.py:241-246: min over [warp_prev, unwarp_prev, warp_next, unwarp_next]; first index wins ties.
+                // Options (wave-uniform): without automasking only the warped maps compete; reduce "mean": their average, both carry
+                // half of the gradient
                 float best = pw[0];
                 int win = 0;
-                if (pu0 < best) { best = pu0; win = 1; }
+                if (p.automask && pu0 < best) { best = pu0; win = 1; }
                 if (pw[1] < best) { best = pw[1]; win = 2; }
-                if (pu1 < best) { best = pu1; win = 3; }
+                if (p.automask && pu1 < best) { best = pu1; win = 3; }
+                const float gshare = p.reduce_mean ? 0.5f : 1.f;
+                if (p.reduce_mean) best = 0.5f * (pw[0] + pw[1]);
                 const bool own = row_own && lane_own;
                 // smoothness (depth.py:18-51, loss.py:257-294), un-normalised: |d inv| * exp(-mean_c |d img|)
                 const float sxv = fabsf(inv1 - dpp_from_right(inv1)) * wxm;
@@ -651,15 +657,15 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 if (GRAD) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const bool G = live && (win == 2 * j);
+                        const bool G = live && (p.reduce_mean || win == 2 * j);
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            const float k = (G && gt[j][c]) ? -0.5f * ssim_w3 : 0.f;
+                            const float k = (G && gt[j][c]) ? -0.5f * ssim_w3 * gshare : 0.f;
                             cA0[j][c] = k * al[j][c];
                             cB0[j][c] = k * be[j][c];
                             cC0[j][c] = k * ga[j][c];
                             const float df = xw1[j][c] - y1[c];
-                            l1g0[j][c] = G ? l1_w3 * (float)((df > 0.f) - (df < 0.f)) : 0.f;
+                            l1g0[j][c] = G ? l1_w3 * gshare * (float)((df > 0.f) - (df < 0.f)) : 0.f;
                         }
                     }
                 }
@@ -1089,7 +1095,9 @@ int make_layout(const mgn_reproj_cfg* c, Layout* L) {
 }
 
 int check_options(const mgn_reproj_cfg* c) {
-    if (c->automask_loss != 1 || c->photometric_reduce_op != 0 || c->padding_mode != 0) return MGN_ENOTSUP;
+    if (c->padding_mode != 0) return MGN_ENOTSUP;                      // "border" / "reflection" grid_sample padding: no kernel
+    if ((c->automask_loss != 0 && c->automask_loss != 1) || (c->photometric_reduce_op != 0 && c->photometric_reduce_op != 1)) return MGN_EINVAL;
+    if (c->automask_loss && c->photometric_reduce_op != 0) return MGN_EINVAL;   // loss.py:105-109: automasking goes with "min"
     if (c->frame_layout < 0 || c->frame_layout > MGN_FRAMES_RGBX_U8) return MGN_EINVAL;
     if (!(c->ssim_loss_weight > 0.f)) return MGN_ENOTSUP;  // ssim_w == 0 makes the reference return a 3-channel L1 map
     return MGN_OK;
@@ -1140,6 +1148,8 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
     p.B = cfg->B; p.H = cfg->H; p.W = cfg->W; p.n = cfg->n_scales;
     p.RH = L.RH; p.nseg = L.nseg; p.nstrips = L.nstrips;
     p.ssim_w = cfg->ssim_loss_weight;
+    p.automask = cfg->automask_loss;
+    p.reduce_mean = cfg->photometric_reduce_op;
 
     hipLaunchKernelGGL(reproj_prep, dim3((cfg->B + 63) / 64), dim3(64), 0, stream, cam, cam_stride, cam_ld, pose, cfg->B,
                        (CamConst*)(ws + L.off_cam));

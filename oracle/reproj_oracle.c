@@ -349,12 +349,24 @@ void SUF(orc_photometric)(const REAL* est, const REAL* img, int B, int H, int W,
  *          stage (optional, may be NULL): minmap[n][B,H,W]
  * returns 0, or -1 on bad arguments.
  * ------------------------------------------------------------------------------------- */
+static int g_automask = 1, g_reduce_mean = 0;   /* loss.py:139-144 automask_loss, :242-246 photometric_reduce_op (set per call, see below) */
+
+/* options of the next orc_reproj_loss call: automask_loss (1 = reference default), photometric_reduce_op (0 = "min", 1 = "mean";
+ * loss.py:105-109 asserts that automasking goes with "min") */
+int SUF(orc_reproj_options)(int automask, int reduce_mean) {
+    if ((automask != 0 && automask != 1) || (reduce_mean != 0 && reduce_mean != 1) || (automask && reduce_mean)) return -1;
+    g_automask = automask;
+    g_reduce_mean = reduce_mean;
+    return 0;
+}
+
 int SUF(orc_reproj_loss)(const REAL* const* inv, int n, const REAL* img, const REAL* prev, const REAL* nxt,
                          const uint8_t* mask, const REAL* K, const REAL* poses, int B, int H, int W,
                          REAL ssim_w, REAL photo_w, REAL smooth_w,
                          REAL* losses, REAL* const* minmap_out,
                          int want_grad, REAL g_photo, REAL g_smooth, REAL* const* d_inv, REAL* d_poses) {
     if (n < 1 || n > 8 || B < 1 || H < 2 || W < 2 || !(ssim_w > 0)) return -1;
+    const int automask = g_automask, reduce_mean = g_reduce_mean;
     const long hw = (long)H * W;
     const REAL* ctx[2] = {prev, nxt};
 
@@ -405,8 +417,15 @@ int SUF(orc_reproj_loss)(const REAL* const* inv, int n, const REAL* img, const R
             for (long p = 0; p < hw; ++p) {
                 int win = 0;
                 REAL best = pm[p];
-                for (int k = 1; k < NSLOT; ++k)
-                    if (pm[k * hw + p] < best) { best = pm[k * hw + p]; win = k; }
+                if (reduce_mean) {   /* loss.py:242-243: mean over the (warped) maps of their masked means = masked mean of their average */
+                    best = (pm[p] + pm[2 * hw + p]) / 2;
+                    win = -1;
+                } else {
+                    for (int k = 1; k < NSLOT; ++k) {
+                        if (!automask && (k & 1)) continue;   /* without automasking only the warped maps compete (loss.py:133-144) */
+                        if (pm[k * hw + p] < best) { best = pm[k * hw + p]; win = k; }
+                    }
+                }
                 if (minmap_out && minmap_out[i]) minmap_out[i][b * hw + p] = best;
                 int m = mask ? mask[b * hw + p] != 0 : 1;
                 if (m) s += best;
@@ -424,7 +443,7 @@ int SUF(orc_reproj_loss)(const REAL* const* inv, int n, const REAL* img, const R
                     /* d loss / d ssim-map_c and L1 */
                     for (long p = 0; p < hw; ++p) {
                         int m = mask ? mask[b * hw + p] != 0 : 1;
-                        REAL G = (m && (int)dmap[p] == 2 * j) ? gscale : 0;
+                        REAL G = (m && (reduce_mean || (int)dmap[p] == 2 * j)) ? (reduce_mean ? gscale / 2 : gscale) : 0;
                         scratch[p] = G * ssim_w / 3;
                         dwarp[c * hw + p] += G * ((REAL)1 - ssim_w) / 3 * r_sign(wj[c * hw + p] - imgb[c * hw + p]);
                     }

@@ -386,3 +386,32 @@ def test_gradient_error_against_fp64_is_what_fp32_costs(name, capsys):
         for i, fh, ah, fr, ar in rows:
             print(f"\n[reproj grad vs fp64] {name} scale {i}: HIP off-fraction {fh:.2e} aggregate {ah:.2e} | reference fp32 {fr:.2e} {ar:.2e}", end="")
         print(f"\n[reproj grad vs fp64] {name} pose: HIP {ph / ps:.2e} | reference fp32 {pr / ps:.2e} (of the largest component)", end="")
+
+
+@pytest.mark.parametrize("name", ["rand_small", "oob_clamp", "no_mask_odd"])
+@pytest.mark.parametrize("automask,reduce_op", [(False, "min"), (False, "mean")])
+def test_non_default_options_match_reference(name, automask, reduce_op):
+    """automask_loss=False with photometric_reduce_op "min" / "mean" (loss.py:92-109, 131-144, 242-246) through the nn.Module against the
+    reference's own outputs (tests/golden/reproj_options.npz, made by tests/golden/make_golden_options.py)"""
+    import os
+    from conftest import GOLDEN
+    from mgnet_amd.modeling import MultiViewPhotometricLoss
+
+    z = np.load(os.path.join(GOLDEN, "reproj_options.npz"))
+    key = lambda k: z[f"{name}.{int(automask)}.{reduce_op}.{k}"]
+    c = golden_case_inputs(name)
+    d = _dev(c)
+    crit = MultiViewPhotometricLoss(0.85, 1.0, 0.001, automask, reduce_op, "zeros")
+    inv = [x.clone().requires_grad_(True) for x in d["inv"]]
+    poses = d["poses"].clone().requires_grad_(True)
+    tg = {"image_orig": d["img"], "image_prev_orig": d["prev"], "image_next_orig": d["nxt"], "camera_matrix": d["K"]}
+    if d["mask"] is not None:
+        tg["reprojection_mask"] = d["mask"]
+    out = crit({"depth": inv, "poses": poses}, tg)
+    assert float(out["loss_photometric"]) == pytest.approx(float(key("loss_photometric")), rel=2e-5, abs=1e-6)
+    assert float(out["loss_smoothness"]) == pytest.approx(float(key("loss_smoothness")), rel=2e-5, abs=1e-9)
+    out["loss_photometric"].backward()
+    for i in range(3):
+        grad_close(inv[i].grad.cpu().numpy(), key(f"dphot_dinv{i}"), f"{name}/{automask}/{reduce_op}/dinv{i}")
+    ref_p = key("dphot_dposes")
+    np.testing.assert_allclose(poses.grad.cpu().numpy(), ref_p, rtol=5e-3, atol=5e-3 * np.abs(ref_p).max())
