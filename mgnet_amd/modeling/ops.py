@@ -376,6 +376,10 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=Fals
         if holder:
             y._mgn_stats = holder[0]
         return (y, skip) if with_skip else y
+    if (x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad))
+            and not os.environ.get("MGNET_ALLOW_TORCH_STAGING") and _fp32_split_supported(x, weight)):
+        y = _conv2d_fp32_split(x, weight, bias, stride, padding, relu)   # [HIP] inference with fp32 activations (AMP off)
+        return (y, x) if with_skip else y
     if x.is_cuda and not os.environ.get("MGNET_ALLOW_TORCH_STAGING"):
         raise NotImplementedError(
             f"conv2d: no HIP kernel for {x.dtype} activations with {tuple(weight.shape)} weights (the conv kernels are bf16, Cin % 32 == 0 "
@@ -470,6 +474,45 @@ def mean_hw(x, scale=1.0):
         return _MeanHWFn.apply(x.t, x.C, float(scale))
     x = real_channels(x).float()
     return scale * x.mean(3).mean(2)
+
+
+def _fp32_split_supported(x, weight):
+    Cin = weight.shape[1]
+    return x.dim() == 4 and (Cin % 32 == 0 or Cin in (3, 9)) and x.shape[1] in (Cin, 8, 16)
+
+
+def _conv2d_fp32_split(x, weight, bias, stride, padding, relu):
+    """fp32-accurate convolution for INFERENCE on fp32 activations (a config with SOLVER.AMP.ENABLED False; the reference's
+    MGNet-*-PseudoLabelGeneration.yaml): the matrix cores have no fp32 mode worth using here, so x and w are split into bf16 high and low
+    parts and the product is three bf16 MFMA passes accumulated in fp32,
+        x w ~= x_hi w_hi + x_hi w_lo + x_lo w_hi          (the dropped x_lo w_lo term is 2^-16 relative),
+    each pass the product's own implicit-GEMM kernel with fp32 output (mgn_conv_igemm, out_f32).  ~1e-5 relative to an fp32 convolution
+    (tests/test_conv_gpu.py); no gradient (training in fp32 has no kernel: MGNET_ALLOW_TORCH_STAGING=1 runs torch's)."""
+    from .. import _C
+    with torch.no_grad():
+        Cout, Cin, KH, KW = weight.shape
+        N, Cx, IH, IW = x.shape
+        OH, OW = (IH + 2 * padding - KH) // stride + 1, (IW + 2 * padding - KW) // stride + 1
+        packed = Cin in (3, 9)
+        if packed and Cx == Cin:       # the stems' channel-padded layout (8 / 16 channels, zeros beyond the real ones)
+            x = F.pad(x, (0, 0, 0, 0, 0, (8 if Cin == 3 else 16) - Cin))
+        Cp = x.shape[1]
+        w32 = weight.detach().float()
+        cout_pad = (Cout + 31) // 32 * 32 if Cout % 32 else 0
+        xh = x.to(torch.bfloat16)
+        xl = (x - xh.float()).to(torch.bfloat16)
+        xh, xl = (t.contiguous(memory_format=torch.channels_last) for t in (xh, xl))
+        wh32 = w32.to(torch.bfloat16).float()
+        parts = []
+        for xa, wa in ((xh, wh32), (xh, w32 - wh32), (xl, wh32)):
+            wl = _C._weight_layout_now(wa.contiguous(), 2 if packed else 0, Cp if packed else 0, None, cout_pad)
+            parts.append(_C.conv_igemm(xa, wl, (OH, OW), None, stride, padding, 1, False, out_dtype=torch.float32, khw=(KH, KW) if packed else None))
+        y = (parts[0] + parts[1]) + parts[2]
+        if cout_pad:
+            y = y[:, :Cout]
+        if bias is not None:
+            y = y + bias.detach().float().view(1, -1, 1, 1)
+        return torch.relu_(y) if relu else y
 
 
 class _FanoutFn(torch.autograd.Function):

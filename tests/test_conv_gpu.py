@@ -425,3 +425,25 @@ def test_statistics_of_many_partial_rows_two_stage():
     mean = s[:, 0] / M
     m2 = s[:, 1] - s[:, 0] * mean
     assert torch.allclose(a[1].double().cpu(), mean, rtol=1e-6) and torch.allclose(a[2].double().cpu(), m2, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,hw,bias", [(64, 64, 3, 1, (40, 72), False), (128, 256, 3, 2, (33, 64), False), (256, 20, 1, 1, (24, 40), False),
+                                                  (3, 64, 7, 2, (64, 96), False), (9, 64, 7, 2, (64, 96), False), (256, 12, 1, 1, (8, 12), True)])
+def test_fp32_inference_conv_as_three_bf16_passes(cin, cout, k, s, hw, bias, monkeypatch):
+    """fp32 activations without a gradient (SOLVER.AMP.ENABLED False at inference): x w ~ x_hi w_hi + x_hi w_lo + x_lo w_hi on the bf16 matrix
+    cores with fp32 accumulation -- ~1e-5 of an fp64 convolution, three orders of magnitude below a plain bf16 convolution; with a gradient
+    there is no fp32 kernel and the op refuses (no silent torch fallback)"""
+    from mgnet_amd.modeling import ops
+    monkeypatch.delenv("MGNET_ALLOW_TORCH_STAGING", raising=False)
+    torch.manual_seed(0)
+    x = torch.randn(2, cin, *hw, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(cout, cin, k, k, device="cuda") * (2.0 / (cin * k * k)) ** 0.5)
+    b = torch.nn.Parameter(torch.randn(cout, device="cuda") * 0.1) if bias else None
+    with torch.no_grad():
+        y = ops.conv2d(x, w, b, stride=s, padding=k // 2)
+    assert y.dtype == torch.float32 and y.shape[1] == cout
+    ref = torch.nn.functional.conv2d(x.double(), w.detach().double(), None if b is None else b.detach().double(), stride=s, padding=k // 2)
+    rel = float((y.double() - ref).norm() / ref.norm())
+    assert rel < 3e-5, rel
+    with pytest.raises(NotImplementedError):
+        ops.conv2d(x, w, b, stride=s, padding=k // 2)      # grad mode: fp32 training has no kernel

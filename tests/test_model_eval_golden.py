@@ -61,6 +61,18 @@ def test_eval_outputs_match_reference_gpu(amp, torch_staging):
 
 
 @pytest.mark.gpu
+def test_eval_fp32_without_staging_matches_reference_gpu(monkeypatch):
+    """SOLVER.AMP.ENABLED False on the GPU (the reference's PseudoLabelGeneration yamls): every convolution runs as three bf16 MFMA passes
+    with fp32 accumulation (ops._conv2d_fp32_split) -- no torch convolution, fp32-level agreement with the reference's outputs"""
+    monkeypatch.delenv("MGNET_ALLOW_TORCH_STAGING", raising=False)
+    from mgnet_amd.modeling import ops
+    ops.STAGING_USED.clear()
+    single, msc = run("cuda", False)
+    assert not ops.STAGING_USED
+    check(single, msc, rtol=5e-3, atol_frac=1e-3)
+
+
+@pytest.mark.gpu
 def test_msc_flip_eval_end_to_end():
     """TEST.MSC_FLIP_EVAL through MGNet.forward: averaged predictions -> the same post-processing."""
     m = _model("cuda", True).eval()

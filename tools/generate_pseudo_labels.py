@@ -67,13 +67,9 @@ def main():
     # (only the panoptic branch is needed; the depth branch's DGC rescaling would ask the mapper for camera matrices)
     cfg.merge_from_list(["MODEL.DEVICE", "cuda:0", "WITH_DEPTH", False] + list(args.opts))
     assert cfg.WITH_PANOPTIC, "WITH_PANOPTIC = True is required for pseudo label generation!"   # (:34)
-    if not cfg.SOLVER.AMP.ENABLED and not os.environ.get("MGNET_ALLOW_TORCH_STAGING"):
-        # the reference's MGNet-*-PseudoLabelGeneration.yaml set SOLVER.AMP.ENABLED False (fp32 inference); this stack's
-        # convolution kernels are 16-bit only, so the trunk runs in bf16 here -- decided at config time, not by
-        # a NotImplementedError in the first convolution (configs/README.md)
-        print("generate_pseudo_labels: SOLVER.AMP.ENABLED False -> True (bf16 trunk: there are no fp32 convolution kernels; "
-              "MGNET_ALLOW_TORCH_STAGING=1 keeps fp32 on torch's convolutions)", file=sys.stderr)
-        cfg.merge_from_list(["SOLVER.AMP.ENABLED", True])
+    # (the reference's MGNet-*-PseudoLabelGeneration.yaml set SOLVER.AMP.ENABLED False: fp32 inference.  The config is respected: every
+    #  convolution then runs as three bf16 MFMA passes with fp32 accumulation, ops._conv2d_fp32_split -- ~1e-5 of an fp32 convolution;
+    #  `SOLVER.AMP.ENABLED True` on the command line selects the faster 16-bit trunk)
     model = build_model(cfg).eval()
     if args.weights:
         Checkpointer(model, save_dir=args.output).load(args.weights)
