@@ -45,8 +45,8 @@ const char* mgn_version(void);
  *
  * Configuration supported by the kernels: the reference defaults (mgnet/config.py:109-117: automask_loss=True,
  *   photometric_reduce_op="min", padding_mode="zeros", ssim_loss_weight>0) and automask_loss=False with "min" or "mean".
- *   padding_mode "border" / "reflection" and ssim_loss_weight = 0 (a 3-channel L1 map in the reference) return MGN_ENOTSUP
- *   (no silent fallback); automask_loss=True with "mean" is MGN_EINVAL (the reference asserts, loss.py:105-109).
+ *   padding_mode "zeros" (default), "border", "reflection".  ssim_loss_weight = 0 (a 3-channel L1 map in the reference) returns
+ *   MGN_ENOTSUP (no silent fallback); automask_loss=True with "mean" is MGN_EINVAL (the reference asserts, loss.py:105-109).
  *
  * Inputs
  *   inv_depth[n_scales] : [B,1,H,W] fp32 each (all scales already at full resolution, mg_net.py:804-807)
@@ -76,7 +76,7 @@ typedef struct {
     float smoothing_loss_weight;   /* 0.001 */
     int automask_loss;        /* 1 (reference default): the un-warped context frames compete in the per-pixel min (loss.py:139-144); 0: off */
     int photometric_reduce_op;/* 0 = "min", 1 = "mean" (loss.py:242-246; "mean" only with automask_loss = 0, loss.py:105-109) */
-    int padding_mode;         /* 0 = "zeros" (only supported value), 1 = "border", 2 = "reflection" */
+    int padding_mode;         /* F.grid_sample padding of the warp (camera_utils.py:24-55): 0 = "zeros", 1 = "border", 2 = "reflection" */
     int rows_per_wave;        /* 0 = choose automatically; else rows each wavefront owns (>=4) */
     int frame_layout;         /* MGN_FRAMES_*: how img / prev / next are laid out (same results for all three):
                                  0 PLANAR_F32   fp32 [B,3,H,W] planes, the reference's tensors (mg_net.py:320-335 `uint8.float() / 255`)

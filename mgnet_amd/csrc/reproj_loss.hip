@@ -66,6 +66,7 @@ struct Params {
     float ssim_w;
     int automask;     // loss.py:139-144: the un-warped context frames compete in the per-pixel min (reference default: 1)
     int reduce_mean;  // loss.py:242-243 photometric_reduce_op "mean": mean over the warped maps instead of their min (automask must be 0)
+    int pad_mode;     // F.grid_sample padding_mode of the warp (camera_utils.py:24-55): 0 "zeros", 1 "border", 2 "reflection"
 };
 
 // bound_ctrl=1: lanes without a source read 0, so no "old" operand has to be materialised (saves a v_mov per shift)
@@ -201,20 +202,50 @@ template <int FMT>
 struct Gather {       // the 12 corner values of one sample position (3 channel planes) and its fractional offsets
     float v[3][4];   // [channel][00, 10, 01, 11]
     float tx, ty;
+    float mx, my;    // d (padded position) / d (projected position); only touched by the PAD instantiations
 };
 template <>
 struct Gather<FMT_RGBX_U8> {   // the four corners as packed pixels: 4 registers carried across the row instead of 12
     uint32_t w[4];   // [00, 10, 01, 11]
     float tx, ty;
+    float mx, my;
 };
+
+// F.grid_sample padding modes for align_corners=True (ATen GridSampler: reflect over [0, 2 (size-1)], then clip; the gradient factor of
+// the transform is 0 where the position was clipped, -1 on a reflected branch).  "reflection" folds |x| modulo 2 (size-1) with a
+// truncated division like the reference's CPU kernel (not an exact fmod); positions far outside the image fold chaotically in fp32
+// whatever the formula (SURVEY: points behind the camera), there the reference's value is noise as well.
+__device__ __forceinline__ float pad_coord(float in, int size, int mode, float& mult) {
+#pragma clang fp contract(off)
+    mult = 1.f;
+    const float hi = (float)(size - 1);
+    if (mode == 2 && size > 1) {
+        const float ts = 2.f * hi;
+        const bool neg = in < 0.f;
+        const float a = fabsf(in);
+        const float df = truncf(a / ts);
+        const float extra = a - df * ts;
+        const float refl = ts - extra;
+        const bool flip = extra > refl;
+        in = flip ? refl : extra;
+        mult = (flip != neg) ? -1.f : 1.f;
+    }
+    if (in <= 0.f) { mult = 0.f; return 0.f; }
+    if (in >= hi) { mult = 0.f; return hi; }
+    return in;
+}
 // first half: corner addresses and the 12 loads (nothing waits for them here)
 // ILV: the context frame is pixel-interleaved RGBx ([H][W][4] fp32 = a 4-channel channels_last torch tensor, 4th channel unused):
 // ONE 16-byte load per corner through one resource instead of three dword loads through three plane resources -- the same 12
 // values, a third of the vector-memory instructions (the kernel's second limiter after VALU issue).  (The compiler
 // narrows the 16-byte load to buffer_load_dwordx3 since only three elements are used; the 16-byte pixel keeps every load aligned.)
-template <int FMT>
-__device__ __forceinline__ void bilinear3_issue(const rsrc_t (&plane)[3], int W, int H, float ix, float iy, Gather<FMT>& g) {
+template <int FMT, bool PAD = false>
+__device__ __forceinline__ void bilinear3_issue(const rsrc_t (&plane)[3], int W, int H, float ix, float iy, Gather<FMT>& g, int pad_mode = 0) {
     constexpr bool ILV = FMT == FMT_RGBX_F32;
+    if constexpr (PAD) {   // (a compile-time variant: the default "zeros" instantiations stay instruction for instruction what they were)
+        ix = pad_coord(ix, W, pad_mode, g.mx);
+        iy = pad_coord(iy, H, pad_mode, g.my);
+    }
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     g.tx = ix - fx0;
     g.ty = iy - fy0;
@@ -342,7 +373,7 @@ __device__ __forceinline__ void row_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool GRAD, int FMT = FMT_PLANAR>
+template <bool GRAD, int FMT = FMT_PLANAR, bool PAD = false>
 __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params p) {
     constexpr bool ILV = FMT == FMT_RGBX_F32, U8 = FMT == FMT_RGBX_U8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -549,6 +580,10 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 float ex[3], ey[3];
                 bilinear3_finish<GRAD, FMT>(gth[j], xw0[j], ex, ey);
                 if (GRAD) {
+                    if constexpr (PAD) {   // chain rule through the padding transform of the sampling position
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { ex[c] *= gth[j].mx; ey[c] *= gth[j].my; }
+                    }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         st[(j * 9 + c) * WAVE] = ex[c];
@@ -580,7 +615,7 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 const bool zf = z >= 1e-5f;             // camera.py:172 clamp(min=1e-5)
                 const float rz = frcp(fmaxf(z, 1e-5f));
                 const float ix = X * rz, iy = Y * rz;   // == ((Xn+1)/2)(W-1) of grid_sample
-                bilinear3_issue<FMT>(plane[j], W, H, ix, iy, gth[j]);
+                bilinear3_issue<FMT, PAD>(plane[j], W, H, ix, iy, gth[j], p.pad_mode);
                 if (GRAD) {
                     st[(j * 9 + 6) * WAVE] = zf ? rz : -rz;  // rz > 0: the sign carries the clamp flag
                     st[(j * 9 + 7) * WAVE] = ix;
@@ -1095,7 +1130,7 @@ int make_layout(const mgn_reproj_cfg* c, Layout* L) {
 }
 
 int check_options(const mgn_reproj_cfg* c) {
-    if (c->padding_mode != 0) return MGN_ENOTSUP;                      // "border" / "reflection" grid_sample padding: no kernel
+    if (c->padding_mode < 0 || c->padding_mode > 2) return MGN_EINVAL;
     if ((c->automask_loss != 0 && c->automask_loss != 1) || (c->photometric_reduce_op != 0 && c->photometric_reduce_op != 1)) return MGN_EINVAL;
     if (c->automask_loss && c->photometric_reduce_op != 0) return MGN_EINVAL;   // loss.py:105-109: automasking goes with "min"
     if (c->frame_layout < 0 || c->frame_layout > MGN_FRAMES_RGBX_U8) return MGN_EINVAL;
@@ -1150,21 +1185,20 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
     p.ssim_w = cfg->ssim_loss_weight;
     p.automask = cfg->automask_loss;
     p.reduce_mean = cfg->photometric_reduce_op;
+    p.pad_mode = cfg->padding_mode;
 
     hipLaunchKernelGGL(reproj_prep, dim3((cfg->B + 63) / 64), dim3(64), 0, stream, cam, cam_stride, cam_ld, pose, cfg->B,
                        (CamConst*)(ws + L.off_cam));
     if (cfg->prof_begin) (void)hipEventRecord((hipEvent_t)cfg->prof_begin, stream);
     const dim3 mgrid(L.nblocks), mblock(WAVE * (cfg->n_scales + 1));
-    if (cfg->frame_layout == MGN_FRAMES_RGBX_U8) {          // img / prev / next are uint8 [B][H][W][4]
-        if (want_grad) hipLaunchKernelGGL((reproj_march<true, FMT_RGBX_U8>), mgrid, mblock, L.lds_bytes, stream, p);
-        else hipLaunchKernelGGL((reproj_march<false, FMT_RGBX_U8>), mgrid, mblock, L.lds_bytes, stream, p);
-    } else if (cfg->frame_layout == MGN_FRAMES_CTX_RGBX_F32) {   // prev / next are fp32 [B][H][W][4] (4th channel unused)
-        if (want_grad) hipLaunchKernelGGL((reproj_march<true, FMT_RGBX_F32>), mgrid, mblock, L.lds_bytes, stream, p);
-        else hipLaunchKernelGGL((reproj_march<false, FMT_RGBX_F32>), mgrid, mblock, L.lds_bytes, stream, p);
-    } else {
-        if (want_grad) hipLaunchKernelGGL((reproj_march<true, FMT_PLANAR>), mgrid, mblock, L.lds_bytes, stream, p);
-        else hipLaunchKernelGGL((reproj_march<false, FMT_PLANAR>), mgrid, mblock, L.lds_bytes, stream, p);
-    }
+#define MGN_MARCH(G, F, P) hipLaunchKernelGGL((reproj_march<G, F, P>), mgrid, mblock, L.lds_bytes, stream, p)
+#define MGN_MARCH_F(F) do { if (cfg->padding_mode) { if (want_grad) MGN_MARCH(true, F, true); else MGN_MARCH(false, F, true); } \
+                            else { if (want_grad) MGN_MARCH(true, F, false); else MGN_MARCH(false, F, false); } } while (0)
+    if (cfg->frame_layout == MGN_FRAMES_RGBX_U8) MGN_MARCH_F(FMT_RGBX_U8);               // img / prev / next are uint8 [B][H][W][4]
+    else if (cfg->frame_layout == MGN_FRAMES_CTX_RGBX_F32) MGN_MARCH_F(FMT_RGBX_F32);    // prev / next are fp32 [B][H][W][4] (4th channel unused)
+    else MGN_MARCH_F(FMT_PLANAR);
+#undef MGN_MARCH_F
+#undef MGN_MARCH
     if (cfg->prof_end) (void)hipEventRecord((hipEvent_t)cfg->prof_end, stream);
     hipLaunchKernelGGL(reproj_fin1, dim3(cfg->B, cfg->n_scales), dim3(256), 0, stream, (const float*)(ws + L.off_partials),
                        cfg->n_scales, L.nseg * L.nstrips, (double*)(ws + L.off_persum));

@@ -124,7 +124,8 @@ def calc_smoothness(inv, img, prec="f32"):
 
 
 def reproj_loss(inv, img, prev, nxt, mask, K, poses, ssim_w=0.85, photo_w=1.0, smooth_w=0.001,
-                want_grad=True, g_photo=1.0, g_smooth=1.0, want_minmap=False, prec="f32", automask=True, reduce_op="min"):
+                want_grad=True, g_photo=1.0, g_smooth=1.0, want_minmap=False, prec="f32", automask=True, reduce_op="min",
+                padding_mode="zeros"):
     """MultiViewPhotometricLoss.forward (+backward) -- loss.py:111-154.
 
     inv: list of [B,1,H,W]; img/prev/nxt [B,3,H,W]; mask [B,1,H,W] bool or None; K [B,3,3] (or
@@ -152,8 +153,8 @@ def reproj_loss(inv, img, prev, nxt, mask, K, poses, ssim_w=0.85, photo_w=1.0, s
     dinv_pp = PP(*[a.ctypes.data for a in d_inv])
     mm_pp = PP(*[a.ctypes.data for a in minmap]) if want_minmap else None
     fo = getattr(_lib(prec), f"orc_reproj_options_{prec}")
-    fo.restype, fo.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_int]
-    if fo(int(bool(automask)), {"min": 0, "mean": 1}[reduce_op]) != 0:
+    fo.restype, fo.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    if fo(int(bool(automask)), {"min": 0, "mean": 1}[reduce_op], {"zeros": 0, "border": 1, "reflection": 2}[padding_mode]) != 0:
         raise ValueError("automask_loss goes with photometric_reduce_op 'min' only (loss.py:105-109)")
     f = getattr(_lib(prec), f"orc_reproj_loss_{prec}")
     f.restype = ctypes.c_int

@@ -157,10 +157,40 @@ void SUF(orc_inv2depth)(const REAL* inv, REAL* depth, long n) {
  * ref: [3,H,W]; depth: [H,W]; outputs warped [3,H,W] and (optionally) per-pixel state.
  * ------------------------------------------------------------------------------------- */
 typedef struct {
-    REAL ix, iy;    /* sampling position in pixel units */
+    REAL ix, iy;    /* sampling position in pixel units (after the padding-mode transform) */
+    REAL mx, my;    /* d (transformed position) / d (projected position): 1 for padding_mode "zeros" */
     REAL P[3];      /* back-projected point */
     REAL X, Y, z;   /* K.(R P + t) before the divide */
 } WarpState;
+
+/* F.grid_sample padding_mode, align_corners=True (ATen GridSampler.h: reflect_coordinates_set_grad over [0, 2 (size-1)], then
+ * clip_coordinates_set_grad): 0 = "zeros" (the position is used as it is; corners outside read 0), 1 = "border", 2 = "reflection" */
+static int g_pad_mode = 0;
+static REAL pad_coord(REAL in, int size, int mode, REAL* mult) {
+    *mult = 1;
+    if (mode == 0) return in;
+    const REAL hi = (REAL)(size - 1);
+    if (mode == 2 && size > 1) {
+        /* the reference's CPU path (ATen/native/cpu/GridSamplerKernel.cpp, ComputeLocationBase<align_corners=true>::reflect_coordinates,
+         * vectorised): |in| folded modulo 2 (size-1) by a truncated division in working precision -- NOT an exact fmod, which matters for
+         * the far-out-of-range positions of points behind the camera -- then min(extra, 2 (size-1) - extra); gradient sign from
+         * reflect_coordinates_get_grad: -1 iff (one more flip) xor (in < 0) */
+        const REAL ts = 2 * hi;
+        const int neg = in < 0;
+        const REAL a = in < 0 ? -in : in;
+        volatile REAL q = a / ts;                 /* (volatile: each operation rounded to REAL, no fused multiply-subtract) */
+        const REAL df = (REAL)trunc((double)q);
+        volatile REAL prod = df * ts;
+        const REAL extra = a - prod;
+        const REAL refl = ts - extra;
+        const int flip = extra > refl;
+        in = flip ? refl : extra;
+        *mult = (flip ^ neg) ? (REAL)-1 : (REAL)1;
+    }
+    if (in <= 0) { *mult = 0; return 0; }
+    if (in >= hi) { *mult = 0; return hi; }
+    return in;
+}
 
 static void view_synthesis_one(const REAL* ref, const REAL* depth, const REAL* K9, const REAL* R, const REAL* t,
                                int H, int W, REAL* warped, WarpState* st) {
@@ -187,6 +217,9 @@ static void view_synthesis_one(const REAL* ref, const REAL* depth, const REAL* K
             REAL Yn = 2 * (Y / Z) / (REAL)(H - 1) - (REAL)1.0;
             REAL ix = ((Xn + 1) / 2) * (REAL)(W - 1);
             REAL iy = ((Yn + 1) / 2) * (REAL)(H - 1);
+            REAL mx, my;
+            ix = pad_coord(ix, W, g_pad_mode, &mx);
+            iy = pad_coord(iy, H, g_pad_mode, &my);
             REAL fx0 = (REAL)floor(ix), fy0 = (REAL)floor(iy);
             REAL tx = ix - fx0, ty = iy - fy0;
             REAL w00 = (1 - tx) * (1 - ty), w10 = tx * (1 - ty), w01 = (1 - tx) * ty, w11 = tx * ty;
@@ -205,7 +238,7 @@ static void view_synthesis_one(const REAL* ref, const REAL* depth, const REAL* K
             }
             if (st) {
                 WarpState* s = st + p;
-                s->ix = ix; s->iy = iy;
+                s->ix = ix; s->iy = iy; s->mx = mx; s->my = my;
                 s->P[0] = P0; s->P[1] = P1; s->P[2] = P2;
                 s->X = X; s->Y = Y; s->z = z;
             }
@@ -352,11 +385,12 @@ void SUF(orc_photometric)(const REAL* est, const REAL* img, int B, int H, int W,
 static int g_automask = 1, g_reduce_mean = 0;   /* loss.py:139-144 automask_loss, :242-246 photometric_reduce_op (set per call, see below) */
 
 /* options of the next orc_reproj_loss call: automask_loss (1 = reference default), photometric_reduce_op (0 = "min", 1 = "mean";
- * loss.py:105-109 asserts that automasking goes with "min") */
-int SUF(orc_reproj_options)(int automask, int reduce_mean) {
-    if ((automask != 0 && automask != 1) || (reduce_mean != 0 && reduce_mean != 1) || (automask && reduce_mean)) return -1;
+ * loss.py:105-109 asserts that automasking goes with "min"), padding_mode of the warp (0 "zeros", 1 "border", 2 "reflection") */
+int SUF(orc_reproj_options)(int automask, int reduce_mean, int pad_mode) {
+    if ((automask != 0 && automask != 1) || (reduce_mean != 0 && reduce_mean != 1) || (automask && reduce_mean) || pad_mode < 0 || pad_mode > 2) return -1;
     g_automask = automask;
     g_reduce_mean = reduce_mean;
+    g_pad_mode = pad_mode;   /* camera_utils.py:24-55 view_synthesis(padding_mode=...) -> F.grid_sample */
     return 0;
 }
 
@@ -474,6 +508,7 @@ int SUF(orc_reproj_loss)(const REAL* const* inv, int n, const REAL* img, const R
                             gix += go * ((v10 - v00) * (1 - ty) + (v11 - v01) * ty);
                             giy += go * ((v01 - v00) * (1 - tx) + (v11 - v10) * tx);
                         }
+                        gix *= s_->mx; giy *= s_->my;   /* padding-mode transform of the sampling position */
                         /* unnormalise (x (W-1)/2) and normalise (x 2/(W-1)) cancel */
                         REAL dXn = gix * ((REAL)(W - 1) / 2), dYn = giy * ((REAL)(H - 1) / 2);
                         REAL da = dXn * 2 / (REAL)(W - 1), db = dYn * 2 / (REAL)(H - 1); /* d/d(X/Z), d/d(Y/Z) */

@@ -200,8 +200,8 @@ def test_module_autograd_matches_reference():
                                atol=5e-3 * np.abs(out["dphot_dposes"]).max())
     with pytest.raises(AssertionError):
         MultiViewPhotometricLoss(0.85, 1.0, 0.001, True, "mean", "zeros")  # loss.py:105-109
-    with pytest.raises(NotImplementedError):
-        bad = MultiViewPhotometricLoss(0.85, 1.0, 0.001, True, "min", "border")
+    with pytest.raises(NotImplementedError):     # ssim_loss_weight = 0 turns the reference's photometric map into a 3-channel L1 map: no kernel
+        bad = MultiViewPhotometricLoss(0.0, 1.0, 0.001, True, "min", "zeros")
         bad({"depth": [x.detach() for x in inv], "poses": poses.detach()},
             {"image_orig": d["img"], "image_prev_orig": d["prev"], "image_next_orig": d["nxt"], "camera_matrix": d["K"]})
 
@@ -389,19 +389,24 @@ def test_gradient_error_against_fp64_is_what_fp32_costs(name, capsys):
 
 
 @pytest.mark.parametrize("name", ["rand_small", "oob_clamp", "no_mask_odd"])
-@pytest.mark.parametrize("automask,reduce_op", [(False, "min"), (False, "mean")])
-def test_non_default_options_match_reference(name, automask, reduce_op):
-    """automask_loss=False with photometric_reduce_op "min" / "mean" (loss.py:92-109, 131-144, 242-246) through the nn.Module against the
-    reference's own outputs (tests/golden/reproj_options.npz, made by tests/golden/make_golden_options.py)"""
+@pytest.mark.parametrize("automask,reduce_op,padding_mode", [(False, "min", "zeros"), (False, "mean", "zeros"), (True, "min", "border"),
+                                                             (True, "min", "reflection"), (False, "mean", "border")])
+def test_non_default_options_match_reference(name, automask, reduce_op, padding_mode):
+    """automask_loss=False with photometric_reduce_op "min" / "mean" (loss.py:92-109, 131-144, 242-246) and padding_mode "border" /
+    "reflection" of the warp (camera_utils.py:24-55 -> F.grid_sample) through the nn.Module against the reference's own outputs
+    (tests/golden/reproj_options.npz, made by tests/golden/make_golden_options.py)"""
     import os
     from conftest import GOLDEN
     from mgnet_amd.modeling import MultiViewPhotometricLoss
 
+    if name == "oob_clamp" and padding_mode == "reflection":
+        pytest.skip("positions ~1e12 px (points behind the camera) fold chaotically in fp32: the reference's own value is round-off noise there")
     z = np.load(os.path.join(GOLDEN, "reproj_options.npz"))
-    key = lambda k: z[f"{name}.{int(automask)}.{reduce_op}.{k}"]
+    tag = f"{name}.{int(automask)}.{reduce_op}" + ("" if padding_mode == "zeros" else "." + padding_mode)
+    key = lambda k: z[f"{tag}.{k}"]
     c = golden_case_inputs(name)
     d = _dev(c)
-    crit = MultiViewPhotometricLoss(0.85, 1.0, 0.001, automask, reduce_op, "zeros")
+    crit = MultiViewPhotometricLoss(0.85, 1.0, 0.001, automask, reduce_op, padding_mode)
     inv = [x.clone().requires_grad_(True) for x in d["inv"]]
     poses = d["poses"].clone().requires_grad_(True)
     tg = {"image_orig": d["img"], "image_prev_orig": d["prev"], "image_next_orig": d["nxt"], "camera_matrix": d["K"]}
@@ -412,6 +417,6 @@ def test_non_default_options_match_reference(name, automask, reduce_op):
     assert float(out["loss_smoothness"]) == pytest.approx(float(key("loss_smoothness")), rel=2e-5, abs=1e-9)
     out["loss_photometric"].backward()
     for i in range(3):
-        grad_close(inv[i].grad.cpu().numpy(), key(f"dphot_dinv{i}"), f"{name}/{automask}/{reduce_op}/dinv{i}")
+        grad_close(inv[i].grad.cpu().numpy(), key(f"dphot_dinv{i}"), f"{tag}/dinv{i}")
     ref_p = key("dphot_dposes")
     np.testing.assert_allclose(poses.grad.cpu().numpy(), ref_p, rtol=5e-3, atol=5e-3 * np.abs(ref_p).max())
