@@ -45,8 +45,9 @@ const char* mgn_version(void);
  *
  * Configuration supported by the kernels: the reference defaults (mgnet/config.py:109-117: automask_loss=True,
  *   photometric_reduce_op="min", padding_mode="zeros", ssim_loss_weight>0) and automask_loss=False with "min" or "mean".
- *   padding_mode "zeros" (default), "border", "reflection".  ssim_loss_weight = 0 (a 3-channel L1 map in the reference) returns
- *   MGN_ENOTSUP (no silent fallback); automask_loss=True with "mean" is MGN_EINVAL (the reference asserts, loss.py:105-109).
+ *   padding_mode "zeros" (default), "border", "reflection".  ssim_loss_weight = 0 (loss.py:196-197: the photometric maps are the
+ *   3-channel L1 maps): "min" runs over channels and sources and needs a mask, "mean" is the ordinary formula and must not have one --
+ *   the other two combinations are MGN_EINVAL (the reference's boolean indexing raises IndexError); automask_loss=True with "mean" is MGN_EINVAL (the reference asserts, loss.py:105-109).
  *
  * Inputs
  *   inv_depth[n_scales] : [B,1,H,W] fp32 each (all scales already at full resolution, mg_net.py:804-807)

@@ -373,7 +373,7 @@ __device__ __forceinline__ void row_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool GRAD, int FMT = FMT_PLANAR, bool PAD = false>
+template <bool GRAD, int FMT = FMT_PLANAR, bool PAD = false, bool L1MIN = false>
 __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params p) {
     constexpr bool ILV = FMT == FMT_RGBX_F32, U8 = FMT == FMT_RGBX_U8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -465,9 +465,15 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                                 Sxx[j] = hsum3(dot3(a, bq, cc, a, bq, cc));
                                 Sxy[j] = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
                             }
-                            const f32x2 v = ssim_from_sums2<false>(Sx, Sy, Sxx, Syy, Sxy, d0, d1, d2, g0, g1);
-                            pu[0] += ssim_w3 * v.x + l1_w3 * fabsf(rf1[0][c] - y1[c]);
-                            pu[1] += ssim_w3 * v.y + l1_w3 * fabsf(rf1[1][c] - y1[c]);
+                            if constexpr (L1MIN) {   // ssim_loss_weight = 0, reduce "min": the map is the per-pixel minimum of the three L1 channels
+                                const float e0 = fabsf(rf1[0][c] - y1[c]), e1 = fabsf(rf1[1][c] - y1[c]);
+                                pu[0] = (c == 0 || e0 < pu[0]) ? e0 : pu[0];
+                                pu[1] = (c == 0 || e1 < pu[1]) ? e1 : pu[1];
+                            } else {
+                                const f32x2 v = ssim_from_sums2<false>(Sx, Sy, Sxx, Syy, Sxy, d0, d1, d2, g0, g1);
+                                pu[0] += ssim_w3 * v.x + l1_w3 * fabsf(rf1[0][c] - y1[c]);
+                                pu[1] += ssim_w3 * v.y + l1_w3 * fabsf(rf1[1][c] - y1[c]);
+                            }
                         }
                         igx += fabsf(y1[c] - dpp_from_right(y1[c]));
                         igy += fabsf(y1[c] - y0[c]);
@@ -645,6 +651,7 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                 float pw[2] = {0.f, 0.f};
                 float al[2][3], be[2][3], ga[2][3];
                 bool gt[2][3];
+                int cwin[2] = {0, 0};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float Sy = sh[(SH_SY + c) * WAVE], Syy = sh[(SH_SYY + c) * WAVE];
@@ -657,12 +664,20 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                             Sxx[j] = hsum3(dot3(a, bq, cc, a, bq, cc));
                             Sxy[j] = hsum3(dot3(a, bq, cc, y2[c], y1[c], y0[c]));
                         }
-                        const f32x2 v = ssim_from_sums2<GRAD>(Sx, Sy, Sxx, Syy, Sxy, a2, b2, g2, gt[0][c], gt[1][c]);
-                        if (GRAD) {
-                            al[0][c] = a2.x; al[1][c] = a2.y; be[0][c] = b2.x; be[1][c] = b2.y; ga[0][c] = g2.x; ga[1][c] = g2.y;
+                        if constexpr (L1MIN) {   // first minimal channel wins (torch.min over the concatenated channels, loss.py:244)
+                            const float e0 = fabsf(xw1[0][c] - y1[c]), e1 = fabsf(xw1[1][c] - y1[c]);
+                            if (c == 0 || e0 < pw[0]) { pw[0] = e0; cwin[0] = c; }
+                            if (c == 0 || e1 < pw[1]) { pw[1] = e1; cwin[1] = c; }
+                            gt[0][c] = gt[1][c] = false;
+                            al[0][c] = al[1][c] = be[0][c] = be[1][c] = ga[0][c] = ga[1][c] = 0.f;
+                        } else {
+                            const f32x2 v = ssim_from_sums2<GRAD>(Sx, Sy, Sxx, Syy, Sxy, a2, b2, g2, gt[0][c], gt[1][c]);
+                            if (GRAD) {
+                                al[0][c] = a2.x; al[1][c] = a2.y; be[0][c] = b2.x; be[1][c] = b2.y; ga[0][c] = g2.x; ga[1][c] = g2.y;
+                            }
+                            pw[0] += ssim_w3 * v.x + l1_w3 * fabsf(xw1[0][c] - y1[c]);
+                            pw[1] += ssim_w3 * v.y + l1_w3 * fabsf(xw1[1][c] - y1[c]);
                         }
-                        pw[0] += ssim_w3 * v.x + l1_w3 * fabsf(xw1[0][c] - y1[c]);
-                        pw[1] += ssim_w3 * v.y + l1_w3 * fabsf(xw1[1][c] - y1[c]);
                     }
                 }
                 const float pu0 = sh[SH_PU * WAVE], pu1 = sh[(SH_PU + 1) * WAVE];
@@ -700,7 +715,8 @@ __global__ __launch_bounds__(WAVE*(MGN_MAX_SCALES + 1)) void reproj_march(Params
                             cB0[j][c] = k * be[j][c];
                             cC0[j][c] = k * ga[j][c];
                             const float df = xw1[j][c] - y1[c];
-                            l1g0[j][c] = G ? l1_w3 * gshare * (float)((df > 0.f) - (df < 0.f)) : 0.f;
+                            if constexpr (L1MIN) l1g0[j][c] = (G && c == cwin[j]) ? (float)((df > 0.f) - (df < 0.f)) : 0.f;
+                            else l1g0[j][c] = G ? l1_w3 * gshare * (float)((df > 0.f) - (df < 0.f)) : 0.f;
                         }
                     }
                 }
@@ -1134,7 +1150,7 @@ int check_options(const mgn_reproj_cfg* c) {
     if ((c->automask_loss != 0 && c->automask_loss != 1) || (c->photometric_reduce_op != 0 && c->photometric_reduce_op != 1)) return MGN_EINVAL;
     if (c->automask_loss && c->photometric_reduce_op != 0) return MGN_EINVAL;   // loss.py:105-109: automasking goes with "min"
     if (c->frame_layout < 0 || c->frame_layout > MGN_FRAMES_RGBX_U8) return MGN_EINVAL;
-    if (!(c->ssim_loss_weight > 0.f)) return MGN_ENOTSUP;  // ssim_w == 0 makes the reference return a 3-channel L1 map
+    if (!(c->ssim_loss_weight >= 0.f)) return MGN_EINVAL;   // (0: 3-channel L1 maps, see mgn_reproj_loss_fwd)
     return MGN_OK;
 }
 
@@ -1164,6 +1180,9 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
     if (rc != MGN_OK) return rc;
     if (!inv_depth || !img || !prev || !next || !cam || !pose || !losses || !workspace) return MGN_EINVAL;
     if (cam_ld < 3 || cam_stride < 2 * cam_ld + 3) return MGN_EINVAL;
+    // ssim_loss_weight = 0 (loss.py:196-197: 3-channel L1 maps): "min" over channels and sources exists only WITH a reprojection mask,
+    // "mean" only WITHOUT one -- the reference's boolean indexing raises IndexError for the other two combinations (loss.py:236-246)
+    if (cfg->ssim_loss_weight == 0.f && ((cfg->photometric_reduce_op == 0) == (mask == nullptr))) return MGN_EINVAL;
     if (want_grad && (!d_pose || !g_inv)) return MGN_EINVAL;
     if (workspace_bytes < L.total) return MGN_ENOSPC;
     if (cfg->B * 2 > 256) return MGN_EINVAL;
@@ -1191,12 +1210,15 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
                        (CamConst*)(ws + L.off_cam));
     if (cfg->prof_begin) (void)hipEventRecord((hipEvent_t)cfg->prof_begin, stream);
     const dim3 mgrid(L.nblocks), mblock(WAVE * (cfg->n_scales + 1));
-#define MGN_MARCH(G, F, P) hipLaunchKernelGGL((reproj_march<G, F, P>), mgrid, mblock, L.lds_bytes, stream, p)
-#define MGN_MARCH_F(F) do { if (cfg->padding_mode) { if (want_grad) MGN_MARCH(true, F, true); else MGN_MARCH(false, F, true); } \
-                            else { if (want_grad) MGN_MARCH(true, F, false); else MGN_MARCH(false, F, false); } } while (0)
+#define MGN_MARCH(G, F, P, M) hipLaunchKernelGGL((reproj_march<G, F, P, M>), mgrid, mblock, L.lds_bytes, stream, p)
+#define MGN_MARCH_P(F, P) do { if (l1min) { if (want_grad) MGN_MARCH(true, F, P, true); else MGN_MARCH(false, F, P, true); } \
+                               else { if (want_grad) MGN_MARCH(true, F, P, false); else MGN_MARCH(false, F, P, false); } } while (0)
+#define MGN_MARCH_F(F) do { if (cfg->padding_mode) MGN_MARCH_P(F, true); else MGN_MARCH_P(F, false); } while (0)
+    const bool l1min = cfg->ssim_loss_weight == 0.f && cfg->photometric_reduce_op == 0;   // 3-channel L1 maps, minimum over channels and sources
     if (cfg->frame_layout == MGN_FRAMES_RGBX_U8) MGN_MARCH_F(FMT_RGBX_U8);               // img / prev / next are uint8 [B][H][W][4]
     else if (cfg->frame_layout == MGN_FRAMES_CTX_RGBX_F32) MGN_MARCH_F(FMT_RGBX_F32);    // prev / next are fp32 [B][H][W][4] (4th channel unused)
     else MGN_MARCH_F(FMT_PLANAR);
+#undef MGN_MARCH_P
 #undef MGN_MARCH_F
 #undef MGN_MARCH
     if (cfg->prof_end) (void)hipEventRecord((hipEvent_t)cfg->prof_end, stream);

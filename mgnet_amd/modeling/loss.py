@@ -144,6 +144,11 @@ class MultiViewPhotometricLoss(nn.Module):
         mask = targets.get("reprojection_mask", None)
         if mask is not None:
             mask = mask.contiguous()
+        if self.ssim_loss_weight == 0 and ((self.photometric_reduce_op == "min") == (mask is None)):
+            # loss.py:196-197: the maps are then the 3-channel L1 maps; the reference's boolean indexing (loss.py:236-246) only works for
+            # "min" WITH a reprojection mask and for "mean" WITHOUT one, and raises this error for the other two combinations
+            raise IndexError("ssim_loss_weight=0: the shape of the mask does not match the shape of the indexed 3-channel L1 map "
+                             "(photometric_reduce_op 'min' needs a reprojection_mask, 'mean' must not have one)")
         f32 = lambda t: t.float().contiguous()
         # frames may arrive pixel-interleaved ([B,4,H,W] channels_last, 4th channel unused; MGNet.forward produces them straight from
         # the uint8 frames): all three as uint8 RGBX (one 4-byte gather per bilinear corner), or the context frames as fp32 RGBx (16)

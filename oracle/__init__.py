@@ -162,6 +162,8 @@ def reproj_loss(inv, img, prev, nxt, mask, K, poses, ssim_w=0.85, photo_w=1.0, s
                  [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, real, real, ctypes.c_void_p, ctypes.c_void_p]
     rc = f(inv_pp, n, _p(img), _p(prev), _p(nxt), None if m8 is None else _p(m8), _p(K), _p(poses), B, H, W,
            ssim_w, photo_w, smooth_w, _p(losses), mm_pp, int(want_grad), g_photo, g_smooth, dinv_pp, _p(d_poses))
+    if rc == -2:   # ssim_loss_weight == 0: "min" needs a reprojection mask, "mean" must not have one (the reference's own IndexError)
+        raise IndexError("ssim_loss_weight=0: the 3-channel L1 maps cannot be indexed by this mask (loss.py:236-246)")
     if rc != 0:
         raise ValueError(f"orc_reproj_loss: bad arguments (rc={rc})")
     return {"loss_photometric": losses[0], "loss_smoothness": losses[1], "d_inv": d_inv, "d_poses": d_poses,

@@ -372,6 +372,24 @@ void SUF(orc_photometric)(const REAL* est, const REAL* img, int B, int H, int W,
     free(scratch);
 }
 
+/* loss.py:185,196-197 with ssim_loss_weight == 0: the photometric "map" is the 3-channel L1 map itself, and reduce "min" (loss.py:244:
+ * cat along the channels, min over ALL of them) takes the per-pixel minimum over the channels as well as over the sources.  out = min_c,
+ * chan = the first minimal channel (torch.min(dim) returns the first minimal index; sources are concatenated in list order, so a
+ * per-source first-channel minimum followed by the first-source minimum is the same winner) */
+static void l1min_one(const REAL* est, const REAL* img, int H, int W, REAL* out, unsigned char* chan) {
+    long hw = (long)H * W;
+    for (long p = 0; p < hw; ++p) {
+        REAL best = r_abs(est[p] - img[p]);
+        int w = 0;
+        for (int c = 1; c < 3; ++c) {
+            REAL v = r_abs(est[c * hw + p] - img[c * hw + p]);
+            if (v < best) { best = v; w = c; }
+        }
+        out[p] = best;
+        chan[p] = (unsigned char)w;
+    }
+}
+
 /* ---------------------------------------------------------------------------------------
  * loss.py:111-154 MultiViewPhotometricLoss.forward  (+ backward)
  *   automask=True, photometric_reduce_op='min', padding_mode='zeros', n scales, 2 context frames.
@@ -399,8 +417,13 @@ int SUF(orc_reproj_loss)(const REAL* const* inv, int n, const REAL* img, const R
                          REAL ssim_w, REAL photo_w, REAL smooth_w,
                          REAL* losses, REAL* const* minmap_out,
                          int want_grad, REAL g_photo, REAL g_smooth, REAL* const* d_inv, REAL* d_poses) {
-    if (n < 1 || n > 8 || B < 1 || H < 2 || W < 2 || !(ssim_w > 0)) return -1;
+    if (n < 1 || n > 8 || B < 1 || H < 2 || W < 2 || !(ssim_w >= 0)) return -1;
     const int automask = g_automask, reduce_mean = g_reduce_mean;
+    /* ssim_loss_weight == 0 (loss.py:196-197): 3-channel L1 maps.  "min": per-pixel minimum over channels and sources (l1min_one).
+     * "mean": loss[mask] indexes a [B,3,H,W] map with the [B,1,H,W] mask, which torch refuses (IndexError) -- only the mask-less
+     * call exists, and there the mean over the three channels is the ordinary formula with weight 0 */
+    const int l1min = (ssim_w == 0) && !reduce_mean;
+    if (ssim_w == 0 && (reduce_mean ? mask != NULL : mask == NULL)) return -2;   /* (and "min" without a mask: the default mask is built [B,3,H,W], loss.py:236-237, and cannot index the [B,1,H,W] minimum) */
     const long hw = (long)H * W;
     const REAL* ctx[2] = {prev, nxt};
 
@@ -422,6 +445,7 @@ int SUF(orc_reproj_loss)(const REAL* const* inv, int n, const REAL* img, const R
     REAL* scratch = (REAL*)malloc(hw * sizeof(REAL));
     REAL* dwarp = (REAL*)malloc(3 * hw * sizeof(REAL));
     REAL* dmap = (REAL*)malloc(hw * sizeof(REAL));
+    unsigned char* cwin = (unsigned char*)malloc(NSLOT * hw);   /* l1min: winning channel of each of the 4 maps */
     double photo_sum[8] = {0};
     double dR_acc[2][9], dt_acc[2][3];
 
@@ -436,7 +460,8 @@ int SUF(orc_reproj_loss)(const REAL* const* inv, int n, const REAL* img, const R
         for (int j = 0; j < 2; ++j) {
             SUF(orc_pose_vec2mat)(poses + (b * 2 + j) * 6, R[j], t[j]); /* loss.py:117-119 */
             /* automask term: unwarped loss, computed once and reused for every scale (loss.py:139-144) */
-            photometric_one(ctx[j] + b * 3 * hw, imgb, H, W, ssim_w, pm + (2 * j + 1) * hw, scratch);
+            if (l1min) l1min_one(ctx[j] + b * 3 * hw, imgb, H, W, pm + (2 * j + 1) * hw, cwin + (2 * j + 1) * hw);
+            else photometric_one(ctx[j] + b * 3 * hw, imgb, H, W, ssim_w, pm + (2 * j + 1) * hw, scratch);
             memset(dR_acc[j], 0, sizeof dR_acc[j]);
             memset(dt_acc[j], 0, sizeof dt_acc[j]);
         }
@@ -444,7 +469,8 @@ int SUF(orc_reproj_loss)(const REAL* const* inv, int n, const REAL* img, const R
             SUF(orc_inv2depth)(inv[i] + b * hw, depth, hw); /* loss.py:126 */
             for (int j = 0; j < 2; ++j) {
                 view_synthesis_one(ctx[j] + b * 3 * hw, depth, K + b * 9, R[j], t[j], H, W, warped + j * 3 * hw, st + j * hw);
-                photometric_one(warped + j * 3 * hw, imgb, H, W, ssim_w, pm + (2 * j) * hw, scratch);
+                if (l1min) l1min_one(warped + j * 3 * hw, imgb, H, W, pm + (2 * j) * hw, cwin + (2 * j) * hw);
+                else photometric_one(warped + j * 3 * hw, imgb, H, W, ssim_w, pm + (2 * j) * hw, scratch);
             }
             /* loss.py:241-246: cat -> min(dim 1) -> [mask] -> mean.  torch.min(dim) returns the FIRST minimal index */
             double s = 0;
@@ -478,10 +504,14 @@ int SUF(orc_reproj_loss)(const REAL* const* inv, int n, const REAL* img, const R
                     for (long p = 0; p < hw; ++p) {
                         int m = mask ? mask[b * hw + p] != 0 : 1;
                         REAL G = (m && (reduce_mean || (int)dmap[p] == 2 * j)) ? (reduce_mean ? gscale / 2 : gscale) : 0;
+                        if (l1min) {   /* the whole gradient goes to the winning channel of the winning map */
+                            if (cwin[(2 * j) * hw + p] == c) dwarp[c * hw + p] += G * r_sign(wj[c * hw + p] - imgb[c * hw + p]);
+                            continue;
+                        }
                         scratch[p] = G * ssim_w / 3;
                         dwarp[c * hw + p] += G * ((REAL)1 - ssim_w) / 3 * r_sign(wj[c * hw + p] - imgb[c * hw + p]);
                     }
-                    ssim_channel_bwd(wj + c * hw, imgb + c * hw, scratch, H, W, dwarp + c * hw);
+                    if (!l1min) ssim_channel_bwd(wj + c * hw, imgb + c * hw, scratch, H, W, dwarp + c * hw);
                 }
                 /* grid_sample backward wrt the grid (zeros padding, align_corners=True), then
                  * camera.py:170-182 project, pose.py:77-82 transform, camera.py:130-133 reconstruct, depth.py:15 */
@@ -608,7 +638,7 @@ int SUF(orc_reproj_loss)(const REAL* const* inv, int n, const REAL* img, const R
 
     losses[0] = (REAL)(Lp * photo_w);
     losses[1] = (REAL)(Ls * smooth_w);
-    free(depth); free(warped); free(st); free(pm); free(scratch); free(dwarp); free(dmap);
+    free(depth); free(warped); free(st); free(pm); free(scratch); free(dwarp); free(dmap); free(cwin);
     return 0;
 }
 

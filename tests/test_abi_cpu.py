@@ -33,10 +33,10 @@ def test_workspace_query_and_validation():
         kw.update(bad)
         with pytest.raises(RuntimeError):
             _C.reproj_workspace_bytes(_C.make_reproj_cfg(**kw))
-    # unsupported reference options are refused (never a silent fallback): checked before any launch
-    cfg = _C.make_reproj_cfg(1, 8, 8, 3, ssim_w=0.0)      # ssim_loss_weight = 0: a 3-channel L1 map in the reference, no kernel
+    # invalid option combinations are refused before any launch
+    cfg = _C.make_reproj_cfg(1, 8, 8, 3, ssim_w=-0.1)     # not a weight
     rc = _C.lib().mgn_reproj_loss_fwd(ctypes.byref(cfg), *([None] * 6), 16, 4, None, 0, *([None] * 5), 0, None)
-    assert rc == -95
+    assert rc == -22
     cfg = _C.make_reproj_cfg(1, 8, 8, 3, automask=True, reduce_op="mean")   # the reference asserts (loss.py:105-109)
     rc = _C.lib().mgn_reproj_loss_fwd(ctypes.byref(cfg), *([None] * 6), 16, 4, None, 0, *([None] * 5), 0, None)
     assert rc == -22

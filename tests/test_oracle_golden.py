@@ -160,3 +160,33 @@ def test_non_default_options_match_reference(name, automask, reduce_op, padding_
     np.testing.assert_allclose(r["d_poses"], ref_p, rtol=5e-3, atol=5e-3 * np.abs(ref_p).max() + 1e-9)
     with pytest.raises(ValueError):
         oracle.reproj_loss(c["inv"], c["img"], c["prev"], c["nxt"], c["mask"], c["K"], c["poses"], automask=True, reduce_op="mean")
+
+
+SSIM0_COMBOS = ((True, "min", "zeros"), (False, "min", "zeros"), (False, "mean", "zeros"), (True, "min", "border"))
+
+
+@pytest.mark.parametrize("name", ["rand_small", "oob_clamp", "no_mask_odd"])
+@pytest.mark.parametrize("automask,reduce_op,padding_mode", SSIM0_COMBOS)
+def test_ssim_weight_zero_matches_reference(name, automask, reduce_op, padding_mode):
+    """ssim_loss_weight = 0 (loss.py:185,196-197): the photometric maps are the 3-channel L1 maps; "min" runs over channels and sources
+    and needs a reprojection mask, "mean" only exists without one -- the other two combinations raise IndexError in the reference
+    (`<tag>.raises` in the fixture) and here."""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "reproj_options.npz"))
+    tag = f"{name}.{int(automask)}.{reduce_op}" + ("" if padding_mode == "zeros" else "." + padding_mode) + ".ssim0"
+    c = golden_case_inputs(name)
+    call = lambda: oracle.reproj_loss(c["inv"], c["img"], c["prev"], c["nxt"], c["mask"], c["K"], c["poses"], ssim_w=0.0, g_photo=1.0,
+                                      g_smooth=0.0, automask=automask, reduce_op=reduce_op, padding_mode=padding_mode)
+    if f"{tag}.raises" in z.files:
+        with pytest.raises(IndexError):
+            call()
+        return
+    r = call()
+    key = lambda k: z[f"{tag}.{k}"]
+    assert float(r["loss_photometric"]) == pytest.approx(float(key("loss_photometric")), rel=2e-5)
+    assert float(r["loss_smoothness"]) == pytest.approx(float(key("loss_smoothness")), rel=2e-5)
+    for i in range(3):
+        _grad_close(r["d_inv"][i], key(f"dphot_dinv{i}"), name=f"{tag}/dphot_dinv{i}")
+    ref_p = key("dphot_dposes")
+    np.testing.assert_allclose(r["d_poses"], ref_p, rtol=5e-3, atol=5e-3 * np.abs(ref_p).max() + 1e-9)

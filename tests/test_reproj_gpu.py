@@ -200,7 +200,7 @@ def test_module_autograd_matches_reference():
                                atol=5e-3 * np.abs(out["dphot_dposes"]).max())
     with pytest.raises(AssertionError):
         MultiViewPhotometricLoss(0.85, 1.0, 0.001, True, "mean", "zeros")  # loss.py:105-109
-    with pytest.raises(NotImplementedError):     # ssim_loss_weight = 0 turns the reference's photometric map into a 3-channel L1 map: no kernel
+    with pytest.raises(IndexError):     # ssim_loss_weight = 0 with "min" and no reprojection mask: the reference's boolean indexing refuses it
         bad = MultiViewPhotometricLoss(0.0, 1.0, 0.001, True, "min", "zeros")
         bad({"depth": [x.detach() for x in inv], "poses": poses.detach()},
             {"image_orig": d["img"], "image_prev_orig": d["prev"], "image_next_orig": d["nxt"], "camera_matrix": d["K"]})
@@ -412,6 +412,42 @@ def test_non_default_options_match_reference(name, automask, reduce_op, padding_
     tg = {"image_orig": d["img"], "image_prev_orig": d["prev"], "image_next_orig": d["nxt"], "camera_matrix": d["K"]}
     if d["mask"] is not None:
         tg["reprojection_mask"] = d["mask"]
+    out = crit({"depth": inv, "poses": poses}, tg)
+    assert float(out["loss_photometric"]) == pytest.approx(float(key("loss_photometric")), rel=2e-5, abs=1e-6)
+    assert float(out["loss_smoothness"]) == pytest.approx(float(key("loss_smoothness")), rel=2e-5, abs=1e-9)
+    out["loss_photometric"].backward()
+    for i in range(3):
+        grad_close(inv[i].grad.cpu().numpy(), key(f"dphot_dinv{i}"), f"{tag}/dinv{i}")
+    ref_p = key("dphot_dposes")
+    np.testing.assert_allclose(poses.grad.cpu().numpy(), ref_p, rtol=5e-3, atol=5e-3 * np.abs(ref_p).max())
+
+
+@pytest.mark.parametrize("name", ["rand_small", "oob_clamp", "no_mask_odd"])
+@pytest.mark.parametrize("automask,reduce_op,padding_mode", [(True, "min", "zeros"), (False, "min", "zeros"), (False, "mean", "zeros"), (True, "min", "border")])
+def test_ssim_weight_zero_matches_reference(name, automask, reduce_op, padding_mode):
+    """ssim_loss_weight = 0 (loss.py:185,196-197): the photometric maps are the 3-channel L1 maps, "min" runs over channels and sources
+    (kernel variant reproj_march<.., L1MIN>), "mean" is the ordinary formula with weight 0; the two mask combinations the reference's
+    boolean indexing refuses (IndexError, `<tag>.raises` in the fixture) raise here as well."""
+    import os
+    from conftest import GOLDEN
+    from mgnet_amd import _C
+    from mgnet_amd.modeling import MultiViewPhotometricLoss
+
+    z = np.load(os.path.join(GOLDEN, "reproj_options.npz"))
+    tag = f"{name}.{int(automask)}.{reduce_op}" + ("" if padding_mode == "zeros" else "." + padding_mode) + ".ssim0"
+    c = golden_case_inputs(name)
+    d = _dev(c)
+    crit = MultiViewPhotometricLoss(0.0, 1.0, 0.001, automask, reduce_op, padding_mode)
+    inv = [x.clone().requires_grad_(True) for x in d["inv"]]
+    poses = d["poses"].clone().requires_grad_(True)
+    tg = {"image_orig": d["img"], "image_prev_orig": d["prev"], "image_next_orig": d["nxt"], "camera_matrix": d["K"]}
+    if d["mask"] is not None:
+        tg["reprojection_mask"] = d["mask"]
+    if f"{tag}.raises" in z.files:
+        with pytest.raises(IndexError):
+            crit({"depth": inv, "poses": poses}, tg)
+        return
+    key = lambda k: z[f"{tag}.{k}"]
     out = crit({"depth": inv, "poses": poses}, tg)
     assert float(out["loss_photometric"]) == pytest.approx(float(key("loss_photometric")), rel=2e-5, abs=1e-6)
     assert float(out["loss_smoothness"]) == pytest.approx(float(key("loss_smoothness")), rel=2e-5, abs=1e-9)
