@@ -40,30 +40,53 @@ class PeerExchange:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         if self.world > lib_const("MGN_P2P_MAX_WORLD"):
             raise RuntimeError(f"world size {self.world} > {lib_const('MGN_P2P_MAX_WORLD')}")
-        own = ctypes.c_void_p()
-        _C.check(lib.mgn_p2p_alloc(ctypes.byref(own)), "mgn_p2p_alloc")
-        self._own = own.value
-        handle = (ctypes.c_ubyte * 64)()
-        _C.check(lib.mgn_p2p_export(self._own, handle), "mgn_p2p_export")
-        mine = (socket.gethostname(), int(torch.cuda.current_device()), bytes(handle))
+        # Set-up is COLLECTIVE and every rank takes the same decision at every step: a rank whose runtime refuses the mailbox still
+        # takes part in the gather and in the agreement below (a rank that left early would leave its peers inside a collective)
+        self._own, self._peers, handle, err = None, [], None, None
+        try:
+            own = ctypes.c_void_p()
+            _C.check(lib.mgn_p2p_alloc(ctypes.byref(own)), "mgn_p2p_alloc")
+            self._own = own.value
+            handle = (ctypes.c_ubyte * 64)()
+            _C.check(lib.mgn_p2p_export(self._own, handle), "mgn_p2p_export")
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        mine = (socket.gethostname(), int(torch.cuda.current_device()), None if err else bytes(handle), err)
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=group)
-        if len({h for h, _, _ in everyone}) != 1:
-            raise RuntimeError("ranks on different hosts: the mailbox exchange is intra-node (xGMI)")
-        self._peers = []
-        for r, (_, _, hb) in enumerate(everyone):
-            if r == self.rank:
-                self._peers.append(self._own)
-                continue
-            p = ctypes.c_void_p()
-            buf = (ctypes.c_ubyte * 64).from_buffer_copy(hb)
-            _C.check(lib.mgn_p2p_open(buf, ctypes.byref(p)), "mgn_p2p_open")
-            self._peers.append(p.value)
+        refused = [f"rank {r}: {e[3]}" for r, e in enumerate(everyone) if e[2] is None]
+        if refused or len({e[0] for e in everyone}) != 1:
+            self._release()
+            raise RuntimeError("; ".join(refused) if refused else "ranks on different hosts: the mailbox exchange is intra-node (xGMI)")
+        try:
+            for r, e in enumerate(everyone):
+                if r == self.rank:
+                    self._peers.append(self._own)
+                    continue
+                p = ctypes.c_void_p()
+                buf = (ctypes.c_ubyte * 64).from_buffer_copy(e[2])
+                _C.check(lib.mgn_p2p_open(buf, ctypes.byref(p)), "mgn_p2p_open")
+                self._peers.append(p.value)
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        mapped = torch.tensor([0.0 if err else 1.0], device=device)
+        dist.all_reduce(mapped, op=dist.ReduceOp.MIN, group=group)   # (also the barrier: every mailbox is mapped everywhere before anyone posts)
+        if mapped.item() != 1.0:
+            self._release()
+            raise RuntimeError(err or "a peer could not map the mailboxes")
         self._arr = (ctypes.c_void_p * self.world)(*self._peers)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self._chan, self._seq = {}, {}
         self.exchanges = 0
-        dist.barrier(group=group)    # every mailbox is mapped everywhere before anyone posts
+
+    def _release(self):
+        lib = _C.lib()
+        for r, p in enumerate(self._peers):
+            if r != self.rank and p:
+                lib.mgn_p2p_close(p)
+        if self._own:
+            lib.mgn_p2p_free(self._own)
+        self._peers, self._own = [], None
 
     def _channel(self):
         sid = torch.cuda.current_stream(self.device).cuda_stream
@@ -103,13 +126,8 @@ class PeerExchange:
         return bad
 
     def close(self):
-        lib = _C.lib()
         torch.cuda.synchronize(self.device)
-        for r, p in enumerate(self._peers):
-            if r != self.rank and p:
-                lib.mgn_p2p_close(p)
-        lib.mgn_p2p_free(self._own)
-        self._peers, self._own = [], None
+        self._release()
 
 
 _CONST = {"MGN_P2P_MAX_WORLD": 8, "MGN_P2P_CHANNELS": 4, "MGN_P2P_SLOT_FLOATS": 3072}   # include/mgnet_hip.h

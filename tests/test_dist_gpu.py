@@ -157,6 +157,45 @@ def test_p2p_mailbox_exchange_matches_collectives(capsys):
         print(f"\n[p2p exchange] 2 processes on one GPU: {out[0][1]} / {out[1][1]} us per all_gather of 3 x 256 floats ({out[0][2]})", end="")
 
 
+def _p2p_refusal(rank, world):
+    """one rank's runtime refuses the mailbox (alloc, then IPC open): set-up is collective, so BOTH ranks must come back with None
+    (torch.distributed stays in place) -- a rank that left the set-up early would leave its peer inside a collective"""
+    from mgnet_amd import _C
+    from mgnet_amd.engine import peer
+
+    real = _C.lib()
+    out = []
+    for entry in ("mgn_p2p_alloc", "mgn_p2p_open"):
+        class Proxy:
+            def __getattr__(self, name, entry=entry):
+                if name == entry and rank == 1:
+                    return lambda *a: -95
+                return getattr(real, name)
+        peer._C.lib = lambda: Proxy()
+        try:
+            ex = peer.enable()
+        finally:
+            peer._C.lib = lambda: real
+        out.append((ex is None, peer.report()["mode"], peer.report()["why"]))
+        if ex is not None:
+            peer.disable()
+    # ... and the exchange still comes up afterwards when nothing refuses
+    ex = peer.enable()
+    out.append(("p2p" in peer.report()["mode"]) if ex is not None else "unavailable")
+    if ex is not None:
+        peer.disable()
+    return out
+
+
+def test_p2p_setup_refused_on_one_rank_falls_back_on_both():
+    out = _spawn(_p2p_refusal)
+    for r in (0, 1):
+        (none_a, mode_a, why_a), (none_o, mode_o, why_o), after = out[r]
+        assert none_a and mode_a == "torch.distributed" and "mgn_p2p_alloc" in why_a, out
+        assert none_o and mode_o == "torch.distributed" and ("mgn_p2p_open" in why_o or "could not map" in why_o), out
+    assert out[0][2] == out[1][2], out
+
+
 def _train_modes(rank, world):
     """the same three training steps with the statistics exchanged by the mailbox kernels and by torch.distributed: identical parameters
     (both combine the rows in rank order), and the mailbox path was really taken"""
