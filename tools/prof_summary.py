@@ -10,9 +10,9 @@ def main(db, out=None):
         "select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels "
         "group by name order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows) or 1
-    lines = [f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}"]
+    lines = [f"{'kernel':110s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}"]
     for n, k, s, a, mn, mx in rows:
-        lines.append(f"{n[:70]:70s} {k:6d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
+        lines.append(f"{n[:110]:110s} {k:6d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
     # GPU idle time between consecutive kernels over the last 60 % of the trace (steady state: no model set-up)
     ks = c.execute("select start, end from kernels order by start").fetchall()
     if len(ks) > 100:
