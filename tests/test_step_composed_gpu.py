@@ -259,4 +259,4 @@ def test_composed_step_is_as_close_to_the_rounding_matched_reference_as_its_fp32
         # the product's losses are as close to the reference's as the control's are (3x its distance + a floor of 1e-3 relative)
         assert abs(hip_losses[k] - v) <= 3 * abs(twin_losses[k] - v) + 1e-3 * abs(v) + 1e-5, (k, hip_losses[k], v, twin_losses[k])
     _check_vs_torch_bf16(rows, rows_twin, f"composed {str(dtype)[6:]} {H}x{W} ", worse_frac=0.5 if H * W < 100000 else 0.05,
-                         names=("HIP", "fp32 twin", "the fp64 rounding-matched reference"))
+                         labels=("HIP", "fp32 twin", "the fp64 rounding-matched reference"))
