@@ -1224,6 +1224,9 @@ __device__ __forceinline__ h16x8 tr_frag(const unsigned char* p) {  // 8 k-value
 // NG = number of 4-wave groups: the strip is 64*NG pixels wide, group q owns pixels [64q, 64q+64) of every row and the
 // groups' accumulators are summed through LDS at the end (half the split partials for NG = 2).
 // Rows are prefetched W3_D = 2 steps ahead (ring of 5 In rows and 3 dOut rows) with a counted s_waitcnt.
+#ifndef W3_PD
+#define W3_PD 4   // fragment prefetch distance of conv_wgrad3x3, in MFMAs
+#endif
 template <int NG>
 struct W3 {
     static constexpr int SW = 64 * NG, INROW = (SW + 8) * 128, OUTROW = SW * 128;
@@ -1290,6 +1293,42 @@ __device__ __forceinline__ void wgrad3x3_body(const Wgrad3Params& p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lds_ptr)(base + (j - C::PIN) * 1024), 16, ok ? voff[i] : OOB, soff, 0, 0);
         }
     };
+    // NG = 2 (two waves per SIMD): inside the row loop the waves of a SIMD ALTERNATE between loading and computing.  A 1-KB LDS-DMA piece
+    // occupies the CU's vector-memory path for ~34 cycles and the issuing wave with it; with every wave issuing its share behind the
+    // barrier (33 pieces per row step) the matrix pipes idled ~1100 of ~3500 cycles per row (measured: the same loop without its DMA
+    // runs at 92 % of the MFMA rate, profiles/r04_wgrad3x3_roles.txt).  Now the 4 waves of group (r - r0) & 1 -- one per SIMD -- issue the
+    // WHOLE row step (pieces (wave & 3) + 4 i) while their SIMD partners start the step's 36 MFMAs at once, then compute themselves while
+    // the partners wait at the next barrier; the roles swap every row.
+    constexpr int LMAX = NG == 2 ? (C::PIN + C::POUT + 3) / 4 : 1;
+    int voffL[LMAX];
+    if (NG == 2) {
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) {
+            const int j = (wave & 3) + 4 * i;
+            const int px = 8 * (j < C::PIN ? j : j - C::PIN) + (lane >> 3);
+            const int seg = (lane & 7) ^ (((px >> 1) & 1) << 2);
+            if (j < C::PIN) {
+                const int iw = ow0 - 1 + px;
+                voffL[i] = (iw >= 0 && iw < p.W) ? (iw * p.Cin + ci0 + seg * 8) * 2 : OOB;
+            } else {
+                const int ow = ow0 + px;
+                voffL[i] = (j < C::PIN + C::POUT && ow < p.W) ? (ow * p.Cout + co0 + seg * 8) * 2 : OOB;
+            }
+        }
+    }
+    auto issue_step_loader = [&](int ih, int islot, int oh, int oslot) {
+        const bool oki = ih >= 0 && ih < p.H, oko = oh < p.H;
+        const int soffi = oki ? ((n * p.H + ih) * p.W) * p.Cin * 2 : 0, soffo = oko ? ((n * p.H + oh) * p.W) * p.Cout * 2 : 0;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) {
+            const int j = (wave & 3) + 4 * i;
+            if (j < C::PIN)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(w3sm + islot * C::INROW + j * 1024), 16, oki ? voffL[i] : OOB, soffi, 0, 0);
+            else if (j < C::PIN + C::POUT)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lds_ptr)(w3sm + C::NIN * C::INROW + oslot * C::OUTROW + (j - C::PIN) * 1024), 16,
+                                                         oko ? voffL[i] : OOB, soffo, 0, 0);
+        }
+    };
     // pieces this wave issues per row step (for the counted wait)
     const int my_cnt = (C::PIN + C::POUT - wave + C::NW - 1) / C::NW;
 
@@ -1320,36 +1359,61 @@ __device__ __forceinline__ void wgrad3x3_body(const Wgrad3Params& p) {
     }
     int si = 0, so = 0;  // slots of In row r-1 and dOut row r
     for (int r = r0; r < r1; ++r) {
-        if (r + 1 < r1) {  // the step group of row r+1 may stay in flight
-            if (my_cnt == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else if (my_cnt == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool pf = r + 2 < r1;   // the rows two steps ahead are loaded during this step
+        const int pf_is = si + 4 >= 5 ? si - 1 : si + 4, pf_os = so + 2 >= 3 ? so - 1 : so + 2;
+        const bool loader = NG == 2 && grp == ((r - r0) & 1);
+        if (NG == 1 || r == r0) {
+            // every wave issued the prologue / (NG = 1) issues its share of every step: the step group of row r+1 may stay in flight
+            if (r + 1 < r1) {
+                if (my_cnt == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else if (my_cnt == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else if (loader || r == r0 + 1) {
+            // the rows of step r were issued at step r-2 by THIS group (nothing since), or in the prologue by everyone; the other group's
+            // step-(r-1) pieces (<= 9 per wave, at least 8) are the only ones that may stay in flight
+            if (!loader && r0 + 2 < r1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (r + 2 < r1) {
-            issue_in(r + 3, si + 4 >= 5 ? si - 1 : si + 4);
-            issue_out(r + 2, so + 2 >= 3 ? so - 1 : so + 2);
+        if (NG == 1) {
+            if (pf) {
+                issue_in(r + 3, pf_is);
+                issue_out(r + 2, pf_os);
+            }
+        } else if (loader && pf) {
+            issue_step_loader(r + 3, pf_is, r + 2, pf_os);
         }
         const int s1 = si + 1 >= 5 ? si - 4 : si + 1, s2 = si + 2 >= 5 ? si - 3 : si + 2;
         const unsigned char* sa = w3sm + aA + so * C::OUTROW;
-        const unsigned char* sb0 = w3sm + si * C::INROW;
-        const unsigned char* sb1 = w3sm + s1 * C::INROW;
-        const unsigned char* sb2 = w3sm + s2 * C::INROW;
+        const unsigned char* sb[3] = {w3sm + si * C::INROW, w3sm + s1 * C::INROW, w3sm + s2 * C::INROW};
+        // The 36 MFMAs of a row step (4 k-slabs of 16 pixels x 9 taps) as ONE software-pipelined stream: the In fragment of
+        // MFMA m is read W3_PD MFMAs ahead into a register ring, the dOut fragment of a slab W3_PD MFMAs before the slab's
+        // first MFMA -- left to itself the scheduler issues each tap's transposing reads right behind the previous tap's MFMA
+        // and waits out the LDS latency in front of 18 of the 36 MFMAs.  sched_barrier pins the order; the s_waitcnt lgkmcnt
+        // values are the compiler's (LDS reads return in order).
+        constexpr int PD = W3_PD, NB = W3_PD + 1;
+        h16x8 fa[2], fb[NB];
+        auto rd_b = [&](int m) {   // m = 9 * ks + 3 * kh + kw
+            const int ks = m / 9, kh = (m % 9) / 3, kw = m % 3;
+            fb[m % NB] = tr_frag(sb[kh] + aB[kw] + ks * 2048);
+        };
+        fa[0] = tr_frag(sa);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const h16x8 a = tr_frag(sa + ks * 2048);
+        for (int m = 0; m < PD; ++m) rd_b(m);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const h16x8 b0 = tr_frag(sb0 + aB[kw] + ks * 2048);
-                const h16x8 b1 = tr_frag(sb1 + aB[kw] + ks * 2048);
-                const h16x8 b2 = tr_frag(sb2 + aB[kw] + ks * 2048);
-                acc[0 + kw] = MGN_MFMA_32x32x16(a, b0, acc[0 + kw]);
-                acc[3 + kw] = MGN_MFMA_32x32x16(a, b1, acc[3 + kw]);
-                acc[6 + kw] = MGN_MFMA_32x32x16(a, b2, acc[6 + kw]);
+        for (int m = 0; m < 36; ++m) {
+            if (m + PD < 36) {
+                if ((m + PD) % 9 == 0) fa[((m + PD) / 9) & 1] = tr_frag(sa + ((m + PD) / 9) * 2048);
+                rd_b(m + PD);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[m % 9] = MGN_MFMA_32x32x16(fa[(m / 9) & 1], fb[m % NB], acc[m % 9]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         si = s1;
         so = so + 1 >= 3 ? 0 : so + 1;
