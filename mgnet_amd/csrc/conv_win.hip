@@ -59,15 +59,33 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {   // block b -> XCD b %
     return k * q + (k < r ? k : r) + j;
 }
 
-// PH = 16: patch 16 x 32 (4 rows per wave); PH = 8: patch 8 x 32 (2 rows per wave) for layers with few pixels
-template <int PH>
+// PH = 16: patch 16 x 32 (4 rows per wave); PH = 8: patch 8 x 32 (2 rows per wave) for layers with few pixels -- 8 waves each (NWM = 4
+// pixel-row groups x 2 channel halves), one block per CU.
+// NWM = 2 (round 4, `conv3x3_win8f`): the 8 x 32 patch with FOUR waves of 4 rows x 32 px x 64 co (the 16-row kernel's wave tile) in
+// 80 KB of LDS, so that TWO independent blocks share a CU, one wave of each per SIMD: what a lone 8-wave block spends outside its
+// k loop (~10 of ~62 us: first window + weight stages, epilogue, block turn-around) runs beside the other
+// block's MFMAs, and a wave stuck issuing LDS-DMA pieces leaves the matrix pipe to its neighbour.  Per k-step a wave issues
+// [window piece | dummy][two weight pieces]; one barrier per k-step (the two waves of a SIMD are not in the same block, so they do
+// not sit in the same bubble), weight ring of 4 stages issued 3 steps ahead.
+template <int PH, int NWM>
 __device__ __forceinline__ void conv_win_body(const WinParams& p) {
-    constexpr int RPW = PH / 4;               // pixel rows (= MFMA tiles) per wave
+    constexpr int NW = 2 * NWM;               // waves
+    constexpr int RPW = PH / NWM;             // pixel rows (= MFMA tiles) per wave
     constexpr int WPX = (PH + 2) * WW;        // real window pixels
-    constexpr int NWP = (WPX + 127) / 128;    // window pieces per wave and chunk (5 for PH = 16, 3 for PH = 8)
+    constexpr int NWP = (WPX + 16 * NW - 1) / (16 * NW);   // window pieces per wave and chunk (5 for PH = 16, 3 for PH = 8; 6 for 4 waves)
+    constexpr int WINB = NWM == 4 ? WIN_BYTES : NWP * NW * 1024;          // one window buffer
+    constexpr int NST = NWM == 4 ? NWST : 4, PDW = NWM == 4 ? PD : 3;     // weight stages, prefetch distance in k-steps
+    constexpr int WPS = 8 / NW;               // weight pieces per wave and k-step
+    constexpr int LPS = 1 + WPS;              // LDS-DMA loads per wave and k-step (window piece or dummy + weight pieces or dummies)
+    constexpr int BAR2 = NWM == 4 ? 1 : 0;    // barrier every second k-step (8 waves) / every k-step (4 waves)
+    constexpr int WAITN = BAR2 ? LPS * (PDW - 3) : LPS * (PDW - 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
     unsigned char* const winb = wsm;
-    unsigned char* const wst = wsm + 2 * WIN_BYTES;
+    unsigned char* const wst = wsm + 2 * WINB;
+    // dummy loads write a KB of zeros: into the scratch KB behind the stages (8 waves), or (4 waves: 80 KB exactly) over the last piece of
+    // window buffer 0, whose 16 pixels lie past the real window and only ever receive the zeros of out-of-range lanes anyway
+    unsigned char* const dummy_kb = NWM == 4 ? wsm + WIN_LDS - 1024 : winb + (NWP * NW - 1) * 1024;
+    static_assert(NWM == 4 || NWP * NW * 16 - 16 >= WPX, "the dummy target must lie past the real window pixels");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
     const int hi = lane >> 5, l31 = lane & 31;
     const int patch = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x, bn = blockIdx.y;
@@ -85,25 +103,29 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
     int wvoff[NWP];
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
-        const int pp = (wave + 8 * i) * 16 + (lane >> 2);
+        const int pp = (wave + NW * i) * 16 + (lane >> 2);
         const int sseg = (lane & 3) ^ ((pp >> 2) & 3);    // source segment that lands in slot lane & 3
         const int wy = pp / WW, wx = pp - wy * WW;
         const int iy = y0 - 1 + wy, ix = x0 - 1 + wx;
         const bool ok = pp < WPX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         wvoff[i] = ok ? (((n * p.H + iy) * p.W + ix) * p.Cin + sseg * 8) * 2 : OOB;
     }
-    int wbase;
-    {
-        const int row = wave * 16 + (lane >> 2);
+    int wbase[WPS];
+#pragma unroll
+    for (int k = 0; k < WPS; ++k) {
+        const int row = (wave * WPS + k) * 16 + (lane >> 2);
         const int sseg = (lane & 3) ^ ((row >> 2) & 3);
-        wbase = ((bn * 128 + row) * 9 * p.Cin + sseg * 8) * 2;
+        wbase[k] = ((bn * 128 + row) * 9 * p.Cin + sseg * 8) * 2;
     }
-    const int nch = p.Cin / 32, ksteps = nch * 9;
+    const int nch = p.Cin / 32;
     auto issue_w = [&](int c, int t, int stage) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(wst + stage * WST_BYTES + wave * 1024), 16, wbase, (t * p.Cin + c * 32) * 2, 0, 0);
+#pragma unroll
+        for (int k = 0; k < WPS; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(wst + stage * WST_BYTES + (wave * WPS + k) * 1024), 16, wbase[k],
+                                                     (t * p.Cin + c * 32) * 2, 0, 0);
     };
     auto issue_win = [&](int c, int i, int buf) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(winb + buf * WIN_BYTES + (wave + 8 * i) * 1024), 16, wvoff[i], c * 64, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(winb + buf * WINB + (wave + NW * i) * 1024), 16, wvoff[i], c * 64, 0, 0);
     };
 
     // fragment byte offsets (kk = 0; kk = 1 flips bit 5): A from the window at (row 4*wm*RPW/4.. + dy, column l31 + kw)
@@ -139,16 +161,21 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
     // run -- W(s + 2).  Ring hazards: step s writes the stage of step s + PD - NWST = s - 2 and, at taps 0 .. NWP-1, the window
     // buffer last read in the previous chunk; a barrier separates both from their last readers (tap 0 always has one).
     auto issue_dummy = [&]() {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(wsm + WIN_LDS - 1024), 16, OOB, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)dummy_kb, 16, OOB, 0, 0, 0);
+    };
+    auto issue_w_dummy = [&]() {
+#pragma unroll
+        for (int k = 0; k < WPS; ++k) issue_dummy();
     };
 #pragma unroll
     for (int i = 0; i < NWP; ++i) issue_win(0, i, 0);
 #pragma unroll
-    for (int k = 0; k < PD; ++k) {   // what steps -PD .. -1 would have issued (ksteps >= 9 > PD)
+    for (int k = 0; k < PDW; ++k) {   // what steps -PDW .. -1 would have issued (ksteps >= 9 > PDW)
         issue_dummy();
         issue_w(0, k, k);
     }
-    wait_vmcnt<2 * (PD - 3)>();
+    // (8 waves: W(0..2) landed, 2 (PD - 3) younger loads; 4 waves: W(0), W(1) landed -- the first step prefetches W(1) -- LPS younger)
+    wait_vmcnt<WAITN>();
     __builtin_amdgcn_s_barrier();
 
     auto load_frags = [&](const unsigned char* win, const unsigned char* ws, int kh, int kw, int kk, h16x8 (&a)[RPW], h16x8 (&b)[2]) {
@@ -169,26 +196,26 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
     int stage = 0;   // stage of k-step s = s % NWST
     auto chunk = [&](int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        const unsigned char* win = winb + (c & 1) * WIN_BYTES;
-        const unsigned char* win_next = winb + ((c + 1) & 1) * WIN_BYTES;
+        const unsigned char* win = winb + (c & 1) * WINB;
+        const unsigned char* win_next = winb + ((c + 1) & 1) * WINB;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            if (t % 2 == 0) {   // one barrier per TWO k-steps (taps 0|1, 2|3, 4|5, 6|7, 8): see the pipeline comment
-                wait_vmcnt<2 * (PD - 3)>();
+            if (!BAR2 || t % 2 == 0) {   // 8 waves: one barrier per TWO k-steps (taps 0|1, 2|3, 4|5, 6|7, 8): see the pipeline comment
+                wait_vmcnt<WAITN>();
                 __builtin_amdgcn_s_barrier();
             }
             if (!LAST && t < NWP) issue_win(c + 1, t, (c + 1) & 1);
             else issue_dummy();
-            if (!LAST || t + PD <= 8) {
-                const int tn = t + PD >= 9 ? t + PD - 9 : t + PD, cn = t + PD >= 9 ? c + 1 : c;
-                if (LAST || cn < nch) issue_w(cn, tn, (stage + PD) & (NWST - 1));
-                else issue_dummy();
+            if (!LAST || t + PDW <= 8) {
+                const int tn = t + PDW >= 9 ? t + PDW - 9 : t + PDW, cn = t + PDW >= 9 ? c + 1 : c;
+                if (LAST || cn < nch) issue_w(cn, tn, (stage + PDW) & (NST - 1));
+                else issue_w_dummy();
             } else {
-                issue_dummy();
+                issue_w_dummy();
             }
             const int kh = t / 3, kw = t - kh * 3;
             const unsigned char* ws = wst + stage * WST_BYTES;
-            const unsigned char* ws_next = wst + ((stage + 1) & (NWST - 1)) * WST_BYTES;
+            const unsigned char* ws_next = wst + ((stage + 1) & (NST - 1)) * WST_BYTES;
             // (sched_barrier: keep the two fragment sets in separate registers and each batch of LDS reads a full batch of MFMAs
             //  ahead of its use -- left alone, the scheduler re-serialises read -> wait -> MFMA to save registers)
             load_frags(win, ws, kh, kw, 1, a1, b1);
@@ -200,7 +227,7 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
             __builtin_amdgcn_sched_barrier(0);
             mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            stage = (stage + 1) & (NWST - 1);
+            stage = (stage + 1) & (NST - 1);
         }
     };
     for (int c = 0; c + 1 < nch; ++c) chunk(c, std::false_type{});
@@ -303,14 +330,16 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
         if (tid < 256) {
             float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t += red[k * 256 + tid];
+            for (int k = 0; k < 2 * NWM; ++k) t += red[k * 256 + tid];
             p.stat_part[((size_t)patch * p.Cout + bn * 128) * 2 + tid] = t;
         }
     }
 }
 
-__global__ __launch_bounds__(512, 1) void conv3x3_win16(WinParams p) { conv_win_body<16>(p); }
-__global__ __launch_bounds__(512, 1) void conv3x3_win8(WinParams p) { conv_win_body<8>(p); }
+constexpr int WIN8F_LDS = 2 * 24 * 1024 + 4 * WST_BYTES;   // 80 KB: two blocks per CU
+__global__ __launch_bounds__(512, 1) void conv3x3_win16(WinParams p) { conv_win_body<16, 4>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_win8(WinParams p) { conv_win_body<8, 4>(p); }
+__global__ __launch_bounds__(256, 2) void conv3x3_win8f(WinParams p) { conv_win_body<8, 2>(p); }
 
 }  // namespace
 
@@ -328,6 +357,7 @@ int mgn_conv_win_patch_rows(int N, int OH, int OW, int Cin, int Cout) {
         return pr == 8 || pr == 16 ? pr : 0;
     }
     const long pc = (long)N * ((OW + 31) / 32) * (Cout / 128);
+    if (pc * ((OH + 7) / 8) >= 1024) return 8;   // enough 8-row patches for two rounds of the two-blocks-per-CU kernel (conv3x3_win8f)
     return pc * ((OH + 15) / 16) >= 200 ? 16 : (pc * ((OH + 7) / 8) >= 64 ? 8 : 0);
 }
 #endif
@@ -351,10 +381,16 @@ int MGN_SYM(mgn_conv3x3_win)(const void* in, const void* w, void* out, int N, in
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_win16), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_win8), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_win8f), hipFuncAttributeMaxDynamicSharedMemorySize, WIN8F_LDS);
         attr = true;
     }
     const dim3 grid((unsigned)npatch, (unsigned)(Cout / 128));
+    // 8-row patches: the 4-wave kernel (two blocks per CU) from 1024 blocks on, the 8-wave kernel for the low-resolution layers whose
+    // few blocks do not fill the chip twice (measured, profiles/r04_conv_win8f.txt); MGN_CONV_WIN8F = 0 | 1 forces one (tests, A/B)
+    const char* e8 = getenv("MGN_CONV_WIN8F");
+    const int fat8 = e8 ? atoi(e8) : (npatch * (Cout / 128) >= 1024);
     if (patch_rows == 16) hipLaunchKernelGGL(conv3x3_win16, grid, dim3(512), WIN_LDS, (hipStream_t)stream, p);
+    else if (fat8) hipLaunchKernelGGL(conv3x3_win8f, grid, dim3(256), WIN8F_LDS, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(conv3x3_win8, grid, dim3(512), WIN_LDS, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }

@@ -268,7 +268,7 @@ def test_row_march_conv_large_and_repeatable(shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("rows", ["16", "8"])
+@pytest.mark.parametrize("rows", ["16", "8", "8f"])   # 8f: the 4-wave 8-row kernel (two blocks per CU), forced for small shapes
 @pytest.mark.parametrize("case", [(1, 32, 128, 16, 32), (2, 128, 128, 12, 20), (1, 96, 256, 33, 70), (3, 128, 128, 7, 5),
                                   (2, 256, 384, 19, 37), (1, 512, 128, 9, 40)])
 def test_windowed_3x3(monkeypatch, case, rows, dtype):
@@ -277,7 +277,8 @@ def test_windowed_3x3(monkeypatch, case, rows, dtype):
     WITH the fused second gradient branch (`with_skip`, the residual epilogue) and weight gradient against F.conv2d in fp64."""
     from mgnet_amd.modeling import ops
 
-    monkeypatch.setenv("MGN_CONV_WIN", rows)
+    monkeypatch.setenv("MGN_CONV_WIN", rows.rstrip("f"))
+    monkeypatch.setenv("MGN_CONV_WIN8F", "1" if rows.endswith("f") else "0")
     N, Cin, Cout, H, W = case
     torch.manual_seed(sum(case))
     x0 = torch.randn(N, Cin, H, W).to(dtype)
@@ -304,13 +305,15 @@ def test_windowed_3x3(monkeypatch, case, rows, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("rows", [16, 8])
+@pytest.mark.parametrize("rows", [16, 8, -8])   # -8: 8-row patches on the 4-wave kernel (conv3x3_win8f)
 @pytest.mark.parametrize("case", [(2, 64 + 32, 128, 21, 45), (1, 128, 256, 40, 64), (3, 32, 128, 7, 5)])
-def test_windowed_3x3_fused_statistics(case, rows, dtype):
+def test_windowed_3x3_fused_statistics(monkeypatch, case, rows, dtype):
     """The windowed kernel's partial sums -> mgn_iabn_coeffs_from_partials against the statistics of its own (rounded) output
     evaluated in fp64: count, mean, sum of squared deviations per channel, with and without a shift, ragged patches."""
     from mgnet_amd import _C
 
+    monkeypatch.setenv("MGN_CONV_WIN8F", "1" if rows < 0 else "0")
+    rows = abs(rows)
     N, Cin, Cout, H, W = case
     torch.manual_seed(sum(case))
     x = (torch.randn(N, Cin, H, W, device="cuda") + 0.3).to(dtype).contiguous(memory_format=torch.channels_last)
