@@ -836,7 +836,8 @@ struct Conv64Params {
 constexpr int C64_NR = 8;   // ring of input rows: r-1 .. r+2 in use by the two output rows of a step, r+3 .. r+6 in flight
 constexpr int C64_INROW = 136 * 128, C64_LDS = C64_NR * C64_INROW;
 
-__global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
+template <bool STATS, bool RES>
+__device__ __forceinline__ void conv3x3_c64_body(const Conv64Params& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char c64sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpx = wave >> 1, wco = wave & 1;
     const int L = blockIdx.x, q = L >> 3;
@@ -863,87 +864,72 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
     const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, (uint32_t)((size_t)p.N * p.H * p.W * 64 * 2), 0x00020000);
     constexpr int OOB = (int)0x80000000;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    // LDS-DMA plan: 17 one-KB pieces (8 pixels x 128 B) per input row; wave w issues pieces w, w+8, w+16
-    int voff[3];
+    // LDS-DMA: 17 one-KB pieces (8 pixels x 128 B) per input row, all issued by the loader waves (below)
+    // Roles (round 4): the two waves of a SIMD (w and w + 4) never issue memory instructions at the same time.  Waves 0-3 COMPUTE
+    // FIRST: the step's 72 MFMAs, then the stores of its two output rows.  Waves 4-7 LOAD FIRST: the stores of their PREVIOUS step's
+    // rows, then ALL 34 LDS-DMA pieces of the two input rows fetched ahead, then their MFMAs -- which run while the partner stores and
+    // waits at the next barrier.  Before, every wave issued its share of the loads behind the barrier and its stores in front of the
+    // next one: ~2200 cycles of vector-memory issue per step (a 1-KB piece or store occupies the CU's memory path ~34 cycles) during
+    // which no wave fed the matrix pipes (68 % longer than the same loop without its stores).
+    const int grp = wave >> 2;
+    int voffL[5];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int j = wave + 8 * i;
+    for (int i = 0; i < 5; ++i) {
+        const int j = (wave & 3) + 4 * i;
         const int px = 8 * j + (lane >> 3);
         const int seg = (lane & 7) ^ ((px >> 1) & 7);
         const int iw = ow0 - 1 + px;
-        voff[i] = (j < 17 && iw >= 0 && iw < p.W) ? (iw * 64 + seg * 8) * 2 : OOB;
+        voffL[i] = (j < 17 && iw >= 0 && iw < p.W) ? (iw * 64 + seg * 8) * 2 : OOB;
     }
-    auto issue_in = [&](int ih, int slot) {
+    auto issue_in_loader = [&](int ih, int slot) {
         const bool ok = ih >= 0 && ih < p.H;
         const int soff = ok ? ((n * p.H + ih) * p.W) * 128 : 0;
         unsigned char* base = c64sm + slot * C64_INROW;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int j = wave + 8 * i;
-            if (j < 17) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(base + j * 1024), 16, ok ? voff[i] : OOB, soff, 0, 0);
+        for (int i = 0; i < 5; ++i) {
+            const int j = (wave & 3) + 4 * i;
+            if (j < 17) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(base + j * 1024), 16, ok ? voffL[i] : OOB, soff, 0, 0);
         }
     };
-    const int my_cnt = wave == 0 ? 3 : 2;
 
-    // A-fragment byte offsets inside an input row for (kw, kk): patch pixel = 32*wpx + (lane & 31) + kw, 16-byte slot
-    // (2*kk + lane>>5) XOR-swizzled by the pixel
+    // A-fragment byte offset inside an input row for (kw, kk): patch pixel px = 32*wpx + (lane & 31) + kw, 16-byte slot (2*kk + lane>>5)
+    // XOR-swizzled by the pixel = aoffk[kw] ^ (kk << 5)  (one register per kw: px * 128 has no bits below 128)
     const int hi = lane >> 5;
-    int aoff[3][4];
+    int aoffk[3];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
         const int px = 32 * wpx + (lane & 31) + kw;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) aoff[kw][kk] = px * 128 + ((((kk * 2 + hi) ^ ((px >> 1) & 7))) << 4);
+        aoffk[kw] = px * 128 + ((hi ^ ((px >> 1) & 7)) << 4);
     }
-
     float st1[4][4], st2[4][4];   // statistics of this lane's 16 channels over its pixels (only with p.stat_part)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) st1[q][e] = st2[q][e] = 0.f;
     // TWO output rows per step (72 MFMAs per wave between barriers; the weight registers serve both rows)
+    if (grp == 1) {   // rows r0-1 .. r0+4: the first step's four rows + one step ahead
 #pragma unroll
-    for (int k = 0; k < 6; ++k) issue_in(r0 - 1 + k, k);   // rows r0-1 .. r0+4: the first step's four rows + one step ahead
+        for (int k = 0; k < 6; ++k) issue_in_loader(r0 - 1 + k, k);
+    }
     int si = 0;  // slot of input row r-1
     const int opx = ow0 + 32 * wpx + (lane & 31);
-    const bool wstore = ow0 + 32 * wpx < p.W;   // wave-uniform: does this wave issue output stores at all
     auto slot = [](int x) { return x >= C64_NR ? x - C64_NR : x; };
-    for (int r = r0; r < r1; r += 2) {
-        // rows up to r+2 must have landed; the two rows issued last (r+3, r+4) and the previous step's 8 output stores may be in flight
-        if (r == r0 || !wstore) {
-            if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            // (allowance = the 2 rows issued last step + its output stores: 4 sixteen-byte stores, or 0 counted on the residual
-            //  path, whose 8-byte accesses must then simply be complete: a smaller allowance only waits for more)
-            if (p.residual) {
-                if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        issue_in(r + 5, slot(si + 6));   // (always issued: rows past the chunk land in unused slots)
-        issue_in(r + 6, slot(si + 7));
-        f32x16 acc0, acc1;   // output rows r and r+1
+    f32x16 acc0, acc1;   // output rows r and r+1
+    // the residual (fused skip gradient) of a step's two rows is fetched BEFORE the step's MFMAs, in the layout of the 16-byte stores:
+    // its HBM latency then passes under the matrix work instead of in front of the stores
+    uint4 resv[2][2];
+    auto load_residual = [&](int r) {
+        if (opx < p.W) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+            for (int rr2 = 0; rr2 < 2; ++rr2) {
+                const int rr = r + rr2 < r1 ? r + rr2 : r;   // (odd number of rows: the last step's second row is not stored)
+                const uint16_t* rpix = p.residual + ((size_t)(n * p.H + rr) * p.W + opx) * p.Cout + co_w;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const unsigned char* rowa = c64sm + slot(si + kh) * C64_INROW;
-            const unsigned char* rowb = c64sm + slot(si + kh + 1) * C64_INROW;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const h16x8 a = *reinterpret_cast<const h16x8*>(rowa + aoff[kw][kk]);
-                    const h16x8 b = *reinterpret_cast<const h16x8*>(rowb + aoff[kw][kk]);
-                    const int idx = (kh * 3 + kw) * 4 + kk;
-                    acc0 = MGN_MFMA_32x32x16(wr[idx], a, acc0);
-                    acc1 = MGN_MFMA_32x32x16(wr[idx], b, acc1);
-                }
+                for (int qp = 0; qp < 2; ++qp) resv[rr2][qp] = *reinterpret_cast<const uint4*>(rpix + 16 * qp + 8 * hi);
             }
         }
+    };
+    auto store_rows = [&](int r) {
         // D = W-rows x pixels: col = lane & 31 -> pixel, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel.
         // v_permlane32_swap exchanges the 4-channel groups between lane l and lane l+32 so that every lane owns 8 CONSECUTIVE
         // channels of its pixel: 16-byte stores, half as many store instructions (pack8x2 below).
@@ -952,30 +938,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
             for (int rr2 = 0; rr2 < 2; ++rr2) {
                 if (r + rr2 >= r1) break;   // wave-uniform (odd number of rows: the last step has one row)
                 uint16_t* opix = p.out + ((size_t)(n * p.H + r + rr2) * p.W + opx) * p.Cout + co_w;
-                if (p.residual) {
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        uint16_t* orow = opix + 4 * hi + 8 * qd;
-                        float v0 = rr2 ? acc1[qd * 4 + 0] : acc0[qd * 4 + 0], v1 = rr2 ? acc1[qd * 4 + 1] : acc0[qd * 4 + 1];
-                        float v2 = rr2 ? acc1[qd * 4 + 2] : acc0[qd * 4 + 2], v3 = rr2 ? acc1[qd * 4 + 3] : acc0[qd * 4 + 3];
-                        const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (orow - p.out));
-                        v0 += mgn_lo2f(rr.x); v1 += mgn_hi2f(rr.x);
-                        v2 += mgn_lo2f(rr.y); v3 += mgn_hi2f(rr.y);
-                        *reinterpret_cast<uint2*>(orow) =
-                            make_uint2((uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16));
-                    }
-                } else {
+                {
 #pragma unroll
                     for (int qp = 0; qp < 2; ++qp) {   // channel groups (qd = 2qp, 2qp+1) -> channels 16*qp + 8*hi .. +7
+                        // optional residual (the fused skip gradient): read with ONE 16-byte load in the layout of the store below and
+                        // brought back to the accumulator layout by the same two v_permlane32_swap (the exchange is its own inverse);
+                        // added in fp32 before the rounding, as the 8-byte form it replaces (which cost 4x the memory instructions)
+                        uint32_t rp[2][2] = {{0u, 0u}, {0u, 0u}};
+                        if (RES) {
+                            const uint4 R = resv[rr2][qp];
+                            const auto u0 = __builtin_amdgcn_permlane32_swap(R.x, R.z, false, false);
+                            const auto u1 = __builtin_amdgcn_permlane32_swap(R.y, R.w, false, false);
+                            rp[0][0] = u0[0]; rp[1][0] = u0[1]; rp[0][1] = u1[0]; rp[1][1] = u1[1];
+                        }
                         uint32_t pk[2][2];
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const int qd = 2 * qp + u;
-                            const float v0 = rr2 ? acc1[qd * 4 + 0] : acc0[qd * 4 + 0], v1 = rr2 ? acc1[qd * 4 + 1] : acc0[qd * 4 + 1];
-                            const float v2 = rr2 ? acc1[qd * 4 + 2] : acc0[qd * 4 + 2], v3 = rr2 ? acc1[qd * 4 + 3] : acc0[qd * 4 + 3];
+                            float v0 = rr2 ? acc1[qd * 4 + 0] : acc0[qd * 4 + 0], v1 = rr2 ? acc1[qd * 4 + 1] : acc0[qd * 4 + 1];
+                            float v2 = rr2 ? acc1[qd * 4 + 2] : acc0[qd * 4 + 2], v3 = rr2 ? acc1[qd * 4 + 3] : acc0[qd * 4 + 3];
+                            if (RES) {
+                                v0 += mgn_lo2f(rp[u][0]); v1 += mgn_hi2f(rp[u][0]);
+                                v2 += mgn_lo2f(rp[u][1]); v3 += mgn_hi2f(rp[u][1]);
+                            }
                             pk[u][0] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
                             pk[u][1] = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
-                            if (p.stat_part) {   // (block-uniform; every lane in here owns a valid pixel)
+                            if (STATS) {   // (every lane in here owns a valid pixel)
 #pragma unroll
                                 for (int h = 0; h < 2; ++h) {
                                     const float d0 = mgn_lo2f(pk[u][h]), d1 = mgn_hi2f(pk[u][h]);
@@ -991,9 +979,45 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
                 }
             }
         }
+    };
+    for (int r = r0; r < r1; r += 2) {
+        // Rows up to r+2 must have landed: the loader waves issued them two steps ago (or in the prologue), and the only LOADS they have
+        // issued since are the two rows of the previous step (>= 8 pieces per wave) and, on the residual path, its 4 residual loads (stores
+        // in between can only make the wait longer).  The other waves issue no LDS-DMA.
+        if (grp == 1) {
+            if (RES) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // (+ the 4 residual loads of the previous step)
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) {
+            if (r > r0) store_rows(r - 2);
+            issue_in_loader(r + 5, slot(si + 6));   // (always issued: rows past the chunk land in unused slots)
+            issue_in_loader(r + 6, slot(si + 7));
+        }
+        if (RES) load_residual(r);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const unsigned char* rowa = c64sm + slot(si + kh) * C64_INROW;
+            const unsigned char* rowb = c64sm + slot(si + kh + 1) * C64_INROW;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const h16x8 a = *reinterpret_cast<const h16x8*>(rowa + (aoffk[kw] ^ (kk << 5)));
+                    const h16x8 b = *reinterpret_cast<const h16x8*>(rowb + (aoffk[kw] ^ (kk << 5)));
+                    const int idx = (kh * 3 + kw) * 4 + kk;
+                    acc0 = MGN_MFMA_32x32x16(wr[idx], a, acc0);
+                    acc1 = MGN_MFMA_32x32x16(wr[idx], b, acc1);
+                }
+            }
+        }
+        if (grp == 0) store_rows(r);
         si = slot(si + 2);
     }
-    if (p.stat_part) {
+    if (grp == 1) store_rows(r0 + ((r1 - r0 - 1) & ~1));   // the loader waves' last step
+    if (STATS) {
         // 16-lane DPP butterflies, the 8 parts of a channel (4 pixel groups x 2 lane rows) through LDS, one partial row per slice
         auto row_sum = [](float v) {
             v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -1023,6 +1047,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) {
         }
     }
 }
+
+__global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) { conv3x3_c64_body<false, false>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_c64_res(Conv64Params p) { conv3x3_c64_body<false, true>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_c64_stats(Conv64Params p) { conv3x3_c64_body<true, false>(p); }
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradient
@@ -2100,9 +2129,14 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
         static bool cattr = false;
         if (!cattr) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_stats), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_res), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
             cattr = true;
         }
-        hipLaunchKernelGGL(conv3x3_c64, dim3((unsigned)((q.nslices + 7) / 8) * 8 * q.co_tiles), dim3(512), C64_LDS, st, q);
+        if (q.stat_part && q.residual) return MGN_ENOTSUP;
+        if (q.residual) hipLaunchKernelGGL(conv3x3_c64_res, dim3((unsigned)((q.nslices + 7) / 8) * 8 * q.co_tiles), dim3(512), C64_LDS, st, q);
+        else if (q.stat_part) hipLaunchKernelGGL(conv3x3_c64_stats, dim3((unsigned)((q.nslices + 7) / 8) * 8 * q.co_tiles), dim3(512), C64_LDS, st, q);
+        else hipLaunchKernelGGL(conv3x3_c64, dim3((unsigned)((q.nslices + 7) / 8) * 8 * q.co_tiles), dim3(512), C64_LDS, st, q);
         return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
     } else if (!getenv("MGN_CONV_NOGLDS")) {
         // up > 1: one grid slice per parity class, sized for the largest class

@@ -257,47 +257,47 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
         const bool ok = ox < p.W;
         const size_t m = ((size_t)n * p.H + oy) * p.W + (ok ? ox : 0);
         uint16_t* opix = p.out + m * p.Cout + bn * 128 + wn * 64;
-        if (p.residual) {
-            if (!ok) continue;
-            const uint16_t* rpix = p.residual + m * p.Cout + bn * 128 + wn * 64;
+        // v_permlane32_swap exchanges the 4-channel groups of lane l and lane l + 32: every lane then owns 8 consecutive channels of its
+        // pixel (16-byte stores, half the store instructions).  An optional residual is read with ONE 16-byte load in that same layout
+        // and brought back to the accumulator layout by the same exchange (it is its own inverse), then added in fp32 before the
+        // rounding -- the 8-byte loads / stores this replaces cost four times the memory instructions.
+        const float msk = ok ? 1.f : 0.f;
+        const uint16_t* rpix = p.residual ? p.residual + m * p.Cout + bn * 128 + wn * 64 : nullptr;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int co = j * 32 + 8 * q + 4 * hi;
-                    const uint2 r = *reinterpret_cast<const uint2*>(rpix + co);
-                    const float v0 = acc[i][j][q * 4 + 0] + mgn_lo2f(r.x), v1 = acc[i][j][q * 4 + 1] + mgn_hi2f(r.x);
-                    const float v2 = acc[i][j][q * 4 + 2] + mgn_lo2f(r.y), v3 = acc[i][j][q * 4 + 3] + mgn_hi2f(r.y);
-                    *reinterpret_cast<uint2*>(opix + co) = make_uint2(mgn_pack2(v0, v1), mgn_pack2(v2, v3));
+            for (int qp = 0; qp < 2; ++qp) {
+                uint32_t rp[2][2] = {{0u, 0u}, {0u, 0u}};
+                if (p.residual) {
+                    const uint4 R = *reinterpret_cast<const uint4*>(rpix + j * 32 + 16 * qp + 8 * hi);
+                    const auto u0 = __builtin_amdgcn_permlane32_swap(R.x, R.z, false, false);
+                    const auto u1 = __builtin_amdgcn_permlane32_swap(R.y, R.w, false, false);
+                    rp[0][0] = u0[0]; rp[1][0] = u0[1]; rp[0][1] = u1[0]; rp[1][1] = u1[1];
                 }
-        } else {
-            // v_permlane32_swap exchanges the 4-channel groups of lane l and lane l + 32: every lane then owns 8 consecutive
-            // channels of its pixel (16-byte stores, half the store instructions)
-            const float msk = ok ? 1.f : 0.f;
+                uint32_t pk[2][2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int u = 0; u < 2; ++u) {
+                    const int q = 2 * qp + u;
+                    float v0 = acc[i][j][q * 4 + 0], v1 = acc[i][j][q * 4 + 1], v2 = acc[i][j][q * 4 + 2], v3 = acc[i][j][q * 4 + 3];
+                    if (p.residual) {
+                        v0 += mgn_lo2f(rp[u][0]); v1 += mgn_hi2f(rp[u][0]);
+                        v2 += mgn_lo2f(rp[u][1]); v3 += mgn_hi2f(rp[u][1]);
+                    }
+                    pk[u][0] = mgn_pack2(v0, v1);
+                    pk[u][1] = mgn_pack2(v2, v3);
+                    if (stats) {
 #pragma unroll
-                for (int qp = 0; qp < 2; ++qp) {
-                    uint32_t pk[2][2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int q = 2 * qp + u;
-                        pk[u][0] = mgn_pack2(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1]);
-                        pk[u][1] = mgn_pack2(acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-                        if (stats) {
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const float d0 = (mgn_lo2f(pk[u][h]) - sh[j][q][2 * h]) * msk, d1 = (mgn_hi2f(pk[u][h]) - sh[j][q][2 * h + 1]) * msk;
-                                s1[j][q][2 * h] += d0; s2[j][q][2 * h] = fmaf(d0, d0, s2[j][q][2 * h]);
-                                s1[j][q][2 * h + 1] += d1; s2[j][q][2 * h + 1] = fmaf(d1, d1, s2[j][q][2 * h + 1]);
-                            }
+                        for (int h = 0; h < 2; ++h) {
+                            const float d0 = (mgn_lo2f(pk[u][h]) - sh[j][q][2 * h]) * msk, d1 = (mgn_hi2f(pk[u][h]) - sh[j][q][2 * h + 1]) * msk;
+                            s1[j][q][2 * h] += d0; s2[j][q][2 * h] = fmaf(d0, d0, s2[j][q][2 * h]);
+                            s1[j][q][2 * h + 1] += d1; s2[j][q][2 * h + 1] = fmaf(d1, d1, s2[j][q][2 * h + 1]);
                         }
                     }
-                    const auto w0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
-                    const auto w1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
-                    if (ok) *reinterpret_cast<uint4*>(opix + j * 32 + 16 * qp + 8 * hi) = make_uint4(w0[0], w1[0], w0[1], w1[1]);
                 }
-        }
+                const auto w0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                const auto w1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                if (ok) *reinterpret_cast<uint4*>(opix + j * 32 + 16 * qp + 8 * hi) = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+            }
     }
     if (stats) {
         // 16-lane butterflies (DPP: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror): every lane of a 16-lane row

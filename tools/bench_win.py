@@ -62,11 +62,12 @@ def bench():
         x = cl(B, Cin, H, W)
         wl = (torch.randn(Cout, 3, 3, Cin, device="cuda") / (Cin * 9) ** 0.5).to(torch.bfloat16)
         fl = 2.0 * B * H * W * Cin * Cout * 9
-        tg = timeit(lambda: generic(x, wl))
-        line = f"{Cin}->{Cout} @{H}x{W}: generic {tg:7.1f} us ({fl / tg / 1e6:6.0f} TF/s)"
+        line = f"{Cin}->{Cout} @{H}x{W}:"
+        res = cl(B, Cout, H, W)
         for pr in (16, 8):
             t = timeit(lambda: _C.conv3x3_win(x, wl, patch_rows=pr))
-            line += f" | win{pr} {t:7.1f} us ({fl / t / 1e6:6.0f} TF/s)"
+            tr = timeit(lambda: _C.conv3x3_win(x, wl, residual=res, patch_rows=pr))
+            line += f" | win{pr} {t:7.1f} us ({fl / t / 1e6:6.0f} TF/s), +residual {tr:7.1f} us"
         print(line, flush=True)
 
 
