@@ -255,6 +255,45 @@ int mgn_conv3x3_win(const void* in, const void* w, void* out, int N, int H, int 
 int mgn_conv_stat_rows(int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int* shifted);
 int mgn_conv_igemm_stats(const void* in, const void* w, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
                          int KW, int stride, int pad, float* stat_partials, const float* stat_shift, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Launch plan: one training step recorded once and replayed from C
+ *   replaces, per step, the host side of the loop tools/train_net.py:232-234 hands to detectron2's trainer
+ *   (`trainer.train()` -> run_step: forward, losses, backward, optimizer): between mgn_plan_begin and
+ *   mgn_plan_end every kernel launch of this library is executed AND written down (kernel, grid, block, LDS bytes, stream,
+ *   arguments by value, each classified as pointer-to-const / pointer / opaque); the host (mgnet_amd/engine/plan.py)
+ *   derives the cross-stream dependencies from the memory the launches touch, hands the schedule back with
+ *   mgn_plan_compile and replays it with one mgn_plan_run per step segment.  Memory must be static across replays
+ *   (the recording runs inside a private allocator pool); values the host changes per step live in device tables.
+ *   One recording at a time per process; replay is single-threaded per plan.
+ * ------------------------------------------------------------------------------------------------ */
+#define MGN_PLAN_OP_LAUNCH 0   /* a = node index (kernel launch or profiling mark)        */
+#define MGN_PLAN_OP_RECORD 1   /* a = event index, recorded on `stream`                   */
+#define MGN_PLAN_OP_WAIT 2     /* `stream` waits for event a                              */
+#define MGN_PLAN_OP_BREAK 3    /* return to the host (collectives, torch ops it replays)  */
+typedef struct mgn_plan_node_info_t {
+    int type;                 /* 0 kernel launch, 1 profiling mark (hipEvent pair around the dominant kernel) */
+    int which;                /* profiling mark: 0 begin, 1 end */
+    void* stream;             /* hipStream_t */
+    const void* func;         /* host address of the kernel */
+    const char* name;         /* kernel name (owned by the runtime) */
+    unsigned grid[3], block[3];
+    size_t shmem;
+    int nargs, nbytes;        /* arguments; size of the by-value argument blob */
+    const unsigned char* blob;
+} mgn_plan_node_info_t;
+int mgn_plan_begin(void);
+int mgn_plan_recorded(void);                       /* nodes recorded so far, -1 outside a recording */
+const void* mgn_plan_current(void);                /* the plan being recorded (node queries while it grows), or NULL */
+int mgn_plan_end(void** plan);
+int mgn_plan_abort(void);
+int mgn_plan_node_count(const void* plan);
+int mgn_plan_node_info(const void* plan, int i, mgn_plan_node_info_t* out);
+int mgn_plan_node_args(const void* plan, int i, int max_args, int* offsets, int* sizes, int* kinds /*0 opaque, 1 const pointer, 2 pointer*/);
+int mgn_plan_compile(void* plan, int n_ops, const int* types, const int* a, void* const* streams, int n_events, int prof_slots);
+int mgn_plan_run(void* plan, int from_op, int prof_slot);   /* -> index of the BREAK it stopped at, or the op count */
+int mgn_plan_prof_elapsed(void* plan, int slot, float* ms);
+int mgn_plan_free(void* plan);
+
 /* The 7x7 / stride 2 / pad 3 stems with 64 output channels (res_net.py:96-104 BasicStem conv1; the 9-channel pose-net stem,
  * res_net.py:169-181) on the channel-padded input of mgn_prep_input (Cin = 8 | 16) and the layout-mode-2 weights of
  * mgn_weight_layout: persistent windowed kernel with the weights in registers (csrc/conv_stem.hip); mgn_conv_igemm dispatches

@@ -27,7 +27,9 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_reduce_x_relu", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4", "mgn_u8_frames_to_rgbx", "mgn_msc_input", "mgn_msc_accumulate", "mgn_uncertainty_fwd", "mgn_uncertainty_bwd", "mgn_head_act_fwd", "mgn_head_act_bwd",
            "mgn_p2p_mailbox_bytes", "mgn_p2p_alloc", "mgn_p2p_free", "mgn_p2p_export", "mgn_p2p_open", "mgn_p2p_close", "mgn_p2p_exchange",
            "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
-           "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd"]
+           "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd",
+           "mgn_plan_begin", "mgn_plan_recorded", "mgn_plan_current", "mgn_plan_end", "mgn_plan_abort", "mgn_plan_node_count", "mgn_plan_node_info", "mgn_plan_node_args",
+           "mgn_plan_compile", "mgn_plan_run", "mgn_plan_prof_elapsed", "mgn_plan_free"]
 SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
 DEPTH_MAX_FILTER_IDS = 16
 
@@ -53,6 +55,12 @@ class TargetsCfg(ctypes.Structure):   # mgn_targets_cfg
                [("depth_ignore_mask", ctypes.c_uint32 * 8)]
 
 
+class PlanNodeInfo(ctypes.Structure):   # mgn_plan_node_info_t
+    _fields_ = [("type", ctypes.c_int), ("which", ctypes.c_int), ("stream", ctypes.c_void_p), ("func", ctypes.c_void_p),
+                ("name", ctypes.c_char_p), ("grid", ctypes.c_uint * 3), ("block", ctypes.c_uint * 3), ("shmem", ctypes.c_size_t),
+                ("nargs", ctypes.c_int), ("nbytes", ctypes.c_int), ("blob", ctypes.c_void_p)]
+
+
 class ReprojCfg(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("n_scales", ctypes.c_int),
                 ("ssim_loss_weight", ctypes.c_float), ("photometric_loss_weight", ctypes.c_float),
@@ -62,6 +70,17 @@ class ReprojCfg(ctypes.Structure):
 
 
 _lib = None
+PLAN_RECORDER = [None]   # engine/plan.py: the recorder of the step being recorded (launch-plan replay), else None
+
+
+def plan_touch(reads=(), writes=()):
+    """tell a running plan recording which tensors the NEXT library call reaches through pointers that live in device memory
+    (descriptor tables) rather than in its arguments; no-op otherwise"""
+    rec = PLAN_RECORDER[0]
+    if rec is not None:
+        rec.touch(list(reads), list(writes))
+
+
 H16 = (torch.bfloat16, torch.float16)   # the 16-bit activation formats: bf16 entry points, or their _f16 twins (csrc/h16.h)
 F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']
 
@@ -181,9 +200,22 @@ def lib():
         L.mgn_reconstruct_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]
         L.mgn_project_fwd.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
         L.mgn_project_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]
+        L.mgn_plan_begin.argtypes = []
+        L.mgn_plan_recorded.argtypes = []
+        L.mgn_plan_current.argtypes = []
+        L.mgn_plan_abort.argtypes = []
+        L.mgn_plan_end.argtypes = [ctypes.POINTER(vp)]
+        L.mgn_plan_node_count.argtypes = [vp]
+        L.mgn_plan_node_info.argtypes = [vp, ci, ctypes.POINTER(PlanNodeInfo)]
+        L.mgn_plan_node_args.argtypes = [vp, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.mgn_plan_compile.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(vp), ci, ci]
+        L.mgn_plan_run.argtypes = [vp, ci, ci]
+        L.mgn_plan_prof_elapsed.argtypes = [vp, ci, ctypes.POINTER(cf)]
+        L.mgn_plan_free.argtypes = [vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
         L.mgn_p2p_mailbox_bytes.restype = sz
+        L.mgn_plan_current.restype = vp
         for n in F16_TWINS:
             getattr(L, n + "_f16").restype = ci
             getattr(L, n + "_f16").argtypes = getattr(L, n).argtypes
@@ -206,6 +238,12 @@ class PinnedStager:
 
     def stage(self, src, device, slot=None):
         """`slot`: one ring per call site (two sites staging equal shapes in the same step must not share buffers)"""
+        if PLAN_RECORDER[0] is not None:
+            # a step being recorded for replay: a pinned buffer of its own that the plan keeps (the rings are rewritten by later eager steps)
+            buf = torch.empty(src.shape, dtype=src.dtype).pin_memory()
+            buf.copy_(src)
+            PLAN_RECORDER[0].keep.append(buf)
+            return buf.to(device, non_blocking=True)
         key = (slot, tuple(src.shape), src.dtype, str(device))
         ring = self.rings.get(key)
         if ring is None:
@@ -864,6 +902,7 @@ def wgrad_reduce_batch(entries):
     if _wgrad_stager is None:
         _wgrad_stager = PinnedStager(depth=8)
     tdev = _wgrad_stager.stage(table, dev, slot=("wgrad", len(rows)))
+    plan_touch(reads=[ws for _d, ws, _v in entries], writes=[dst for _d, _w, dst in entries])
     check(lib().mgn_conv_wgrad_reduce_batch(tdev.data_ptr(), len(rows), start, _stream()), "mgn_conv_wgrad_reduce_batch")
     return tdev
 
@@ -984,6 +1023,9 @@ class _WeightCache:
         if self.dirty:
             self._rebuild()
         for dtype, (table, blocks) in self.tables.items():
+            if PLAN_RECORDER[0] is not None:
+                ents = [e for e in self.entries.values() if e["dtype"] == dtype and e["ref"]() is not None]
+                plan_touch(reads=[e["ref"]() for e in ents], writes=[e["out"] for e in ents])
             check(_fn("mgn_weight_layout_batch", dtype)(table.data_ptr(), table.shape[0], blocks, _stream()), "mgn_weight_layout_batch")
         for e in self.entries.values():
             w = e["ref"]()

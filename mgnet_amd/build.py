@@ -14,7 +14,8 @@ LIB = os.path.join(HERE, "lib", "libmgnet_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-          "-I" + os.path.join(HERE, "csrc")]
+          "-I" + os.path.join(HERE, "csrc"),
+          "-include", os.path.join(HERE, "csrc", "mgn_launch.h")]   # every launch through mgn_plan::launch (launch-plan recording)
 
 
 def sources():

@@ -1,0 +1,223 @@
+// plan.hip -- recorder and replayer of a launch plan: one training step as a table of kernel launches with by-value arguments,
+// event records / waits between its streams and break points where the host has something of its own to do.
+//
+// Replaces, per training step, the Python / autograd / ctypes issue of the step's ~700 launches (the loop tools/train_net.py:232-234
+// delegates to detectron2's trainer: forward -> losses -> backward -> optimizer) by ONE pass over the table from C.  The
+// recording is made by the product's own C-ABI calls while they execute a real step (csrc/mgn_launch.h writes every launch down); the
+// cross-stream dependencies are NOT recorded from the host's stream calls but derived by engine/plan.py from the memory each launch
+// reads and writes (pointer arguments resolved against the allocator's blocks), which is also what makes the reuse of freed blocks
+// across streams safe on replay.  What a step needs from the host (learning-rate tables) lives in device tables that are refreshed
+// before the replay, exactly as for the hipGraph path it supersedes (engine/trainer.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "mgnet_hip.h"
+
+namespace mgn_plan {
+
+extern "C" int g_mgn_plan_recording = 0;
+
+struct Node {
+    int type;   // 0 launch, 1 prof mark
+    const void* func;
+    dim3 grid, block;
+    size_t shmem;
+    hipStream_t stream;
+    int which;             // prof mark: 0 begin, 1 end
+    int blob_off, nbytes;  // into Plan::blob
+    int arg_off, nargs;    // into Plan::args
+};
+
+struct Op {
+    int type, a;        // MGN_PLAN_OP_*; a = node / event index
+    hipStream_t stream; // record / wait
+};
+
+struct Plan {
+    std::vector<Node> nodes;
+    std::vector<unsigned char> blob;
+    std::vector<ArgDesc> args;
+    std::vector<Op> ops;
+    std::vector<hipEvent_t> events;
+    std::vector<void*> argv;   // per launch op: pointers into blob (filled by compile)
+    std::vector<int> argv_off; // node -> offset into argv
+    std::vector<hipEvent_t> prof[2];
+    bool overflow = false;
+};
+
+static Plan* g_rec = nullptr;
+
+void record_launch(const void* func, dim3 grid, dim3 block, size_t shmem, hipStream_t stream, const unsigned char* blob, int nbytes,
+                   const ArgDesc* args, int nargs) {
+    Plan* p = g_rec;
+    if (!p) return;
+    if (nargs > MAX_ARGS || nbytes > MAX_ARG_BYTES) { p->overflow = true; return; }
+    Node n{};
+    n.type = 0; n.func = func; n.grid = grid; n.block = block; n.shmem = shmem; n.stream = stream;
+    n.blob_off = (int)((p->blob.size() + 15) / 16 * 16);
+    n.nbytes = nbytes;
+    p->blob.resize((size_t)n.blob_off + (size_t)nbytes);
+    memcpy(p->blob.data() + n.blob_off, blob, (size_t)nbytes);
+    n.arg_off = (int)p->args.size(); n.nargs = nargs;
+    p->args.insert(p->args.end(), args, args + nargs);
+    p->nodes.push_back(n);
+}
+
+void record_prof_mark(int which, hipStream_t stream) {
+    Plan* p = g_rec;
+    if (!p) return;
+    Node n{};
+    n.type = 1; n.which = which; n.stream = stream;
+    p->nodes.push_back(n);
+}
+
+}  // namespace mgn_plan
+
+using namespace mgn_plan;
+
+extern "C" {
+
+int mgn_plan_begin(void) {
+    if (g_rec) return MGN_EINVAL;   // one recording at a time
+    g_rec = new Plan();
+    g_mgn_plan_recording = 1;
+    return MGN_OK;
+}
+
+int mgn_plan_recorded(void) { return g_rec ? (int)g_rec->nodes.size() : -1; }
+
+/* the plan being recorded (for mgn_plan_node_info / _args while it grows), or NULL */
+const void* mgn_plan_current(void) { return g_rec; }
+
+int mgn_plan_end(void** plan) {
+    if (!g_rec || !plan) return MGN_EINVAL;
+    g_mgn_plan_recording = 0;
+    Plan* p = g_rec;
+    g_rec = nullptr;
+    if (p->overflow) { delete p; return MGN_ENOSPC; }
+    *plan = p;
+    return MGN_OK;
+}
+
+int mgn_plan_abort(void) {
+    g_mgn_plan_recording = 0;
+    delete g_rec;
+    g_rec = nullptr;
+    return MGN_OK;
+}
+
+int mgn_plan_node_count(const void* plan) { return plan ? (int)((const Plan*)plan)->nodes.size() : -1; }
+
+int mgn_plan_node_info(const void* plan, int i, mgn_plan_node_info_t* out) {
+    const Plan* p = (const Plan*)plan;
+    if (!p || !out || i < 0 || i >= (int)p->nodes.size()) return MGN_EINVAL;
+    const Node& n = p->nodes[i];
+    out->type = n.type; out->stream = (void*)n.stream; out->func = n.func; out->nargs = n.nargs; out->nbytes = n.nbytes;
+    out->grid[0] = n.grid.x; out->grid[1] = n.grid.y; out->grid[2] = n.grid.z;
+    out->block[0] = n.block.x; out->block[1] = n.block.y; out->block[2] = n.block.z;
+    out->shmem = n.shmem; out->which = n.which;
+    out->blob = n.type == 0 ? p->blob.data() + n.blob_off : nullptr;
+    out->name = n.type == 0 ? hipKernelNameRefByPtr(n.func, n.stream) : (n.which ? "prof_end" : "prof_begin");
+    return MGN_OK;
+}
+
+/* per argument of node i: offset into the blob, size, kind (0 opaque, 1 pointer to const, 2 pointer) */
+int mgn_plan_node_args(const void* plan, int i, int max_args, int* offsets, int* sizes, int* kinds) {
+    const Plan* p = (const Plan*)plan;
+    if (!p || i < 0 || i >= (int)p->nodes.size() || !offsets || !sizes || !kinds) return MGN_EINVAL;
+    const Node& n = p->nodes[i];
+    if (n.nargs > max_args) return MGN_ENOSPC;
+    for (int k = 0; k < n.nargs; ++k) {
+        const ArgDesc& d = p->args[n.arg_off + k];
+        offsets[k] = d.offset; sizes[k] = d.size; kinds[k] = d.kind;
+    }
+    return n.nargs;
+}
+
+/* the replay schedule: ops[k] = (type, a, stream).  LAUNCH a = node; RECORD / WAIT a = event index (n_events are created here);
+ * BREAK = return to the host (mgn_plan_run stops in front of it).  prof_slots > 0 creates that many hipEvent pairs for the prof marks. */
+int mgn_plan_compile(void* plan, int n_ops, const int* types, const int* a, void* const* streams, int n_events, int prof_slots) {
+    Plan* p = (Plan*)plan;
+    if (!p || n_ops < 0 || (n_ops && (!types || !a || !streams)) || n_events < 0 || prof_slots < 0) return MGN_EINVAL;
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    for (int w = 0; w < 2; ++w) { for (hipEvent_t e : p->prof[w]) (void)hipEventDestroy(e); p->prof[w].clear(); }
+    p->events.clear(); p->ops.clear();
+    for (int k = 0; k < n_events; ++k) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return MGN_ELAUNCH;
+        p->events.push_back(e);
+    }
+    for (int w = 0; w < 2; ++w)
+        for (int k = 0; k < prof_slots; ++k) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return MGN_ELAUNCH;
+            p->prof[w].push_back(e);
+        }
+    // argument pointer vectors of the launches
+    p->argv.clear(); p->argv_off.assign(p->nodes.size(), 0);
+    for (size_t i = 0; i < p->nodes.size(); ++i) {
+        const Node& n = p->nodes[i];
+        p->argv_off[i] = (int)p->argv.size();
+        for (int k = 0; k < n.nargs; ++k) p->argv.push_back(p->blob.data() + n.blob_off + p->args[n.arg_off + k].offset);
+    }
+    for (int k = 0; k < n_ops; ++k) {
+        const int t = types[k];
+        if (t == MGN_PLAN_OP_LAUNCH) { if (a[k] < 0 || a[k] >= (int)p->nodes.size()) return MGN_EINVAL; }
+        else if (t == MGN_PLAN_OP_RECORD || t == MGN_PLAN_OP_WAIT) { if (a[k] < 0 || a[k] >= n_events) return MGN_EINVAL; }
+        else if (t != MGN_PLAN_OP_BREAK) return MGN_EINVAL;
+        p->ops.push_back(Op{t, a[k], (hipStream_t)streams[k]});
+    }
+    return MGN_OK;
+}
+
+/* runs ops [from, ...) up to the next BREAK or the end; returns the index of the op it stopped in front of (== op count at the end),
+ * or a negative error.  A BREAK at `from` itself is stepped over.  prof_slot: which event pair the prof marks of this pass record. */
+int mgn_plan_run(void* plan, int from, int prof_slot) {
+    Plan* p = (Plan*)plan;
+    if (!p || from < 0 || from > (int)p->ops.size()) return MGN_EINVAL;
+    const int n = (int)p->ops.size();
+    int k = from;
+    if (k < n && p->ops[k].type == MGN_PLAN_OP_BREAK) ++k;
+    for (; k < n; ++k) {
+        const Op& o = p->ops[k];
+        if (o.type == MGN_PLAN_OP_LAUNCH) {
+            const Node& nd = p->nodes[o.a];
+            if (nd.type == 0) {
+                if (hipLaunchKernel(nd.func, nd.grid, nd.block, p->argv.data() + p->argv_off[o.a], nd.shmem, nd.stream) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return MGN_ELAUNCH;
+                }
+            } else if (prof_slot >= 0 && prof_slot < (int)p->prof[nd.which].size()) {
+                (void)hipEventRecord(p->prof[nd.which][prof_slot], nd.stream);
+            }
+        } else if (o.type == MGN_PLAN_OP_RECORD) {
+            if (hipEventRecord(p->events[o.a], o.stream) != hipSuccess) return MGN_ELAUNCH;
+        } else if (o.type == MGN_PLAN_OP_WAIT) {
+            if (hipStreamWaitEvent(o.stream, p->events[o.a], 0) != hipSuccess) return MGN_ELAUNCH;
+        } else {
+            return k;   // BREAK
+        }
+    }
+    return n;
+}
+
+int mgn_plan_prof_elapsed(void* plan, int slot, float* ms) {
+    Plan* p = (Plan*)plan;
+    if (!p || !ms || slot < 0 || slot >= (int)p->prof[0].size()) return MGN_EINVAL;
+    return hipEventElapsedTime(ms, p->prof[0][slot], p->prof[1][slot]) == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_plan_free(void* plan) {
+    Plan* p = (Plan*)plan;
+    if (!p) return MGN_OK;
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    for (int w = 0; w < 2; ++w)
+        for (hipEvent_t e : p->prof[w]) (void)hipEventDestroy(e);
+    delete p;
+    return MGN_OK;
+}
+
+}  // extern "C"

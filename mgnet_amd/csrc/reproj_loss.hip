@@ -1208,7 +1208,7 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
 
     hipLaunchKernelGGL(reproj_prep, dim3((cfg->B + 63) / 64), dim3(64), 0, stream, cam, cam_stride, cam_ld, pose, cfg->B,
                        (CamConst*)(ws + L.off_cam));
-    if (cfg->prof_begin) (void)hipEventRecord((hipEvent_t)cfg->prof_begin, stream);
+    mgn_plan::prof_mark(0, cfg->prof_begin, (hipStream_t)stream);
     const dim3 mgrid(L.nblocks), mblock(WAVE * (cfg->n_scales + 1));
 #define MGN_MARCH(G, F, P, M) hipLaunchKernelGGL((reproj_march<G, F, P, M>), mgrid, mblock, L.lds_bytes, stream, p)
 #define MGN_MARCH_P(F, P) do { if (l1min) { if (want_grad) MGN_MARCH(true, F, P, true); else MGN_MARCH(false, F, P, true); } \
@@ -1221,7 +1221,7 @@ int mgn_reproj_loss_fwd(const mgn_reproj_cfg* cfg, const float* const* inv_depth
 #undef MGN_MARCH_P
 #undef MGN_MARCH_F
 #undef MGN_MARCH
-    if (cfg->prof_end) (void)hipEventRecord((hipEvent_t)cfg->prof_end, stream);
+    mgn_plan::prof_mark(1, cfg->prof_end, (hipStream_t)stream);
     hipLaunchKernelGGL(reproj_fin1, dim3(cfg->B, cfg->n_scales), dim3(256), 0, stream, (const float*)(ws + L.off_partials),
                        cfg->n_scales, L.nseg * L.nstrips, (double*)(ws + L.off_persum));
     hipLaunchKernelGGL(reproj_fin2, dim3(1), dim3(256), 0, stream, (const double*)(ws + L.off_persum),

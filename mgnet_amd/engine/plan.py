@@ -1,0 +1,426 @@
+"""Launch-plan replay of the training step: one eager step is RECORDED -- every kernel launch of libmgnet_hip.so with its arguments by
+value (csrc/mgn_launch.h, csrc/plan.hip) and the few torch ops left in the step -- and later steps are REPLAYED from C with one
+`mgn_plan_run` call per segment instead of ~700 Python -> autograd -> ctypes round trips (the loop tools/train_net.py:232-234 hands
+to detectron2's trainer).  hipGraph is not an option on this ROCm (hipGraphLaunch of the step costs more host time than
+the eager issue and capturing the side-stream branches crashes); this keeps the side streams.
+
+How a replay stays correct:
+* static memory: the recorded step allocates from a private pool of torch's caching allocator that nothing else uses afterwards, so
+  every address in the recorded arguments stays valid; the batch is a set of device tensors refilled in place; what the host changes
+  per step (learning-rate tables, bias corrections) lives in device tables uploaded before the replay (FusedAdam.prepare_step);
+* ordering: launches of one stream replay in their recorded order; dependencies BETWEEN streams are not copied from the host's
+  wait_stream / record_stream calls (the autograd engine and the allocator add their own, and freed blocks are reused across streams
+  once the HOST has seen an event complete -- none of which a replay repeats) but derived from the memory each launch reads and
+  writes: pointer arguments (const = read, other = written; by-value structs are scanned for pointers) resolved to the allocator
+  block they point into, a vector clock per stream, one event per needed edge.  Any two launches on different streams that touch
+  overlapping memory with at least one writer are ordered as in the recording -- which also covers the reuse of a block;
+* torch ops inside the step (gradient accumulations of shared feature maps, bucket packs, small host -> device table copies) are
+  captured by a TorchDispatchMode with their tensors and replayed between plan segments on their stream, writing into the recorded
+  output tensors (`out=` overloads); an op this cannot express aborts the recording and the trainer stays eager.
+"""
+import bisect
+import ctypes
+import gc
+import threading
+
+import numpy as np
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+from .. import _C
+
+
+class PlanUnsupported(RuntimeError):
+    pass
+
+
+_ALLOC_ONLY = {"empty.memory_format", "empty_like.default", "empty_strided.default", "new_empty.default", "new_empty_strided.default"}
+
+
+def _tensors(x):
+    if isinstance(x, torch.Tensor):
+        yield x
+    elif isinstance(x, (list, tuple)):
+        for y in x:
+            yield from _tensors(y)
+
+
+def _detached(x):
+    """the same storage without autograd: a replayed torch op runs outside the graph of the recorded step"""
+    if isinstance(x, torch.Tensor):
+        return x.detach()
+    if isinstance(x, (list, tuple)):
+        return type(x)(_detached(y) for y in x)
+    if isinstance(x, dict):
+        return {k: _detached(v) for k, v in x.items()}
+    return x
+
+
+def _extent(t):
+    """byte range of the storage a tensor lives in (conservative: the whole storage)"""
+    st = t.untyped_storage()
+    p = st.data_ptr()
+    return (p, p + max(int(st.nbytes()), 1))
+
+
+class _Blocks:
+    """non-overlapping [start, end) intervals of device memory in use, newest allocation wins"""
+
+    def __init__(self):
+        self.starts, self.ends = [], []
+
+    def add(self, s, e):
+        i = bisect.bisect_left(self.starts, s)
+        if i > 0 and self.ends[i - 1] > s:
+            i -= 1
+        j = i
+        while j < len(self.starts) and self.starts[j] < e:
+            j += 1
+        if j - i == 1 and self.starts[i] == s and self.ends[i] == e:
+            return
+        self.starts[i:j] = [s]
+        self.ends[i:j] = [e]
+
+    def find(self, p):
+        i = bisect.bisect_right(self.starts, p) - 1
+        if i >= 0 and self.ends[i] > p:
+            return (self.starts[i], self.ends[i])
+        return None
+
+    def load_snapshot(self):
+        for seg in torch.cuda.memory_snapshot():
+            a = seg["address"]
+            for b in seg["blocks"]:
+                if b["state"] != "inactive":
+                    self.add(a, a + b["size"])
+                a += b["size"]
+
+
+class _Recorder(TorchDispatchMode):
+    """collects, in issue order, the library's launches (through the proxy below) and the torch ops that do device work"""
+
+    def __init__(self, lib, device):
+        super().__init__()
+        self.lib, self.device = lib, device
+        self.timeline = []          # ("node", index) | ("torch", closure dict)
+        self.blocks = _Blocks()
+        self.blocks.load_snapshot()
+        self.keep = []              # tensors / buffers the plan refers to
+        self.pending_touch = ([], [])
+        self.lock = threading.RLock()
+        self.unresolved = set()
+        self.error = None
+        self._info = _C.PlanNodeInfo()
+        self._offs, self._sizes, self._kinds = (ctypes.c_int * 64)(), (ctypes.c_int * 64)(), (ctypes.c_int * 64)()
+
+    # ---- library calls -------------------------------------------------------------------------------------------------
+    def wrap(self, name, fn):
+        if name.startswith("mgn_plan_") or not callable(fn):
+            return fn
+
+        def call(*args):
+            with self.lock:
+                n0 = self.lib.mgn_plan_recorded()
+                rc = fn(*args)
+                n1 = self.lib.mgn_plan_recorded()
+                if n1 > n0:
+                    touch, self.pending_touch = self.pending_touch, ([], [])
+                    cur = self.lib.mgn_plan_current()
+                    for i in range(n0, n1):
+                        st, r, w, nm = self._node_accesses(cur, i)   # (resolved NOW: the allocator's blocks change as the step goes on)
+                        if i == n1 - 1:
+                            r, w = r + touch[0], w + touch[1]
+                        self.timeline.append(("node", dict(node=i, stream=int(st), reads=r, writes=w, name=nm)))
+                return rc
+        return call
+
+    def _node_accesses(self, plan, i):
+        """-> (stream, reads, writes, kernel name) of recorded node i: pointer arguments resolved to the blocks they point into"""
+        lib, info, offs, sizes, kinds, blocks = self.lib, self._info, self._offs, self._sizes, self._kinds, self.blocks
+        _C.check(lib.mgn_plan_node_info(plan, i, ctypes.byref(info)), "mgn_plan_node_info")
+        if info.type != 0:
+            return info.stream or 0, [], [], "prof"
+        n = lib.mgn_plan_node_args(plan, i, len(offs), offs, sizes, kinds)
+        if n < 0:
+            raise PlanUnsupported("a kernel with more arguments than the recorder holds")
+        raw = ctypes.string_at(info.blob, info.nbytes) if info.nbytes else b""
+        lo = blocks.starts[0] if blocks.starts else 0
+        hi = blocks.ends[-1] if blocks.ends else 0
+        reads, writes = [], []
+        for k in range(n):
+            o, sz, kd = offs[k], sizes[k], kinds[k]
+            if kd:
+                p = int.from_bytes(raw[o:o + 8], "little")
+                if p:
+                    b = blocks.find(p)
+                    if b is None:
+                        self.unresolved.add(p)
+                    else:
+                        (reads if kd == 1 else writes).append(b)
+            elif sz >= 8:   # by-value struct: every aligned 8-byte word that points into a live block counts as read + written
+                words = np.frombuffer(raw[o:o + (sz // 8) * 8], dtype=np.uint64)
+                for p in words[(words >= lo) & (words < hi)]:
+                    b = blocks.find(int(p))
+                    if b is not None:
+                        writes.append(b)
+        return info.stream or 0, reads, writes, info.name.decode() if info.name else "?"
+
+    def touch(self, reads, writes):
+        """memory the NEXT library call reaches through pointers stored in device memory (descriptor tables)"""
+        with self.lock:
+            self.pending_touch[0].extend(_extent(t) for t in reads)
+            self.pending_touch[1].extend(_extent(t) for t in writes)
+
+    # ---- torch ops -----------------------------------------------------------------------------------------------------
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        out = func(*args, **kwargs)
+        try:
+            self._note(func, args, kwargs, out)
+        except PlanUnsupported as e:   # (raised later, outside the dispatcher)
+            self.error = self.error or e
+        return out
+
+    def _note(self, func, args, kwargs, out):
+        outs = list(_tensors(out))
+        ins = list(_tensors(args)) + list(_tensors(list(kwargs.values())))
+        cuda_out = [t for t in outs if t.is_cuda]
+        if not cuda_out and not any(t.is_cuda for t in ins):
+            return
+        with self.lock:
+            for t in cuda_out:
+                if t.untyped_storage().nbytes():
+                    self.blocks.add(*_extent(t))
+        sch = func._schema
+        name = sch.name.split("::")[-1] + "." + (func._overloadname or "default")
+        if sch.name == "aten::_local_scalar_dense":
+            raise PlanUnsupported("a device -> host read (.item()) inside the step")
+        if name in _ALLOC_ONLY or sch.name.startswith("c10d") or sch.name in ("aten::record_stream", "aten::is_pinned", "aten::detach",
+                                                                               "aten::alias", "aten::lift_fresh"):
+            return
+        written = [a for a, s in zip(args, sch.arguments) if s.alias_info is not None and s.alias_info.is_write]
+        written += [kwargs[s.name] for s in sch.arguments if s.name in kwargs and s.alias_info is not None and s.alias_info.is_write]
+        in_ptrs = {t.untyped_storage().data_ptr() for t in ins}
+        is_view = bool(outs) and not written and all(t.untyped_storage().data_ptr() in in_ptrs for t in outs)
+        if is_view or (not outs and not written):
+            return
+        stream = torch.cuda.current_stream(self.device)
+        wset = list(_tensors(written))
+        args, kwargs, outs = _detached(args), _detached(kwargs), _detached(outs)
+        cuda_out = [t for t in outs if t.is_cuda]
+        if written:      # in-place / out= form: replays as it is
+            call = (func, args, kwargs)
+            w_ext = [_extent(t) for t in wset if t.is_cuda]
+            r_ext = [_extent(t) for t in ins if t.is_cuda and not any(t is w for w in wset)]
+        else:            # functional form: replay into the recorded outputs
+            if sch.name == "aten::_to_copy" and len(outs) == 1:
+                src = args[0]
+                call = (torch.ops.aten.copy_.default, (outs[0], src, bool(kwargs.get("non_blocking", False))), {})
+            else:
+                outv = getattr(func.overloadpacket, "out", None)
+                if outv is None or len(outs) != 1:
+                    raise PlanUnsupported(f"torch op {name} inside the step has no out= form")
+                names = {a.name for a in outv._schema.arguments}
+                kw = {k: v for k, v in kwargs.items() if k in names}
+                kw["out"] = outs[0]
+                try:
+                    with torch.no_grad():
+                        outv(*args, **kw)   # (validates the form now, not at the first replay; rewrites the same values)
+                except Exception as e:  # noqa: BLE001
+                    raise PlanUnsupported(f"torch op {name} inside the step: out= form failed ({type(e).__name__}: {e})")
+                call = (outv, args, kw)
+            w_ext = [_extent(t) for t in cuda_out]
+            r_ext = [_extent(t) for t in ins if t.is_cuda]
+        with self.lock:
+            self.keep.append((args, kwargs, out))
+            self.timeline.append(("torch", dict(call=call, stream=stream, name=name, reads=r_ext, writes=w_ext)))
+
+
+class _LibProxy:
+    def __init__(self, lib, rec):
+        self._lib, self._rec, self._cache = lib, rec, {}
+
+    def __getattr__(self, name):
+        f = self._cache.get(name)
+        if f is None:
+            f = self._cache[name] = self._rec.wrap(name, getattr(self._lib, name))
+        return f
+
+
+class StepPlan:
+    """`StepPlan.record(body, device)` runs `body()` (one training step: zero_grad, forward, backward, finish, optimizer launches) eagerly
+    and returns the plan; `replay(prof_slot)` issues the same device work again."""
+
+    def __init__(self):
+        self.handle, self.pool, self.closures, self.keep, self.report = None, None, [], [], {}
+
+    # ---------------------------------------------------------------------------------------------------------------------
+    @classmethod
+    def record(cls, body, device, prof_slots=0):
+        lib = _C.lib()
+        self = cls()
+        dev_index = device.index if device.index is not None else torch.cuda.current_device()
+        gc.collect()
+        torch.cuda.synchronize(device)
+        main = torch.cuda.current_stream(device)
+        self.pool = torch.cuda.MemPool()
+        rec = _Recorder(lib, device)
+        _C.check(lib.mgn_plan_begin(), "mgn_plan_begin")
+        torch._C._cuda_beginAllocateToPool(dev_index, self.pool.id)
+        _C._lib = _LibProxy(lib, rec)
+        _C.PLAN_RECORDER[0] = rec
+        result = None
+        try:
+            with rec:
+                result = body()
+        except BaseException:
+            lib.mgn_plan_abort()
+            raise
+        finally:
+            _C._lib = lib
+            _C.PLAN_RECORDER[0] = None
+            torch._C._cuda_endAllocateToPool(dev_index, self.pool.id)
+        if rec.error is not None:
+            lib.mgn_plan_abort()
+            raise rec.error
+        h = ctypes.c_void_p()
+        _C.check(lib.mgn_plan_end(ctypes.byref(h)), "mgn_plan_end")
+        self.handle = h
+        torch.cuda.synchronize(device)
+        self.keep = [rec.keep, result]
+        self._schedule(rec, main, prof_slots)
+        return self, result
+
+    # ---------------------------------------------------------------------------------------------------------------------
+    def _schedule(self, rec, main, prof_slots):
+        lib = _C.lib()
+        self._unresolved = rec.unresolved
+        items = []
+        for ent in rec.timeline:
+            if ent[0] == "node":
+                items.append(dict(ent[1], kind=0))
+            else:
+                c = ent[1]
+                items.append(dict(kind=1, closure=c, stream=int(c["stream"].cuda_stream), reads=c["reads"], writes=c["writes"], name=c["name"]))
+        main_id = int(main.cuda_stream)
+        streams = sorted({it["stream"] for it in items} | {main_id})
+        sidx = {s: k for k, s in enumerate(streams)}
+        ns = len(streams)
+        # ---- dependency analysis: vector clocks over per-stream positions ------------------------------------------------------
+        clock = np.zeros((ns, ns), dtype=np.int64)        # clock[s][t] = position on t that s is ordered behind (1-based, 0 = start)
+        pos = [0] * ns
+        acc_s, acc_e, acc_stream, acc_pos, acc_w = [], [], [], [], []
+        need_event = {}                                   # (stream index, pos) -> event id
+        waits = [[] for _ in items]                       # per item: event ids to wait for
+        clock_at = {}
+        where = {}                                        # (stream index, pos) -> item index
+        S = E = ST = PS = WR = np.zeros(0, dtype=np.int64)
+        flushed = 0
+        for k, it in enumerate(items):
+            s = sidx[it["stream"]]
+            pos[s] += 1
+            mine = [(a, b, 0) for a, b in it["reads"]] + [(a, b, 1) for a, b in it["writes"]]
+            if len(acc_s) > flushed:
+                S = np.concatenate([S, np.array(acc_s[flushed:], dtype=np.int64)])
+                E = np.concatenate([E, np.array(acc_e[flushed:], dtype=np.int64)])
+                ST = np.concatenate([ST, np.array(acc_stream[flushed:], dtype=np.int64)])
+                PS = np.concatenate([PS, np.array(acc_pos[flushed:], dtype=np.int64)])
+                WR = np.concatenate([WR, np.array(acc_w[flushed:], dtype=np.int64)])
+                flushed = len(acc_s)
+            need = np.zeros(ns, dtype=np.int64)
+            if len(S):
+                for a, b, w in mine:
+                    m = (S < b) & (E > a) & (ST != s) & ((WR == 1) | (w == 1))
+                    if m.any():
+                        np.maximum.at(need, ST[m], PS[m])
+            for t in range(ns):
+                if t != s and need[t] > clock[s][t]:
+                    key = (t, int(need[t]))
+                    ev = need_event.get(key)
+                    if ev is None:
+                        ev = need_event[key] = len(need_event)
+                    waits[k].append(ev)
+                    clock[s] = np.maximum(clock[s], clock_at[key])
+            clock[s][s] = pos[s]
+            clock_at[(s, pos[s])] = clock[s].copy()
+            where[(s, pos[s])] = k
+            for a, b, w in mine:
+                acc_s.append(a); acc_e.append(b); acc_stream.append(s); acc_pos.append(pos[s]); acc_w.append(w)
+        record_after = {}
+        for (t, q), ev in need_event.items():
+            record_after.setdefault(where[(t, q)], []).append(ev)
+        # ---- the op list ------------------------------------------------------------------------------------------------------
+        LAUNCH, RECORD, WAIT, BREAK = 0, 1, 2, 3
+        n_ev = len(need_event)
+        ops = []
+        e_start = n_ev
+        n_ev += 1
+        ops.append((RECORD, e_start, main_id))
+        for st in streams:
+            if st != main_id:
+                ops.append((WAIT, e_start, st))
+        self.closures = []
+        for k, it in enumerate(items):
+            for ev in waits[k]:
+                ops.append((WAIT, ev, it["stream"]))
+            if it["kind"] == 0:
+                ops.append((LAUNCH, it["node"], it["stream"]))
+            else:
+                ops.append((BREAK, 0, it["stream"]))
+                self.closures.append(it["closure"])
+            for ev in record_after.get(k, []):
+                ops.append((RECORD, ev, it["stream"]))
+        for st in streams:
+            if st != main_id:
+                ops.append((RECORD, n_ev, st))
+                ops.append((WAIT, n_ev, main_id))
+                n_ev += 1
+        n = len(ops)
+        types = (ctypes.c_int * n)(*[o[0] for o in ops])
+        aa = (ctypes.c_int * n)(*[o[1] for o in ops])
+        ss = (ctypes.c_void_p * n)(*[o[2] or None for o in ops])
+        _C.check(lib.mgn_plan_compile(self.handle, n, types, aa, ss, n_ev, prof_slots), "mgn_plan_compile")
+        self.main, self.n_ops = main, n
+        kernels = sum(1 for it in items if it["kind"] == 0)
+        by_name = {}
+        for it in items:
+            if it["kind"] == 1:
+                by_name[it["name"]] = by_name.get(it["name"], 0) + 1
+        self.report = {"kernel_launches": kernels, "torch_ops_replayed": len(self.closures), "torch_ops": by_name, "streams": ns,
+                       "cross_stream_events": len(need_event), "plan_ops": n, "pointers_outside_torch_memory": len(self._unresolved)}
+
+    # ---------------------------------------------------------------------------------------------------------------------
+    def replay(self, prof_slot=-1):
+        lib, h = _C.lib(), self.handle
+        k = 0
+        run = lib.mgn_plan_run
+        for c in self.closures:
+            k = run(h, k, prof_slot)
+            if k < 0:
+                _C.check(k, "mgn_plan_run")
+            f, a, kw = c["call"]
+            torch.cuda.set_stream(c["stream"])
+            with torch.no_grad():
+                f(*a, **kw)
+        if self.closures:
+            torch.cuda.set_stream(self.main)
+        k = run(h, k, prof_slot)
+        if k != self.n_ops:
+            _C.check(k if k < 0 else -5, "mgn_plan_run")
+
+    def prof_elapsed_ms(self, slot):
+        ms = ctypes.c_float()
+        _C.check(_C.lib().mgn_plan_prof_elapsed(self.handle, slot, ctypes.byref(ms)), "mgn_plan_prof_elapsed")
+        return ms.value
+
+    def close(self):
+        if self.handle is not None:
+            _C.lib().mgn_plan_free(self.handle)
+            self.handle = None
+        self.closures, self.keep = [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -93,6 +93,52 @@ class Trainer:
         self.storage.step()
         return self._graph_losses
 
+    # ---- launch-plan replay (engine/plan.py) -------------------------------------------------------------------------------
+    # The eager step issues ~700 launches from Python (autograd nodes, ctypes calls, torch allocations): 19-25 ms of host time against a
+    # ~29 ms GPU-bound step.  One eager step is recorded as a table of launches with by-value arguments (side streams included, their
+    # dependencies derived from the memory each launch touches) and replayed from C; per replay the host uploads the learning-rate
+    # tables and walks the table.  Unlike the hipGraph above it keeps the concurrent branches and costs a few ms of host time per step.
+    def record_plan(self, batched_inputs, prof_slots=0):
+        """Record forward + backward + clip + Adam for `batched_inputs` (device tensors that stay alive and are refilled in place between
+        replays) as a launch plan.  Needs a few eager steps before it (lazy workspaces, layout cache, allocator warm-up).  Single-process
+        runs; raises engine.plan.PlanUnsupported when the step contains something a replay cannot express (the trainer then stays eager)."""
+        from .plan import PlanUnsupported, StepPlan
+        if self.reducer.world != 1:
+            raise PlanUnsupported("multi-rank steps stay eager (collectives are issued by torch.distributed)")
+        if not hasattr(self.optimizer, "launch_step"):
+            raise PlanUnsupported("plan replay needs the fused optimizer")
+        self.model.train()
+        from .. import _C
+        _C.weight_cache.refresh()   # (drop the rows of collected models now: the recorded refresh launch keeps this table)
+        dev = next(self.model.parameters()).device
+        self.optimizer.prepare_step()
+
+        def body():
+            self.reducer.zero_grad()
+            with self.storage:
+                loss_dict = self.model(batched_inputs)
+                self._backward(loss_dict)
+            self.reducer.finish()
+            self.optimizer.launch_step()
+            return {k: v.detach() for k, v in loss_dict.items()}
+
+        plan, losses = StepPlan.record(body, dev, prof_slots=prof_slots)
+        self.scheduler.step()
+        self.iter += 1
+        self.storage.step()
+        self._plan, self._plan_losses, self._plan_inputs = plan, losses, batched_inputs
+        self._plan_keep = [_C.weight_cache.table]
+        return plan
+
+    def replay_plan(self, prof_slot=-1):
+        """one training step = upload the per-step tables + replay the recorded launches"""
+        self.optimizer.prepare_step()
+        self._plan.replay(prof_slot)
+        self.scheduler.step()
+        self.iter += 1
+        self.storage.step()
+        return self._plan_losses
+
     def _backward(self, loss_dict):
         """sum of the loss dict -> backward; with fp16 activations the sum is multiplied by the dynamic loss scale first
         (GradScaler.scale(losses).backward(), detectron2 AMPTrainer.run_step)"""

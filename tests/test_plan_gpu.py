@@ -1,0 +1,84 @@
+"""Launch-plan replay (engine/plan.py, csrc/plan.hip): a step recorded once and replayed from C gives the SAME trajectory, bit for bit,
+as eager steps -- losses and every parameter after several optimizer steps, side streams on, refilled inputs seen."""
+import copy
+import os
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(seed=0, H=128, W=256, B=2, dtype="bfloat16"):
+    from mgnet_amd import add_mgnet_config, get_cfg
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.engine import Trainer
+    from mgnet_amd.registry import build_model
+
+    dev = torch.device("cuda:0")
+    cfg = get_cfg()
+    add_mgnet_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "bench-c4-cityscapes-videosequence.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", str(dev), "SOLVER.IMS_PER_BATCH", B, "MODEL.SEM_SEG_HEAD.OHEM_N_MIN", B * H * W // 16,
+                         "SOLVER.AMP.DTYPE", dtype])
+    torch.manual_seed(seed)
+    model = build_model(cfg)
+    return Trainer(cfg, model), synthetic_batch(B, H, W, dev, seed=11), synthetic_batch(B, H, W, dev, seed=12)
+
+
+def _refill(dst, src):
+    for d, s in zip(dst, src):
+        for k, v in d.items():
+            if isinstance(v, torch.Tensor):
+                v.copy_(s[k])
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_replayed_steps_equal_eager_steps_bit_for_bit(dtype):
+    steps = 4
+    ta, batch_a, other_a = _trainer(dtype=dtype)
+    tb, batch_b, other_b = _trainer(dtype=dtype)
+    # reference: eager steps (3 warm-up + `steps`, the input changes half way)
+    la = []
+    for k in range(3 + steps):
+        if k == 3 + steps // 2:
+            _refill(batch_a, other_a)
+        la.append({n: float(v) for n, v in ta.run_step(batch_a).items()})
+    # plan: 3 eager warm-up steps, one recorded step, then replays
+    lb = []
+    for k in range(3):
+        lb.append({n: float(v) for n, v in tb.run_step(batch_b).items()})
+    plan = tb.record_plan(batch_b)
+    lb.append({n: float(v) for n, v in tb._plan_losses.items()})
+    for k in range(4, 3 + steps):
+        if k == 3 + steps // 2:
+            _refill(batch_b, other_b)
+        lb.append({n: float(v) for n, v in tb.replay_plan().items()})
+    torch.cuda.synchronize()
+    assert plan.report["kernel_launches"] > 300 and plan.report["streams"] >= 2, plan.report
+    for k, (a, b) in enumerate(zip(la, lb)):
+        assert a == b, (k, a, b, plan.report)
+    for (na, pa), (nb, pb) in zip(ta.model.named_parameters(), tb.model.named_parameters()):
+        assert torch.equal(pa, pb), na
+    for (na, ba), (nb, bb) in zip(ta.model.named_buffers(), tb.model.named_buffers()):
+        assert torch.equal(ba, bb), na
+
+
+def test_replay_is_repeatable_and_coexists_with_eager_work():
+    """eager work between replays (another model's steps: allocator traffic, library counters) does not disturb the plan's memory"""
+    ta, batch_a, _ = _trainer(seed=1)
+    for _ in range(3):
+        ta.run_step(batch_a)
+    ta.record_plan(batch_a)
+    tb, batch_b, _ = _trainer(seed=2)
+    ref, _, _ = _trainer(seed=1)
+    ref_batch = batch_a
+    for _ in range(4):
+        ref.run_step(ref_batch)
+    for k in range(3):
+        tb.run_step(batch_b)
+        la = {n: float(v) for n, v in ta.replay_plan().items()}
+        lr = {n: float(v) for n, v in ref.run_step(ref_batch).items()}
+        assert la == lr, (k, la, lr)
