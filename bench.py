@@ -198,15 +198,23 @@ def fp16_leg(args, dev, B, H, W, steps=5):
     batch = synthetic_batch(B, H, W, dev, seed=1234)
     for _ in range(4):
         trainer.run_step(batch)
+    step, mode, warm = (lambda: trainer.run_step(batch)), "eager", 4
+    if args.exec in ("auto", "plan"):
+        try:   # the same execution mode as the headline measurement: launch-plan replay
+            trainer.record_plan(batch)
+            trainer.replay_plan()
+            step, mode, warm = trainer.replay_plan, "plan", 6
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] fp16 leg: plan recording failed ({type(e).__name__}: {e}); eager steps timed", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        last = trainer.run_step(batch)
+        last = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     sc = [float(v) for v in trainer.optimizer.scaler.tolist()]
-    return {"dtype": "fp16", "ms_per_step": round(dt * 1e3, 3), "value": round(B / dt, 2), "unit": "img/s", "steps": steps,
-            "loss_scale": sc[0], "optimizer_steps_taken": int(sc[2]), "steps_attempted": 4 + steps,
+    return {"dtype": "fp16", "ms_per_step": round(dt * 1e3, 3), "value": round(B / dt, 2), "unit": "img/s", "steps": steps, "step_execution": mode,
+            "loss_scale": sc[0], "optimizer_steps_taken": int(sc[2]), "steps_attempted": warm + steps,
             "losses_finite": bool(all(torch.isfinite(v.detach()).item() for v in last.values()))}
 
 
@@ -242,9 +250,20 @@ def full_step_bench(args, world, rank, dev):
     # latency); "graph" (--graph on, one rank only) = the whole step captured once in a hipGraph on ONE stream and replayed.
     # Measured (end of round 2): eager + side streams 30.2 ms, graph 32.5 ms (capturing the side-stream branches crashes hipGraph on ROCm 7.0).
     use_graph = args.graph == "on" and world == 1
-    mode = "eager"
-    for _ in range(max(args.warmup, 3) if use_graph else args.warmup):
+    use_plan = args.exec in ("auto", "plan") and world == 1 and not use_graph
+    mode, plan_note = "eager", None
+    for _ in range(max(args.warmup, 3) if (use_graph or use_plan) else args.warmup):
         trainer.run_step(batch)
+    if use_plan:
+        # launch-plan replay (engine/plan.py): one eager step recorded, the timed steps replayed from C with the side streams kept
+        try:
+            plan = trainer.record_plan(batch, prof_slots=args.steps)
+            for _ in range(2):
+                trainer.replay_plan()
+            mode = "plan"
+        except Exception as e:  # noqa: BLE001 -- report and fall back to the eager step rather than lose the measurement
+            plan_note = f"plan recording failed ({type(e).__name__}: {e}); eager steps timed"
+            print(f"[bench] {plan_note}", file=sys.stderr, flush=True)
     if use_graph:
         try:
             trainer.capture_step(batch)
@@ -258,6 +277,9 @@ def full_step_bench(args, world, rank, dev):
     if mode == "graph":
         for k in range(args.steps):
             last = trainer.replay_step()
+    elif mode == "plan":
+        for k in range(args.steps):
+            last = trainer.replay_plan(prof_slot=k)
     else:
         for k in range(args.steps):
             depth_loss.prof_events = ev.pairs[k]
@@ -272,11 +294,27 @@ def full_step_bench(args, world, rank, dev):
             depth_loss.prof_events = ev.pairs[k]
             trainer.run_step(batch)
         fence()
+    # What the host needs to ISSUE one step at the benchmark size: the issue call timed with an EMPTY launch queue (device synchronised
+    # before each step, none inside), so that it measures the host's own work and not the wait for queue slots -- over the K timed steps
+    # the issue loop runs ahead of a GPU-bound step only until the hardware queues are full, and its wall time then equals the GPU's.
+    issue_one = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        if mode == "plan":
+            trainer.replay_plan()
+        elif mode == "graph":
+            trainer.replay_step()
+        else:
+            trainer.run_step(batch)
+        issue_one.append(time.perf_counter() - ti)
+    torch.cuda.synchronize()
+    host_issue_ms = float(np.median(issue_one)) * 1e3
     # What the host needs to ISSUE a step, measured where the GPU cannot back-pressure the launch queue: the same model and launch
     # sequence on two 512x1024 frames (an eighth of the device work, the same host work).  `host_issue_ms_per_step` above is the
     # wall time of the launch loop at the benchmark size, which mostly waits for queue slots once the GPU is the bottleneck.
     host_unloaded = None
-    if rank == 0 and world == 1 and mode == "eager" and not args.no_host_probe:
+    if rank == 0 and world == 1 and mode in ("eager", "plan") and not args.no_host_probe:
         try:
             small = synthetic_batch(2, 512, 1024, dev, seed=7)
             for _ in range(2):
@@ -319,7 +357,7 @@ def full_step_bench(args, world, rank, dev):
                      "exposed_grad_allreduce_ms_per_step": round(dt / args.steps * 1e3 - float(t_no.item()) * 1e3, 3)}
     if rank == 0:
         state_dict_cpu = None if (args.no_cpu_baseline or world > 1) else {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
-        kern_ms = float(np.median(ev.elapsed_ms()))
+        kern_ms = float(np.median([plan.prof_elapsed_ms(k) for k in range(args.steps)] if mode == "plan" else ev.elapsed_ms()))
         npx = B * H * W
         u8_frames = model._orig_frames_u8(batch) is not None     # the layout MGNet.forward hands to the loss for this batch
         traffic = None
@@ -342,16 +380,21 @@ def full_step_bench(args, world, rank, dev):
                                    f"{B} frames/GPU of {H}x{W}",
                        "frames_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
                        "parallelism": f"dp{world}", "step_execution": mode + (" (one hipGraph replay per step, one stream)" if mode == "graph" else
+                                                  (" replay: one recorded step's launches re-issued from C (csrc/plan.hip), side streams kept; " + json.dumps(plan.report)) if mode == "plan" else
                                                   " (launches issued from Python; side streams for the independent branches: " +
-                                                  ("on" if model._side_streams() is not None else "off") + ")"),
-                       "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2),
-                       "host_issue_ms_per_step_unloaded": None if host_unloaded is None else round(host_unloaded, 2), "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
+                                                  ("on" if model._side_streams() is not None else "off") + ")" + (f"; {plan_note}" if plan_note else "")),
+                       "host_issue_ms_per_step": round(host_issue_ms, 2),
+                       "host_issue_is": "wall time of issuing ONE step of this workload into an empty launch queue (median of 5, after the timed region)",
+                       "host_issue_loop_wall_ms_per_step": round(t_issue / args.steps * 1e3, 2),
+                       "host_issue_loop_wall_is": "wall time of the K-step issue loop / K: includes waiting for launch-queue slots once the GPU is the bottleneck",
+                       "host_issue_ms_per_step_unloaded": None if host_unloaded is None else round(host_unloaded, 2),
+                       "host_issue_unloaded_is": "the EAGER issue of the same step (Python / autograd / ctypes), measured at an eighth of the device work", "conv_tflops_per_gpu": round(3 * gflop_fwd * img_s / world / 1e3, 1),
                        "losses": {k: round(float(v.detach()), 5) for k, v in last.items()},
                        "torch_staging_ops": sorted(__import__("mgnet_amd.modeling.ops", fromlist=["x"]).STAGING_USED)},
             "roofline": reproj_roofline(kern_ms, npx, u8_frames, traffic, {
                 "timed_with": "hipEvent pairs around the kernel on its launch stream, " +
                               (f"{args.steps} eager steps run right after the graph-replayed timed region" if mode == "graph"
-                               else "inside the timed steps")}),
+                               else "recorded by the replayed plan inside the timed steps" if mode == "plan" else "inside the timed steps")}),
         }
         if dist_info is not None:
             line["config"]["distributed"] = dist_info
@@ -450,6 +493,8 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
                     help="16-bit activation format of the trunk: bf16 (default) or the reference's AMP format fp16 with dynamic loss "
                          "scaling (BASELINE C5)")
+    ap.add_argument("--exec", choices=["auto", "plan", "eager"], default="auto",
+                    help="how the timed steps are issued on one rank: plan = launch-plan replay from C (default when it records), eager = from Python")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="on: replay the captured step as a hipGraph (1 GPU, one stream); auto/off: issue every launch from Python "
                          "with the independent branches on side streams (the faster mode)")
