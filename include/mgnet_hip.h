@@ -446,7 +446,11 @@ int mgn_head_act_bwd(const float* g, long sb, long sc, long sp, const float* y, 
  *                             = one per stream that issues exchanges; seq = 1, 2, 3, ... per channel, the same on every rank; payload:
  *                             n <= MGN_P2P_SLOT_FLOATS fp32; reduce = 0: out[world][n] = every rank's payload (all_gather), 1: out[n] =
  *                             sum over ranks in rank order (all_reduce; bit-identical on every rank).  payload and out must not overlap.
- *                             status: device int, set to 1 if a peer did not post within timeout_s (results then undefined).
+ *                             seq_counters (optional): DEVICE array [MGN_P2P_CHANNELS][MGN_P2P_MAX_WORLD] of uint32, zeroed once; when
+ *                             given, the kernel counts the channel's exchanges itself and `seq` is ignored (no per-launch host value:
+ *                             a recorded step can be replayed, mgn_plan_*).
+ *                             status: int in HOST-VISIBLE memory (pinned), set to 1 if a peer did not post within timeout_s; the
+ *                             output is then filled with NaN (a timed-out exchange makes the step's losses non-finite at once).
  * Every rank must issue the same exchanges in the same order per channel, and exchanges of one channel must be stream-ordered.
  * ---------------------------------------------------------------------------------------------- */
 #define MGN_P2P_CHANNELS 4
@@ -459,8 +463,8 @@ int mgn_p2p_free(void* mailbox);
 int mgn_p2p_export(void* mailbox, void* handle64);
 int mgn_p2p_open(const void* handle64, void** peer_mailbox);
 int mgn_p2p_close(void* peer_mailbox);
-int mgn_p2p_exchange(void* const* mailboxes, int world, int rank, int channel, unsigned seq, const float* payload, int n, int reduce,
-                     float* out, int* status, float timeout_s, void* stream);
+int mgn_p2p_exchange(void* const* mailboxes, int world, int rank, int channel, unsigned seq, unsigned* seq_counters, const float* payload,
+                     int n, int reduce, float* out, int* status, float timeout_s, void* stream);
 
 /* The stem's activated batch norm folded into the pooling (BasicStem, res_net.py:82-110: conv -> InPlaceABNSync -> max_pool):
  * forward pools y = act(scale * x + offset) evaluated on the fly (bf16-rounded like mgn_iabn_apply stores it; the

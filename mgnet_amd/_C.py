@@ -176,7 +176,7 @@ def lib():
         L.mgn_p2p_export.argtypes = [vp, vp]
         L.mgn_p2p_open.argtypes = [vp, ctypes.POINTER(vp)]
         L.mgn_p2p_close.argtypes = [vp]
-        L.mgn_p2p_exchange.argtypes = [vp, ci, ci, ci, ctypes.c_uint, vp, ci, ci, vp, vp, cf, vp]
+        L.mgn_p2p_exchange.argtypes = [vp, ci, ci, ci, ctypes.c_uint, vp, vp, ci, ci, vp, vp, cf, vp]
         L.mgn_msc_input.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_msc_accumulate.argtypes = [vp, ci, cl, cl, cl, cl] + [ci] * 9 + [cf, cf, cf, vp, vp]
         L.mgn_iabn_bwd_reduce_x.argtypes = [vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, ci, cf, vp, vp, vp, sz, vp]
@@ -884,8 +884,15 @@ def conv_igemm(x, w_ohwi, out_shape, bias, stride, pad, up=1, relu=False, out_dt
 # Deferred split-K reductions (engine/reducer.py): while WGRAD_LAZY[0] is set, conv_wgrad(lazy=True) leaves the partial tiles in their
 # workspace, returns an UNWRITTEN gradient tensor and registers the reduction under the tensor's address; the gradient reducer
 # collects the entries of a bucket's parameters and runs them as ONE launch that writes straight into the bucket (wgrad_reduce_batch)
-WGRAD_LAZY = [False]
-WGRAD_PENDING = {}
+WGRAD_LAZY = [False]      # False, or the id() of the GradReducer whose backward is running (the owner of the entries it registers)
+WGRAD_PENDING = {}        # gradient tensor address -> (descriptor, workspace, shape, owner)
+
+
+def wgrad_pending_drop(owner):
+    """forget the deferred reductions registered by one reducer (its backward raised / a new step starts): entries of ANOTHER reducer in
+    the same process -- a second model, a teacher / student pair, bench legs -- are not touched"""
+    for k in [k for k, e in WGRAD_PENDING.items() if e[3] == owner]:
+        del WGRAD_PENDING[k]
 _wgrad_stager = None
 
 
@@ -922,7 +929,7 @@ def conv_wgrad(dy, x, kh, kw, stride, pad, cin_real=None, lazy=False):
         rc = _fn("mgn_conv_wgrad_partial", dy)(dy.data_ptr(), x.data_ptr(), N, IH, IW, Cin, OH, OW, Cout, kh, kw, stride, pad, cin_real,
                                                ws.data_ptr(), nb.value, desc, _stream())
         if rc == 0:
-            WGRAD_PENDING[dw.data_ptr()] = (list(desc), ws, tuple(dw.shape))
+            WGRAD_PENDING[dw.data_ptr()] = (list(desc), ws, tuple(dw.shape), WGRAD_LAZY[0])
             return dw
         if rc != -95:
             check(rc, "mgn_conv_wgrad_partial")

@@ -17,7 +17,7 @@
 //   Memory model: payload stores, __threadfence_system(), flag store with release / system scope; the reader spins with acquire /
 //   system-scope loads (s_sleep between polls), fences, then reads its own (local) mailbox.  The combination over ranks runs in rank
 //   order on every rank: bit-identical results everywhere, as with the gather + local combine it replaces.
-//   A wait that exceeds its budget (a peer that died) sets status[0] and leaves; the host checks the word when it synchronises anyway.
+//   A wait that exceeds its budget (a peer that died) sets status[0] (host-visible) and fills the output with NaN: see the kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -43,16 +43,35 @@ __device__ __forceinline__ uint32_t* slot_flag(float* mail, int chan, int slot, 
 
 // grid = world blocks: block b pushes this rank's payload into peer b's mailbox; block 0 then waits for every rank's flag in the OWN
 // mailbox and writes  REDUCE ? out[i] = sum_r data_r[i] : out[r][i] = data_r[i]
+//
+// seq: the exchange number of the channel.  Either the host counts it (`seq`), or -- seq_ctr != null -- the DEVICE does: block b keeps
+// its own counter seq_ctr[chan][b] (every launch has exactly `world` blocks and each advances its own, so all blocks of a launch, and
+// the same launch on every rank, agree without talking to each other).  The device form has no per-launch host value, which is what
+// lets a recorded step be replayed (csrc/plan.hip).
+// A wait that runs out of its budget (a peer that died or diverged in its launch order) is LOUD: `status` (host-visible pinned memory,
+// polled by the trainer every step without a device synchronisation) is set, and the output is filled with NaN so that the losses of
+// this very step are non-finite -- never silently wrong statistics in the forward, the running means and the optimizer.
 template <bool REDUCE>
-__global__ __launch_bounds__(256) void p2p_exchange(Peers peers, int world, int rank, int chan, uint32_t seq, const float* __restrict__ payload,
-                                                    int n, float* __restrict__ out, int* status, long long budget_ticks) {
-    const int slot = (int)(seq % P2P_RING), tid = threadIdx.x, b = blockIdx.x;
+__global__ __launch_bounds__(256) void p2p_exchange(Peers peers, int world, int rank, int chan, uint32_t seq, uint32_t* seq_ctr,
+                                                    const float* __restrict__ payload, int n, float* __restrict__ out, int* status,
+                                                    long long budget_ticks) {
+    const int tid = threadIdx.x, b = blockIdx.x;
+    __shared__ int bad;
+    if (seq_ctr) {
+        uint32_t* c = seq_ctr + chan * P2P_MAXW + b;
+        seq = *c + 1u;          // (block-uniform: read by every thread before thread 0 advances it behind the barrier below)
+    }
+    const int slot = (int)(seq % P2P_RING);
+    if (tid == 0) bad = 0;
     {   // ---- post to peer b ----
         float* dst = slot_data(peers.mail[b], chan, slot, rank);
         for (int i = tid; i < n; i += 256) dst[i] = payload[i];
         __threadfence_system();
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(slot_flag(peers.mail[b], chan, slot, rank), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) {
+            __hip_atomic_store(slot_flag(peers.mail[b], chan, slot, rank), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (seq_ctr) seq_ctr[chan * P2P_MAXW + b] = seq;
+        }
     }
     if (b != 0) return;
     // ---- wait for all ranks (own mailbox) ----
@@ -62,14 +81,21 @@ __global__ __launch_bounds__(256) void p2p_exchange(Peers peers, int world, int 
         const long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
             __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > budget_ticks) {   // a peer never posted: flag the failure and leave (results are garbage)
-                atomicExch(status, 1);
+            if (wall_clock64() - t0 > budget_ticks) {   // a peer never posted
+                bad = 1;
+                __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
     }
     __syncthreads();
     __threadfence_system();
+    if (bad) {
+        const float qnan = __builtin_nanf("");
+        const int total = REDUCE ? n : world * n;
+        for (int i = tid; i < total; i += 256) out[i] = qnan;
+        return;
+    }
     if (REDUCE) {
         for (int i = tid; i < n; i += 256) {
             float s = 0.f;
@@ -135,10 +161,10 @@ int mgn_p2p_open(const void* handle64, void** peer_mailbox) {
 
 int mgn_p2p_close(void* peer_mailbox) { return (!peer_mailbox || hipIpcCloseMemHandle(peer_mailbox) == hipSuccess) ? MGN_OK : MGN_EINVAL; }
 
-int mgn_p2p_exchange(void* const* mailboxes, int world, int rank, int channel, unsigned seq, const float* payload, int n, int reduce,
-                     float* out, int* status, float timeout_s, void* stream) {
-    if (!mailboxes || world < 1 || world > P2P_MAXW || rank < 0 || rank >= world || channel < 0 || channel >= P2P_CHANNELS || seq == 0 ||
-        !payload || n < 1 || n > P2P_SLOT || !out || !status || !(timeout_s > 0.f))
+int mgn_p2p_exchange(void* const* mailboxes, int world, int rank, int channel, unsigned seq, unsigned* seq_counters, const float* payload, int n,
+                     int reduce, float* out, int* status, float timeout_s, void* stream) {
+    if (!mailboxes || world < 1 || world > P2P_MAXW || rank < 0 || rank >= world || channel < 0 || channel >= P2P_CHANNELS ||
+        (seq == 0 && !seq_counters) || !payload || n < 1 || n > P2P_SLOT || !out || !status || !(timeout_s > 0.f))
         return MGN_EINVAL;
     Peers pr;
     for (int r = 0; r < P2P_MAXW; ++r) {
@@ -147,9 +173,9 @@ int mgn_p2p_exchange(void* const* mailboxes, int world, int rank, int channel, u
     }
     const long long ticks = (long long)((double)timeout_s * 100.0e6);   // wall_clock64: constant 100 MHz
     if (reduce)
-        hipLaunchKernelGGL(p2p_exchange<true>, dim3(world), dim3(256), 0, (hipStream_t)stream, pr, world, rank, channel, seq, payload, n, out, status, ticks);
+        hipLaunchKernelGGL(p2p_exchange<true>, dim3(world), dim3(256), 0, (hipStream_t)stream, pr, world, rank, channel, seq, seq_counters, payload, n, out, status, ticks);
     else
-        hipLaunchKernelGGL(p2p_exchange<false>, dim3(world), dim3(256), 0, (hipStream_t)stream, pr, world, rank, channel, seq, payload, n, out, status, ticks);
+        hipLaunchKernelGGL(p2p_exchange<false>, dim3(world), dim3(256), 0, (hipStream_t)stream, pr, world, rank, channel, seq, seq_counters, payload, n, out, status, ticks);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

@@ -34,8 +34,12 @@ def report():
 
 
 class PeerExchange:
-    def __init__(self, group, device, timeout_s=20.0):
+    def __init__(self, group, device, timeout_s=None):
         lib = _C.lib()
+        # wait budget of one exchange: minutes, like the process group's own collectives (a rank may legitimately be late by a data-loader
+        # warm-up, a rank-0 checkpoint or an evaluation); MGNET_P2P_TIMEOUT_S overrides.  A wait that does run out is loud (see failed()).
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("MGNET_P2P_TIMEOUT_S", "600"))
         self.group, self.device, self.timeout_s = group, device, float(timeout_s)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         if self.world > lib_const("MGN_P2P_MAX_WORLD"):
@@ -75,8 +79,13 @@ class PeerExchange:
             self._release()
             raise RuntimeError(err or "a peer could not map the mailboxes")
         self._arr = (ctypes.c_void_p * self.world)(*self._peers)
-        self.status = torch.zeros(1, dtype=torch.int32, device=device)
-        self._chan, self._seq = {}, {}
+        # the time-out flag lives in pinned HOST memory the kernel writes through (system scope): the trainer polls it every step
+        # without synchronising the device
+        self.status = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._status_np = self.status.numpy()
+        # exchange numbers per channel are counted by the kernels themselves (no per-launch host value: replayable, csrc/plan.hip)
+        self.seq_dev = torch.zeros(lib_const("MGN_P2P_CHANNELS") * lib_const("MGN_P2P_MAX_WORLD"), dtype=torch.int32, device=device)
+        self._chan = {}
         self.exchanges = 0
 
     def _release(self):
@@ -88,25 +97,39 @@ class PeerExchange:
             lib.mgn_p2p_free(self._own)
         self._peers, self._own = [], None
 
-    def _channel(self):
+    def _channel(self, claim=True):
+        """channel of the current stream (numbered in order of first use -- the same on every rank, which runs the same program), or None
+        when all channels are taken"""
         sid = torch.cuda.current_stream(self.device).cuda_stream
         c = self._chan.get(sid)
         if c is None:
+            if len(self._chan) >= lib_const("MGN_P2P_CHANNELS"):
+                return None
+            if not claim:
+                return len(self._chan)
             c = self._chan[sid] = len(self._chan)
-            if c >= lib_const("MGN_P2P_CHANNELS"):
-                raise RuntimeError("more streams issue SyncBN exchanges than the mailbox has channels")
-            self._seq[c] = 0
-        self._seq[c] += 1
-        return c, self._seq[c]
+        return c
+
+    def release_channels(self):
+        """forget which stream uses which channel (after the self-test: its side stream must not keep one of the four).  Every rank calls
+        it at the same point of the program; the channels' exchange counters live on the device and simply continue."""
+        self._chan = {}
+
+    def can(self, t):
+        """can this payload go through the mailbox from the current stream?  Decided identically on every rank (same shapes, same streams);
+        otherwise the caller uses torch.distributed for this call."""
+        return t.is_cuda and t.dtype == torch.float32 and t.numel() <= lib_const("MGN_P2P_SLOT_FLOATS") and self._channel(claim=False) is not None
 
     def _run(self, payload, reduce):
         payload = payload.contiguous()
         assert payload.is_cuda and payload.dtype == torch.float32 and payload.numel() <= lib_const("MGN_P2P_SLOT_FLOATS")
         n = payload.numel()
         out = torch.empty(tuple(payload.shape) if reduce else (self.world,) + tuple(payload.shape), dtype=torch.float32, device=payload.device)
-        c, seq = self._channel()
-        _C.check(_C.lib().mgn_p2p_exchange(self._arr, self.world, self.rank, c, seq, payload.data_ptr(), n, int(reduce), out.data_ptr(),
-                                           self.status.data_ptr(), self.timeout_s, _C._stream()), "mgn_p2p_exchange")
+        c = self._channel()
+        if c is None:
+            raise RuntimeError("more streams issue SyncBN exchanges than the mailbox has channels (callers check can() first)")
+        _C.check(_C.lib().mgn_p2p_exchange(self._arr, self.world, self.rank, c, 0, self.seq_dev.data_ptr(), payload.data_ptr(), n, int(reduce),
+                                           out.data_ptr(), self.status.data_ptr(), self.timeout_s, _C._stream()), "mgn_p2p_exchange")
         self.exchanges += 1
         return out
 
@@ -119,10 +142,11 @@ class PeerExchange:
         return self._run(t, True)
 
     def failed(self):
-        """True if a wait ran out of time since the last call (synchronises the device)"""
-        bad = bool(int(self.status.item()))
+        """True if a wait ran out of time since the last call.  Reads the pinned host flag: no device synchronisation, so it sees a
+        time-out of kernels that have RUN (the trainer calls it every step; before a checkpoint it synchronises first)."""
+        bad = bool(self._status_np[0])
         if bad:
-            self.status.zero_()
+            self._status_np[0] = 0
         return bad
 
     def close(self):
@@ -155,6 +179,8 @@ def _self_test(ex, rounds=24):
         return _self_test_burst(ex, rounds)
     finally:
         ex.timeout_s = budget
+        torch.cuda.synchronize(dev)
+        ex.release_channels()   # (the burst's side stream must not keep one of the four channels: training needs three)
 
 
 def _self_test_burst(ex, rounds):

@@ -56,6 +56,28 @@ def _detached(x):
     return x
 
 
+_FACTORY_OPTS = {"dtype", "layout", "device", "pin_memory", "memory_format"}
+
+
+def _out_overload(func, n_out):
+    """the overload of the same op that writes its result(s) into given tensors: same arguments plus `n_out` written ones
+    (`out`, `grad_input`, ...) -> (overload, names of the written arguments) or (None, None)"""
+    base = {a.name: str(a.type) for a in func._schema.arguments}
+    order = [a.name for a in func._schema.arguments]
+    pk = func.overloadpacket
+    for ov_name in sorted(pk.overloads(), key=lambda n: (n != "out", n)):
+        ov = getattr(pk, ov_name)
+        args = ov._schema.arguments
+        wr = [a.name for a in args if a.alias_info is not None and a.alias_info.is_write]
+        plain = [a for a in args if not (a.alias_info is not None and a.alias_info.is_write)]
+        names = [a.name for a in plain]
+        dropped = [n for n in order if n not in names]   # (factory options the out= form takes from the given tensor)
+        if (len(wr) == n_out and [n for n in order if n in names] == names and all(base.get(a.name) == str(a.type) for a in plain)
+                and set(dropped) <= _FACTORY_OPTS and all(a.kwarg_only for a in args if a.name in wr)):
+            return ov, wr
+    return None, None
+
+
 def _extent(t):
     """byte range of the storage a tensor lives in (conservative: the whole storage)"""
     st = t.untyped_storage()
@@ -110,6 +132,7 @@ class _Recorder(TorchDispatchMode):
         self.lock = threading.RLock()
         self.unresolved = set()
         self.error = None
+        self.in_host_call = 0
         self._info = _C.PlanNodeInfo()
         self._offs, self._sizes, self._kinds = (ctypes.c_int * 64)(), (ctypes.c_int * 64)(), (ctypes.c_int * 64)()
 
@@ -165,6 +188,20 @@ class _Recorder(TorchDispatchMode):
                         writes.append(b)
         return info.stream or 0, reads, writes, info.name.decode() if info.name else "?"
 
+    def host_call(self, fn, name, reads=(), writes=()):
+        """something the HOST does inside the step that is neither a library launch nor a torch op the dispatcher shows -- a collective of
+        the gradient reducer, the wait for it: executed now and again at the same place of every replay, on the stream that is current now"""
+        stream = torch.cuda.current_stream(self.device)
+        self.in_host_call += 1
+        try:
+            out = fn()
+        finally:
+            self.in_host_call -= 1
+        with self.lock:
+            self.timeline.append(("torch", dict(call=(fn, (), {}), stream=stream, name=name, reads=[_extent(t) for t in reads if t.is_cuda],
+                                                writes=[_extent(t) for t in writes if t.is_cuda])))
+        return out
+
     def touch(self, reads, writes):
         """memory the NEXT library call reaches through pointers stored in device memory (descriptor tables)"""
         with self.lock:
@@ -195,7 +232,12 @@ class _Recorder(TorchDispatchMode):
         name = sch.name.split("::")[-1] + "." + (func._overloadname or "default")
         if sch.name == "aten::_local_scalar_dense":
             raise PlanUnsupported("a device -> host read (.item()) inside the step")
-        if name in _ALLOC_ONLY or sch.name.startswith("c10d") or sch.name in ("aten::record_stream", "aten::is_pinned", "aten::detach",
+        if self.in_host_call:
+            return     # (part of a host_call: replayed as a whole)
+        if sch.name.startswith("c10d"):
+            raise PlanUnsupported(f"a torch.distributed collective ({name}) inside the step outside the gradient reducer -- e.g. SyncBN "
+                                  "statistics on the process group instead of the peer-to-peer mailbox")
+        if name in _ALLOC_ONLY or sch.name in ("aten::record_stream", "aten::is_pinned", "aten::detach",
                                                                                "aten::alias", "aten::lift_fresh"):
             return
         written = [a for a, s in zip(args, sch.arguments) if s.alias_info is not None and s.alias_info.is_write]
@@ -217,12 +259,12 @@ class _Recorder(TorchDispatchMode):
                 src = args[0]
                 call = (torch.ops.aten.copy_.default, (outs[0], src, bool(kwargs.get("non_blocking", False))), {})
             else:
-                outv = getattr(func.overloadpacket, "out", None)
-                if outv is None or len(outs) != 1:
+                outv, onames = _out_overload(func, len(outs))
+                if outv is None:
                     raise PlanUnsupported(f"torch op {name} inside the step has no out= form")
                 names = {a.name for a in outv._schema.arguments}
                 kw = {k: v for k, v in kwargs.items() if k in names}
-                kw["out"] = outs[0]
+                kw.update(zip(onames, outs))
                 try:
                     with torch.no_grad():
                         outv(*args, **kw)   # (validates the form now, not at the first replay; rewrites the same values)

@@ -96,12 +96,12 @@ class GradReducer:
         """(de)activate deferred split-K reductions for the backward that follows (Trainer); leftovers are an error"""
         from .. import _C
         if self.buckets and self.buckets[0]["flat_g"].is_cuda:
-            _C.WGRAD_LAZY[0] = bool(on)
+            _C.WGRAD_LAZY[0] = id(self) if on else False
 
     def abort(self):
         """a backward raised: drop the deferred weight-gradient entries it registered (keyed by address, see _C.WGRAD_PENDING)"""
         from .. import _C
-        _C.WGRAD_PENDING.clear()
+        _C.wgrad_pending_drop(id(self))
 
     def zero_grad(self):
         """Gradients are not zeroed: `.grad` is dropped, so autograd hands over each freshly computed gradient without an
@@ -110,7 +110,7 @@ class GradReducer:
         self._next = 0
         if self.buckets and self.buckets[0]["flat_g"].is_cuda:
             from .. import _C
-            _C.WGRAD_PENDING.clear()   # leftovers of a backward that raised: stale addresses must never match a later gradient
+            _C.wgrad_pending_drop(id(self))   # leftovers of a backward that raised: stale addresses must never match a later gradient
         for b in self.buckets:
             b["pending"] = b["n"]
             b["seen"] = set()
@@ -204,7 +204,8 @@ class GradReducer:
                     if b.get("packed_on") != cur:
                         cur.wait_event(b["packed_ev"])
                         self.cross_stream_waits += 1
-                self._handles.append(dist.all_reduce(b["flat_g"], group=self.group, async_op=True))
+                self._issue(lambda b=b: self._handles.append(dist.all_reduce(b["flat_g"], group=self.group, async_op=True)),
+                            "grad_all_reduce", b["flat_g"])
                 self.collectives += 1
             self._next += 1
 
@@ -215,14 +216,30 @@ class GradReducer:
         if self.buckets and self.buckets[0]["flat_g"].is_cuda:
             from .. import _C
             # (an entry left over means autograd handed a COPY of a deferred gradient to its parameter: its values were never computed)
-            assert not _C.WGRAD_PENDING, "weight gradients with a deferred split-K reduction were never packed into a bucket"
+            assert not any(e[3] == id(self) for e in _C.WGRAD_PENDING.values()), \
+                "weight gradients with a deferred split-K reduction were never packed into a bucket"
         if self.world > 1:
-            for h in self._handles:
-                h.wait()
-            self._handles.clear()
+            self._issue(self._wait_all, "grad_all_reduce_wait", *[b["flat_g"] for b in self.buckets])
             if self.average:
                 for b in self.buckets:
                     b["flat_g"].mul_(1.0 / self.world)
+
+    def _wait_all(self):
+        for h in self._handles:
+            h.wait()
+        self._handles.clear()
+
+    def _issue(self, fn, name, *written):
+        """a collective call / the wait for it: run now -- and, while a step is being recorded for replay (engine/plan.py), written down so
+        that every replay issues it again at the same place of the launch sequence, on the same stream"""
+        rec = None
+        if written and written[0].is_cuda:
+            from .. import _C
+            rec = _C.PLAN_RECORDER[0]
+        if rec is not None:
+            rec.host_call(fn, name, writes=written)
+        else:
+            fn()
 
     def grad_bytes(self):
         return sum(b["flat_g"].numel() * 4 for b in self.buckets)

@@ -46,6 +46,7 @@ class Trainer:
         return extra
 
     def save(self, name=None):
+        self._check_peers(sync=True)   # never checkpoint parameters that a timed-out statistics exchange may have poisoned
         return self.checkpointer.save(name or f"model_{self.iter - 1:07d}", iteration=self.iter - 1)
 
     # ---- whole-step hipGraph -----------------------------------------------------------------------------------------
@@ -104,7 +105,13 @@ class Trainer:
         runs; raises engine.plan.PlanUnsupported when the step contains something a replay cannot express (the trainer then stays eager)."""
         from .plan import PlanUnsupported, StepPlan
         if self.reducer.world != 1:
-            raise PlanUnsupported("multi-rank steps stay eager (collectives are issued by torch.distributed)")
+            # multi-rank: the gradient all-reduces are host calls the plan re-issues at their place (reducer._issue); the SyncBN statistics
+            # must be on the mailbox kernels (device-counted exchange numbers: replayable) -- collectives of the process group inside the
+            # layers are refused by the recorder
+            from . import peer
+            if peer.exchange() is None:
+                raise PlanUnsupported("multi-rank plan replay needs the peer-to-peer SyncBN exchange (engine/peer.py); it is not active: "
+                                      + peer.report()["why"])
         if not hasattr(self.optimizer, "launch_step"):
             raise PlanUnsupported("plan replay needs the fused optimizer")
         self.model.train()
@@ -165,10 +172,20 @@ class Trainer:
         self.scheduler.step()
         self.iter += 1
         self.storage.step()
-        if self.reducer.world > 1 and self.iter % 200 == 0:
+        self._check_peers()
+        return loss_dict
+
+    def _check_peers(self, sync=False):
+        """a SyncBN mailbox wait that timed out is an error, not a statistic: polled EVERY step from the pinned host flag the kernel
+        writes (no device synchronisation; the NaN it leaves in the statistics makes that step's losses non-finite anyway), and with a
+        synchronisation before anything is written to disk"""
+        if self.reducer.world > 1:
             from . import peer
             ex = peer.exchange()
-            if ex is not None and ex.failed():   # (one device synchronisation every 200 steps)
-                raise RuntimeError("SyncBN mailbox exchange: a peer did not post its statistics in time (a rank died or diverged in its "
-                                   "launch order); set MGNET_SYNCBN=rccl to use torch.distributed collectives")
-        return loss_dict
+            if ex is not None:
+                if sync:
+                    torch.cuda.synchronize()
+                if ex.failed():
+                    raise RuntimeError("SyncBN mailbox exchange: a peer did not post its statistics in time (a rank died or diverged in its "
+                                       "launch order); the step's statistics were set to NaN. MGNET_SYNCBN=rccl uses torch.distributed "
+                                       "collectives, MGNET_P2P_TIMEOUT_S sets the wait budget")

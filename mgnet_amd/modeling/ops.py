@@ -41,17 +41,25 @@ def _dist_active(group):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
-def _peer_exchange(t):
-    """the mailbox exchange of engine/peer.py when it is active for CUDA tensors (else None: torch.distributed)"""
+def _peer_exchange(t, group=None):
+    """the mailbox exchange of engine/peer.py when it is active for CUDA tensors AND spans exactly the layer's process group AND has a
+    channel / slot for this payload -- else None: torch.distributed for this call (every rank decides the same: same shapes, same
+    streams, same groups)"""
     if not t.is_cuda:
         return None
     from ..engine import peer
-    return peer.exchange()
+    ex = peer.exchange()
+    if ex is None or not ex.can(t):
+        return None
+    if group is not None and group is not dist.group.WORLD and group is not ex.group:
+        if dist.get_world_size(group) != ex.world or dist.get_process_group_ranks(group) != dist.get_process_group_ranks(ex.group):
+            return None
+    return ex
 
 
 def _allreduce_sums(sums, group):
     """backward sums of a SyncBN layer over the ranks: [HIP] mailbox exchange (a new tensor), or dist.all_reduce in place"""
-    ex = _peer_exchange(sums)
+    ex = _peer_exchange(sums, group)
     if ex is not None:
         SYNCBN_P2P[0] += 1
         return ex.all_reduce(sums)
@@ -63,7 +71,7 @@ def _allreduce_sums(sums, group):
 def _gather_stats(stats, world, group):
     """[world, 3, C] statistics of all ranks.  [HIP] mailbox exchange when active; RCCL: one all_gather_into_tensor (no per-rank output
     list and its copies); other backends (gloo in the CPU tests): the list form."""
-    ex = _peer_exchange(stats)
+    ex = _peer_exchange(stats, group)
     if ex is not None:
         SYNCBN_P2P[0] += 1
         return ex.all_gather(stats)

@@ -22,10 +22,17 @@ def _free_port():
 
 def _worker(rank, world, port, fn, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("MGNET_P2P_TIMEOUT_S", "30")   # a diverged exchange fails the test in seconds instead of hanging for the default 10 min
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)    # a hung rank prints where it is and exits (the parent then fails on its exit code)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         q.put((rank, fn(rank, world)))
+    except BaseException as e:   # report instead of leaving the parent blocked on the queue
+        import traceback
+        q.put((rank, "worker failed: " + "".join(traceback.format_exception_only(type(e), e)).strip()))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -39,8 +46,10 @@ def _spawn(fn, world=2):
         p.start()
     out = dict(q.get() for _ in range(world))
     for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+        p.join(180)
+    failed = {r: v for r, v in out.items() if isinstance(v, str) and v.startswith("worker failed")}
+    assert not failed, failed
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     return out
 
 
@@ -134,7 +143,10 @@ def _p2p_exchange(rank, world):
     for t, (ga, rs) in zip(rows, got):
         ref = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(ref, t)
-        if not (torch.equal(ga, torch.stack(ref)) and torch.equal(rs, ref[0] + ref[1])):
+        want = ref[0].clone()
+        for r in range(1, world):
+            want += ref[r]
+        if not (torch.equal(ga, torch.stack(ref)) and torch.equal(rs, want)):
             return "mismatch"
     # latency of one exchange (both ranks time the same 200 exchanges)
     t = torch.randn(3, 256, device=dev)
@@ -155,6 +167,102 @@ def test_p2p_mailbox_exchange_matches_collectives(capsys):
     assert all(isinstance(v, tuple) and v[0] == "ok" for v in out.values()), out
     with capsys.disabled():
         print(f"\n[p2p exchange] 2 processes on one GPU: {out[0][1]} / {out[1][1]} us per all_gather of 3 x 256 floats ({out[0][2]})", end="")
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_p2p_mailbox_exchange_world_4_and_8(world, capsys):
+    """the mailbox is laid out for 8 ranks ([channel][slot][source] indexing, 8 posting blocks while block 0 spins): 4 and 8 PROCESSES
+    sharing the one GPU through IPC, same assertions as the two-rank test (150 exchanges on three channels, one rank lagging)"""
+    out = _spawn(_p2p_exchange, world=world)
+    if any(isinstance(v, str) and v.startswith("unavailable") for v in out.values()):
+        pytest.skip(f"fine-grained IPC memory is not available to {world} processes on this box: {out}")
+    assert all(isinstance(v, tuple) and v[0] == "ok" for v in out.values()), out
+    with capsys.disabled():
+        print(f"\n[p2p exchange] {world} processes on one GPU: {out[0][1]} us per all_gather of 3 x 256 floats", end="")
+
+
+def test_p2p_mailbox_exchange_with_two_hardware_queues():
+    """the three exchange streams and a spinning kernel on only TWO hardware queues (GPU_MAX_HW_QUEUES=2): every rank issues the same
+    exchanges in the same order, so a wait on one queue never blocks the post it waits for"""
+    os.environ["GPU_MAX_HW_QUEUES"] = "2"
+    try:
+        out = _spawn(_p2p_exchange, world=2)
+    finally:
+        del os.environ["GPU_MAX_HW_QUEUES"]
+    if any(isinstance(v, str) and v.startswith("unavailable") for v in out.values()):
+        pytest.skip(f"fine-grained IPC memory is not available on this box: {out}")
+    assert all(isinstance(v, tuple) and v[0] == "ok" for v in out.values()), out
+
+
+def _p2p_timeout(rank, world):
+    """rank 1 does not post: rank 0's wait runs out of its (short) budget -> NaN in the result, host-visible flag set, no hang"""
+    from mgnet_amd.engine import peer
+    os.environ["MGNET_SYNCBN"] = "auto"
+    ex = peer.enable()
+    if ex is None:
+        return "unavailable: " + peer.report()["why"]
+    ex.timeout_s = 0.5
+    t = torch.ones(3, 64, device="cuda")
+    res = None
+    if rank == 0:
+        g, r = ex.all_gather(t), ex.all_reduce(t)
+        torch.cuda.synchronize()
+        res = (bool(torch.isnan(g).all()), bool(torch.isnan(r).all()), ex.failed(), ex.failed())
+    dist.barrier()
+    return res if rank == 0 else "idle"
+
+
+def test_p2p_timeout_is_loud():
+    out = _spawn(_p2p_timeout)
+    if any(isinstance(v, str) and v.startswith("unavailable") for v in out.values()):
+        pytest.skip(f"peer-to-peer exchange not available on this box: {out}")
+    assert out[0] == (True, True, True, False), out   # NaN results, flag raised once and cleared by the poll
+
+
+def _plan_two_ranks(rank, world):
+    """launch-plan replay on two ranks: mailbox SyncBN kernels (device-counted exchange numbers) as plan nodes, the gradient all-reduces
+    re-issued by the plan at their place in the launch sequence: same parameters as eager steps, bit for bit, on both ranks"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_network_cpu import small_model
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.engine import Trainer, peer
+    os.environ["MGNET_SYNCBN"] = "auto"
+    res = {}
+    for mode in ("eager", "plan"):
+        peer.disable()
+        cfg, m = small_model(with_depth=True, seed=7)
+        m = m.cuda()
+        m.amp_dtype = torch.bfloat16
+        tr = Trainer(cfg, m)
+        if peer.exchange() is None:
+            return "unavailable: " + peer.report()["why"]
+        batch = synthetic_batch(1, 64, 96, "cuda", seed=100 + rank)
+        for _ in range(3):
+            tr.run_step(batch)
+        rep = None
+        if mode == "plan":
+            rep = tr.record_plan(batch).report
+            for _ in range(2):
+                tr.replay_plan()
+        else:
+            for _ in range(3):
+                tr.run_step(batch)
+        torch.cuda.synchronize()
+        tr._check_peers(sync=True)
+        res[mode] = (torch.stack([p.detach().double().sum() for p in m.parameters()]).cpu(), rep)
+    same = bool(torch.equal(res["eager"][0], res["plan"][0]))
+    other = [torch.zeros_like(res["plan"][0]) for _ in range(world)]
+    dist.all_gather(other, res["plan"][0])
+    return same and bool(torch.equal(other[0], other[1])), res["plan"][1]
+
+
+def test_two_rank_plan_replay_equals_eager():
+    out = _spawn(_plan_two_ranks)
+    if any(isinstance(v, str) for v in out.values()):
+        pytest.skip(f"peer-to-peer exchange not available on this box: {out}")
+    assert all(v[0] is True for v in out.values()), out
+    assert all(v[1]["torch_ops"].get("grad_all_reduce", 0) >= 1 for v in out.values()), out
 
 
 def _p2p_refusal(rank, world):
