@@ -250,20 +250,27 @@ def full_step_bench(args, world, rank, dev):
     # latency); "graph" (--graph on, one rank only) = the whole step captured once in a hipGraph on ONE stream and replayed.
     # Measured (end of round 2): eager + side streams 30.2 ms, graph 32.5 ms (capturing the side-stream branches crashes hipGraph on ROCm 7.0).
     use_graph = args.graph == "on" and world == 1
-    use_plan = args.exec in ("auto", "plan") and world == 1 and not use_graph
+    use_plan = args.exec in ("auto", "plan") and not use_graph
     mode, plan_note = "eager", None
     for _ in range(max(args.warmup, 3) if (use_graph or use_plan) else args.warmup):
         trainer.run_step(batch)
     if use_plan:
         # launch-plan replay (engine/plan.py): one eager step recorded, the timed steps replayed from C with the side streams kept
+        plan = None
         try:
             plan = trainer.record_plan(batch, prof_slots=args.steps)
-            for _ in range(2):
-                trainer.replay_plan()
-            mode = "plan"
         except Exception as e:  # noqa: BLE001 -- report and fall back to the eager step rather than lose the measurement
             plan_note = f"plan recording failed ({type(e).__name__}: {e}); eager steps timed"
             print(f"[bench] {plan_note}", file=sys.stderr, flush=True)
+        ok = torch.tensor([0.0 if plan is None else 1.0], device=dev)
+        if world > 1:   # every rank replays, or none does (a rank issuing another launch sequence would leave its peers waiting)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if ok.item() == 1.0:
+            for _ in range(2):
+                trainer.replay_plan()
+            mode = "plan"
+        elif plan is not None:
+            plan_note = "plan recording failed on another rank; eager steps timed"
     if use_graph:
         try:
             trainer.capture_step(batch)

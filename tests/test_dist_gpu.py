@@ -371,3 +371,81 @@ def test_rccl_single_rank_statistics_exchange():
     rank, ok = q.get()
     p.join(120)
     assert ok is True, ok
+
+
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_self_launch_end_to_end_on_gloo(gpus):
+    """`python bench.py --gpus N` as the driver runs it (self-launch of the N ranks, barrier + max-over-ranks timing, one JSON line with
+    config.distributed) -- here with MGNET_DIST_BACKEND=gloo and all ranks on the one GPU (RCCL refuses that): a functional check of the
+    whole multi-rank path including the mailbox SyncBN, the launch-plan replay and the time-out plumbing, not a measurement"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGNET_DIST_BACKEND="gloo", MGNET_P2P_TIMEOUT_S="120")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2" if gpus == 2 else "1", "--warmup", "1", "--batch", "2", "--height", "128",
+           "--width", "256", "--no-cpu-baseline", "--timeout", "500"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == gpus and d["value"] > 0 and d["scaling"] == "weak", d
+    dist_cfg = d["config"]["distributed"]
+    assert dist_cfg["rccl_world_size"] == gpus and dist_cfg["grad_allreduce_calls_per_step"] >= 1, dist_cfg
+    if "p2p" in dist_cfg["syncbn_exchange"]["mode"]:
+        assert dist_cfg["syncbn_collectives_per_step"] == 0 and dist_cfg["syncbn_p2p_exchanges_per_step"] >= 100, dist_cfg
+        assert dist_cfg["syncbn_exchange"]["wait_timed_out"] is False, dist_cfg
+    assert all(v == v for v in d["config"]["losses"].values()), d["config"]["losses"]   # finite (NaN != NaN)
+
+
+def _overlap_structure(rank, world):
+    """how much of backward is still to be issued when the first bucket's all-reduce goes out: the reducer starts a bucket's collective from
+    the hook of its last gradient (ready-order buckets), so most of backward's launches must come AFTER the first all_reduce call"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_network_cpu import small_model
+    from mgnet_amd import _C
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.engine import Trainer
+    cfg, m = small_model(with_depth=True, seed=7)
+    m = m.cuda()
+    m.amp_dtype = torch.bfloat16
+    tr = Trainer(cfg, m, bucket_bytes=1 << 20)    # (small model: small buckets, so that there are several)
+    batch = synthetic_batch(1, 64, 96, "cuda", seed=100 + rank)
+    for _ in range(2):
+        tr.run_step(batch)
+    calls = {"n": 0, "at_first_allreduce": None, "at_backward_start": None}
+    real_stream = _C._stream
+
+    def counting_stream():
+        calls["n"] += 1
+        return real_stream()
+    _C._stream = counting_stream           # one call per library launch
+    real_ar = dist.all_reduce
+
+    def spy_all_reduce(*a, **k):
+        if calls["at_first_allreduce"] is None and a and a[0].numel() > 64:
+            calls["at_first_allreduce"] = calls["n"]
+        return real_ar(*a, **k)
+    dist.all_reduce = spy_all_reduce
+    real_bw = tr._backward
+
+    def spy_backward(loss_dict):
+        calls["at_backward_start"] = calls["n"]
+        return real_bw(loss_dict)
+    tr._backward = spy_backward
+    try:
+        tr.run_step(batch)
+    finally:
+        _C._stream, dist.all_reduce = real_stream, real_ar
+    torch.cuda.synchronize()
+    bw_total = calls["n"] - calls["at_backward_start"]
+    after = calls["n"] - calls["at_first_allreduce"]
+    return len(tr.reducer.buckets), bw_total, after
+
+
+def test_first_bucket_allreduce_is_issued_early_in_backward():
+    out = _spawn(_overlap_structure)
+    for r, (nb, bw_total, after) in out.items():
+        assert nb >= 3, out
+        assert after >= 0.6 * bw_total, out   # >= 60 % of backward's launches are issued after the first bucket's all_reduce call
