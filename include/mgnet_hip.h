@@ -291,6 +291,7 @@ int mgn_plan_node_info(const void* plan, int i, mgn_plan_node_info_t* out);
 int mgn_plan_node_args(const void* plan, int i, int max_args, int* offsets, int* sizes, int* kinds /*0 opaque, 1 const pointer, 2 pointer*/);
 int mgn_plan_compile(void* plan, int n_ops, const int* types, const int* a, void* const* streams, int n_events, int prof_slots);
 int mgn_plan_run(void* plan, int from_op, int prof_slot);   /* -> index of the BREAK it stopped at, or the op count */
+int mgn_plan_set_stream(void* plan, int node, void* stream);   /* replay a node on another stream (the schedule must order it accordingly) */
 int mgn_plan_prof_elapsed(void* plan, int slot, float* ms);
 int mgn_plan_free(void* plan);
 
@@ -418,6 +419,12 @@ int mgn_uncertainty_fwd(const float* const* raw_losses, int n, const float* log_
                         void* stream);
 int mgn_uncertainty_bwd(const float* const* raw_losses, const float* const* grads, int n, int n_log_vars, const float* log_vars,
                         unsigned tau_one_mask, float* d_raw, float* d_log_vars, void* stream);
+
+/* Small host -> device table upload (per-step learning-rate tables of the optimizer, descriptor tables of the batched launches) as a
+ * kernel that reads PINNED host memory directly: dst_dev[0 .. nbytes) = src_pinned_host[0 .. nbytes), nbytes a multiple of 4, both 4-byte
+ * aligned; stream-ordered (the host buffer must stay unchanged until the launch has run).  Replaces the `tensor.to(device,
+ * non_blocking=True)` of those tables (detectron2's / torch.optim's per-step host values reach the device the same way). */
+int mgn_copy_from_host(void* dst_dev, const void* src_pinned_host, size_t nbytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tails of the prediction heads: between a 1x1 predictor (output channels padded to P = 32, channels-last, 16-bit) and its loss.

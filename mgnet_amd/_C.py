@@ -24,12 +24,12 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_panoptic_targets_workspace_bytes", "mgn_panoptic_targets",
            "mgn_panoptic_post_workspace_bytes", "mgn_panoptic_post", "mgn_instance_post_workspace_bytes", "mgn_instance_post", "mgn_instance_masks", "mgn_pseudo_label_ids", "mgn_depth_post_workspace_bytes", "mgn_depth_post",
            "mgn_depth_metrics_workspace_bytes", "mgn_depth_metrics", "mgn_abn_maxpool_fwd", "mgn_abn_maxpool_bwd",
-           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_reduce_x_relu", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4", "mgn_u8_frames_to_rgbx", "mgn_msc_input", "mgn_msc_accumulate", "mgn_uncertainty_fwd", "mgn_uncertainty_bwd", "mgn_head_act_fwd", "mgn_head_act_bwd",
+           "mgn_iabn_bwd_reduce_x", "mgn_iabn_bwd_reduce_x_relu", "mgn_iabn_bwd_apply_x", "mgn_abn_add_relu_fwd", "mgn_u8_frames_to_f32", "mgn_u8_frames_to_f32_nhwc4", "mgn_u8_frames_to_rgbx", "mgn_msc_input", "mgn_msc_accumulate", "mgn_uncertainty_fwd", "mgn_uncertainty_bwd", "mgn_copy_from_host", "mgn_head_act_fwd", "mgn_head_act_bwd",
            "mgn_p2p_mailbox_bytes", "mgn_p2p_alloc", "mgn_p2p_free", "mgn_p2p_export", "mgn_p2p_open", "mgn_p2p_close", "mgn_p2p_exchange",
            "mgn_geometry_partial_rows", "mgn_view_synthesis_fwd", "mgn_view_synthesis_bwd", "mgn_reconstruct_fwd",
            "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd",
            "mgn_plan_begin", "mgn_plan_recorded", "mgn_plan_current", "mgn_plan_end", "mgn_plan_abort", "mgn_plan_node_count", "mgn_plan_node_info", "mgn_plan_node_args",
-           "mgn_plan_compile", "mgn_plan_run", "mgn_plan_prof_elapsed", "mgn_plan_free"]
+           "mgn_plan_compile", "mgn_plan_set_stream", "mgn_plan_run", "mgn_plan_prof_elapsed", "mgn_plan_free"]
 SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
 DEPTH_MAX_FILTER_IDS = 16
 
@@ -168,6 +168,7 @@ def lib():
         L.mgn_u8_frames_to_rgbx.argtypes = [vp, ci, cl, vp, vp]
         L.mgn_uncertainty_fwd.argtypes = [vp, ci, vp, ctypes.c_uint, vp, vp, vp]
         L.mgn_uncertainty_bwd.argtypes = [vp, vp, ci, ci, vp, ctypes.c_uint, vp, vp, vp]
+        L.mgn_copy_from_host.argtypes = [vp, vp, sz, vp]
         L.mgn_head_act_fwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_head_act_bwd.argtypes = [vp, cl, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp]
         L.mgn_p2p_mailbox_bytes.argtypes = []
@@ -210,6 +211,7 @@ def lib():
         L.mgn_plan_node_args.argtypes = [vp, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.mgn_plan_compile.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(vp), ci, ci]
         L.mgn_plan_run.argtypes = [vp, ci, ci]
+        L.mgn_plan_set_stream.argtypes = [vp, ci, vp]
         L.mgn_plan_prof_elapsed.argtypes = [vp, ci, ctypes.POINTER(cf)]
         L.mgn_plan_free.argtypes = [vp]
         for n in SYMBOLS[4:]:
@@ -239,11 +241,16 @@ class PinnedStager:
     def stage(self, src, device, slot=None):
         """`slot`: one ring per call site (two sites staging equal shapes in the same step must not share buffers)"""
         if PLAN_RECORDER[0] is not None:
-            # a step being recorded for replay: a pinned buffer of its own that the plan keeps (the rings are rewritten by later eager steps)
+            # a step being recorded for replay: the table's content is the same in every replay (addresses of the recorded step), so it is
+            # uploaded ONCE, now, into a device tensor the plan keeps alive -- the launch goes to the library directly, past the recorder,
+            # and is therefore not part of the replayed schedule
+            rec = PLAN_RECORDER[0]
             buf = torch.empty(src.shape, dtype=src.dtype).pin_memory()
             buf.copy_(src)
-            PLAN_RECORDER[0].keep.append(buf)
-            return buf.to(device, non_blocking=True)
+            out = rec.static_table(src.shape, src.dtype)   # (the plan's own arena: never a block the step's temporaries pass through)
+            check(rec.lib.mgn_copy_from_host(out.data_ptr(), buf.data_ptr(), out.numel() * out.element_size(), _stream()), "mgn_copy_from_host")
+            rec.keep.append((buf, out))
+            return out
         key = (slot, tuple(src.shape), src.dtype, str(device))
         ring = self.rings.get(key)
         if ring is None:
@@ -263,11 +270,44 @@ class PinnedStager:
             np.copyto(views[i], src.numpy())
         else:
             ring["bufs"][i].copy_(src)
-        out = ring["bufs"][i].to(device, non_blocking=True)
+        nb = src.numel() * src.element_size()
+        if nb % 4 == 0 and nb > 0:
+            # (a kernel that reads the pinned buffer instead of an async memcpy: see mgn_copy_from_host)
+            out = torch.empty(src.shape, dtype=src.dtype, device=device)
+            check(lib().mgn_copy_from_host(out.data_ptr(), ring["bufs"][i].data_ptr(), nb, _stream()), "mgn_copy_from_host")
+        else:
+            out = ring["bufs"][i].to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         ring["evs"][i] = ev
         return out
+
+
+def _stage_into(self, dst, src, slot=None):
+    """like stage(), straight into the existing device tensor `dst` (contiguous, same dtype and element count)"""
+    assert dst.is_cuda and dst.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel() and (src.numel() * src.element_size()) % 4 == 0
+    key = (slot, tuple(src.shape), src.dtype, "into")
+    ring = self.rings.get(key)
+    if ring is None:
+        ring = self.rings[key] = dict(bufs=[torch.empty(src.shape, dtype=src.dtype).pin_memory() for _ in range(self.depth)],
+                                      evs=[None] * self.depth, turn=0)
+        ring["np"] = [b.numpy() for b in ring["bufs"]] if src.dtype in _NP_OK else None
+    i = ring["turn"]
+    ring["turn"] = (i + 1) % self.depth
+    if ring["evs"][i] is not None:
+        ring["evs"][i].synchronize()
+    if ring["np"] is not None and src.is_contiguous() and not src.requires_grad:
+        np.copyto(ring["np"][i], src.numpy())
+    else:
+        ring["bufs"][i].copy_(src)
+    check(lib().mgn_copy_from_host(dst.data_ptr(), ring["bufs"][i].data_ptr(), src.numel() * src.element_size(), _stream()), "mgn_copy_from_host")
+    ev = torch.cuda.Event()
+    ev.record()
+    ring["evs"][i] = ev
+    return dst
+
+
+PinnedStager.stage_into = _stage_into
 
 
 def check(rc, what):

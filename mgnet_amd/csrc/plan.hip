@@ -204,6 +204,14 @@ int mgn_plan_run(void* plan, int from, int prof_slot) {
     return n;
 }
 
+/* replay node i on another stream than it was recorded on (the caller's schedule must order it accordingly) */
+int mgn_plan_set_stream(void* plan, int i, void* stream) {
+    Plan* p = (Plan*)plan;
+    if (!p || i < 0 || i >= (int)p->nodes.size()) return MGN_EINVAL;
+    p->nodes[i].stream = (hipStream_t)stream;
+    return MGN_OK;
+}
+
 int mgn_plan_prof_elapsed(void* plan, int slot, float* ms) {
     Plan* p = (Plan*)plan;
     if (!p || !ms || slot < 0 || slot >= (int)p->prof[0].size()) return MGN_EINVAL;

@@ -33,9 +33,25 @@ __global__ void uncertainty_bwd(UncPtrs raw, UncPtrs g, int n, int n_lv, const f
     d_lv[k] = (0.5f - e * raw.p[k][0]) * gk;
 }
 
+// small host -> device table uploads as a KERNEL that reads pinned host memory through the fabric (zero copy): an async hipMemcpy of a
+// few KB goes through the copy path of the runtime, whose hand-over with the compute queue showed up as 0.3-0.7 ms holes in the step's
+// kernel trace (profiles/r04_v1_kernel_trace.txt: "... -> __amd_rocclr_copyBuffer"); a 240 KB table takes ~15 us this way
+__global__ __launch_bounds__(256) void copy_from_host_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
+        dst[i] = __builtin_nontemporal_load(src + i);
+}
+
 }  // namespace
 
 extern "C" {
+
+int mgn_copy_from_host(void* dst_dev, const void* src_pinned_host, size_t nbytes, void* stream) {
+    if (!dst_dev || !src_pinned_host || nbytes == 0 || nbytes % 4 || ((uintptr_t)dst_dev | (uintptr_t)src_pinned_host) % 4) return MGN_EINVAL;
+    const long n = (long)(nbytes / 4);
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
+    hipLaunchKernelGGL(copy_from_host_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src_pinned_host, (uint32_t*)dst_dev, n);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
 
 int mgn_uncertainty_fwd(const float* const* raw_losses, int n, const float* log_vars, unsigned tau_one_mask, float* weighted, float* uncertainty,
                         void* stream) {

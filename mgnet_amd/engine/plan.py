@@ -21,6 +21,7 @@ How a replay stays correct:
 import bisect
 import ctypes
 import gc
+import os
 import threading
 
 import numpy as np
@@ -132,6 +133,10 @@ class _Recorder(TorchDispatchMode):
         self.lock = threading.RLock()
         self.unresolved = set()
         self.error = None
+        # memory for the small descriptor tables the step uploads once (see _C.PinnedStager.stage): allocated BEFORE the step and outside
+        # its pool -- a table living in a block that an earlier launch of the step used as scratch would be overwritten on every replay
+        self.arena = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+        self.arena_used = 0
         self.in_host_call = 0
         self._info = _C.PlanNodeInfo()
         self._offs, self._sizes, self._kinds = (ctypes.c_int * 64)(), (ctypes.c_int * 64)(), (ctypes.c_int * 64)()
@@ -201,6 +206,15 @@ class _Recorder(TorchDispatchMode):
             self.timeline.append(("torch", dict(call=(fn, (), {}), stream=stream, name=name, reads=[_extent(t) for t in reads if t.is_cuda],
                                                 writes=[_extent(t) for t in writes if t.is_cuda])))
         return out
+
+    def static_table(self, shape, dtype):
+        """a device tensor in the plan's own arena (never shared with the step's temporaries)"""
+        nb = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        off = (self.arena_used + 255) // 256 * 256
+        if off + nb > self.arena.numel():
+            raise PlanUnsupported("the step uploads more descriptor-table bytes than the plan's arena holds")
+        self.arena_used = off + nb
+        return self.arena[off:off + nb].view(dtype).view(tuple(shape))
 
     def touch(self, reads, writes):
         """memory the NEXT library call reaches through pointers stored in device memory (descriptor tables)"""
@@ -329,7 +343,7 @@ class StepPlan:
         _C.check(lib.mgn_plan_end(ctypes.byref(h)), "mgn_plan_end")
         self.handle = h
         torch.cuda.synchronize(device)
-        self.keep = [rec.keep, result]
+        self.keep = [rec.keep, result, rec.arena]
         self._schedule(rec, main, prof_slots)
         return self, result
 
@@ -344,6 +358,23 @@ class StepPlan:
             else:
                 c = ent[1]
                 items.append(dict(kind=1, closure=c, stream=int(c["stream"].cuda_stream), reads=c["reads"], writes=c["writes"], name=c["name"]))
+        # Optional re-streaming (MGN_PLAN_SPLIT="substring[,substring]"): launches whose kernel name contains a substring move to an extra
+        # stream of their own.  The dependency analysis below works from memory accesses alone, so it orders them correctly wherever they
+        # run; what it buys is that their launch gaps overlap with the chain they were queued in (e.g. the weight-gradient kernels, which
+        # nothing reads before the bucket is packed).
+        import os
+        self.extra_streams = []
+        for sub in [x for x in os.environ.get("MGN_PLAN_SPLIT", "").split(",") if x]:
+            st = torch.cuda.Stream(main.device)
+            self.extra_streams.append(st)
+            moved = 0
+            for it in items:
+                if it["kind"] == 0 and sub in it["name"] and "reduce" not in it["name"]:
+                    it["stream"] = int(st.cuda_stream)
+                    it["moved"] = True
+                    moved += 1
+            self.report_split = getattr(self, "report_split", {})
+            self.report_split[sub] = moved
         main_id = int(main.cuda_stream)
         streams = sorted({it["stream"] for it in items} | {main_id})
         sidx = {s: k for k, s in enumerate(streams)}
@@ -370,6 +401,10 @@ class StepPlan:
                 WR = np.concatenate([WR, np.array(acc_w[flushed:], dtype=np.int64)])
                 flushed = len(acc_s)
             need = np.zeros(ns, dtype=np.int64)
+            if os.environ.get("MGN_PLAN_SERIAL"):     # debugging aid: global program order (every launch behind every earlier one)
+                for t in range(ns):
+                    if t != s:
+                        need[t] = pos[t]
             if len(S):
                 for a, b, w in mine:
                     m = (S < b) & (E > a) & (ST != s) & ((WR == 1) | (w == 1))
@@ -402,10 +437,13 @@ class StepPlan:
             if st != main_id:
                 ops.append((WAIT, e_start, st))
         self.closures = []
+        moved_nodes = []
         for k, it in enumerate(items):
             for ev in waits[k]:
                 ops.append((WAIT, ev, it["stream"]))
             if it["kind"] == 0:
+                if it.get("moved"):
+                    moved_nodes.append((it["node"], it["stream"]))
                 ops.append((LAUNCH, it["node"], it["stream"]))
             else:
                 ops.append((BREAK, 0, it["stream"]))
@@ -422,6 +460,8 @@ class StepPlan:
         aa = (ctypes.c_int * n)(*[o[1] for o in ops])
         ss = (ctypes.c_void_p * n)(*[o[2] or None for o in ops])
         _C.check(lib.mgn_plan_compile(self.handle, n, types, aa, ss, n_ev, prof_slots), "mgn_plan_compile")
+        for node, st in moved_nodes:
+            _C.check(lib.mgn_plan_set_stream(self.handle, node, st), "mgn_plan_set_stream")
         self.main, self.n_ops = main, n
         kernels = sum(1 for it in items if it["kind"] == 0)
         by_name = {}
@@ -430,6 +470,8 @@ class StepPlan:
                 by_name[it["name"]] = by_name.get(it["name"], 0) + 1
         self.report = {"kernel_launches": kernels, "torch_ops_replayed": len(self.closures), "torch_ops": by_name, "streams": ns,
                        "cross_stream_events": len(need_event), "plan_ops": n, "pointers_outside_torch_memory": len(self._unresolved)}
+        if getattr(self, "report_split", None):
+            self.report["moved_to_extra_streams"] = self.report_split
 
     # ---------------------------------------------------------------------------------------------------------------------
     def replay(self, prof_slot=-1):
