@@ -181,9 +181,12 @@ def kernel_census(trainer, batch, steps=2):
     return out
 
 
-def fp16_leg(args, dev, B, H, W, steps=5):
-    """BASELINE C5's dtype on the same workload: fp16 activations + dynamic loss scaling, a few steps after the bf16 measurement (a
-    driver-run number for the reference's AMP format; the headline `value` stays the bf16 run)."""
+def fp16_leg(args, dev, B, H, W, steps=None):
+    """BASELINE C5's dtype on the same workload: fp16 activations + dynamic loss scaling, measured after the bf16 run like the bf16 run
+    (same number of timed steps, same warm-up, same execution mode) -- round 3 timed 5 steps right behind the other legs and reported
+    +2.3 ms; the same comparison as two full runs on one box is +0.44 ms (profiles/r04_fp16_vs_bf16.txt).  A driver-run number for the
+    reference's AMP format; the headline `value` stays the bf16 run."""
+    steps = args.steps if steps is None else steps
     from mgnet_amd import add_mgnet_config, get_cfg
     from mgnet_amd.data import synthetic_batch
     from mgnet_amd.engine import Trainer
@@ -202,8 +205,9 @@ def fp16_leg(args, dev, B, H, W, steps=5):
     if args.exec in ("auto", "plan"):
         try:   # the same execution mode as the headline measurement: launch-plan replay
             trainer.record_plan(batch)
-            trainer.replay_plan()
-            step, mode, warm = trainer.replay_plan, "plan", 6
+            for _ in range(max(2, args.warmup)):
+                trainer.replay_plan()
+            step, mode, warm = trainer.replay_plan, "plan", 5 + max(2, args.warmup)
         except Exception as e:  # noqa: BLE001
             print(f"[bench] fp16 leg: plan recording failed ({type(e).__name__}: {e}); eager steps timed", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
