@@ -70,7 +70,7 @@ def _check(rows, cos_min, rel_max, what):
     assert not bad, (what, f"{len(bad)} of {len(sig)} tensors", bad[:12])
 
 
-def _check_vs_torch_bf16(rows, tb_rows, what, worse_frac=0.05, labels=("HIP bf16", "torch bf16 autocast", "fp32 oracle")):
+def _check_vs_torch_bf16(rows, tb_rows, what, worse_frac=0.05, labels=("HIP bf16", "torch bf16 autocast", "fp32 oracle"), strict=False):
     """bf16 criterion.  SURVEY 8(d) asks for cosine >= 0.999 on bf16 gradients; for THIS network (about 60 batch-norm layers in
     the path, random initialisation, batch of 2) no bf16 evaluation meets it: the oracle network itself, run by plain torch
     ops under bf16 autocast on the same GPU, has a median cosine of 0.3 (64x96) to 0.7 (256x512) against its own fp32
@@ -95,6 +95,9 @@ def _check_vs_torch_bf16(rows, tb_rows, what, worse_frac=0.05, labels=("HIP bf16
     # tensor's worst of three yardstick evaluations does not remove the bimodality), so the per-tensor COUNT is only a loose bound --
     # a systematically wrong backward puts most tensors there -- and the sharp per-tensor statement is on tensors that are FAR off,
     # which is what a wrong (uncorrelated) gradient looks like: relative error >= 1
+    if strict:   # a reproducible yardstick (tests/test_step_composed_gpu.py): at most `worse_frac` of the tensors worse, none far worse
+        assert worse <= worse_frac * len(common) and not far, (what, worse, len(common), far[:10])
+        return
     assert worse <= max(2 * worse_frac, 0.35) * len(common), (what, worse, len(common))
     assert len(far) <= 0.2 * worse_frac * len(common) + 1, (what, far[:10])
 

@@ -26,6 +26,8 @@ node from its own recorded inputs, <= 0.7 ulp of a tensor norm), and what this f
 INDISTINGUISHABLE from the fp32 twin of the rounding-matched reference: losses within 3x the control's distance, per-tensor gradient
 errors no worse than the control's in aggregate and none far off (a wrong fused term in any conv / norm node -- they carry > 95 % of
 the step's arithmetic -- is an O(1) difference in every tensor upstream of it, in every precision)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -222,7 +224,15 @@ def _substitute(monkeypatch, ops, calls):
         monkeypatch.setattr(cls, "backward", staticmethod(ref.backward))
 
 
-@pytest.mark.parametrize("dtype,H,W", [(torch.bfloat16, 64, 96), (torch.bfloat16, 192, 640), (torch.bfloat16, 256, 512), (torch.float16, 192, 640)])
+# bf16 at 64x96 was part of this list until round 4 and passed only on a 10x looser bound.  It is not a meaningful comparison: with a 64x96 input
+# res5 is 2x3 pixels (12 samples per deep norm, 2 for the global-context norm), and the gradients that have passed through all of that --
+# the backbone's conv weights, 90 % of the squared gradient norm, 64 % in backbone.stem.conv1.weight alone -- are rounding noise in EVERY
+# evaluation: against the fp64 rounding-matched reference the product has cosine -0.03 (stem) / 0.11-0.26 (res2-res5) at 1.1x the norm,
+# the fp32 twin 0.46 / 0.51-0.55 at 2.3-2.8x the norm (profiles/r04_composed_64x96_diagnosis.txt; MGN_COMPOSED_DIAG=1 prints the table).
+# The same tensors agree to 0.43 / 0.66-0.69 (twin 0.55 / 0.53-0.58) at 192x640 in bf16 and to 0.99 in fp16 (8x smaller ulp): the
+# disagreement scales with the rounding unit and the sample count of the norms, not with the path.  What the small shape can prove -- every
+# fused node right in composition -- is asserted sharply by test_step_nodes_gpu.py (<= 0.7 ulp per node from its own recorded inputs).
+@pytest.mark.parametrize("dtype,H,W", [(torch.bfloat16, 192, 640), (torch.bfloat16, 256, 512), (torch.float16, 192, 640)])
 def test_composed_step_is_as_close_to_the_rounding_matched_reference_as_its_fp32_twin(dtype, H, W, monkeypatch):
     import sys
 
@@ -254,9 +264,18 @@ def test_composed_step_is_as_close_to_the_rounding_matched_reference_as_its_fp32
           f"HIP median cosine {med([r[1] for r in rows if r[0] in sig]):.4f} / relative error {med([r[2] for r in rows if r[0] in sig]):.3f} / whole gradient {whole(hip):.4f};  "
           f"fp32 twin {med([r[1] for r in rows_twin if r[0] in sig]):.4f} / {med([r[2] for r in rows_twin if r[0] in sig]):.3f} / {whole(twin):.4f}")
     print("   losses HIP / fp64 reference / fp32 twin:", {k: (round(hip_losses[k], 5), round(v, 5), round(twin_losses[k], 5)) for k, v in ref_losses.items()})
+    if os.environ.get("MGN_COMPOSED_DIAG"):
+        # which tensors carry the whole-gradient comparison: share of the reference gradient's squared norm, and each tensor's cosine
+        tot = sum(float(ref[n].norm()) ** 2 for n in ref)
+        big = sorted(ref, key=lambda n: -float(ref[n].norm()))[:10]
+        cosn = lambda a, n: float((a[n] @ ref[n]) / (a[n].norm() * ref[n].norm() + 1e-300))
+        for n in big:
+            print(f"      {n:58s} share {float(ref[n].norm()) ** 2 / tot:6.3f}  numel {ref[n].numel():8d}  cos HIP {cosn(hip, n):7.4f}  twin {cosn(twin, n):7.4f}  "
+                  f"|HIP|/|ref| {float(hip[n].norm() / ref[n].norm()):.3f}  |twin|/|ref| {float(twin[n].norm() / ref[n].norm()):.3f}")
     for k, v in ref_losses.items():
         assert hip_losses[k] == pytest.approx(v, rel=2e-2, abs=2e-4), (k, hip_losses[k], v)
         # the product's losses are as close to the reference's as the control's are (3x its distance + a floor of 1e-3 relative)
         assert abs(hip_losses[k] - v) <= 3 * abs(twin_losses[k] - v) + 1e-3 * abs(v) + 1e-5, (k, hip_losses[k], v, twin_losses[k])
-    _check_vs_torch_bf16(rows, rows_twin, f"composed {str(dtype)[6:]} {H}x{W} ", worse_frac=0.5 if H * W < 100000 else 0.05,
+    # (strict: the yardstick here is deterministic torch fp32 arithmetic, not MIOpen's bf16 convolutions -- measured 0 worse, 0 far worse)
+    _check_vs_torch_bf16(rows, rows_twin, f"composed {str(dtype)[6:]} {H}x{W} ", worse_frac=0.05, strict=True,
                          labels=("HIP", "fp32 twin", "the fp64 rounding-matched reference"))
