@@ -390,7 +390,8 @@ int mgn_u8_frames_to_rgbx(const void* const* frames_u8, int n_frames, long hw, v
  *
  * mgn_msc_input: `x = F.interpolate(norm_images, scale_factor=scale, bilinear, align_corners=True)` (+ `torch.flip(x, dims=(3,))`,
  *   mg_net.py:451-455) written as the network input: norm_nchw [N,3,H,W] fp32 -> out [N,h,w,8] bf16 (out_f16 = 0) or fp16 (1),
- *   channels-last, channels 3..7 zero (the stem kernels' layout, like mgn_prep_input); h, w = floor(H * scale), floor(W * scale).
+ *   channels-last, channels 3..7 zero (the stem kernels' layout, like mgn_prep_input); out_f16 = 2: [N,h,w,3] fp32 for an fp32 trunk
+ *   (SOLVER.AMP.ENABLED False, the reference's PseudoLabelGeneration yamls); h, w = floor(H * scale), floor(W * scale).
  * mgn_msc_accumulate: one head output of one pass added to its running average (mg_net.py:462-512):
  *   lr      low-resolution head output [N,C,h,w] with element strides sn, sc, sh, sw; dtype 0 = fp32, 1 = bf16, 2 = fp16; C <= 32
  *   acc     [N,C,H,W] fp32 contiguous: the running sum; first != 0: written, not added to (no zero fill needed)

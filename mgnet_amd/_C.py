@@ -675,9 +675,11 @@ def msc_input(norm, h, w, flip, dtype):
     """[N,3,H,W] fp32 normalised frames -> bilinear(align_corners) rescale to (h, w) (+ horizontal flip) as the network input
     [N,8,h,w] `dtype` channels_last (channels 3..7 zero): one launch instead of interpolate + flip + pad + cast + layout change"""
     N, C, H, W = norm.shape
-    assert C == 3 and norm.dtype == torch.float32 and norm.is_cuda and norm.is_contiguous() and dtype in H16
-    out = torch.empty((N, 8, h, w), dtype=dtype, device=norm.device, memory_format=torch.channels_last)
-    check(lib().mgn_msc_input(norm.data_ptr(), N, H, W, h, w, int(bool(flip)), int(dtype == torch.float16), out.data_ptr(), _stream()), "mgn_msc_input")
+    assert C == 3 and norm.dtype == torch.float32 and norm.is_cuda and norm.is_contiguous() and (dtype in H16 or dtype == torch.float32)
+    # 16-bit trunks: 8 channels (3..7 zero, the packed-tap stem's layout); fp32 trunk: the 3 real channels, channels_last
+    out = torch.empty((N, 3 if dtype == torch.float32 else 8, h, w), dtype=dtype, device=norm.device, memory_format=torch.channels_last)
+    code = 2 if dtype == torch.float32 else int(dtype == torch.float16)
+    check(lib().mgn_msc_input(norm.data_ptr(), N, H, W, h, w, int(bool(flip)), code, out.data_ptr(), _stream()), "mgn_msc_input")
     return out
 
 

@@ -165,6 +165,11 @@ __global__ __launch_bounds__(256) void msc_input(InParams p) {
         const float v10 = s[(long)ay.i1 * p.W + ax.i0], v11 = s[(long)ay.i1 * p.W + ax.i1];
         v[c] = ay.l0 * (ax.l0 * v00 + ax.l1 * v01) + ay.l1 * (ax.l0 * v10 + ax.l1 * v11);
     }
+    if (p.f16 == 2) {   // fp32 trunk (SOLVER.AMP.ENABLED False): [N,h,w,3] fp32 = a channels_last [N,3,h,w] tensor
+        float* d = reinterpret_cast<float*>(p.dst) + (((long)n * p.h + y) * p.w + x) * 3;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2];
+        return;
+    }
     uint16_t hv[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -180,7 +185,8 @@ extern "C" {
 
 int mgn_msc_input(const float* norm_nchw, int N, int H, int W, int h, int w, int flip, int out_f16, void* out_nhwc8, void* stream) {
     if (!norm_nchw || !out_nhwc8 || N < 1 || H < 1 || W < 1 || h < 1 || w < 1 || ((uintptr_t)out_nhwc8 & 15)) return MGN_EINVAL;
-    InParams p{norm_nchw, (uint16_t*)out_nhwc8, N, H, W, h, w, flip ? 1 : 0, out_f16 ? 1 : 0};
+    if (out_f16 < 0 || out_f16 > 2) return MGN_EINVAL;
+    InParams p{norm_nchw, (uint16_t*)out_nhwc8, N, H, W, h, w, flip ? 1 : 0, out_f16};   // out_f16: 0 bf16, 1 fp16 ([N,h,w,8]); 2 fp32 ([N,h,w,3])
     hipLaunchKernelGGL(msc_input, dim3((w + 63) / 64, (h + 3) / 4, N), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }

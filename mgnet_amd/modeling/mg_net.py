@@ -330,15 +330,16 @@ def _as_net_input(self, x):
     return x.contiguous(memory_format=torch.channels_last) if x.is_cuda else x.contiguous()
 
 
-def forward_multi_scale_flip(self, norm_images, scales=None, flip=True):
+def forward_multi_scale_flip(self, norm_images, scales=None, flip=True, _torch_formulation=False):
     """mg_net.py:427-520: average the raw predictions over rescaled (bilinear, align_corners=True) and horizontally
     flipped copies of the normalised frames; softmax probabilities for sem_seg, offsets rescaled by stride / scale and
     their x component negated for the flipped pass.
-    CUDA + 16-bit trunk: [HIP] csrc/mscflip.hip -- one launch builds each pass's network input, one launch per head output folds
+    CUDA (16-bit and fp32 trunks): [HIP] csrc/mscflip.hip -- one launch builds each pass's network input, one launch per head output folds
     upsample -> softmax | offset scaling | 1 / depth -> un-flip -> running sum (the last pass divides); no full-resolution torch op."""
     scales = [0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0] if scales is None else scales
     n_flip = 2 if flip else 1
-    if norm_images.is_cuda and self.amp_dtype in (torch.bfloat16, torch.float16):
+    if norm_images.is_cuda and self.amp_dtype in (torch.bfloat16, torch.float16, None) and not _torch_formulation:   # (the flag: tests only)
+        # (None: the fp32 trunk of the reference's PseudoLabelGeneration yamls, SOLVER.AMP.ENABLED False -- same kernels, fp32 maps)
         return _msc_flip_hip(self, norm_images.float().contiguous(), scales, n_flip)
     import torch.nn.functional as F
     up = lambda t, stride, scale: F.interpolate(t.float(), scale_factor=stride / scale, mode="bilinear", align_corners=True)
@@ -393,7 +394,7 @@ def _msc_flip_hip(self, norm, scales, n_flip):
     for scale in scales:
         h, w = int(math.floor(H * scale)), int(math.floor(W * scale))
         for f in range(n_flip):
-            x = _C.msc_input(norm, h, w, f, self.amp_dtype)
+            x = _C.msc_input(norm, h, w, f, self.amp_dtype or torch.float32)
             features = self.backbone(x)
             features["global_context"] = self.global_context(features[self.bb_features[-1]])
             if self.with_panoptic:

@@ -67,8 +67,17 @@ def test_eval_fp32_without_staging_matches_reference_gpu(monkeypatch):
     monkeypatch.delenv("MGNET_ALLOW_TORCH_STAGING", raising=False)
     from mgnet_amd.modeling import ops
     ops.STAGING_USED.clear()
+    # ... and the multi-scale + flip averages of the fp32 trunk are folded by csrc/mscflip.hip (row f4), not by torch ops: the reference's own
+    # forward_multi_scale_flip fixture is then a DIRECT check of mgn_msc_input / mgn_msc_accumulate at fp32 tolerances
+    from mgnet_amd import _C
+    calls = {"input": 0, "acc": 0}
+    real_in, real_acc = _C.msc_input, _C.msc_accumulate
+    monkeypatch.setattr(_C, "msc_input", lambda *a, **k: (calls.__setitem__("input", calls["input"] + 1), real_in(*a, **k))[1])
+    monkeypatch.setattr(_C, "msc_accumulate", lambda *a, **k: (calls.__setitem__("acc", calls["acc"] + 1), real_acc(*a, **k))[1])
     single, msc = run("cuda", False)
     assert not ops.STAGING_USED
+    n_pass = 2 * len(GM.EVAL_SCALES)
+    assert calls == {"input": n_pass, "acc": 4 * n_pass}, calls
     check(single, msc, rtol=5e-3, atol_frac=1e-3)
 
 

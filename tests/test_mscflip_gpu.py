@@ -94,13 +94,7 @@ def test_hip_path_matches_torch_formulation_end_to_end():
     with torch.no_grad():
         x = ((img[None].float() / 255.0) - m.pixel_mean) / m.pixel_std
         got = m.forward_multi_scale_flip(x, scales=[0.5, 1.0, 1.5], flip=True)
-        amp, m.amp_dtype = m.amp_dtype, None
-        try:     # torch formulation: force it by hiding the 16-bit trunk from the dispatcher, then feed the same 16-bit inputs
-            m._as_net_input = lambda t, _amp=amp: torch.nn.functional.pad(t, (0, 0, 0, 0, 0, 5)).to(_amp).contiguous(memory_format=torch.channels_last)
-            want = m.forward_multi_scale_flip(x, scales=[0.5, 1.0, 1.5], flip=True)
-        finally:
-            m.amp_dtype = amp
-            del m._as_net_input
+        want = m.forward_multi_scale_flip(x, scales=[0.5, 1.0, 1.5], flip=True, _torch_formulation=True)   # the same network, torch algebra
     # the two paths feed the network inputs that differ in the last bf16 bit at a few pixels (two fp32 evaluation orders of the rescale):
     # the outputs agree to bf16 noise almost everywhere, a soft-max probability next to a near-tie of two logits moves further
     for k in ("sem_seg", "center", "offset"):
