@@ -86,6 +86,22 @@ def test_input_rescale_flip_matches_torch(dtype):
             assert bool((d <= ulp * 1.01 + 4e-6).all()) and float((d > 0).float().mean()) < 2e-2, (scale, f, float(d.max()))
 
 
+def test_input_rescale_flip_fp32_matches_torch():
+    """the fp32 trunk's network input (SOLVER.AMP.ENABLED False): [N,3,h,w] fp32 channels_last, two fp32 evaluation orders apart"""
+    from mgnet_amd import _C
+    torch.manual_seed(2)
+    N, H, W = 2, 70, 122
+    norm = torch.randn(N, 3, H, W, device="cuda")
+    for scale in (0.5, 1.0, 1.75):
+        x = F.interpolate(norm, scale_factor=scale, mode="bilinear", align_corners=True)
+        h, w = x.shape[2:]
+        for f in (0, 1):
+            want = torch.flip(x, dims=(3,)) if f else x
+            got = _C.msc_input(norm, h, w, f, torch.float32)
+            assert got.shape == (N, 3, h, w) and got.dtype == torch.float32 and got.is_contiguous(memory_format=torch.channels_last)
+            assert float((got - want).abs().max()) < 4e-6, (scale, f)
+
+
 def test_hip_path_matches_torch_formulation_end_to_end():
     """forward_multi_scale_flip on the bf16 HIP trunk: device path (mscflip.hip) vs the torch formulation driving the SAME network"""
     from test_model_golden import GM, _model
