@@ -384,7 +384,7 @@ def test_bench_self_launch_end_to_end_on_gloo(gpus):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MGNET_DIST_BACKEND="gloo", MGNET_P2P_TIMEOUT_S="120")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2" if gpus == 2 else "1", "--warmup", "1", "--batch", "2", "--height", "128",
-           "--width", "256", "--no-cpu-baseline", "--timeout", "500"]
+           "--width", "256", "--no-cpu-baseline", "--timeout", "500", "--exec", "plan"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
