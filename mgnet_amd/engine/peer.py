@@ -161,7 +161,7 @@ def lib_const(name):
     return _CONST[name]
 
 
-def _self_test(ex, rounds=24):
+def _self_test(ex, rounds=96):
     """the exchange against the process group's own all_gather on random rows, on two streams (two channels), back to back without host
     synchronisation in between (so that ring slots are reused while peers lag); agreement on every rank decides.  Runs with a 2 s wait
     budget and starts with ONE synchronised exchange, so that a node on which the mailboxes do not work costs seconds, not minutes."""
@@ -186,13 +186,16 @@ def _self_test(ex, rounds=24):
 def _self_test_burst(ex, rounds):
     dev, group = ex.device, ex.group
     g = torch.Generator(device=dev).manual_seed(1234 + ex.rank)
-    side = torch.cuda.Stream(dev)
+    # three streams = the three channels of a training step, every payload size the 68 norm sites produce (3 C forward, 2 C backward,
+    # C = 64 .. 1024), a few hundred exchanges without host synchronisation so that ring slots are reused while peers lag
+    sides = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
     rows, got = [], []
     for k in range(rounds):
-        n = (3 * 64, 3 * 256, 2 * 512, 3 * 1024)[k % 4]
+        n = (3 * 64, 2 * 64, 3 * 128, 2 * 128, 3 * 256, 2 * 256, 3 * 512, 2 * 512, 3 * 1024, 2 * 1024)[k % 10]
         t = torch.randn(n, device=dev, generator=g)
         rows.append(t)
-        if k % 3 == 2:
+        if k % 3:
+            side = sides[k % 3 - 1]
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 got.append((ex.all_gather(t), ex.all_reduce(t)))
