@@ -37,7 +37,8 @@ def reproj_roofline(kern_ms, npx, u8, traffic, extra=None):
     achieved = bpp * npx / (kern_ms * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": "reproj_march<true, %s> (fused reprojection loss + photometric gradient)" % ("uint8 RGBX frames" if u8 else "fp32 planar frames"),
          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-         "traffic": traffic, "bytes_per_px": bpp, "bytes_per_launch": bpp * npx, "avg_launch_ms": round(kern_ms, 4),
+         "traffic": traffic, "traffic_source": "profiles/traffic.json: PMC measurement (FETCH_SIZE + WRITE_SIZE, calibrated in the same pass) of this kernel "
+                                                 "in this frame layout, not re-measured in this run", "bytes_per_px": bpp, "bytes_per_launch": bpp * npx, "avg_launch_ms": round(kern_ms, 4),
          "achieved_at_61_B_per_px": round(FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9, 1),
          "frac_at_61_B_per_px": round(FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
          "limiter": "VALU issue + vector-memory instruction rate, not HBM (DESIGN.md 2.4: counted)"}
@@ -170,9 +171,12 @@ def kernel_census(trainer, batch, steps=2):
     cnt = {"mgn": [0, 0.0], "torch": [0, 0.0], "rocclr_copy_fill": [0, 0.0], "rccl": [0, 0.0]}
     for e in prof.key_averages():
         t = float(getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0))
-        if t <= 0 or e.key.startswith(("hip", "Memcpy", "Memset")):
+        if t <= 0 or e.key.startswith("hip"):
             continue
-        k = ("torch" if "at::" in e.key else "rocclr_copy_fill" if "__amd_rocclr" in e.key else "rccl" if "nccl" in e.key.lower() else "mgn")
+        # (the runtime's copies show up as `Memcpy DtoD / HtoD (...)` / `Memset (...)` activities or as __amd_rocclr_* kernels depending on
+        #  the path they take: both are counted -- round 3 dropped the former and reported 0 next to ~38 copyBuffer kernels per step)
+        k = ("torch" if "at::" in e.key else "rocclr_copy_fill" if ("__amd_rocclr" in e.key or e.key.startswith(("Memcpy", "Memset")))
+             else "rccl" if "nccl" in e.key.lower() else "mgn")
         cnt[k][0] += e.count
         cnt[k][1] += t
     out = {k: {"launches_per_step": round(v[0] / steps, 1)} for k, v in cnt.items()}

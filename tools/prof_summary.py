@@ -51,6 +51,18 @@ def main(db, out=None):
                 gaps.append((st - last_end, last_name, nm))
             if en >= last_end:
                 last_end, last_name = en, nm
+        # idle time of the steady-state window by the kernel that ENDS the gap (what the chip was waiting to start) and by the one before it
+        by_next, by_prev = {}, {}
+        for g, a, b in gaps:
+            if g < 200e3:   # (not the gaps between phases of the script)
+                by_next[b[:70]] = by_next.get(b[:70], [0, 0]); by_next[b[:70]][0] += g; by_next[b[:70]][1] += 1
+                by_prev[a[:70]] = by_prev.get(a[:70], [0, 0]); by_prev[a[:70]][0] += g; by_prev[a[:70]][1] += 1
+        lines.append("idle time by the kernel that starts after the gap (ms total, gaps, mean us):")
+        for k, (t, n) in sorted(by_next.items(), key=lambda kv: -kv[1][0])[:14]:
+            lines.append(f"  {t/1e6:8.2f} {n:6d} {t/n/1e3:7.1f}  {k}")
+        lines.append("idle time by the kernel that ran before the gap:")
+        for k, (t, n) in sorted(by_prev.items(), key=lambda kv: -kv[1][0])[:14]:
+            lines.append(f"  {t/1e6:8.2f} {n:6d} {t/n/1e3:7.1f}  {k}")
         gaps.sort(reverse=True)
         lines.append("largest idle gaps (us): after kernel -> before kernel")
         for g, a, b in gaps[:24]:
