@@ -338,7 +338,7 @@ def full_step_bench(args, world, rank, dev):
     # before each step, none inside), so that it measures the host's own work and not the wait for queue slots -- over the K timed steps
     # the issue loop runs ahead of a GPU-bound step only until the hardware queues are full, and its wall time then equals the GPU's.
     issue_one = []
-    for _ in range(5):
+    for _ in range(5 if world == 1 else 0):   # (multi-rank: every extra step costs a round of collectives; the loop's wall time is reported)
         torch.cuda.synchronize()
         ti = time.perf_counter()
         if mode == "plan":
@@ -349,7 +349,7 @@ def full_step_bench(args, world, rank, dev):
             trainer.run_step(batch)
         issue_one.append(time.perf_counter() - ti)
     torch.cuda.synchronize()
-    host_issue_ms = float(np.median(issue_one)) * 1e3
+    host_issue_ms = float(np.median(issue_one)) * 1e3 if issue_one else t_issue / args.steps * 1e3
     # What the host needs to ISSUE a step, measured where the GPU cannot back-pressure the launch queue: the same model and launch
     # sequence on two 512x1024 frames (an eighth of the device work, the same host work).  `host_issue_ms_per_step` above is the
     # wall time of the launch loop at the benchmark size, which mostly waits for queue slots once the GPU is the bottleneck.

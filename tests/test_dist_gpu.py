@@ -126,7 +126,7 @@ def _p2p_exchange(rank, world):
     g = torch.Generator(device=dev).manual_seed(77 + rank)
     streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
     rows, got = [], []
-    for k in range(150):
+    for k in range(150 if world == 2 else 60):   # (more than two processes time-slice the one GPU: ~40 ms per exchange at world 8)
         C = (64, 128, 256, 512, 1024)[k % 5]
         t = torch.randn(3 if k % 2 else 2, C, device=dev, generator=g)
         rows.append(t)
@@ -153,11 +153,12 @@ def _p2p_exchange(rank, world):
     torch.cuda.synchronize(); dist.barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(200):
+    nlat = 200 if world == 2 else 20
+    for _ in range(nlat):
         ex.all_gather(t)
     e1.record()
     torch.cuda.synchronize()
-    return ("ok", round(e0.elapsed_time(e1) / 200 * 1e3, 1), peer.report()["mode"])
+    return ("ok", round(e0.elapsed_time(e1) / nlat * 1e3, 1), peer.report()["mode"])
 
 
 def test_p2p_mailbox_exchange_matches_collectives(capsys):
@@ -384,7 +385,7 @@ def test_bench_self_launch_end_to_end_on_gloo(gpus):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MGNET_DIST_BACKEND="gloo", MGNET_P2P_TIMEOUT_S="120")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2" if gpus == 2 else "1", "--warmup", "1", "--batch", "2", "--height", "128",
-           "--width", "256", "--no-cpu-baseline", "--timeout", "500", "--exec", "plan"]
+           "--width", "256", "--no-cpu-baseline", "--timeout", "500", "--exec", "plan" if gpus == 2 else "eager"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
