@@ -1595,6 +1595,38 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+    // Role-alternating waves (round 4, as in wgrad3x3_body): in the row loop the four waves of group (r - r0) & 1 -- one per SIMD -- issue
+    // the WHOLE step (two input rows + one dOut row, pieces (wave & 3) + 4 i) while their SIMD partners start the step's MFMAs; a 1-KB
+    // LDS-DMA piece occupies the CU's vector-memory path ~34 cycles, and with every wave issuing its share behind the barrier that was
+    // 1150 (CP = 16) / 880 (CP = 8) cycles per step without an MFMA in flight, against 3580 / 1790 cycles of MFMA issue.
+    const int grp = wave >> 2;
+    constexpr int TOT = 2 * C::PIN + C::POUT, LMAX = (TOT + 3) / 4, LMIN = TOT / 4;
+    auto issue_step_loader = [&](int iha, int sa, int ihb, int sb, int oh, int oslot) {
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) {
+            const int jj = (wave & 3) + 4 * i;
+            if (jj < 2 * C::PIN) {
+                const bool second = jj >= C::PIN;
+                const int j = second ? jj - C::PIN : jj, ih = second ? ihb : iha, slot = second ? sb : sa;
+                const bool ok = ih >= 0 && ih < p.IH;
+                const int soff = ok ? ((n * p.IH + ih) * p.IW) * C::PXB : 0;
+                const int boff = j * 1024 + lane * 16;
+                const int iw = iw_base + boff / C::PXB;
+                const int vo = (ok && iw >= 0 && iw < p.IW) ? iw_base * C::PXB + boff : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(wssm + slot * C::INROW + j * 1024), 16, vo, soff, 0, 0);
+            } else if (jj < TOT) {
+                const int jo = jj - 2 * C::PIN;
+                const bool ok = oh < p.OH;
+                const int soff = ok ? ((n * p.OH + oh) * p.OW) * p.Cout * 2 : 0;
+                const int px = 8 * jo + (lane >> 3);
+                const int seg = (lane & 7) ^ (((px >> 1) & 1) << 2);
+                const int ow = ow0 + px;
+                const int vo = (ok && ow < p.OW) ? (ow * p.Cout + co0 + seg * 8) * 2 : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lds_ptr)(wssm + C::NIN * C::INROW + oslot * C::OUTROW + jo * 1024), 16, vo, soff, 0, 0);
+            }
+        }
+    };
+
     // ring slots: input row ih -> (ih - (2*r0 - 3)) % 11, dOut row oh -> (oh - r0) % 3
     for (int k = 0; k < 7; ++k) issue_in(2 * r0 - 3 + k, k, (k & 1) * 4);
     issue_out(r0, 0);
@@ -1603,32 +1635,57 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
     issue_out(r0 + 1, 1);
     int s0 = 0, so = 0;  // slots of input row 2r-3 and dOut row r
     for (int r = r0; r < r1; ++r) {
-        if (my_cnt == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (my_cnt == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if (my_cnt == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        const bool loader = grp == ((r - r0) & 1);
+        if (r == r0) {
+            // the prologue (every wave its share): the group of step r0+1 may stay in flight
+            if (my_cnt == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (my_cnt == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (my_cnt == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else if (loader) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this group issued step r's rows two steps ago (or in the prologue), nothing since
+        } else if (r == r0 + 1) {
+            // the prologue's rows of step r0+1 must have landed; this group's pieces of step r0 (>= LMIN per wave) may stay in flight
+            if (LMIN == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        {   // rows of step r+2 (always issued: out-of-range rows read as zeros into slots nobody uses)
+        if (loader) {   // rows of step r+2 (always issued: out-of-range rows read as zeros into slots nobody uses)
             const int sa = s0 + 9 >= 11 ? s0 - 2 : s0 + 9, sb = s0 + 10 >= 11 ? s0 - 1 : s0 + 10;
-            issue_in(2 * r + 6, sa, 0);
-            issue_in(2 * r + 7, sb, 4);
-            issue_out(r + 2, so + 2 >= 3 ? so - 1 : so + 2);
+            issue_step_loader(2 * r + 6, sa, 2 * r + 7, sb, r + 2, so + 2 >= 3 ? so - 1 : so + 2);
         }
         const unsigned char* sa_ = wssm + aA + so * C::OUTROW;
+        const unsigned char* bp[7];
 #pragma unroll
-        for (int ks = 0; ks < C::KSW; ++ks) {
-            const h16x8 a = tr_frag(sa_ + ks * 2048);
+        for (int i = 0; i < 7; ++i) {
+            const int t = ngrp * 7 + i, kh = t / C::TPK, qq = t % C::TPK;
+            const int sl = s0 + kh >= 11 ? s0 + kh - 11 : s0 + kh;
+            bp[i] = wssm + sl * C::INROW + bB + qq * 64;
+        }
+        // the KSW x 7 MFMAs of a step as one software-pipelined stream (input fragment of MFMA m read 4 MFMAs ahead)
+        constexpr int NM = C::KSW * 7, PD = 4, NB = PD + 1;
+        h16x8 fa[2], fb[NB];
+        auto rd_b = [&](int m) {
+            const int ks = m / 7, i = m % 7;
+            const unsigned char* q = bp[i] + ks * (32 * C::PXB);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(q));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(q + 8 * C::PXB));
+            fb[m % NB] = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        fa[0] = tr_frag(sa_);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                const int t = ngrp * 7 + i, kh = t / C::TPK, qq = t % C::TPK;
-                const int sl = s0 + kh >= 11 ? s0 + kh - 11 : s0 + kh;
-                const unsigned char* bp = wssm + sl * C::INROW + bB + qq * 64 + ks * (32 * C::PXB);
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bp));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bp + 8 * C::PXB));
-                const h16x8 b = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                acc[i] = MGN_MFMA_32x32x16(a, b, acc[i]);
+        for (int m = 0; m < PD; ++m) rd_b(m);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            if (m + PD < NM) {
+                if ((m + PD) % 7 == 0) fa[((m + PD) / 7) & 1] = tr_frag(sa_ + ((m + PD) / 7) * 2048);
+                rd_b(m + PD);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[m % 7] = MGN_MFMA_32x32x16(fa[(m / 7) & 1], fb[m % NB], acc[m % 7]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         s0 = s0 + 2 >= 11 ? s0 - 9 : s0 + 2;
         so = so + 1 >= 3 ? 0 : so + 1;

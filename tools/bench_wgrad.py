@@ -39,3 +39,17 @@ for Cin, Cout, H, W, cnt in SHAPES:
     tot += cnt * us
     print(f"wgrad3x3 {Cin:3d}->{Cout:3d} @{H}x{W}: {us:7.1f} us  {gf / us * 1e-3 * 1e3:6.0f} TF/s  x{cnt}")
 print(f"sum over the step's calls: {tot / 1e3:.3f} ms   lib={os.environ.get('MGNET_HIP_LIB', 'in-tree')}")
+
+# the 7x7 / stride-2 stems (conv_wgrad_stem16 / _stem8): channel-padded inputs, cin_real 9 / 3
+for Cp, cr in ((16, 9), (8, 3)):
+    x, dy = cl(B, Cp, 1024, 2048), cl(B, 64, 512, 1024)
+    f = lambda: _C.conv_wgrad(dy, x, 7, 7, 2, 3, cin_real=cr)
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(10):
+        f()
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t) / 10 * 1e6
+    print(f"wgrad stem 7x7 s2 Cp={Cp} (cin {cr}) @1024x2048: {us:7.1f} us")
