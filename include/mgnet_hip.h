@@ -192,6 +192,12 @@ int mgn_adam_step(float* p, const float* g, float* m, float* v, long n, const fl
 int mgn_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* chunk_lr, const float* chunk_wd,
                       float beta1, float beta2, float eps, const float* hyper, const float* clip_coef, float grad_scale,
                       void* stream);
+/* The other optimizers tools/train_net.py:129-154 can build, on the same flat buckets / tables / clip coefficient: kind 0 = Adam (above),
+ * 1 = AdamW (torch.optim.AdamW: decoupled decay p <- p (1 - lr wd), v = second moment), 2 = SGD (torch.optim.SGD with momentum `beta1`,
+ * dampening 0, optional Nesterov; m = momentum buffer, v unused / may be NULL).  hyper as for mgn_adam_step_dev (ignored by SGD). */
+int mgn_optim_step_dev(int kind, float* p, const float* g, float* m, float* v, long n, const float* chunk_lr, const float* chunk_wd,
+                       float beta1, float beta2, float eps, int nesterov, const float* hyper, const float* clip_coef, float grad_scale,
+                       void* stream);
 /* Dynamic loss scaling for fp16 activations -- torch.cuda.amp.GradScaler as used by detectron2's AMPTrainer
  * (tools/train_net.py:162), evaluated on the device.  The gradients in the buckets are `S` times the true ones
  * (the caller multiplied the loss by scaler_state[0] before backward).  After mgn_sqnorm:

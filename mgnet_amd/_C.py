@@ -16,7 +16,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv_win_patch_rows", "mgn_conv_stem7", "mgn_conv_stem7_blocks", "mgn_iabn_coeffs_from_partials", "mgn_iabn_partials_reduce", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_optim_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv_win_patch_rows", "mgn_conv_stem7", "mgn_conv_stem7_blocks", "mgn_iabn_coeffs_from_partials", "mgn_iabn_partials_reduce", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_adjoint_footprint_floats", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_sum3", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -121,6 +121,7 @@ def lib():
         L.mgn_clip_coef.argtypes = [vp, ci, cf, cf, vp, vp]
         L.mgn_adam_step.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, ci, vp, cf, vp]
         L.mgn_adam_step_dev.argtypes = [vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, vp, vp, cf, vp]
+        L.mgn_optim_step_dev.argtypes = [ci, vp, vp, vp, vp, cl, vp, vp, cf, cf, cf, ci, vp, vp, cf, vp]
         L.mgn_clip_coef_scaled.argtypes = [vp, ci, cf, cf, cf, cf, ci, vp, vp, vp, vp]
         L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp, vp]
         L.mgn_conv3x3_win.argtypes = [vp, vp, vp] + [ci] * 5 + [vp, ci, vp, vp, vp]
@@ -563,6 +564,16 @@ def adam_step_dev(p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, hyper, coef
     check(lib().mgn_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), chunk_lr.data_ptr(),
                                   chunk_wd.data_ptr(), beta1, beta2, eps, hyper.data_ptr(), coef.data_ptr(), grad_scale, _stream()),
           "mgn_adam_step_dev")
+
+
+OPTIM_KIND = {"ADAM": 0, "ADAMW": 1, "SGD": 2}
+
+
+def optim_step_dev(kind, p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, nesterov, hyper, coef, grad_scale):
+    """Adam | AdamW | SGD (momentum) on one flat bucket (mgn_optim_step_dev); v may be None for SGD"""
+    check(lib().mgn_optim_step_dev(OPTIM_KIND[kind], p.data_ptr(), g.data_ptr(), m.data_ptr(), None if v is None else v.data_ptr(), p.numel(),
+                                   chunk_lr.data_ptr(), chunk_wd.data_ptr(), beta1, beta2, eps, int(bool(nesterov)), hyper.data_ptr(),
+                                   coef.data_ptr(), grad_scale, _stream()), "mgn_optim_step_dev")
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -135,6 +135,52 @@ __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// AdamW (torch.optim.AdamW, tools/train_net.py:150-154): decoupled weight decay p <- p (1 - lr wd), then Adam on the plain gradient.
+// SGD (torch.optim.SGD, tools/train_net.py:136-141; dampening 0): g <- g + wd p; buf <- mu buf + g; p <- p - lr (nesterov ? g + mu buf : buf).
+// Same flat buckets, per-chunk lr / wd tables, clip coefficient and skip-on-overflow as adam_kernel.
+template <int KIND>   // 1 AdamW, 2 SGD
+__global__ __launch_bounds__(TPB) void optim_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, const float* __restrict__ chunk_lr,
+                                                    const float* __restrict__ chunk_wd, float beta1, float beta2, float eps, int nesterov,
+                                                    const float* __restrict__ hyper, const float* __restrict__ clip, float grad_scale) {
+    const float inv_bc1 = hyper[0], inv_sqrt_bc2 = hyper[1];
+    if (clip[2] != 0.f) return;   // dynamic loss scaling found inf/NaN gradients: the step is skipped
+    const float gs = grad_scale * clip[0];
+    const long nv = n / 4;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nv; i += (long)gridDim.x * TPB) {
+        const int ch = (int)((i * 4) / CHUNK);
+        const float lr = chunk_lr[ch], wd = chunk_wd[ch];
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x;
+        if (KIND == 1) {
+            float4 vv = reinterpret_cast<float4*>(v)[i];
+            float* vp = &vv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = gp[k] * gs;
+                pp[k] *= 1.f - lr * wd;
+                mp[k] = fmaf(beta1, mp[k], (1.f - beta1) * gk);
+                vp[k] = fmaf(beta2, vp[k], (1.f - beta2) * gk * gk);
+                const float denom = sqrtf(vp[k]) * inv_sqrt_bc2 + eps;
+                pp[k] -= lr * inv_bc1 * (mp[k] / denom);
+            }
+            reinterpret_cast<float4*>(v)[i] = vv;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float gk = gp[k] * gs;
+                if (wd != 0.f) gk = fmaf(wd, pp[k], gk);
+                mp[k] = fmaf(beta1, mp[k], gk);                    // beta1 = momentum
+                pp[k] -= lr * (nesterov ? fmaf(beta1, mp[k], gk) : mp[k]);
+            }
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+    }
+}
+
 inline int blocks_for(long n) {
     long b = (n / 4 + TPB - 1) / TPB;
     return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
@@ -185,6 +231,21 @@ int mgn_adam_step_dev(float* p, const float* g, float* m, float* v, long n, cons
     if (!p || !g || !m || !v || n < 1 || n % CHUNK != 0 || !chunk_lr || !chunk_wd || !clip_coef || !hyper) return MGN_EINVAL;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, chunk_lr, chunk_wd, beta1,
                        beta2, eps, 0.f, 0.f, hyper, clip_coef, grad_scale);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+
+int mgn_optim_step_dev(int kind, float* p, const float* g, float* m, float* v, long n, const float* chunk_lr, const float* chunk_wd,
+                       float beta1, float beta2, float eps, int nesterov, const float* hyper, const float* clip_coef, float grad_scale,
+                       void* stream) {
+    if (kind == 0) return mgn_adam_step_dev(p, g, m, v, n, chunk_lr, chunk_wd, beta1, beta2, eps, hyper, clip_coef, grad_scale, stream);
+    if ((kind != 1 && kind != 2) || !p || !g || !m || (kind == 1 && !v) || n < 1 || n % CHUNK != 0 || !chunk_lr || !chunk_wd || !clip_coef || !hyper)
+        return MGN_EINVAL;
+    if (kind == 1)
+        hipLaunchKernelGGL(optim_kernel<1>, dim3(blocks_for(n)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, chunk_lr, chunk_wd, beta1, beta2,
+                           eps, 0, hyper, clip_coef, grad_scale);
+    else
+        hipLaunchKernelGGL(optim_kernel<2>, dim3(blocks_for(n)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, chunk_lr, chunk_wd, beta1, 0.f,
+                           0.f, nesterov ? 1 : 0, hyper, clip_coef, grad_scale);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

@@ -15,7 +15,7 @@ class Trainer:
     def __init__(self, cfg, model, bucket_bytes=32 << 20):
         self.cfg, self.model = cfg, model
         on_gpu = next(model.parameters()).is_cuda
-        if on_gpu and cfg.SOLVER.OPTIMIZER == "ADAM":
+        if on_gpu and cfg.SOLVER.OPTIMIZER in ("ADAM", "ADAMW", "SGD"):
             from .. import _C
             from ..solver import get_mgnet_optimizer_params
             groups = get_mgnet_optimizer_params(model, cfg.SOLVER.BASE_LR, head_lr_factor=cfg.SOLVER.HEAD_LR_FACTOR)

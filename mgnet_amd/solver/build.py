@@ -63,12 +63,15 @@ def build_optimizer(cfg, model, reducer=None):
     clip = s.CLIP_GRADIENTS
     enable = clip.ENABLED and clip.CLIP_TYPE == "full_model" and clip.CLIP_VALUE > 0.0
     wrap = (lambda c: _with_full_model_clipping(c, clip.CLIP_VALUE, clip.NORM_TYPE)) if enable else (lambda c: c)
-    if reducer is not None and s.OPTIMIZER == "ADAM":
+    if reducer is not None and s.OPTIMIZER in ("ADAM", "ADAMW", "SGD"):
+        # [HIP] one fused clip + step over the reducer's flat buckets for each of the three optimizers tools/train_net.py:129-154 builds
         from .fused_adam import FusedAdam
         fp16 = getattr(model, "amp_dtype", None) == torch.float16   # the reference's AMP: fp16 needs GradScaler's dynamic loss scale
+        extra = dict(weight_decay=0.01) if s.OPTIMIZER == "ADAMW" else {}   # (torch.optim.AdamW's default for groups without their own)
         return FusedAdam(groups, s.BASE_LR, reducer, max_grad_norm=clip.CLIP_VALUE if enable else 0.0,
                          loss_scale=float(s.AMP.LOSS_SCALE_INIT) if fp16 else None,
-                         growth_interval=int(s.AMP.LOSS_SCALE_GROWTH_INTERVAL))
+                         growth_interval=int(s.AMP.LOSS_SCALE_GROWTH_INTERVAL), kind=s.OPTIMIZER, momentum=s.MOMENTUM, nesterov=s.NESTEROV,
+                         **extra)
     if s.OPTIMIZER == "SGD":
         return wrap(torch.optim.SGD)(groups, s.BASE_LR, momentum=s.MOMENTUM, nesterov=s.NESTEROV)
     if s.OPTIMIZER == "ADAM":

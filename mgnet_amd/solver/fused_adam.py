@@ -1,4 +1,4 @@
-"""[HIP] Adam + full-model gradient-norm clipping on the flat buckets of GradReducer (mgnet_amd/csrc/optim.hip).
+"""[HIP] Adam (and, round 4, AdamW / SGD) + full-model gradient-norm clipping on the flat buckets of GradReducer (mgnet_amd/csrc/optim.hip).
 Same update rule as torch.optim.Adam behind FullModelGradientClippingOptimizer (tools/train_net.py:129-148); a
 torch.optim.Optimizer subclass so that the LR scheduler and `param_groups` work unchanged.
 
@@ -14,15 +14,21 @@ from .. import _C
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr, reducer, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=0.0, loss_scale=None,
-                 growth_interval=2000):
+                 growth_interval=2000, kind="ADAM", momentum=0.9, nesterov=False):
+        """kind: "ADAM" (default), "ADAMW" (torch.optim.AdamW: decoupled weight decay) or "SGD" (torch.optim.SGD with `momentum`,
+        dampening 0, optional Nesterov) -- the three optimizers tools/train_net.py:129-154 builds, one fused step each"""
+        assert kind in _C.OPTIM_KIND
+        if kind == "SGD":
+            betas = (float(momentum), 0.0)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.kind, self.nesterov = kind, bool(nesterov)
         self.reducer, self.max_grad_norm = reducer, float(max_grad_norm)
         assert reducer.align == _C.optim_chunk() and all(b["flat_p"] is not None for b in reducer.buckets)
         self.chunk = reducer.align
         dev = reducer.buckets[0]["flat_g"].device
         self._t = 0
         self._m = [torch.zeros_like(b["flat_g"]) for b in reducer.buckets]
-        self._v = [torch.zeros_like(b["flat_g"]) for b in reducer.buckets]
+        self._v = [torch.zeros_like(b["flat_g"]) if kind != "SGD" else None for b in reducer.buckets]   # (SGD: momentum buffer only)
         # ONE static device table for everything the host computes per step: [lr per chunk | weight decay per chunk] of every bucket,
         # then the two bias corrections -- one pinned staging copy + one device copy per step instead of three per bucket
         nch = [b["flat_g"].numel() // self.chunk for b in reducer.buckets]
@@ -84,8 +90,8 @@ class FusedAdam(torch.optim.Optimizer):
             _C.clip_coef_scaled(self._partials, n, self.max_grad_norm, grad_scale, g0["betas"][0], g0["betas"][1], self.growth_interval,
                                 self.scaler, self._hyper, self._coef)
         for k, b in enumerate(self.reducer.buckets):
-            _C.adam_step_dev(b["flat_p"], b["flat_g"], self._m[k], self._v[k], self._lr_dev[k], self._wd_dev[k],
-                             g0["betas"][0], g0["betas"][1], g0["eps"], self._hyper, self._coef, grad_scale)
+            _C.optim_step_dev(self.kind, b["flat_p"], b["flat_g"], self._m[k], self._v[k], self._lr_dev[k], self._wd_dev[k],
+                              g0["betas"][0], g0["betas"][1], g0["eps"], self.nesterov, self._hyper, self._coef, grad_scale)
         # the kernel rewrote the flat parameter buffers behind torch's version counters: re-derive the bf16 conv layouts
         _C.weight_cache.refresh()
 
@@ -115,7 +121,9 @@ class FusedAdam(torch.optim.Optimizer):
         for g in self.param_groups:
             for p in g["params"]:
                 k, o = where[p]
-                if self._t:
+                if self._t and self.kind == "SGD":   # torch.optim.SGD's state layout
+                    state[idx] = {"momentum_buffer": self._m[k][o:o + p.numel()].view(p.shape).clone()}
+                elif self._t:
                     state[idx] = {"step": torch.tensor(float(steps)),
                                   "exp_avg": self._m[k][o:o + p.numel()].view(p.shape).clone(),
                                   "exp_avg_sq": self._v[k][o:o + p.numel()].view(p.shape).clone()}
@@ -133,7 +141,11 @@ class FusedAdam(torch.optim.Optimizer):
                     g[key] = val
             for p in g["params"]:
                 st = sd["state"].get(idx, sd["state"].get(str(idx)))
-                if st is not None:
+                if st is not None and self.kind == "SGD":
+                    k, o = where[p]
+                    if st.get("momentum_buffer") is not None:
+                        self._m[k][o:o + p.numel()].copy_(st["momentum_buffer"].reshape(-1))
+                elif st is not None:
                     k, o = where[p]
                     self._m[k][o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
                     self._v[k][o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))

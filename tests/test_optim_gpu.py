@@ -109,3 +109,41 @@ def test_grad_scale_of_a_two_rank_world():
     assert na == pytest.approx(nb, rel=1e-6)
     for x, y in zip(a, b):
         assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("kind,nesterov", [("ADAMW", False), ("SGD", False), ("SGD", True)])
+def test_fused_adamw_and_sgd_match_torch(kind, nesterov):
+    """the other two optimizers tools/train_net.py:129-154 can build (SOLVER.OPTIMIZER "ADAMW" / "SGD"): fused clip + step on the flat
+    buckets against torch.optim.AdamW / torch.optim.SGD(momentum, nesterov) + clip_grad_norm_, per-group lr and weight decay, an LR schedule"""
+    from mgnet_amd import _C
+    from mgnet_amd.engine import GradReducer
+    from mgnet_amd.solver.fused_adam import FusedAdam
+
+    torch.manual_seed(4)
+    shapes = [(64, 3, 7, 7), (64,), (128, 64, 3, 3), (5,), (1000, 37), (1,)]
+    ref_p = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    my_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    lrs = [1e-2 if i % 2 else 1e-3 for i in range(len(shapes))]
+    wds = [0.0 if i % 3 else 0.05 for i in range(len(shapes))]
+    groups = lambda ps: [dict(params=[p], lr=lr, weight_decay=wd) for p, lr, wd in zip(ps, lrs, wds)]
+    if kind == "ADAMW":
+        ref_opt = torch.optim.AdamW(groups(ref_p), 1e-3)
+    else:
+        ref_opt = torch.optim.SGD(groups(ref_p), 1e-3, momentum=0.9, nesterov=nesterov)
+    red = GradReducer(my_p, bucket_bytes=300_000, align=_C.optim_chunk(), flatten_params=True, average=False)
+    my_opt = FusedAdam(groups(my_p), 1e-3, red, max_grad_norm=0.5, kind=kind, momentum=0.9, nesterov=nesterov)
+    for step in range(6):
+        my_opt.zero_grad()
+        for p, q in zip(ref_p, my_p):
+            g = torch.randn_like(p) * (10.0 ** (step % 3 - 1))
+            p.grad, q.grad = g.clone(), g.clone()
+        red.finish()
+        torch.nn.utils.clip_grad_norm_(ref_p, 0.5)
+        ref_opt.step()
+        my_opt.step()
+        for g in ref_opt.param_groups + my_opt.param_groups:
+            g["lr"] *= 0.9
+    for p, q in zip(ref_p, my_p):
+        assert torch.allclose(p, q, rtol=3e-5, atol=2e-7), (kind, float((p - q).abs().max()))
+    sd = my_opt.state_dict()
+    assert ("momentum_buffer" in sd["state"][0]) == (kind == "SGD")
