@@ -303,6 +303,90 @@ class _LibProxy:
         return f
 
 
+LAUNCH, RECORD, WAIT, BREAK = 0, 1, 2, 3
+
+
+def derive_schedule(items, main_id, serial=False):
+    """The replay schedule of a recorded step.  `items`, in issue order: dicts with `kind` (0 library launch with `node`, 1 host closure),
+    `stream` (raw handle) and `reads` / `writes` = lists of [start, end) byte ranges.  Launches of one stream keep their order; between
+    streams every pair of accesses to overlapping memory with at least one writer is ordered as issued -- one vector clock per stream
+    (clock[s][t] = how far into stream t stream s is known to be ordered behind), one event per edge that the clocks do not already
+    imply.  Returns (ops, n_events, n_cross_stream_events, n_streams, moved): ops = [(LAUNCH, node, stream) | (RECORD, ev, stream) |
+    (WAIT, ev, stream) | (BREAK, 0, stream)]; all streams are joined behind the main stream's position at the start and the main stream
+    behind all of them at the end, so consecutive replays are ordered whatever the step's last launches were.  Pure host logic
+    (tests/test_plan_cpu.py)."""
+    streams = sorted({it["stream"] for it in items} | {main_id})
+    sidx = {s: k for k, s in enumerate(streams)}
+    ns = len(streams)
+    clock = np.zeros((ns, ns), dtype=np.int64)        # 1-based positions, 0 = the start of the step
+    pos = [0] * ns
+    acc_s, acc_e, acc_stream, acc_pos, acc_w = [], [], [], [], []
+    need_event = {}                                   # (stream index, pos) -> event id
+    waits = [[] for _ in items]
+    clock_at, where = {}, {}
+    S = E = ST = PS = WR = np.zeros(0, dtype=np.int64)
+    flushed = 0
+    for k, it in enumerate(items):
+        s = sidx[it["stream"]]
+        pos[s] += 1
+        mine = [(a, b, 0) for a, b in it["reads"]] + [(a, b, 1) for a, b in it["writes"]]
+        if len(acc_s) > flushed:
+            S = np.concatenate([S, np.array(acc_s[flushed:], dtype=np.int64)])
+            E = np.concatenate([E, np.array(acc_e[flushed:], dtype=np.int64)])
+            ST = np.concatenate([ST, np.array(acc_stream[flushed:], dtype=np.int64)])
+            PS = np.concatenate([PS, np.array(acc_pos[flushed:], dtype=np.int64)])
+            WR = np.concatenate([WR, np.array(acc_w[flushed:], dtype=np.int64)])
+            flushed = len(acc_s)
+        need = np.zeros(ns, dtype=np.int64)
+        if serial:     # debugging aid: global program order (every launch behind every earlier one)
+            for t in range(ns):
+                if t != s:
+                    need[t] = pos[t]
+        if len(S):
+            for a, b, w in mine:
+                m = (S < b) & (E > a) & (ST != s) & ((WR == 1) | (w == 1))
+                if m.any():
+                    np.maximum.at(need, ST[m], PS[m])
+        for t in range(ns):
+            if t != s and need[t] > clock[s][t]:
+                key = (t, int(need[t]))
+                ev = need_event.get(key)
+                if ev is None:
+                    ev = need_event[key] = len(need_event)
+                waits[k].append(ev)
+                clock[s] = np.maximum(clock[s], clock_at[key])
+        clock[s][s] = pos[s]
+        clock_at[(s, pos[s])] = clock[s].copy()
+        where[(s, pos[s])] = k
+        for a, b, w in mine:
+            acc_s.append(a); acc_e.append(b); acc_stream.append(s); acc_pos.append(pos[s]); acc_w.append(w)
+    record_after = {}
+    for (t, q), ev in need_event.items():
+        record_after.setdefault(where[(t, q)], []).append(ev)
+    n_ev = len(need_event)
+    ops = [(RECORD, n_ev, main_id)]
+    ops += [(WAIT, n_ev, st) for st in streams if st != main_id]
+    n_ev += 1
+    moved = []
+    for k, it in enumerate(items):
+        for ev in waits[k]:
+            ops.append((WAIT, ev, it["stream"]))
+        if it["kind"] == 0:
+            if it.get("moved"):
+                moved.append((it["node"], it["stream"]))
+            ops.append((LAUNCH, it["node"], it["stream"]))
+        else:
+            ops.append((BREAK, 0, it["stream"]))
+        for ev in record_after.get(k, []):
+            ops.append((RECORD, ev, it["stream"]))
+    for st in streams:
+        if st != main_id:
+            ops.append((RECORD, n_ev, st))
+            ops.append((WAIT, n_ev, main_id))
+            n_ev += 1
+    return ops, n_ev, len(need_event), ns, moved
+
+
 class StepPlan:
     """`StepPlan.record(body, device)` runs `body()` (one training step: zero_grad, forward, backward, finish, optimizer launches) eagerly
     and returns the plan; `replay(prof_slot)` issues the same device work again."""
@@ -376,85 +460,8 @@ class StepPlan:
             self.report_split = getattr(self, "report_split", {})
             self.report_split[sub] = moved
         main_id = int(main.cuda_stream)
-        streams = sorted({it["stream"] for it in items} | {main_id})
-        sidx = {s: k for k, s in enumerate(streams)}
-        ns = len(streams)
-        # ---- dependency analysis: vector clocks over per-stream positions ------------------------------------------------------
-        clock = np.zeros((ns, ns), dtype=np.int64)        # clock[s][t] = position on t that s is ordered behind (1-based, 0 = start)
-        pos = [0] * ns
-        acc_s, acc_e, acc_stream, acc_pos, acc_w = [], [], [], [], []
-        need_event = {}                                   # (stream index, pos) -> event id
-        waits = [[] for _ in items]                       # per item: event ids to wait for
-        clock_at = {}
-        where = {}                                        # (stream index, pos) -> item index
-        S = E = ST = PS = WR = np.zeros(0, dtype=np.int64)
-        flushed = 0
-        for k, it in enumerate(items):
-            s = sidx[it["stream"]]
-            pos[s] += 1
-            mine = [(a, b, 0) for a, b in it["reads"]] + [(a, b, 1) for a, b in it["writes"]]
-            if len(acc_s) > flushed:
-                S = np.concatenate([S, np.array(acc_s[flushed:], dtype=np.int64)])
-                E = np.concatenate([E, np.array(acc_e[flushed:], dtype=np.int64)])
-                ST = np.concatenate([ST, np.array(acc_stream[flushed:], dtype=np.int64)])
-                PS = np.concatenate([PS, np.array(acc_pos[flushed:], dtype=np.int64)])
-                WR = np.concatenate([WR, np.array(acc_w[flushed:], dtype=np.int64)])
-                flushed = len(acc_s)
-            need = np.zeros(ns, dtype=np.int64)
-            if os.environ.get("MGN_PLAN_SERIAL"):     # debugging aid: global program order (every launch behind every earlier one)
-                for t in range(ns):
-                    if t != s:
-                        need[t] = pos[t]
-            if len(S):
-                for a, b, w in mine:
-                    m = (S < b) & (E > a) & (ST != s) & ((WR == 1) | (w == 1))
-                    if m.any():
-                        np.maximum.at(need, ST[m], PS[m])
-            for t in range(ns):
-                if t != s and need[t] > clock[s][t]:
-                    key = (t, int(need[t]))
-                    ev = need_event.get(key)
-                    if ev is None:
-                        ev = need_event[key] = len(need_event)
-                    waits[k].append(ev)
-                    clock[s] = np.maximum(clock[s], clock_at[key])
-            clock[s][s] = pos[s]
-            clock_at[(s, pos[s])] = clock[s].copy()
-            where[(s, pos[s])] = k
-            for a, b, w in mine:
-                acc_s.append(a); acc_e.append(b); acc_stream.append(s); acc_pos.append(pos[s]); acc_w.append(w)
-        record_after = {}
-        for (t, q), ev in need_event.items():
-            record_after.setdefault(where[(t, q)], []).append(ev)
-        # ---- the op list ------------------------------------------------------------------------------------------------------
-        LAUNCH, RECORD, WAIT, BREAK = 0, 1, 2, 3
-        n_ev = len(need_event)
-        ops = []
-        e_start = n_ev
-        n_ev += 1
-        ops.append((RECORD, e_start, main_id))
-        for st in streams:
-            if st != main_id:
-                ops.append((WAIT, e_start, st))
-        self.closures = []
-        moved_nodes = []
-        for k, it in enumerate(items):
-            for ev in waits[k]:
-                ops.append((WAIT, ev, it["stream"]))
-            if it["kind"] == 0:
-                if it.get("moved"):
-                    moved_nodes.append((it["node"], it["stream"]))
-                ops.append((LAUNCH, it["node"], it["stream"]))
-            else:
-                ops.append((BREAK, 0, it["stream"]))
-                self.closures.append(it["closure"])
-            for ev in record_after.get(k, []):
-                ops.append((RECORD, ev, it["stream"]))
-        for st in streams:
-            if st != main_id:
-                ops.append((RECORD, n_ev, st))
-                ops.append((WAIT, n_ev, main_id))
-                n_ev += 1
+        ops, n_ev, n_cross, ns, moved_nodes = derive_schedule(items, main_id, serial=bool(os.environ.get("MGN_PLAN_SERIAL")))
+        self.closures = [it["closure"] for it in items if it["kind"] == 1]
         n = len(ops)
         types = (ctypes.c_int * n)(*[o[0] for o in ops])
         aa = (ctypes.c_int * n)(*[o[1] for o in ops])
@@ -469,7 +476,7 @@ class StepPlan:
             if it["kind"] == 1:
                 by_name[it["name"]] = by_name.get(it["name"], 0) + 1
         self.report = {"kernel_launches": kernels, "torch_ops_replayed": len(self.closures), "torch_ops": by_name, "streams": ns,
-                       "cross_stream_events": len(need_event), "plan_ops": n, "pointers_outside_torch_memory": len(self._unresolved)}
+                       "cross_stream_events": n_cross, "plan_ops": n, "pointers_outside_torch_memory": len(self._unresolved)}
         if getattr(self, "report_split", None):
             self.report["moved_to_extra_streams"] = self.report_split
 

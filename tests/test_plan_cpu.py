@@ -1,0 +1,101 @@
+"""CPU: the host logic of the launch-plan replay (engine/plan.py) on synthetic timelines -- which cross-stream edges the memory accesses of
+a recorded step imply, and the allocator-block map that resolves pointer arguments.  (The replay itself is tested on the GPU:
+tests/test_plan_gpu.py.)"""
+from mgnet_amd.engine.plan import BREAK, LAUNCH, RECORD, WAIT, _Blocks, derive_schedule
+
+A, B, C, D = (0x1000, 0x2000), (0x3000, 0x4000), (0x5000, 0x6000), (0x7000, 0x8000)
+MAIN, S1, S2 = 11, 22, 33
+
+
+def item(node, stream, reads=(), writes=(), kind=0):
+    return dict(kind=kind, node=node, stream=stream, reads=list(reads), writes=list(writes), name=f"k{node}")
+
+
+def ordered_before(ops, first, second):
+    """is launch `first` ordered before launch `second` by stream order and record / wait pairs?  (reachability over the op list)"""
+    # happens-before frontier per stream: set of launches known complete when the stream reaches a point
+    done = {}                 # stream -> set of nodes
+    at_event = {}
+    for typ, a, st in ops:
+        cur = done.setdefault(st, set())
+        if typ == LAUNCH:
+            if a == second:
+                return first in cur
+            cur.add(a)
+        elif typ == RECORD:
+            at_event[a] = set(cur)
+        elif typ == WAIT:
+            cur |= at_event.get(a, set())
+    raise AssertionError("second launch not found")
+
+
+def test_same_stream_needs_no_events():
+    ops, n_ev, n_cross, ns, _ = derive_schedule([item(0, MAIN, writes=[A]), item(1, MAIN, reads=[A], writes=[B]), item(2, MAIN, reads=[B])], MAIN)
+    assert n_cross == 0 and ns == 1 and [o[0] for o in ops] == [RECORD, LAUNCH, LAUNCH, LAUNCH]
+
+
+def test_raw_war_waw_across_streams_and_read_read_is_free():
+    items = [item(0, MAIN, writes=[A]),                 # producer
+             item(1, S1, reads=[A], writes=[B]),        # RAW on A -> must wait for 0
+             item(2, S2, reads=[A], writes=[C]),        # RAW on A; read-read with 1: no edge between 1 and 2
+             item(3, MAIN, writes=[A]),                 # WAR: must wait for the readers 1 and 2
+             item(4, S1, writes=[C])]                   # WAW with 2
+    ops, n_ev, n_cross, ns, _ = derive_schedule(items, MAIN)
+    assert ns == 3
+    assert ordered_before(ops, 0, 1) and ordered_before(ops, 0, 2)
+    assert ordered_before(ops, 1, 3) and ordered_before(ops, 2, 3)
+    assert ordered_before(ops, 2, 4)
+    assert not ordered_before(ops, 1, 2)                # two readers of A on different streams stay concurrent
+    # every wait refers to an event recorded earlier in the list
+    seen = set()
+    for typ, a, st in ops:
+        if typ == RECORD:
+            seen.add(a)
+        if typ == WAIT:
+            assert a in seen
+
+
+def test_block_reuse_across_streams_is_ordered():
+    """a block freed by stream S1's tensor and handed to a later tensor of MAIN (the allocator did that after the HOST saw S1's work
+    complete -- nothing a replay repeats): the overlapping addresses order the two launches"""
+    big, part = (0x10000, 0x20000), (0x14000, 0x15000)
+    items = [item(0, S1, reads=[big]), item(1, MAIN, writes=[part])]
+    ops, *_ = derive_schedule(items, MAIN)
+    assert ordered_before(ops, 0, 1)
+
+
+def test_transitive_edges_are_not_duplicated():
+    items = [item(0, S1, writes=[A]), item(1, S1, writes=[B]), item(2, MAIN, reads=[B]), item(3, MAIN, reads=[A])]
+    ops, n_ev, n_cross, ns, _ = derive_schedule(items, MAIN)
+    assert n_cross == 1                                  # waiting for launch 1 covers launch 0 (same stream, earlier)
+    assert ordered_before(ops, 0, 3) and ordered_before(ops, 1, 2)
+
+
+def test_closures_become_breaks_and_streams_join_at_both_ends():
+    items = [item(0, S1, writes=[A]), item(None, MAIN, reads=[A], writes=[B], kind=1), item(2, MAIN, reads=[B])]
+    ops, n_ev, n_cross, ns, _ = derive_schedule(items, MAIN)
+    kinds = [o[0] for o in ops]
+    assert kinds.count(BREAK) == 1 and kinds[0] == RECORD and ops[1] == (WAIT, ops[0][1], S1)      # the side stream starts behind main
+    assert ops[-1][0] == WAIT and ops[-1][2] == MAIN and ops[-2] == (RECORD, ops[-1][1], S1)         # main ends behind the side stream
+    i_break = kinds.index(BREAK)
+    assert (WAIT, 0, MAIN) in ops[:i_break]              # the closure's stream waited for launch 0 before the host acts
+
+
+def test_serial_mode_orders_everything():
+    items = [item(0, S1, writes=[A]), item(1, S2, writes=[B]), item(2, MAIN, writes=[C])]
+    ops, *_ = derive_schedule(items, MAIN, serial=True)
+    assert ordered_before(ops, 0, 1) and ordered_before(ops, 1, 2)
+
+
+def test_block_map_newest_allocation_wins():
+    b = _Blocks()
+    b.add(0x1000, 0x9000)                                # a large tensor ...
+    assert b.find(0x4000) == (0x1000, 0x9000)
+    b.add(0x1000, 0x2000)                                # ... freed, its block re-split into smaller ones
+    b.add(0x3000, 0x5000)
+    assert b.find(0x1800) == (0x1000, 0x2000) and b.find(0x4000) == (0x3000, 0x5000)
+    assert b.find(0x2800) is None and b.find(0x8000) is None      # the rest of the old block is nobody's now
+    b.add(0x4000, 0x6000)                                # overlapping the previous one: it must be dead
+    assert b.find(0x3800) is None and b.find(0x4800) == (0x4000, 0x6000)
+    b.add(0x4000, 0x6000)                                # the same block again: unchanged
+    assert b.find(0x5fff) == (0x4000, 0x6000) and b.find(0x6000) is None
