@@ -14,6 +14,7 @@
 //             dx = A (dz - sum_dz / n) - (z - beta) B with z = scale * x + offset recomputed from the saved conv output.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mgnet_hip.h"
 #include "h16.h"
@@ -202,6 +203,105 @@ __global__ __launch_bounds__(256) void abn_maxpool_fwd(const uint16_t* __restric
     }
 }
 
+// The same, marching down POOL_ROWS output rows per thread: of the three input rows of a window the top one (2 oh - 1) was the bottom one of
+// the previous output row, so its activated values are kept in registers and each input row is loaded and activated ONCE per column pair
+// instead of 1.5 times (round 4).  Same arithmetic per value and the same comparison order (kh outer, column inner): bit-identical outputs
+// and arg-max bytes.
+constexpr int POOL_ROWS = 8;
+__global__ __launch_bounds__(256) void abn_maxpool_fwd_march(const uint16_t* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ offset, int leaky, float slope,
+                                                             uint16_t* __restrict__ y, uint8_t* __restrict__ idx, int N, int IH, int IW, int C,
+                                                             int OH, int OW) {
+    const int cv = C / 8, OWP = (OW + 1) / 2, OHC = (OH + POOL_ROWS - 1) / POOL_ROWS;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * OHC * OWP * cv) return;
+    const int c8 = (int)(i % cv);
+    long r = i / cv;
+    const int ow0 = (int)(r % OWP) * 2; r /= OWP;
+    const int oh0 = (int)(r % OHC) * POOL_ROWS;
+    const int n = (int)(r / OHC);
+    float sc[8], of[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[c8 * 8 + k]; of[k] = offset[c8 * 8 + k]; }
+    bool okc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { const int iw = ow0 * 2 - 1 + j; okc[j] = iw >= 0 && iw < IW; }
+    auto load_row = [&](int ih, uint4 (&v)[5]) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int iw = ow0 * 2 - 1 + j;
+            v[j] = (okc[j] && ih >= 0 && ih < IH) ? *reinterpret_cast<const uint4*>(x + (((long)n * IH + ih) * IW + iw) * C + c8 * 8)
+                                                  : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto activate = [&](const uint4 (&v)[5], float (&f)[5][8]) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float z = fmaf(bf2f((uint16_t)(w[k >> 1] >> ((k & 1) * 16))), sc[k], of[k]);   // iabn_apply's arithmetic
+                if (leaky) z = z > 0.f ? z : z * slope;
+                f[j][k] = bf2f((uint16_t)f2bf_rne(z));
+            }
+        }
+    };
+    float top[5][8];          // activated row 2 oh - 1 (kh = 0)
+    bool top_ok;
+    {
+        uint4 v[5];
+        load_row(2 * oh0 - 1, v);
+        activate(v, top);
+        top_ok = 2 * oh0 - 1 >= 0;
+    }
+    for (int oh = oh0; oh < oh0 + POOL_ROWS && oh < OH; ++oh) {
+        uint4 v1[5], v2[5];
+        load_row(2 * oh, v1);
+        load_row(2 * oh + 1, v2);
+        float f1[5][8], f2[5][8];
+        activate(v1, f1);
+        activate(v2, f2);
+        const bool ok1 = 2 * oh < IH, ok2 = 2 * oh + 1 < IH;
+        float best[2][8];
+        uint8_t arg[2][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { best[0][k] = best[1][k] = -3.4e38f; arg[0][k] = arg[1][k] = 0; }
+        auto scan = [&](const float (&f)[5][8], bool rowok, int kh) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (!(rowok && okc[j])) continue;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    // column j is tap kw = j of the left pixel (j <= 2) and tap kw = j - 2 of the right one (j >= 2)
+                    if (j <= 2 && f[j][k] > best[0][k]) { best[0][k] = f[j][k]; arg[0][k] = (uint8_t)(kh * 3 + j); }
+                    if (j >= 2 && f[j][k] > best[1][k]) { best[1][k] = f[j][k]; arg[1][k] = (uint8_t)(kh * 3 + j - 2); }
+                }
+            }
+        };
+        scan(top, top_ok, 0);
+        scan(f1, ok1, 1);
+        scan(f2, ok2, 2);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (ow0 + u >= OW) break;
+            uint4 o;
+            o.x = mgn_pack2(best[u][0], best[u][1]); o.y = mgn_pack2(best[u][2], best[u][3]);   // (exact: the maxima are 16-bit values)
+            o.z = mgn_pack2(best[u][4], best[u][5]); o.w = mgn_pack2(best[u][6], best[u][7]);
+            const long op = (((long)n * OH + oh) * OW + ow0 + u) * C + c8 * 8;
+            *reinterpret_cast<uint4*>(y + op) = o;
+            uint2 a;
+            a.x = arg[u][0] | (arg[u][1] << 8) | (arg[u][2] << 16) | ((uint32_t)arg[u][3] << 24);
+            a.y = arg[u][4] | (arg[u][5] << 8) | (arg[u][6] << 16) | ((uint32_t)arg[u][7] << 24);
+            *reinterpret_cast<uint2*>(idx + op) = a;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) top[j][k] = f2[j][k];
+        top_ok = ok2;
+    }
+}
+
 struct AbnBwd {
     const float* scale; const float* offset; const float* weight; const float* bias; const float* rstd; const float* sums;
     float inv_n, eps, slope;
@@ -226,6 +326,10 @@ __global__ __launch_bounds__(256) void abn_maxpool_bwd(const uint16_t* __restric
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[a][b][k] = 0.f;
+    // pooled (i + wo, j + wx) looks at input (2 (i + wo) - 1 + kh, 2 (j + wx) - 1 + kw), so with tap = 3 kh + kw the patch cells it can feed are
+    //   (wo, wx) = (0, 0): taps 4, 5, 7, 8 -> cells (0,0), (0,1), (1,0), (1,1)      (0, 1): taps 3, 6 -> cells (0,1), (1,1)
+    //   (wo, wx) = (1, 0): taps 1, 2       -> cells (1,0), (1,1)                    (1, 1): tap 0     -> cell (1,1)
+    // = nine compare-selects per channel (round 4; the generic form decoded kh, kw by division and tested all 16 (window, cell) pairs)
 #pragma unroll
     for (int wo = 0; wo < 2; ++wo) {
         const int oh = i + wo;
@@ -243,13 +347,16 @@ __global__ __launch_bounds__(256) void abn_maxpool_bwd(const uint16_t* __restric
             for (int k = 0; k < 8; ++k) {
                 const int tap = (int)((aw[k >> 2] >> ((k & 3) * 8)) & 0xff);
                 const float v = bf2f((uint16_t)(gw[k >> 1] >> ((k & 1) * 16)));
-                const int kh = tap / 3, kw = tap - kh * 3;
-                const int a = 2 * wo - 1 + kh, b = 2 * wx - 1 + kw;
-#pragma unroll
-                for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                    for (int bb = 0; bb < 2; ++bb)
-                        if (a == aa && b == bb) acc[aa][bb][k] += v;
+                if (wo == 0 && wx == 0) {
+                    acc[0][0][k] += tap == 4 ? v : 0.f; acc[0][1][k] += tap == 5 ? v : 0.f;
+                    acc[1][0][k] += tap == 7 ? v : 0.f; acc[1][1][k] += tap == 8 ? v : 0.f;
+                } else if (wo == 0) {
+                    acc[0][1][k] += tap == 3 ? v : 0.f; acc[1][1][k] += tap == 6 ? v : 0.f;
+                } else if (wx == 0) {
+                    acc[1][0][k] += tap == 1 ? v : 0.f; acc[1][1][k] += tap == 2 ? v : 0.f;
+                } else {
+                    acc[1][1][k] += tap == 0 ? v : 0.f;
+                }
             }
         }
     }
@@ -298,9 +405,16 @@ int MGN_SYM(mgn_abn_maxpool_fwd)(const void* x_bf16, const float* scale, const f
     if (!x_bf16 || !scale || !offset || !y_bf16 || !argmax || N < 1 || IH < 1 || IW < 1 || C < 8 || C % 8) return MGN_EINVAL;
     if (activation != 0 && activation != 1) return MGN_EINVAL;
     const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
-    const long n = (long)N * OH * ((OW + 1) / 2) * (C / 8);   // a thread per 8-channel vector of two adjacent output pixels
-    hipLaunchKernelGGL(abn_maxpool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16, scale,
-                       offset, activation, slope, (uint16_t*)y_bf16, argmax, N, IH, IW, C, OH, OW);
+    static const bool plain = getenv("MGN_POOL_NO_MARCH") != nullptr;   // (A/B switch: the one-row-per-thread kernel)
+    if (plain || OH < 4 * POOL_ROWS) {
+        const long n = (long)N * OH * ((OW + 1) / 2) * (C / 8);   // a thread per 8-channel vector of two adjacent output pixels
+        hipLaunchKernelGGL(abn_maxpool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16, scale,
+                           offset, activation, slope, (uint16_t*)y_bf16, argmax, N, IH, IW, C, OH, OW);
+    } else {   // the same pair of pixels for POOL_ROWS consecutive output rows: every input row is loaded and activated once
+        const long n = (long)N * ((OH + POOL_ROWS - 1) / POOL_ROWS) * ((OW + 1) / 2) * (C / 8);
+        hipLaunchKernelGGL(abn_maxpool_fwd_march, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16,
+                           scale, offset, activation, slope, (uint16_t*)y_bf16, argmax, N, IH, IW, C, OH, OW);
+    }
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 
