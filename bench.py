@@ -226,6 +226,27 @@ def fp16_leg(args, dev, B, H, W, steps=None):
             "losses_finite": bool(all(torch.isfinite(v.detach()).item() for v in last.values()))}
 
 
+def fp16_leg_child(args):
+    """The fp16 leg as a CHILD process running this script with --dtype fp16 (a fresh process, started -- not exec'ed -- after the
+    bf16 measurement): inside the parent, behind its other legs, the same steps ran 1-1.5 ms slower than as a run of their own (so did the
+    conv roofline leg: 289 vs 249 us for the same launch), which is what round 3 reported as the 'fp16 gap'.  Two stand-alone runs per dtype
+    on one box differ by +0.44 ms (profiles/r04_fp16_vs_bf16.txt)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp16", "--no-fp16-leg", "--no-cpu-baseline", "--no-host-probe", "--steps",
+           str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width),
+           "--exec", args.exec, "--timeout", str(min(args.timeout, 600.0))]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(args.timeout, 600.0) + 30)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"child run exited with code {r.returncode}", "stderr_tail": r.stderr.splitlines()[-5:]}
+    d = json.loads(lines[-1])
+    out = {"dtype": "fp16", "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+           "step_execution": d["config"]["step_execution"].split(" ")[0], "measured_as": "a run of this script of its own (child process), like the headline",
+           "losses_finite": all(v == v and abs(v) != float("inf") for v in d["config"]["losses"].values())}
+    out.update(d["config"].get("loss_scaling", {}))
+    return out
+
+
 def full_step_bench(args, world, rank, dev):
     """The benchmark: one full MGNet training step (SURVEY 3.1 hot loop) per per-GPU batch of synthetic frames."""
     from mgnet_amd import add_mgnet_config, get_cfg
@@ -444,11 +465,14 @@ def full_step_bench(args, world, rank, dev):
             except Exception as e:  # noqa: BLE001 -- informative only
                 line["config"]["kernels_per_step"] = f"unavailable ({type(e).__name__}: {e})"
         line["roofline_mfma"] = conv_roofline(dev, B)
+        if args.dtype == "fp16" and getattr(trainer.optimizer, "scaler", None) is not None:
+            sc = [float(v) for v in trainer.optimizer.scaler.tolist()]
+            line["config"]["loss_scaling"] = {"loss_scale": sc[0], "optimizer_steps_taken": int(sc[2]), "steps_attempted": trainer.iter}
         if world == 1 and args.dtype == "bf16" and not args.no_fp16_leg:
             try:
                 del trainer, model
                 torch.cuda.empty_cache()
-                line["fp16"] = fp16_leg(args, dev, B, H, W)
+                line["fp16"] = fp16_leg_child(args)
             except Exception as e:  # noqa: BLE001
                 line["fp16"] = {"error": f"{type(e).__name__}: {e}"}
             model = None
@@ -523,8 +547,8 @@ def rank_watchdog(timeout_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU (C4/C5: 8)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
