@@ -384,9 +384,11 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=Fals
         if holder:
             y._mgn_stats = holder[0]
         return (y, skip) if with_skip else y
-    if (x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad))
-            and not os.environ.get("MGNET_ALLOW_TORCH_STAGING") and _fp32_split_supported(x, weight)):
-        y = _conv2d_fp32_split(x, weight, bias, stride, padding, relu)   # [HIP] inference with fp32 activations (AMP off)
+    if x.is_cuda and x.dtype == torch.float32 and not os.environ.get("MGNET_ALLOW_TORCH_STAGING") and _fp32_split_supported(x, weight):
+        if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+            y = _Conv32Fn.apply(x, weight, bias, stride, padding, relu)   # [HIP] fp32 TRAINING (SOLVER.AMP.ENABLED False, detectron2's default)
+        else:
+            y = _conv2d_fp32_split(x, weight, bias, stride, padding, relu)   # [HIP] inference with fp32 activations (AMP off)
         return (y, x) if with_skip else y
     if x.is_cuda and not os.environ.get("MGNET_ALLOW_TORCH_STAGING"):
         raise NotImplementedError(
@@ -495,7 +497,7 @@ def _conv2d_fp32_split(x, weight, bias, stride, padding, relu):
     parts and the product is three bf16 MFMA passes accumulated in fp32,
         x w ~= x_hi w_hi + x_hi w_lo + x_lo w_hi          (the dropped x_lo w_lo term is 2^-16 relative),
     each pass the product's own implicit-GEMM kernel with fp32 output (mgn_conv_igemm, out_f32).  ~1e-5 relative to an fp32 convolution
-    (tests/test_conv_gpu.py); no gradient (training in fp32 has no kernel: MGNET_ALLOW_TORCH_STAGING=1 runs torch's)."""
+    (tests/test_conv_gpu.py).  With gradients: _Conv32Fn (the same three-pass form for the data and weight gradients)."""
     from .. import _C
     with torch.no_grad():
         Cout, Cin, KH, KW = weight.shape
@@ -521,6 +523,65 @@ def _conv2d_fp32_split(x, weight, bias, stride, padding, relu):
         if bias is not None:
             y = y + bias.detach().float().view(1, -1, 1, 1)
         return torch.relu_(y) if relu else y
+
+
+def _split16(t):
+    """fp32 -> (hi, lo) bf16 parts with t ~= hi + lo to 2^-16 relative; channels_last"""
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(memory_format=torch.channels_last), lo.contiguous(memory_format=torch.channels_last)
+
+
+class _Conv32Fn(torch.autograd.Function):
+    """[HIP] convolution on fp32 activations WITH gradients (a config with SOLVER.AMP.ENABLED False -- detectron2's default, which
+    mgnet/config.py leaves; tools/train_net.py:37): forward, data gradient and weight gradient are each three bf16 MFMA passes over hi / lo
+    splits of both operands with fp32 accumulation, a b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi (the dropped term is 2^-16 relative), on the
+    product's own kernels (mgn_conv_igemm with fp32 output, mgn_conv_wgrad).  ~1e-5 of an fp32 convolution; 3x the 16-bit cost, which is
+    what fp32 training costs on matrix cores without an fp32 mode worth using."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, relu):
+        y = _conv2d_fp32_split(x, weight, bias, stride, pad, relu)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.cfg = (stride, pad, relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _C
+        x, weight, y = ctx.saved_tensors
+        stride, pad, relu, has_bias = ctx.cfg
+        Cout, Cin, KH, KW = weight.shape
+        dy = dy.float()
+        if relu:
+            dy = dy * (y > 0)
+        dx = dw = db = None
+        packed = Cin in (3, 9)
+        xp = x
+        if packed and x.shape[1] == Cin:
+            xp = F.pad(x, (0, 0, 0, 0, 0, (8 if Cin == 3 else 16) - Cin))
+        cout_pad = (Cout + 31) // 32 * 32 if Cout % 32 else 0
+        if cout_pad:     # the kernels work on 32-padded output channels: zero gradient for the padding
+            dy = F.pad(dy, (0, 0, 0, 0, 0, cout_pad - Cout))
+        dyh, dyl = _split16(dy)
+        if ctx.needs_input_grad[0]:
+            assert not packed, "no data gradient for the channel-padded stem input"
+            w32 = weight.detach().float()
+            wh = w32.to(torch.bfloat16).float()
+            parts = []
+            for ga, wa in ((dyh, wh), (dyh, w32 - wh), (dyl, wh)):
+                wl = _C._weight_layout_now(wa.contiguous(), 1, 0, None, cout_pad)   # flipped / transposed layout of the data gradient
+                parts.append(_C.conv_igemm(ga, wl, x.shape[2:], None, 1, KH - 1 - pad, up=stride, out_dtype=torch.float32))
+            dx = (parts[0] + parts[1]) + parts[2]
+        if ctx.needs_input_grad[1]:
+            xh, xl = _split16(xp)
+            dw = None
+            for ga, xa in ((dyh, xh), (dyh, xl), (dyl, xh)):
+                part = _C.conv_wgrad(ga, xa, KH, KW, stride, pad, cin_real=Cin)[:Cout]
+                dw = part if dw is None else dw + part
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))[:Cout]
+        return dx, dw, db, None, None, None
 
 
 class _FanoutFn(torch.autograd.Function):

@@ -434,8 +434,7 @@ def test_statistics_of_many_partial_rows_two_stage():
                                                   (3, 64, 7, 2, (64, 96), False), (9, 64, 7, 2, (64, 96), False), (256, 12, 1, 1, (8, 12), True)])
 def test_fp32_inference_conv_as_three_bf16_passes(cin, cout, k, s, hw, bias, monkeypatch):
     """fp32 activations without a gradient (SOLVER.AMP.ENABLED False at inference): x w ~ x_hi w_hi + x_hi w_lo + x_lo w_hi on the bf16 matrix
-    cores with fp32 accumulation -- ~1e-5 of an fp64 convolution, three orders of magnitude below a plain bf16 convolution; with a gradient
-    there is no fp32 kernel and the op refuses (no silent torch fallback)"""
+    cores with fp32 accumulation -- ~1e-5 of an fp64 convolution, three orders of magnitude below a plain bf16 convolution"""
     from mgnet_amd.modeling import ops
     monkeypatch.delenv("MGNET_ALLOW_TORCH_STAGING", raising=False)
     torch.manual_seed(0)
@@ -448,5 +447,22 @@ def test_fp32_inference_conv_as_three_bf16_passes(cin, cout, k, s, hw, bias, mon
     ref = torch.nn.functional.conv2d(x.double(), w.detach().double(), None if b is None else b.detach().double(), stride=s, padding=k // 2)
     rel = float((y.double() - ref).norm() / ref.norm())
     assert rel < 3e-5, rel
-    with pytest.raises(NotImplementedError):
-        ops.conv2d(x, w, b, stride=s, padding=k // 2)      # grad mode: fp32 training has no kernel
+    # ... and WITH gradients (fp32 training, detectron2's default SOLVER.AMP.ENABLED False): the data and weight gradients in the same
+    # three-pass form (ops._Conv32Fn), against autograd of the fp64 convolution; no torch convolution on the way
+    ops.STAGING_USED.clear()
+    xg = x.clone().requires_grad_(cin not in (3, 9))      # (the stems' input carries no gradient)
+    y2 = ops.conv2d(xg, w, b, stride=s, padding=k // 2)
+    g = torch.randn_like(y2)
+    (y2 * g).sum().backward()
+    assert not ops.STAGING_USED and torch.equal(y2.detach(), y)
+    xd = x.double().requires_grad_(True)
+    wd = w.detach().double().requires_grad_(True)
+    bd = None if b is None else b.detach().double().requires_grad_(True)
+    (torch.nn.functional.conv2d(xd, wd, bd, stride=s, padding=k // 2) * g.double()).sum().backward()
+    relw = float((w.grad.double() - wd.grad).norm() / wd.grad.norm())
+    assert relw < 5e-5, relw
+    if xg.requires_grad:
+        relx = float((xg.grad.double() - xd.grad).norm() / xd.grad.norm())
+        assert relx < 5e-5, relx
+    if b is not None:
+        assert torch.allclose(b.grad.double(), bd.grad, rtol=1e-4, atol=1e-5)
