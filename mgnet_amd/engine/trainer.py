@@ -144,7 +144,85 @@ class Trainer:
         self.scheduler.step()
         self.iter += 1
         self.storage.step()
+        self._check_peers()
         return self._plan_losses
+
+    # ---- the training-loop entry on top of record/replay: a NEW batch every call ------------------------------------------------
+    @staticmethod
+    def _batch_signature(batched_inputs):
+        return tuple(tuple(sorted((k, (tuple(v.shape), v.dtype) if isinstance(v, torch.Tensor) else repr(v))
+                                  for k, v in d.items())) for d in batched_inputs)
+
+    @staticmethod
+    def _layout(batched_inputs):
+        """(collated buffers, how every per-frame entry views them): per-frame entries that are slices of one collated buffer
+        (data/synthetic.py, data/target_generator.py) are described as (buffer index, offset, shape, stride)"""
+        bases, index, layout = [], {}, []
+        for d in batched_inputs:
+            for k in sorted(d):
+                v = d[k]
+                if isinstance(v, torch.Tensor):
+                    b = v._base if v._base is not None else v
+                    if id(b) not in index:
+                        index[id(b)] = len(bases)
+                        bases.append(b)
+                    layout.append((index[id(b)], v.storage_offset() - b.storage_offset(), tuple(v.shape), tuple(v.stride()), v.dtype))
+        return bases, (tuple(layout), tuple((tuple(b.shape), tuple(b.stride()), b.dtype) for b in bases))
+
+    def _static_copy(self, batched_inputs):
+        """plan-owned copies of a batch with the SAME view structure, so that the recorded step keeps the zero-copy batch assembly of
+        MGNet._stack and a refill is one copy per collated buffer"""
+        bases, layout = self._layout(batched_inputs)
+        static_bases = [b.clone(memory_format=torch.preserve_format) for b in bases]
+        index = {id(b): k for k, b in enumerate(bases)}
+        out = []
+        for d in batched_inputs:
+            o = {}
+            for k, v in d.items():
+                if isinstance(v, torch.Tensor):
+                    b = v._base if v._base is not None else v
+                    sb = static_bases[index[id(b)]]
+                    o[k] = sb.as_strided(v.shape, v.stride(), sb.storage_offset() + v.storage_offset() - b.storage_offset())
+                else:
+                    o[k] = v
+            out.append(o)
+        return out, static_bases, layout
+
+    def _refill_static(self, batched_inputs):
+        """new batch -> the static buffers the plan reads: one copy per collated buffer when the new batch is collated the same way,
+        one per entry otherwise"""
+        bases, layout = self._layout(batched_inputs)
+        if layout == self._static_layout:
+            for s, sb in zip(bases, self._static_bases):
+                sb.copy_(s, non_blocking=True)
+            return
+        for st, d in zip(self._plan_inputs, batched_inputs):
+            for k, v in d.items():
+                if isinstance(v, torch.Tensor):
+                    st[k].copy_(v, non_blocking=True)
+
+    def run_step_planned(self, batched_inputs, warmup=3):
+        """`run_step` for a training loop that wants the recorded step: the first `warmup` calls run eagerly (lazy workspaces, layout cache,
+        allocator), the next one records the step on plan-owned copies of the batch, every later call copies its batch into those buffers
+        and replays.  A batch of another shape (or a step the recorder refuses) runs eagerly -- `self.plan_note` says why -- so the
+        loop never depends on the plan.  Returns the loss dict of the step like `run_step` (device scalars, overwritten by the next replay)."""
+        if getattr(self, "_plan", None) is None:
+            if self.iter < warmup or getattr(self, "plan_note", None):
+                return self.run_step(batched_inputs)
+            from .plan import PlanUnsupported
+            static, bases, layout = self._static_copy(batched_inputs)
+            try:
+                self.record_plan(static)
+            except PlanUnsupported as e:
+                self.plan_note = f"eager steps: {e}"
+                return self.run_step(batched_inputs)
+            self._static_bases, self._static_layout, self._plan_sig = bases, layout, self._batch_signature(batched_inputs)
+            return self._plan_losses
+        if self._batch_signature(batched_inputs) != self._plan_sig:
+            self.plan_eager_steps = getattr(self, "plan_eager_steps", 0) + 1
+            return self.run_step(batched_inputs)
+        self._refill_static(batched_inputs)
+        return self.replay_plan()
 
     def _backward(self, loss_dict):
         """sum of the loss dict -> backward; with fp16 activations the sum is multiplied by the dynamic loss scale first

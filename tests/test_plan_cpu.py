@@ -99,3 +99,32 @@ def test_block_map_newest_allocation_wins():
     assert b.find(0x3800) is None and b.find(0x4800) == (0x4000, 0x6000)
     b.add(0x4000, 0x6000)                                # the same block again: unchanged
     assert b.find(0x5fff) == (0x4000, 0x6000) and b.find(0x6000) is None
+
+
+def test_static_batch_copy_keeps_the_view_structure_and_refills():
+    """Trainer.run_step_planned's input side: plan-owned copies of a collated batch are views of as many buffers as the batch had, a batch
+    collated the same way refills them with one copy per buffer, a batch of separate tensors entry by entry"""
+    import torch
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.engine.trainer import Trainer
+    t = Trainer.__new__(Trainer)
+    b = synthetic_batch(2, 32, 64, "cpu")
+    static, bases, layout = t._static_copy(b)
+    n_buffers = len({id(v._base) for d in b for v in d.values() if isinstance(v, torch.Tensor) and v._base is not None})
+    assert len(bases) == n_buffers
+    for d, o in zip(b, static):
+        for k, v in d.items():
+            if isinstance(v, torch.Tensor):
+                assert torch.equal(v, o[k]) and v.data_ptr() != o[k].data_ptr() and o[k].stride() == v.stride(), k
+    t._static_bases, t._static_layout, t._plan_inputs = bases, layout, static
+    same = synthetic_batch(2, 32, 64, "cpu", seed=5)
+    assert t._layout(same)[1] == layout
+    loose = [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in d.items()} for d in synthetic_batch(2, 32, 64, "cpu", seed=6)]
+    assert t._layout(loose)[1] != layout
+    for new in (same, loose):
+        t._refill_static(new)
+        for d, o in zip(new, static):
+            for k, v in d.items():
+                if isinstance(v, torch.Tensor):
+                    assert torch.equal(v, o[k]), k
+    assert Trainer._batch_signature(b) == Trainer._batch_signature(loose) != Trainer._batch_signature(synthetic_batch(2, 32, 96, "cpu"))

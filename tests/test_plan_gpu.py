@@ -82,3 +82,27 @@ def test_replay_is_repeatable_and_coexists_with_eager_work():
         la = {n: float(v) for n, v in ta.replay_plan().items()}
         lr = {n: float(v) for n, v in ref.run_step(ref_batch).items()}
         assert la == lr, (k, la, lr)
+
+
+def test_run_step_planned_is_run_step_with_a_new_batch_every_call():
+    """the training-loop entry: eager warm-up, one recorded step, then refill + replay with a DIFFERENT batch per call -- the trajectory of
+    run_step on the same batches, bit for bit; a batch of another shape takes the eager step and the plan survives it"""
+    from mgnet_amd.data import synthetic_batch
+    ta, _, _ = _trainer()
+    tb, _, _ = _trainer()
+    dev = torch.device("cuda:0")
+    batches = [synthetic_batch(2, 128, 256, dev, seed=20 + k) for k in range(7)]
+    batches[5] = [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in d.items()} for d in batches[5]]   # (not collated)
+    la = [{n: float(v) for n, v in ta.run_step(b).items()} for b in batches]
+    lb = [{n: float(v) for n, v in tb.run_step_planned(b).items()} for b in batches]
+    assert tb._plan is not None and getattr(tb, "plan_note", None) is None and getattr(tb, "plan_eager_steps", 0) == 0
+    assert la == lb
+    odd = synthetic_batch(2, 128, 192, dev, seed=40)
+    la.append({n: float(v) for n, v in ta.run_step(odd).items()})
+    lb.append({n: float(v) for n, v in tb.run_step_planned(odd).items()})
+    la.append({n: float(v) for n, v in ta.run_step(batches[0]).items()})
+    lb.append({n: float(v) for n, v in tb.run_step_planned(batches[0]).items()})
+    assert tb.plan_eager_steps == 1 and la == lb
+    torch.cuda.synchronize()
+    for (na, pa), (nb, pb) in zip(ta.model.named_parameters(), tb.model.named_parameters()):
+        assert torch.equal(pa, pb), na
