@@ -2300,7 +2300,14 @@ static void wgrad_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW,
     const long M = (long)N * OH * OW;
     const int tiles = *co_tiles * (*pack ? 1 : KH * KW) * *ci_tiles;
     long splits = (768 + tiles - 1) / tiles;              // ~768 blocks: 3 resident per CU on 256 CUs
-    const long max_splits = (M + 2047) / 2048;            // >= 2048 pixels (32 k-steps) per block
+    long max_splits = (M + 2047) / 2048;                  // >= 2048 pixels (32 k-steps) per block ...
+    // ... unless that leaves most of the chip idle (the 1x1 layers of the 32x64 / 64x128 maps: 16-64 blocks, 44-56 us for 0.3-4 GFLOP):
+    // then down to 256 pixels per block, up to one block per CU
+    static const int min_px = getenv("MGN_WGRAD_MINPX") ? atoi(getenv("MGN_WGRAD_MINPX")) : 256;
+    if (tiles * max_splits < 256 && min_px < 2048) {
+        const long want = (256 + tiles - 1) / tiles, cap = (M + min_px - 1) / min_px;
+        max_splits = want < cap ? want : cap;
+    }
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
