@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "mgnet_hip.h"
@@ -49,9 +50,11 @@ struct Plan {
 };
 
 static Plan* g_rec = nullptr;
+static std::mutex g_rec_mutex;   // launches are recorded from the caller's thread AND from the autograd thread of the backward pass
 
 void record_launch(const void* func, dim3 grid, dim3 block, size_t shmem, hipStream_t stream, const unsigned char* blob, int nbytes,
                    const ArgDesc* args, int nargs) {
+    std::lock_guard<std::mutex> lock(g_rec_mutex);
     Plan* p = g_rec;
     if (!p) return;
     if (nargs > MAX_ARGS || nbytes > MAX_ARG_BYTES) { p->overflow = true; return; }
@@ -67,6 +70,7 @@ void record_launch(const void* func, dim3 grid, dim3 block, size_t shmem, hipStr
 }
 
 void record_prof_mark(int which, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_rec_mutex);
     Plan* p = g_rec;
     if (!p) return;
     Node n{};
@@ -81,6 +85,7 @@ using namespace mgn_plan;
 extern "C" {
 
 int mgn_plan_begin(void) {
+    std::lock_guard<std::mutex> lock(g_rec_mutex);
     if (g_rec) return MGN_EINVAL;   // one recording at a time
     g_rec = new Plan();
     g_mgn_plan_recording = 1;
@@ -93,6 +98,7 @@ int mgn_plan_recorded(void) { return g_rec ? (int)g_rec->nodes.size() : -1; }
 const void* mgn_plan_current(void) { return g_rec; }
 
 int mgn_plan_end(void** plan) {
+    std::lock_guard<std::mutex> lock(g_rec_mutex);
     if (!g_rec || !plan) return MGN_EINVAL;
     g_mgn_plan_recording = 0;
     Plan* p = g_rec;
@@ -103,6 +109,7 @@ int mgn_plan_end(void** plan) {
 }
 
 int mgn_plan_abort(void) {
+    std::lock_guard<std::mutex> lock(g_rec_mutex);
     g_mgn_plan_recording = 0;
     delete g_rec;
     g_rec = nullptr;

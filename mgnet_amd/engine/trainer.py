@@ -207,7 +207,9 @@ class Trainer:
         and replays.  A batch of another shape (or a step the recorder refuses) runs eagerly -- `self.plan_note` says why -- so the
         loop never depends on the plan.  Returns the loss dict of the step like `run_step` (device scalars, overwritten by the next replay)."""
         if getattr(self, "_plan", None) is None:
-            if self.iter < warmup or getattr(self, "plan_note", None):
+            # (eager steps THIS process has run, not `self.iter`: a run resumed from a checkpoint still has to warm up)
+            if getattr(self, "_eager_steps", 0) < warmup or getattr(self, "plan_note", None):
+                self._eager_steps = getattr(self, "_eager_steps", 0) + 1
                 return self.run_step(batched_inputs)
             from .plan import PlanUnsupported
             static, bases, layout = self._static_copy(batched_inputs)
