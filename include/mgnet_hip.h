@@ -252,6 +252,13 @@ int mgn_conv3x3_win(const void* in, const void* w, void* out, int N, int H, int 
                                             (r - shift)^2 over the ROUNDED outputs r, the input of mgn_iabn_coeffs_from_partials: the
                                             statistics pass of the InPlaceABNSync that follows the conv (res_net.py:35,49,59) */,
                     const float* stat_shift /* [Cout] or NULL (= 0): e.g. the layer's running_mean */, void* stream);
+/* Data gradient of a 3x3 / stride 2 / pad 1 convolution (res_net.py:28-60 with stride 2: conv1 of the down-sampling BasicBlocks) as a
+ * windowed implicit GEMM over the LOW-resolution gradient (csrc/conv_up2.hip): in = d(conv output) [N,H,W,Cin], w = the flipped /
+ * transposed weights [Cout][3][3][Cin] (mgn_weight_layout mode 1), out = d(conv input) [N,OH,OW,Cout] with OH in {2H-1, 2H}, OW alike;
+ * the same sums as mgn_conv_igemm(stride 1, pad 1, up 2), which dispatches here (Cin % 32 == 0, Cout % 64 == 0; MGN_ENOTSUP otherwise).
+ * residual: 16-bit [N,OH,OW,Cout] added before rounding (the shortcut's gradient), or NULL. */
+int mgn_conv3x3_up2_win(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, int OH, int OW,
+                        const void* residual, void* stream);
 /* Convolution + the batch statistics of its output in one launch (forward of conv -> InPlaceABNSync, res_net.py:35,49,59,
  * layers.py:63,71): mgn_conv_stat_rows says how many partial rows the kernel mgn_conv_igemm would pick for this layer leaves behind
  * (0: that kernel has no statistics epilogue -- run mgn_iabn_train_coeffs over the output instead; *shifted = 1: the sums are taken
@@ -728,6 +735,8 @@ int mgn_conv_igemm_stats_f16(const void* in, const void* w, void* out, int N, in
     int KW, int stride, int pad, float* stat_partials, const float* stat_shift, void* stream);
 int mgn_conv3x3_win_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
     int patch_rows, float* stat_partials, const float* stat_shift, void* stream);
+int mgn_conv3x3_up2_win_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, int OH, int OW,
+    const void* residual, void* stream);
 int mgn_conv_wgrad_partial_f16(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
     int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
 int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);

@@ -1065,7 +1065,19 @@ struct WgradParams {
     long m_per_split;      // pixels per blockIdx.z (multiple of 64)
     int oihw, cin_real;    // final layout of dw: [Cout][cin_real][KH][KW] (torch parameter layout) or [Cout][KH][KW][Cin]
     float* partial;        // [gridDim.z][Cout][taps*Cin] per-split partial results (plain stores, no atomics)
+    int remap_tiles, co_tiles;   // remap_tiles > 0: 1-D grid, see wgrad_block
 };
+
+// Which (output-channel tile, tap x input-channel tile, pixel split) a block of the split-K tile kernels works on.  With the plain 3-D
+// grid the tile blocks of ONE pixel split -- which read the same dOut / input pixels -- have consecutive linear ids and therefore land
+// on different XCDs (block id % 8), each with its own L2: every tile re-reads its operands from HBM / the memory-side cache.  Remapped
+// (1-D grid of T x 8 x ceil(splits / 8) blocks), the T tile blocks of a split share an XCD and are dispatched together.
+struct WgradBlock { int bco, by, bz; };
+__device__ __forceinline__ WgradBlock wgrad_block(const WgradParams& p) {
+    if (!p.remap_tiles) return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const int h = blockIdx.x, xcd = h & 7, slot = h >> 3, tile = slot % p.remap_tiles;
+    return {tile % p.co_tiles, tile / p.co_tiles, (slot / p.remap_tiles) * 8 + xcd};
+}
 
 constexpr int WBK = 64;            // pixels per k-step
 constexpr int WPITCH = 128;        // 64 pixels x 2 bytes per channel row, XOR-swizzled (no padding)
@@ -1095,11 +1107,12 @@ template <int MT, int NT, bool PACK = false>
 __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];  // [2 buffers][A | B][WTILE]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
-    const int bco = blockIdx.x;
-    const int tap_blk = PACK ? 0 : blockIdx.y / p.ci_tiles, bci = PACK ? blockIdx.y : blockIdx.y % p.ci_tiles;
+    const WgradBlock wb = wgrad_block(p);
+    const int bco = wb.bco;
+    const int tap_blk = PACK ? 0 : wb.by / p.ci_tiles, bci = PACK ? wb.by : wb.by % p.ci_tiles;
     int kh = tap_blk / p.KW, kw = tap_blk % p.KW;
     const long M = (long)p.N * p.OH * p.OW;
-    const long m_begin = (long)blockIdx.z * p.m_per_split;
+    const long m_begin = (long)wb.bz * p.m_per_split;
     const long m_end = m_begin + p.m_per_split < M ? m_begin + p.m_per_split : M;
     if (m_begin >= M) return;
     const bool isB = tid >= 128;
@@ -1213,7 +1226,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
                 // per-split partial tile in [Cout][tap][Cin] order: coalesced plain stores; conv_wgrad_reduce sums the splits
                 const size_t wsize = (size_t)p.Cout * p.KH * p.KW * p.Cin;
                 const size_t idx = PACK ? (size_t)co * ncols + ci : (((size_t)co * p.KH * p.KW + tap_blk) * p.Cin + ci);
-                p.partial[(size_t)blockIdx.z * wsize + idx] = acc[i][j][e];
+                p.partial[(size_t)wb.bz * wsize + idx] = acc[i][j][e];
             }
     }
 }
@@ -1784,11 +1797,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgradParams p) {
     constexpr int PA = MT, PB = NT;                             // 1-KB pieces per wave and stage (4*MT resp. 4*NT per block)
     __shared__ __attribute__((aligned(16))) unsigned char sm[3 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
-    const int bco = blockIdx.x;
-    const int tap = blockIdx.y / p.ci_tiles, bci = blockIdx.y % p.ci_tiles;
+    const WgradBlock wb = wgrad_block(p);
+    const int bco = wb.bco;
+    const int tap = wb.by / p.ci_tiles, bci = wb.by % p.ci_tiles;
     const int kh = tap / p.KW, kw = tap % p.KW;
     const long M = (long)p.N * p.OH * p.OW;
-    const long m_begin = (long)blockIdx.z * p.m_per_split;
+    const long m_begin = (long)wb.bz * p.m_per_split;
     const long m_end = m_begin + p.m_per_split < M ? m_begin + p.m_per_split : M;
     if (m_begin >= M) return;
     const int ksteps = (int)((m_end - m_begin + 31) / 32);
@@ -1914,7 +1928,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgradParams p) {
             for (int e = 0; e < 16; ++e) {
                 const int co = bco * 64 * MT + wm * 32 * MT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
-                p.partial[(size_t)blockIdx.z * wsize + (((size_t)co * p.KH * p.KW + tap) * p.Cin + ci)] = acc[i][j][e];
+                p.partial[(size_t)wb.bz * wsize + (((size_t)co * p.KH * p.KW + tap) * p.Cin + ci)] = acc[i][j][e];
             }
     }
 }
@@ -2154,6 +2168,12 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
             const int rcw = MGN_SYM(mgn_conv3x3_win)(in, w, out, N, OH, OW, Cin, Cout, residual, pr, stat_part, stat_shift, stream);
             if (rcw != MGN_ENOTSUP || stat_part) return rcw;
         }
+    }
+    if (!pack && KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 2 && !bias && !relu && !out_f32 && !stat_part && !plan_rows &&
+        Cout % 64 == 0 && !getenv("MGN_CONV_NOUP2WIN")) {
+        // data gradient of a 3x3 / stride-2 conv: all four parity classes from one low-resolution window (csrc/conv_up2.hip)
+        const int rcu = MGN_SYM(mgn_conv3x3_up2_win)(in, w, out, N, IH, IW, Cin, Cout, OH, OW, residual, stream);
+        if (rcu != MGN_ENOTSUP) return rcu;
     }
     const bool c64 = !pack && !bias && !relu && !out_f32 && c64_eligible(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up);
     if (stat_part && !stats_ok) return MGN_ENOTSUP;   // (mgn_conv_stat_rows says which layers leave statistics behind)
@@ -2433,7 +2453,13 @@ static int wgrad_impl(const void* dout, const void* in, float* dw, int N, int IH
     wgrad_plan(N, OH, OW, Cin, Cout, KH, KW, &pack, &NT, &MT, &p.ci_tiles, &co_tiles, &p.m_per_split, &gz);
     if (workspace_bytes < sizeof(float) * gz * wsize) return MGN_ENOSPC;
     p.partial = (float*)workspace;
-    const dim3 grid(co_tiles, (pack ? 1 : KH * KW) * p.ci_tiles, (unsigned)gz);
+    dim3 grid(co_tiles, (pack ? 1 : KH * KW) * p.ci_tiles, (unsigned)gz);
+    p.remap_tiles = 0; p.co_tiles = co_tiles;
+    const long tiles_per_split = (long)grid.x * grid.y;
+    if (tiles_per_split > 1 && gz >= 8 && tiles_per_split * ((gz + 7) / 8 * 8) < 0x7fffffffL && !getenv("MGN_WGRAD_NOREMAP")) {
+        p.remap_tiles = (int)tiles_per_split;      // the tile blocks of a pixel split on one XCD (wgrad_block)
+        grid = dim3((unsigned)(tiles_per_split * ((gz + 7) / 8 * 8)), 1, 1);
+    }
     const size_t lds = 4 * (size_t)WTILE;
     static bool attr_done = false;
     if (!attr_done) {
