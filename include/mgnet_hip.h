@@ -258,6 +258,8 @@ int mgn_conv3x3_win(const void* in, const void* w, void* out, int N, int H, int 
  * the same sums as mgn_conv_igemm(stride 1, pad 1, up 2), which dispatches here (Cin % 32 == 0, Cout % 64 == 0; MGN_ENOTSUP otherwise).
  * residual: 16-bit [N,OH,OW,Cout] added before rounding (the shortcut's gradient), or NULL. */
 int mgn_conv3x3_up2_win(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, int OH, int OW,
+                        int ksize /* 3, or 1: the 1x1 / stride 2 / pad 0 shortcut conv (res_net.py `downsample`), w = [Cout][1][1][Cin]:
+                                     only the even output pixels receive a product, the rest is zeros (+ residual) */,
                         const void* residual, void* stream);
 /* Convolution + the batch statistics of its output in one launch (forward of conv -> InPlaceABNSync, res_net.py:35,49,59,
  * layers.py:63,71): mgn_conv_stat_rows says how many partial rows the kernel mgn_conv_igemm would pick for this layer leaves behind
@@ -736,7 +738,7 @@ int mgn_conv_igemm_stats_f16(const void* in, const void* w, void* out, int N, in
 int mgn_conv3x3_win_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
     int patch_rows, float* stat_partials, const float* stat_shift, void* stream);
 int mgn_conv3x3_up2_win_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, int OH, int OW,
-    const void* residual, void* stream);
+    int ksize, const void* residual, void* stream);
 int mgn_conv_wgrad_partial_f16(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
     int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
 int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);

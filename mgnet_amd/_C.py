@@ -125,7 +125,7 @@ def lib():
         L.mgn_clip_coef_scaled.argtypes = [vp, ci, cf, cf, cf, cf, ci, vp, vp, vp, vp]
         L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp, vp]
         L.mgn_conv3x3_win.argtypes = [vp, vp, vp] + [ci] * 5 + [vp, ci, vp, vp, vp]
-        L.mgn_conv3x3_up2_win.argtypes = [vp, vp, vp] + [ci] * 7 + [vp, vp]
+        L.mgn_conv3x3_up2_win.argtypes = [vp, vp, vp] + [ci] * 8 + [vp, vp]
         L.mgn_conv_stem7.argtypes = [vp, vp, vp] + [ci] * 7 + [vp, vp]
         L.mgn_conv_stem7_blocks.argtypes = [ci] * 7
         L.mgn_conv_win_patch_rows.argtypes = [ci] * 5

@@ -42,26 +42,33 @@ struct Up2Params {
 
 constexpr int PH = 8, PW = 32, RPW = 2, WW = PW + 1, WPX = (PH + 1) * WW;   // 297 window pixels
 constexpr int NWP = (WPX + 15) / 16;                                          // 19 window pieces of 16 pixels
-constexpr int NWT = 36;                                                       // weight pieces: 9 taps x 64 channels x 64 B
-constexpr int WINB = NWP * 1024, WTB = NWT * 1024;                            // 19 KB, 36 KB
+constexpr int WINB = NWP * 1024;                                              // 19 KB
 constexpr int NWS = 3;                                                        // weight stages: the weights travel TWO steps ahead
-constexpr int UP2_LDS = 2 * WINB + NWS * WTB;                                 // 146 KB
-constexpr int LWP = (NWP + 3) / 4, LWT = NWT / 4;                             // pieces per LOADER wave and step (5 window, 9 weight)
+constexpr int LWP = (NWP + 3) / 4;                                            // window pieces per LOADER wave and step
+// KS = 3: the 3x3 conv's gradient; KS = 1: the 1x1 / stride-2 shortcut conv's gradient (res_net.py:52-60 `downsample`) -- one tap, only
+// the class (0, 0) pixels receive a product, the other three quarters of the output are zeros (+ residual) written by the same pass
+template <int KS> struct Up2 {
+    static constexpr int NT = KS * KS, NWT = NT * 4, WTB = NWT * 1024;        // weight pieces per chunk: taps x 64 channels x 64 B
+    static constexpr int LWT = NWT / 4;                                       // weight pieces per loader wave and step (9 | 1)
+    static constexpr int LDS = 2 * WINB + NWS * WTB;                          // 146 KB | 50 KB
+};
 
 // the nine MFMA steps of a chunk: (class = 2 a + b, window shift (sy, sx), tap kh' * 3 + kw' of the flipped weights).  Output row
 // 2 i + a reads the zero-upsampled gradient at row 2 i + a - 1 + kh' = 2 (i + sy): a = 0 -> kh' = 1 (sy 0); a = 1 -> kh' = 0 (sy 0),
 // kh' = 2 (sy 1); columns alike.
 struct Step { int cls, sy, sx, tap; };
+__device__ constexpr Step STEP1[1] = {{0, 0, 0, 0}};
 __device__ constexpr Step STEPS[9] = {{0, 0, 0, 4}, {1, 0, 0, 3}, {1, 0, 1, 5}, {2, 0, 0, 1}, {2, 1, 0, 7},
                                       {3, 0, 0, 0}, {3, 0, 1, 2}, {3, 1, 0, 6}, {3, 1, 1, 8}};
 
-template <bool RES>
+template <bool RES, int KS>
 __device__ __forceinline__ void up2_body(const Up2Params& p) {
+    constexpr int NT = Up2<KS>::NT, WTB = Up2<KS>::WTB, LWT = Up2<KS>::LWT;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
     const int hi = lane >> 5, l31 = lane & 31;
     if ((int)blockIdx.x >= p.nitems) return;
-    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.H * p.W * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * 9 * p.Cin * 2);
+    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.H * p.W * p.Cin * 2), w_bytes = (uint32_t)((size_t)p.Cout * NT * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, w_bytes, 0x00020000);
     constexpr int OOB = (int)0x80000000;
@@ -101,7 +108,7 @@ __device__ __forceinline__ void up2_body(const Up2Params& p) {
         for (int k = 0; k < LWT; ++k) {
             const int idx = lw + 4 * k, tap = idx >> 2, row = (idx & 3) * 16 + (lane >> 2);
             const int sseg = (lane & 3) ^ ((row >> 2) & 3);
-            wboff[k] = (((bn * 64 + row) * 9 + tap) * p.Cin + sseg * 8) * 2;
+            wboff[k] = (((bn * 64 + row) * NT + tap) * p.Cin + sseg * 8) * 2;
         }
     };
     unsigned char* const wts = sm + 2 * WINB;
@@ -189,8 +196,9 @@ __device__ __forceinline__ void up2_body(const Up2Params& p) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) a[dy][sx][kk] = *reinterpret_cast<const h16x8*>(win + (aoff[dy][sx] ^ (kk << 5)));
 #pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            const int cls = STEPS[s].cls, sy = STEPS[s].sy, sx = STEPS[s].sx, tap = STEPS[s].tap;
+        for (int s = 0; s < NT; ++s) {
+            const Step st = KS == 3 ? STEPS[s] : STEP1[0];
+            const int cls = st.cls, sy = st.sy, sx = st.sx, tap = st.tap;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const h16x8 b = *reinterpret_cast<const h16x8*>(b0 + tap * 4096 + (boff ^ (kk << 5)));
@@ -252,19 +260,21 @@ __device__ __forceinline__ void up2_body(const Up2Params& p) {
     }
 }
 
-__global__ __launch_bounds__(512, 1) void conv3x3_up2_win(Up2Params p) { up2_body<false>(p); }
-__global__ __launch_bounds__(512, 1) void conv3x3_up2_win_res(Up2Params p) { up2_body<true>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_up2_win(Up2Params p) { up2_body<false, 3>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_up2_win_res(Up2Params p) { up2_body<true, 3>(p); }
+__global__ __launch_bounds__(512, 1) void conv1x1_up2_win(Up2Params p) { up2_body<false, 1>(p); }
+__global__ __launch_bounds__(512, 1) void conv1x1_up2_win_res(Up2Params p) { up2_body<true, 1>(p); }
 
 }  // namespace
 
 extern "C" {
 
 int MGN_SYM(mgn_conv3x3_up2_win)(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, int OH, int OW,
-                                 const void* residual, void* stream) {
-    if (!in || !w || !out || N < 1 || H < 1 || W < 1) return MGN_EINVAL;
+                                 int ksize, const void* residual, void* stream) {
+    if (!in || !w || !out || N < 1 || H < 1 || W < 1 || (ksize != 3 && ksize != 1)) return MGN_EINVAL;
     if (Cin < 32 || Cin % 32 != 0 || Cout < 64 || Cout % 64 != 0) return MGN_ENOTSUP;
     if ((OH != 2 * H && OH != 2 * H - 1) || (OW != 2 * W && OW != 2 * W - 1)) return MGN_ENOTSUP;
-    if ((size_t)N * H * W * Cin * 2 >= 0x7fffffffu || (size_t)Cout * 9 * Cin * 2 >= 0x7fffffffu) return MGN_ENOTSUP;   // 32-bit byte offsets
+    if ((size_t)N * H * W * Cin * 2 >= 0x7fffffffu || (size_t)Cout * ksize * ksize * Cin * 2 >= 0x7fffffffu) return MGN_ENOTSUP;   // 32-bit byte offsets
     Up2Params p;
     p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = (uint16_t*)out; p.residual = (const uint16_t*)residual;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.OH = OH; p.OW = OW;
@@ -275,16 +285,23 @@ int MGN_SYM(mgn_conv3x3_up2_win)(const void* in, const void* w, void* out, int N
     static int cus = 0;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_win), hipFuncAttributeMaxDynamicSharedMemorySize, UP2_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_win_res), hipFuncAttributeMaxDynamicSharedMemorySize, UP2_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_win), hipFuncAttributeMaxDynamicSharedMemorySize, Up2<3>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_win_res), hipFuncAttributeMaxDynamicSharedMemorySize, Up2<3>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_up2_win), hipFuncAttributeMaxDynamicSharedMemorySize, Up2<1>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_up2_win_res), hipFuncAttributeMaxDynamicSharedMemorySize, Up2<1>::LDS);
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
             cus = 256;
         attr = true;
     }
-    const unsigned grid = (unsigned)(nitems < cus ? nitems : cus);   // one persistent 8-wave block per CU
-    if (residual) hipLaunchKernelGGL(conv3x3_up2_win_res, dim3(grid), dim3(512), UP2_LDS, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(conv3x3_up2_win, dim3(grid), dim3(512), UP2_LDS, (hipStream_t)stream, p);
+    // persistent 8-wave blocks: one per CU for the 3x3 kernel (146 KB of LDS), two for the 1x1 kernel (50 KB; it is a stream of stores)
+    const long want = ksize == 3 ? cus : 2L * cus;
+    const dim3 grid((unsigned)(nitems < want ? nitems : want)), block(512);
+    hipStream_t st = (hipStream_t)stream;
+    if (ksize == 3 && residual) hipLaunchKernelGGL(conv3x3_up2_win_res, grid, block, Up2<3>::LDS, st, p);
+    else if (ksize == 3) hipLaunchKernelGGL(conv3x3_up2_win, grid, block, Up2<3>::LDS, st, p);
+    else if (residual) hipLaunchKernelGGL(conv1x1_up2_win_res, grid, block, Up2<1>::LDS, st, p);
+    else hipLaunchKernelGGL(conv1x1_up2_win, grid, block, Up2<1>::LDS, st, p);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

@@ -469,9 +469,10 @@ def test_fp32_inference_conv_as_three_bf16_passes(cin, cout, k, s, hw, bias, mon
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("ks", [3, 1])
 @pytest.mark.parametrize("case", [(2, 64, 128, 70, 150, False), (1, 128, 256, 33, 67, True), (3, 256, 512, 16, 40, True), (1, 64, 128, 9, 7, False),
                                   (8, 128, 256, 128, 256, True)])
-def test_strided_3x3_data_gradient_from_one_low_resolution_window(case, dtype, monkeypatch):
+def test_strided_3x3_data_gradient_from_one_low_resolution_window(case, ks, dtype, monkeypatch):
     """csrc/conv_up2.hip (all four parity classes of the stride-2 data gradient from one window, persistent blocks with several work
     items each, odd and even sizes, fused shortcut gradient) against the fp64 gradient of F.conv2d and against the parity-class
     launch of the generic kernel it replaces (same sums in another order)."""
@@ -480,16 +481,17 @@ def test_strided_3x3_data_gradient_from_one_low_resolution_window(case, dtype, m
     N, Cin, Cout, H, W, res = case
     torch.manual_seed(sum(case[:5]))
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / (Cin * 9) ** 0.5).requires_grad_(True)
+    pad = ks // 2      # (ks = 1: the shortcut's 1x1 / stride 2 / pad 0 conv -- three quarters of its data gradient are zeros)
+    w = (torch.randn(Cout, Cin, ks, ks, device="cuda") / (Cin * ks * ks) ** 0.5).requires_grad_(True)
     dy = torch.randn(N, Cout, OH, OW, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
     r = torch.randn(N, Cin, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last) if res else None
     wl = _C._weight_layout_now(w, 1, 0, None, 0, dtype)
-    got = _C.conv_igemm(dy, wl, (H, W), None, 1, 1, up=2, residual=r)
+    got = _C.conv_igemm(dy, wl, (H, W), None, 1, ks - 1 - pad, up=2, residual=r)
     monkeypatch.setenv("MGN_CONV_NOUP2WIN", "1")
-    old = _C.conv_igemm(dy, wl, (H, W), None, 1, 1, up=2, residual=r)
+    old = _C.conv_igemm(dy, wl, (H, W), None, 1, ks - 1 - pad, up=2, residual=r)
     monkeypatch.delenv("MGN_CONV_NOUP2WIN")
     w16 = w.detach().to(dtype).double()
-    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w16, dy.double(), stride=2, padding=1)
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w16, dy.double(), stride=2, padding=pad)
     if res:
         ref = ref + r.double()
     scale = float(ref.abs().max())
@@ -499,5 +501,5 @@ def test_strided_3x3_data_gradient_from_one_low_resolution_window(case, dtype, m
         assert err < 1.2 * ulp, (name, err)     # fp32 accumulation, ONE rounding to 16 bits
     # the two kernels differ only in the order of the fp32 sums: the same 16-bit value except next to a rounding tie
     assert float((got != old).float().mean()) < 2e-2
-    again = _C.conv_igemm(dy, wl, (H, W), None, 1, 1, up=2, residual=r)
+    again = _C.conv_igemm(dy, wl, (H, W), None, 1, ks - 1 - pad, up=2, residual=r)
     assert torch.equal(got, again)
