@@ -39,7 +39,8 @@ __global__ __launch_bounds__(VT) void vec_linear_fwd(const float* __restrict__ i
     for (int i = threadIdx.x; i < N * K; i += VT) sin[i] = in[i];
     __syncthreads();
     // thread = (channel, k-part): partial dot products for all samples, combined through LDS
-    const int cl = threadIdx.x % CB, part = threadIdx.x / CB, nparts = VT / CB;   // 16 parts
+    // (k fastest across lanes: a wave reads 4 weight rows x 16 consecutive k = four 64-byte segments per load instead of sixteen rows)
+    const int nparts = VT / CB, part = threadIdx.x % nparts, cl = threadIdx.x / nparts;   // 16 parts
     const int c = c0 + cl;
     float* sp = sz + (size_t)N * CB;        // partials [nparts][N][CB]
     {
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(VT) void vec_linear_fwd(const float* __restrict__ i
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
             if (c < C)
+#pragma unroll 8   // (eight weight loads in flight: left rolled, every iteration waits for its own load -- 32 round trips = the kernel's 14 us)
                 for (int k = part; k < K; k += nparts) {
                     const float w = W[(size_t)c * K + k];
 #pragma unroll
@@ -141,13 +143,18 @@ __global__ __launch_bounds__(VT) void vec_linear_bwd(const float* __restrict__ d
         dW[(size_t)(c0 + cc) * K + k] = acc;
     }
     float* dp = din_parts + (size_t)blockIdx.x * N * K;
-    for (int o = threadIdx.x; o < N * K; o += VT) {            // partial din[n][k] = sum_{c in block} dz[n][c] * W[c][k]
-        const int k = o % K, n = o / K;
-        float acc = 0.f;
-#pragma unroll 4
-        for (int cc = 0; cc < CB; ++cc)
-            if (c0 + cc < C) acc = fmaf(dz[n * CB + cc], W[(size_t)(c0 + cc) * K + k], acc);
-        dp[o] = acc;
+    // partial din[n][k] = sum_{c in block} dz[n][c] * W[c][k]: a thread owns column k -- its CB weights are loaded once (all in flight
+    // together) and reused for the N samples (per (n, k) output they were N x CB dependent round trips: ~16 of the kernel's 25 us)
+    for (int k = threadIdx.x; k < K; k += VT) {
+        float w[CB];
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc) w[cc] = c0 + cc < C ? W[(size_t)(c0 + cc) * K + k] : 0.f;
+        for (int n = 0; n < N; ++n) {
+            float acc = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < CB; ++cc) acc = fmaf(dz[n * CB + cc], w[cc], acc);
+            dp[(size_t)n * K + k] = acc;
+        }
     }
 }
 
@@ -155,9 +162,14 @@ __global__ __launch_bounds__(VT) void vec_linear_bwd(const float* __restrict__ d
 __global__ void vec_sum_parts(const float* __restrict__ parts, int nparts, int n, float scale, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float acc = 0.f;
-    for (int q = 0; q < nparts; ++q) acc += parts[(size_t)q * n + i];
-    out[i] = acc * scale;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // (independent chains: the loads of all parts in flight at once; fixed order)
+    int q = 0;
+#pragma unroll 4
+    for (; q + 3 < nparts; q += 4) {
+        a0 += parts[(size_t)q * n + i]; a1 += parts[(size_t)(q + 1) * n + i]; a2 += parts[(size_t)(q + 2) * n + i]; a3 += parts[(size_t)(q + 3) * n + i];
+    }
+    for (; q < nparts; ++q) a0 += parts[(size_t)q * n + i];
+    out[i] = ((a0 + a1) + (a2 + a3)) * scale;
 }
 
 inline bool shape_ok(int N, int K, int C) { return N >= 1 && N <= VMAXN && K >= 1 && C >= 1 && (size_t)N * K * 4 <= 96 * 1024; }
