@@ -128,3 +128,4 @@ def test_static_batch_copy_keeps_the_view_structure_and_refills():
                 if isinstance(v, torch.Tensor):
                     assert torch.equal(v, o[k]), k
     assert Trainer._batch_signature(b) == Trainer._batch_signature(loose) != Trainer._batch_signature(synthetic_batch(2, 32, 96, "cpu"))
+
