@@ -325,6 +325,44 @@ def full_step_bench(args, world, rank, dev):
             mode = "plan"
         elif plan is not None:
             plan_note = "plan recording failed on another rank; eager steps timed"
+    exec_probe = None
+    if mode == "plan" and args.exec == "auto" and world == 1:
+        # Which way of ISSUING the same step is faster on this box?  The replay takes the host from 15-25 ms to 2.5-3.5 ms per step, but
+        # the step is GPU-bound either way, and the replay's minimal cross-stream dependencies let the branches overlap a little more
+        # than the eager step's do -- which costs the one-block-per-CU kernels more than it hides: measured -0.1 ... +0.9 ms per step
+        # depending on the box (profiles/r04_same_box_r3_vs_r4.txt).  A short untimed calibration (2 x 8 steps each, interleaved)
+        # picks the mode of the timed steps; both figures and both host costs are reported (`config.step_execution_probe`).
+        def probe(fn, n=8):
+            fence()
+            tp = time.perf_counter()
+            for _ in range(n):
+                fn()
+            fence()
+            return (time.perf_counter() - tp) / n * 1e3
+
+        def issue(fn, n=3):
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                ti = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - ti) * 1e3)
+            torch.cuda.synchronize()
+            return float(np.median(ts))
+
+        eager_fn, plan_fn = (lambda: trainer.run_step(batch)), (lambda: trainer.replay_plan())
+        ms_p, ms_e = [], []
+        for _ in range(2):
+            ms_p.append(probe(plan_fn))
+            ms_e.append(probe(eager_fn))
+        exec_probe = {"plan_ms_per_step": round(min(ms_p), 3), "eager_ms_per_step": round(min(ms_e), 3),
+                      "plan_host_issue_ms": round(issue(plan_fn), 2), "eager_host_issue_ms": round(issue(eager_fn), 2),
+                      "how": "untimed calibration before the timed region: 2 x 8 steps per mode, interleaved, best of two; host issue = one step "
+                             "into an empty queue, median of 3"}
+        if min(ms_e) < 0.997 * min(ms_p):
+            mode = "eager"
+            plan_note = "launch-plan replay recorded and available (--exec plan); the calibration found the eager issue faster on this box"
+        exec_probe["timed"] = mode
     if use_graph:
         try:
             trainer.capture_step(batch)
@@ -444,6 +482,7 @@ def full_step_bench(args, world, rank, dev):
                                                   (" replay: one recorded step's launches re-issued from C (csrc/plan.hip), side streams kept; " + json.dumps(plan.report)) if mode == "plan" else
                                                   " (launches issued from Python; side streams for the independent branches: " +
                                                   ("on" if model._side_streams() is not None else "off") + ")" + (f"; {plan_note}" if plan_note else "")),
+                       **({"step_execution_probe": exec_probe} if exec_probe else {}),
                        "host_issue_ms_per_step": round(host_issue_ms, 2),
                        "host_issue_is": "wall time of issuing ONE step of this workload into an empty launch queue (median of 5, after the timed region)",
                        "host_issue_loop_wall_ms_per_step": round(t_issue / args.steps * 1e3, 2),
