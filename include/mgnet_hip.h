@@ -260,7 +260,11 @@ int mgn_conv3x3_win(const void* in, const void* w, void* out, int N, int H, int 
 int mgn_conv3x3_up2_win(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, int OH, int OW,
                         int ksize /* 3, or 1: the 1x1 / stride 2 / pad 0 shortcut conv (res_net.py `downsample`), w = [Cout][1][1][Cin]:
                                      only the even output pixels receive a product, the rest is zeros (+ residual) */,
-                        const void* residual, void* stream);
+                        const void* residual,
+                        int residual_lowres /* 1 (ksize 3): `residual` is [N,H,W,Cout] at the LOW resolution and is added to the even output
+                                               pixels only -- the data gradient of the block's 1x1 / stride-2 shortcut conv as the plain
+                                               1x1 product it is, without its zero-filled full-resolution form */,
+                        void* stream);
 /* Convolution + the batch statistics of its output in one launch (forward of conv -> InPlaceABNSync, res_net.py:35,49,59,
  * layers.py:63,71): mgn_conv_stat_rows says how many partial rows the kernel mgn_conv_igemm would pick for this layer leaves behind
  * (0: that kernel has no statistics epilogue -- run mgn_iabn_train_coeffs over the output instead; *shifted = 1: the sums are taken
@@ -738,7 +742,7 @@ int mgn_conv_igemm_stats_f16(const void* in, const void* w, void* out, int N, in
 int mgn_conv3x3_win_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
     int patch_rows, float* stat_partials, const float* stat_shift, void* stream);
 int mgn_conv3x3_up2_win_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, int OH, int OW,
-    int ksize, const void* residual, void* stream);
+    int ksize, const void* residual, int residual_lowres, void* stream);
 int mgn_conv_wgrad_partial_f16(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
     int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
 int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);

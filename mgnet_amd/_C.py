@@ -125,7 +125,7 @@ def lib():
         L.mgn_clip_coef_scaled.argtypes = [vp, ci, cf, cf, cf, cf, ci, vp, vp, vp, vp]
         L.mgn_conv_igemm.argtypes = [vp, vp, vp, vp] + [ci] * 14 + [vp, vp]
         L.mgn_conv3x3_win.argtypes = [vp, vp, vp] + [ci] * 5 + [vp, ci, vp, vp, vp]
-        L.mgn_conv3x3_up2_win.argtypes = [vp, vp, vp] + [ci] * 8 + [vp, vp]
+        L.mgn_conv3x3_up2_win.argtypes = [vp, vp, vp] + [ci] * 8 + [vp, ci, vp]
         L.mgn_conv_stem7.argtypes = [vp, vp, vp] + [ci] * 7 + [vp, vp]
         L.mgn_conv_stem7_blocks.argtypes = [ci] * 7
         L.mgn_conv_win_patch_rows.argtypes = [ci] * 5
@@ -883,6 +883,23 @@ def conv3x3_win(x, w_ohwi, residual=None, patch_rows=16, stats_shift=None, want_
                                     None if part is None else part.data_ptr(), None if stats_shift is None else stats_shift.data_ptr(),
                                     _stream()), "mgn_conv3x3_win")
     return (out, part) if want_stats else out
+
+
+def conv_up2(dy, w_ihwo, out_hw, residual=None, residual_lowres=False):
+    """csrc/conv_up2.hip directly: data gradient of a 3x3 / stride 2 / pad 1 (or 1x1 / stride 2 / pad 0) conv.  dy [N,Cin_k,H,W] 16-bit
+    channels_last (gradient of the conv's output), w_ihwo = the layout-mode-1 weights [Cout_k][k][k][Cin_k], out_hw = the conv input's
+    (OH, OW).  residual: a full-resolution 16-bit tensor added everywhere, or (residual_lowres) a [N,Cout_k,H,W] tensor added to the even
+    pixels.  Returns None when the shape is not one for this kernel (the caller falls back to conv_igemm(up=2))."""
+    N, Cin, H, W = dy.shape
+    Cout, ks = w_ihwo.shape[0], w_ihwo.shape[1]
+    OH, OW = out_hw
+    out = torch.empty((N, Cout, OH, OW), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    rc = _fn("mgn_conv3x3_up2_win", dy)(dy.data_ptr(), w_ihwo.data_ptr(), out.data_ptr(), N, H, W, Cin, Cout, OH, OW, ks,
+                                        None if residual is None else residual.data_ptr(), int(bool(residual_lowres)), _stream())
+    if rc == -95:   # MGN_ENOTSUP
+        return None
+    check(rc, "mgn_conv3x3_up2_win")
+    return out
 
 
 def iabn_from_partials(partials, C, M, shift, w32=None, b32=None, eps=1e-5, momentum=0.0, running_mean=None, running_var=None, stats_only=False):

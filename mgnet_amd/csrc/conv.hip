@@ -2173,7 +2173,7 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
         !out_f32 && !stat_part && !plan_rows && Cout % 64 == 0 && !getenv("MGN_CONV_NOUP2WIN")) {
         // data gradient of a 3x3 (or the shortcut's 1x1) stride-2 conv: all four parity classes from one low-resolution window
         // (csrc/conv_up2.hip)
-        const int rcu = MGN_SYM(mgn_conv3x3_up2_win)(in, w, out, N, IH, IW, Cin, Cout, OH, OW, KH, residual, stream);
+        const int rcu = MGN_SYM(mgn_conv3x3_up2_win)(in, w, out, N, IH, IW, Cin, Cout, OH, OW, KH, residual, 0, stream);
         if (rcu != MGN_ENOTSUP) return rcu;
     }
     const bool c64 = !pack && !bias && !relu && !out_f32 && c64_eligible(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up);

@@ -61,7 +61,10 @@ __device__ constexpr Step STEP1[1] = {{0, 0, 0, 0}};
 __device__ constexpr Step STEPS[9] = {{0, 0, 0, 4}, {1, 0, 0, 3}, {1, 0, 1, 5}, {2, 0, 0, 1}, {2, 1, 0, 7},
                                       {3, 0, 0, 0}, {3, 0, 1, 2}, {3, 1, 0, 6}, {3, 1, 1, 8}};
 
-template <bool RES, int KS>
+// RES: 0 none, 1 a full-resolution tensor added to every output pixel, 2 a LOW-resolution tensor [N, H, W, Cout] added to the class (0, 0)
+// pixels only -- the data gradient of the block's 1x1 / stride-2 shortcut conv, which is non-zero exactly there (its zeros are never written
+// nor read back: ops._ConvFn with_skip = 2)
+template <int RES, int KS>
 __device__ __forceinline__ void up2_body(const Up2Params& p) {
     constexpr int NT = Up2<KS>::NT, WTB = Up2<KS>::WTB, LWT = Up2<KS>::LWT;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -220,13 +223,15 @@ __device__ __forceinline__ void up2_body(const Up2Params& p) {
                     const bool ok = oy < p.OH && ox < p.OW;
                     const size_t m = ((size_t)n * p.OH + (oy < p.OH ? oy : 0)) * p.OW + (ox < p.OW ? ox : 0);
                     uint16_t* opix = p.out + m * p.Cout + bn * 64 + wn * 32;
-                    const uint16_t* rpix = RES ? p.residual + m * p.Cout + bn * 64 + wn * 32 : nullptr;
+                    const bool add = RES == 1 || (RES == 2 && cls == 0);
+                    const size_t mr = RES == 2 ? ((size_t)n * p.H + (y0 + wm * RPW + r < p.H ? y0 + wm * RPW + r : 0)) * p.W + (x0 + l31 < p.W ? x0 + l31 : 0) : m;
+                    const uint16_t* rpix = add ? p.residual + mr * p.Cout + bn * 64 + wn * 32 : nullptr;
 #pragma unroll
                     for (int qp = 0; qp < 2; ++qp) {
                         // v_permlane32_swap exchanges the 4-channel groups of lane l and l + 32: a lane then owns 8 consecutive channels
                         // (16-byte stores); the residual is read in that layout and brought to the accumulator layout by the same exchange
                         uint32_t rp[2][2] = {{0u, 0u}, {0u, 0u}};
-                        if (RES) {
+                        if (add) {
                             const uint4 R = *reinterpret_cast<const uint4*>(rpix + 16 * qp + 8 * hi);
                             const auto u0 = __builtin_amdgcn_permlane32_swap(R.x, R.z, false, false);
                             const auto u1 = __builtin_amdgcn_permlane32_swap(R.y, R.w, false, false);
@@ -237,7 +242,7 @@ __device__ __forceinline__ void up2_body(const Up2Params& p) {
                         for (int u = 0; u < 2; ++u) {
                             const int q = 2 * qp + u;
                             float v0 = acc[r][cls][q * 4 + 0], v1 = acc[r][cls][q * 4 + 1], v2 = acc[r][cls][q * 4 + 2], v3 = acc[r][cls][q * 4 + 3];
-                            if (RES) {
+                            if (add) {
                                 v0 += mgn_lo2f(rp[u][0]); v1 += mgn_hi2f(rp[u][0]);
                                 v2 += mgn_lo2f(rp[u][1]); v3 += mgn_hi2f(rp[u][1]);
                             }
@@ -260,18 +265,20 @@ __device__ __forceinline__ void up2_body(const Up2Params& p) {
     }
 }
 
-__global__ __launch_bounds__(512, 1) void conv3x3_up2_win(Up2Params p) { up2_body<false, 3>(p); }
-__global__ __launch_bounds__(512, 1) void conv3x3_up2_win_res(Up2Params p) { up2_body<true, 3>(p); }
-__global__ __launch_bounds__(512, 1) void conv1x1_up2_win(Up2Params p) { up2_body<false, 1>(p); }
-__global__ __launch_bounds__(512, 1) void conv1x1_up2_win_res(Up2Params p) { up2_body<true, 1>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_up2_win(Up2Params p) { up2_body<0, 3>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_up2_win_res(Up2Params p) { up2_body<1, 3>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_up2_win_reslo(Up2Params p) { up2_body<2, 3>(p); }
+__global__ __launch_bounds__(512, 1) void conv1x1_up2_win(Up2Params p) { up2_body<0, 1>(p); }
+__global__ __launch_bounds__(512, 1) void conv1x1_up2_win_res(Up2Params p) { up2_body<1, 1>(p); }
 
 }  // namespace
 
 extern "C" {
 
 int MGN_SYM(mgn_conv3x3_up2_win)(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, int OH, int OW,
-                                 int ksize, const void* residual, void* stream) {
+                                 int ksize, const void* residual, int residual_lowres, void* stream) {
     if (!in || !w || !out || N < 1 || H < 1 || W < 1 || (ksize != 3 && ksize != 1)) return MGN_EINVAL;
+    if (residual_lowres && (!residual || ksize != 3)) return MGN_EINVAL;
     if (Cin < 32 || Cin % 32 != 0 || Cout < 64 || Cout % 64 != 0) return MGN_ENOTSUP;
     if ((OH != 2 * H && OH != 2 * H - 1) || (OW != 2 * W && OW != 2 * W - 1)) return MGN_ENOTSUP;
     if ((size_t)N * H * W * Cin * 2 >= 0x7fffffffu || (size_t)Cout * ksize * ksize * Cin * 2 >= 0x7fffffffu) return MGN_ENOTSUP;   // 32-bit byte offsets
@@ -287,6 +294,7 @@ int MGN_SYM(mgn_conv3x3_up2_win)(const void* in, const void* w, void* out, int N
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_win), hipFuncAttributeMaxDynamicSharedMemorySize, Up2<3>::LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_win_res), hipFuncAttributeMaxDynamicSharedMemorySize, Up2<3>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_win_reslo), hipFuncAttributeMaxDynamicSharedMemorySize, Up2<3>::LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_up2_win), hipFuncAttributeMaxDynamicSharedMemorySize, Up2<1>::LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_up2_win_res), hipFuncAttributeMaxDynamicSharedMemorySize, Up2<1>::LDS);
         int dev = 0;
@@ -298,7 +306,8 @@ int MGN_SYM(mgn_conv3x3_up2_win)(const void* in, const void* w, void* out, int N
     const long want = ksize == 3 ? cus : 2L * cus;
     const dim3 grid((unsigned)(nitems < want ? nitems : want)), block(512);
     hipStream_t st = (hipStream_t)stream;
-    if (ksize == 3 && residual) hipLaunchKernelGGL(conv3x3_up2_win_res, grid, block, Up2<3>::LDS, st, p);
+    if (ksize == 3 && residual && residual_lowres) hipLaunchKernelGGL(conv3x3_up2_win_reslo, grid, block, Up2<3>::LDS, st, p);
+    else if (ksize == 3 && residual) hipLaunchKernelGGL(conv3x3_up2_win_res, grid, block, Up2<3>::LDS, st, p);
     else if (ksize == 3) hipLaunchKernelGGL(conv3x3_up2_win, grid, block, Up2<3>::LDS, st, p);
     else if (residual) hipLaunchKernelGGL(conv1x1_up2_win_res, grid, block, Up2<1>::LDS, st, p);
     else hipLaunchKernelGGL(conv1x1_up2_win, grid, block, Up2<1>::LDS, st, p);

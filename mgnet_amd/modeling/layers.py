@@ -54,11 +54,13 @@ class Conv2d(nn.Conv2d):
         self.norm = norm
         self.activation = activation
 
-    def forward(self, x, with_skip=False):
+    def forward(self, x, with_skip=False, full=None):
         skip = None
         sf = self.norm if isinstance(self.norm, InPlaceABNSync) else None
-        if with_skip:   # also hand back the input for a second consumer (its gradient is fused into the conv's backward)
-            x, skip = ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, with_skip=True, stats_for=sf)
+        if full is not None:   # a block's 1x1 / stride-2 shortcut conv fed with conv1's `xsub` (ops._ShortcutS2Fn)
+            x = ops.conv2d_shortcut_s2(x, full, self.weight, stats_for=sf)
+        elif with_skip:   # also hand back the input for a second consumer (its gradient is fused into the conv's backward)
+            x, skip = ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, with_skip=with_skip, stats_for=sf)
         else:
             x = ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, stats_for=sf)
         if self.norm is not None:

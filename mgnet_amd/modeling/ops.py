@@ -318,6 +318,12 @@ class _ConvFn(torch.autograd.Function):
             return out              # padded gradient with zero padding channels: no slice, no zero-fill + strided copy in the backward
         if cout_pad:    # few-class predictors: the kernels work on 32-padded output channels, the caller sees the real ones
             return out[:, :Cout]
+        if with_skip == 2:
+            # second output: the input at the pixels a stride-2 conv with no padding looks at (a strided VIEW: never read, it only carries
+            # the autograd edge).  The block's 1x1 / stride-2 shortcut conv takes it as its differentiable input (_ShortcutS2Fn), so what
+            # comes back into backward is that conv's data gradient as the plain LOW-resolution 1x1 product -- not its full-resolution
+            # form, three quarters zeros, written by one kernel and read back by the next
+            return out, x[:, :, ::2, ::2]
         if with_skip:   # second output: the input itself (autograd makes it an alias); its gradient comes back into backward
             return out, x
         return out
@@ -343,7 +349,15 @@ class _ConvFn(torch.autograd.Function):
             assert Cx == Cin, "no data gradient for the channel-padded stem input"
             # the gradient of the skip branch is added in the kernel's epilogue instead of by a separate accumulate pass
             res = None if dskip is None else dskip.to(xs.dtype).contiguous(memory_format=torch.channels_last)
-            dx = _C.conv_igemm(dy, _C.weight_layout(weight, 1, 0, cout_pad, dtype=xs.dtype), xs.shape[2:], None, 1, KH - 1 - pad, up=stride, residual=res)
+            wl = _C.weight_layout(weight, 1, 0, cout_pad, dtype=xs.dtype)
+            if res is not None and tuple(res.shape[2:]) != tuple(xs.shape[2:]):
+                # with_skip = 2: the shortcut's gradient at the low resolution, added to the even pixels inside the window kernel
+                dx = _C.conv_up2(dy, wl, xs.shape[2:], residual=res, residual_lowres=True)
+                if dx is None:   # (a shape the window kernel does not take: the generic kernel + a strided accumulate)
+                    dx = _C.conv_igemm(dy, wl, xs.shape[2:], None, 1, KH - 1 - pad, up=stride)
+                    dx[:, :, ::2, ::2] += res
+            else:
+                dx = _C.conv_igemm(dy, wl, xs.shape[2:], None, 1, KH - 1 - pad, up=stride, residual=res)
         if ctx.needs_input_grad[1]:
             # (lazy: under a gradient reducer the split-K sums of a whole bucket run as one launch, engine/reducer.py)
             dw = _C.conv_wgrad(dy, xs, KH, KW, stride, pad, cin_real=Cin, lazy=not cout_pad)[:Cout]
@@ -351,6 +365,56 @@ class _ConvFn(torch.autograd.Function):
             # [HIP] per-channel sum over N*H*W: the column-sum kernel with the batch folded into the rows (deterministic two-stage sum)
             db = (_C.colsum_all(dy)[:Cout] if _C.elt_supported(dy) else dy.float().sum((0, 2, 3))[:Cout])
         return dx, dw, db, None, None, None, None, None, None, None
+
+
+class _ShortcutS2Fn(torch.autograd.Function):
+    """The 1x1 / stride 2 / pad 0 shortcut conv of a down-sampling BasicBlock (res_net.py:52-60 `downsample`) next to a conv1 that
+    returned `xsub` (with_skip = 2).  Forward: the ordinary strided 1x1 conv on the full input.  Backward: the gradient goes to `xsub`
+    -- [N, Cin, OH, OW], a plain 1x1 conv of dy with the transposed weights -- and from there into conv1's data-gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, xsub, xfull, weight, stats):
+        from .. import _C
+        Cout = weight.shape[0]
+        xs = xfull.contiguous(memory_format=torch.channels_last)
+        out = _C.conv_igemm(xs, _C.weight_layout(weight, 0, 0, 0, dtype=xs.dtype), tuple(xsub.shape[2:]), None, 2, 0, 1, False, stats=stats)
+        ctx.save_for_backward(xs, weight)
+        assert out.shape[1] == Cout
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _C
+        xs, weight = ctx.saved_tensors
+        dy = dy.to(xs.dtype).contiguous(memory_format=torch.channels_last)
+        dsub = dw = None
+        if ctx.needs_input_grad[0]:
+            dsub = _C.conv_igemm(dy, _C.weight_layout(weight, 1, 0, 0, dtype=xs.dtype), tuple(dy.shape[2:]), None, 1, 0)
+        if ctx.needs_input_grad[2]:
+            dw = _C.conv_wgrad(dy, xs, 1, 1, 2, 0, cin_real=weight.shape[1], lazy=True)
+        return dsub, None, dw, None
+
+
+def sub2_supported(x, w3, w1):
+    """conv1 (3x3 / s2 / p1) + shortcut (1x1 / s2 / p0) of a down-sampling block on the fused path: 16-bit CUDA activations that carry a
+    gradient, channel counts the window kernel takes"""
+    from .. import _C
+    return (x.is_cuda and x.dtype in _C.H16 and torch.is_grad_enabled() and x.requires_grad and x.shape[1] % 64 == 0 and w3.shape[0] % 32 == 0
+            and w3.shape[1] == x.shape[1] == w1.shape[1] and tuple(w3.shape[2:]) == (3, 3) and tuple(w1.shape[2:]) == (1, 1)
+            and not os.environ.get("MGN_NO_SKIPFUSE") and not os.environ.get("MGN_NO_SUB2"))
+
+
+def conv2d_shortcut_s2(xsub, xfull, weight, stats_for=None):
+    """the shortcut conv of a down-sampling block when conv1 was called with with_skip=2 (see _ShortcutS2Fn)"""
+    holder = []
+    stats = None
+    if (stats_for is not None and stats_for.training and torch.is_grad_enabled() and not os.environ.get("MGN_NO_STATFUSE")
+            and stats_for.running_mean.dtype == torch.float32):
+        stats = (stats_for.running_mean, holder)
+    y = _ShortcutS2Fn.apply(xsub, xfull, weight, stats)
+    if holder:
+        y._mgn_stats = holder[0]
+    return y
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=False, stats_for=None, keep_pad=False):
@@ -378,7 +442,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, with_skip=Fals
                 and stats_for.running_mean.dtype == torch.float32):
             stats = (stats_for.running_mean, holder)
         if with_skip and x.requires_grad and x.shape[1] == weight.shape[1] and not os.environ.get("MGN_NO_SKIPFUSE"):
-            y, skip = _ConvFn.apply(x, weight, bias, stride, padding, relu, True, 0, stats)
+            y, skip = _ConvFn.apply(x, weight, bias, stride, padding, relu, with_skip, 0, stats)
         else:
             y, skip = _ConvFn.apply(x, weight, bias, stride, padding, relu, False, 0, stats), x
         if holder:

@@ -33,8 +33,14 @@ class BasicBlock(nn.Module):  # res_net.py:11-79
                 c2_msra_fill(layer)
 
     def forward(self, x):
-        out, skip = self.conv1(x, with_skip=True)   # res_net.py:62-79; `skip` is x: the shortcut's gradient joins conv1's dgrad
-        sc = skip if self.shortcut is None else self.shortcut(skip)
+        if self.shortcut is not None and self.stride == 2 and ops.sub2_supported(x, self.conv1.weight, self.shortcut.weight):
+            # down-sampling block: the shortcut conv's data gradient travels at the LOW resolution into conv1's data-gradient kernel
+            out, xsub = self.conv1(x, with_skip=2)
+            # (a conv2d that did not take the fused path hands back x itself: the ordinary shortcut then)
+            sc = self.shortcut(xsub, full=x) if xsub.shape[2] == (x.shape[2] + 1) // 2 and xsub.shape[2] != x.shape[2] else self.shortcut(xsub)
+        else:
+            out, skip = self.conv1(x, with_skip=True)   # res_net.py:62-79; `skip` is x: the shortcut's gradient joins conv1's dgrad
+            sc = skip if self.shortcut is None else self.shortcut(skip)
         c2 = self.conv2   # conv -> InPlaceABNSync(identity) -> + shortcut -> ReLU; norm, add and ReLU run as one fused op on the GPU
         return ops.abn_add_relu(ops.conv2d(out, c2.weight, c2.bias, c2.stride, c2.padding, stats_for=c2.norm), c2.norm, sc)
 

@@ -70,6 +70,8 @@ class _RefConv:
             return out
         if cout_pad:
             return out[:, :cout]
+        if with_skip == 2:     # (down-sampling block: the shortcut conv's differentiable input, see ops._ShortcutS2Fn)
+            return out, x[:, :, ::2, ::2]
         if with_skip:
             return out, x
         return out
@@ -94,12 +96,37 @@ class _RefConv:
         dx = None
         if need[0]:
             dx = got[id(xd)]
-            if dskip is not None:
+            if dskip is not None and dskip.shape != dx.shape:   # with_skip = 2: the shortcut's gradient belongs to the even pixels
+                dx = dx.clone()
+                dx[:, :, ::2, ::2] += dskip.to(dt).to(ACC)
+            elif dskip is not None:
                 dx = dx + dskip.to(dt).to(ACC)        # the shortcut gradient joins before the one rounding of the kernel's epilogue
             dx = _cl(dx.to(dt))
         dw = got[id(wd)].to(weight.dtype) if need[1] else None
         db = got[id(bd)].to(bias.dtype) if bd is not None and need[2] else None
         return dx, dw, db, None, None, None, None, None, None, None
+
+
+class _RefShortcutS2:
+    """ops._ShortcutS2Fn: 1x1 / stride 2 / pad 0 conv of `xfull`, its data gradient handed to `xsub` at the low resolution"""
+
+    @staticmethod
+    def forward(ctx, xsub, xfull, weight, stats):
+        dt = xfull.dtype
+        y = F.conv2d(xfull.to(ACC), weight.detach().to(dt).to(ACC), None, stride=2, padding=0)
+        ctx.save_for_backward(xfull, weight)
+        return _cl(y.to(dt))
+
+    @staticmethod
+    def backward(ctx, dy):
+        xfull, weight = ctx.saved_tensors
+        dt = xfull.dtype
+        with torch.enable_grad():
+            xd = xfull.to(ACC).requires_grad_(True)
+            wd = weight.detach().to(dt).to(ACC).requires_grad_(True)
+            y = F.conv2d(xd, wd, None, stride=2, padding=0)
+        dx, dw = torch.autograd.grad(y, (xd, wd), dy.to(dt).to(ACC))
+        return _cl(dx[:, :, ::2, ::2].to(dt)), None, dw.to(weight.dtype), None
 
 
 def _stats(xd):
@@ -213,7 +240,7 @@ def _step(m, batch, scale):
 
 
 def _substitute(monkeypatch, ops, calls):
-    for cls, ref, kind in ((ops._ConvFn, _RefConv, "conv"), (ops._IABNFn, _RefIABN, "norm"), (ops._AbnAddReluFn, _RefAbnAddRelu, "norm"),
+    for cls, ref, kind in ((ops._ConvFn, _RefConv, "conv"), (ops._ShortcutS2Fn, _RefShortcutS2, "conv"), (ops._IABNFn, _RefIABN, "norm"), (ops._AbnAddReluFn, _RefAbnAddRelu, "norm"),
                            (ops._AbnPoolFn, _RefAbnPool, "norm")):
         def counted(f, kind=kind):
             def g(*a, **k):

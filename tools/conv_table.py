@@ -31,9 +31,15 @@ def r_wg(dy, x, kh, kw, stride, pad, cin_real=None, lazy=False):
     calls[("wgrad", tuple(dy.shape), tuple(x.shape), kh, kw, stride, pad, cin_real)] += 1
     return o_wg(dy, x, kh, kw, stride, pad, cin_real, lazy=lazy)
 
-_C.conv_igemm, _C.conv_wgrad = r_ig, r_wg
+o_up2 = _C.conv_up2
+
+def r_up2(dy, w, out_hw, residual=None, residual_lowres=False):   # (the stride-2 data gradients with the shortcut's gradient at low resolution)
+    calls[("up2", tuple(dy.shape), tuple(w.shape), tuple(out_hw), bool(residual_lowres))] += 1
+    return o_up2(dy, w, out_hw, residual, residual_lowres)
+
+_C.conv_igemm, _C.conv_wgrad, _C.conv_up2 = r_ig, r_wg, r_up2
 trainer.run_step(batch)
-_C.conv_igemm, _C.conv_wgrad = o_ig, o_wg
+_C.conv_igemm, _C.conv_wgrad, _C.conv_up2 = o_ig, o_wg, o_up2
 torch.cuda.synchronize()
 
 def timeit(fn, n=8):
@@ -56,6 +62,13 @@ for sig, cnt in calls.items():
         gf = 2.0 * xs[0] * osz[0] * osz[1] * ws[0] * xs[1] * kh * kw / 1e9 / (up * up)
         t = timeit(lambda: o_ig(x, w, osz, None, s, p, up, False, odt, khw))
         desc = f"igemm x{xs} w{ws} out{osz} s{s} p{p} up{up}{' packed' if khw else ''}{' f32' if odt == torch.float32 else ''}"
+    elif sig[0] == "up2":
+        _, dys, ws, osz, lo = sig
+        dy = cl(dys); w = (torch.randn(*ws, device=dev) * 0.05).to(torch.bfloat16)
+        res = cl((dys[0], ws[0], dys[2], dys[3])) if lo else None
+        gf = 2.0 * dys[0] * dys[2] * dys[3] * dys[1] * ws[0] * ws[1] * ws[2] / 1e9
+        t = timeit(lambda: o_up2(dy, w, osz, res, lo))
+        desc = f"up2   dy{dys} w{ws} out{osz} s2 data gradient (conv_up2.hip){' + low-res shortcut gradient' if lo else ''}"
     else:
         _, dys, xs, kh, kw, s, p, cr = sig
         dy = cl(dys); x = cl(xs)
