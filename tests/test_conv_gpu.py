@@ -503,3 +503,27 @@ def test_strided_3x3_data_gradient_from_one_low_resolution_window(case, ks, dtyp
     assert float((got != old).float().mean()) < 2e-2
     again = _C.conv_igemm(dy, wl, (H, W), None, 1, ks - 1 - pad, up=2, residual=r)
     assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 64, 128, 70, 150), (1, 128, 256, 33, 67), (8, 64, 128, 256, 512)])
+def test_strided_3x3_data_gradient_with_the_shortcut_gradient_at_low_resolution(case, dtype):
+    """`residual_lowres` of csrc/conv_up2.hip: the 1x1 / stride-2 shortcut conv's data gradient [N, Cin, ceil(H/2), ceil(W/2)] is added to
+    the even output pixels inside the kernel -- equal to adding its zero-filled full-resolution form, bit for bit"""
+    from mgnet_amd import _C
+
+    N, Cin, Cout, H, W = case
+    torch.manual_seed(sum(case))
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda") / (Cin * 9) ** 0.5
+    dy = torch.randn(N, Cout, OH, OW, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    lo = torch.randn(N, Cin, OH, OW, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    wl = _C._weight_layout_now(w, 1, 0, None, 0, dtype)
+    got = _C.conv_up2(dy, wl, (H, W), residual=lo, residual_lowres=True)
+    full = torch.zeros(N, Cin, H, W, device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last)
+    full[:, :, ::2, ::2] = lo
+    want = _C.conv_up2(dy, wl, (H, W), residual=full)
+    assert got is not None and torch.equal(got, want)
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w.to(dtype).double(), dy.double(), stride=2, padding=1) + full.double()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert float((got.double() - ref).abs().max()) / float(ref.abs().max()) < 1.2 * ulp
