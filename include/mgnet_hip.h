@@ -312,6 +312,16 @@ int mgn_plan_compile(void* plan, int n_ops, const int* types, const int* a, void
 int mgn_plan_run(void* plan, int from_op, int prof_slot);   /* -> index of the BREAK it stopped at, or the op count */
 int mgn_plan_set_stream(void* plan, int node, void* stream);   /* replay a node on another stream (the schedule must order it accordingly) */
 int mgn_plan_prof_elapsed(void* plan, int slot, float* ms);
+/* Measuring the step from inside un-profiled replays (tools/critical_path.py):
+ * mgn_plan_trace(on): the launches of the following replays carry a hipEvent pair bound to the dispatch itself (no marker packets);
+ * mgn_plan_trace_read after such a replay has completed: per node (n = node count), ms relative to the begin of node `ref`:
+ *   t_a = elapsed(ref.begin_event, node.begin_event), t_b = elapsed(ref.begin_event, node.end_event), dur = elapsed(node.begin_event,
+ *   node.end_event); NaN for marks and skipped nodes;
+ * mgn_plan_set_skip: what-if replays -- skip 1: the node is not launched (results meaningless, timing = the step without it);
+ *   skip 2: the node is launched twice back to back (its cost as an increase, data intact for pure kernels); skip 0: as recorded. */
+int mgn_plan_trace(void* plan, int on);
+int mgn_plan_trace_read(void* plan, int ref, int n, float* t_a, float* t_b, float* dur);
+int mgn_plan_set_skip(void* plan, int node, int skip);
 int mgn_plan_free(void* plan);
 
 /* The 7x7 / stride 2 / pad 3 stems with 64 output channels (res_net.py:96-104 BasicStem conv1; the 9-channel pose-net stem,

@@ -9,6 +9,7 @@
 // across streams safe on replay.  What a step needs from the host (learning-rate tables) lives in device tables that are refreshed
 // before the replay, exactly as for the hipGraph path it supersedes (engine/trainer.py).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -46,6 +47,11 @@ struct Plan {
     std::vector<void*> argv;   // per launch op: pointers into blob (filled by compile)
     std::vector<int> argv_off; // node -> offset into argv
     std::vector<hipEvent_t> prof[2];
+    // in-situ kernel trace of a replay (mgn_plan_trace): per launch node a hipEvent pair bound to the dispatch itself
+    // (hipExtLaunchKernel: the events take the dispatch's own begin / end timestamps, no marker packets enter the queues)
+    std::vector<hipEvent_t> tr[2];
+    bool trace = false;
+    std::vector<unsigned char> skip;   // what-if replays (mgn_plan_set_skip): node not launched
     bool overflow = false;
 };
 
@@ -193,7 +199,19 @@ int mgn_plan_run(void* plan, int from, int prof_slot) {
         if (o.type == MGN_PLAN_OP_LAUNCH) {
             const Node& nd = p->nodes[o.a];
             if (nd.type == 0) {
-                if (hipLaunchKernel(nd.func, nd.grid, nd.block, p->argv.data() + p->argv_off[o.a], nd.shmem, nd.stream) != hipSuccess) {
+                if (!p->skip.empty() && p->skip[o.a] == 1) continue;
+                if (!p->skip.empty() && p->skip[o.a] == 2 &&   // what-if "twice": the extra launch first, the traced / ordinary one after it
+                    hipLaunchKernel(nd.func, nd.grid, nd.block, p->argv.data() + p->argv_off[o.a], nd.shmem, nd.stream) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return MGN_ELAUNCH;
+                }
+                if (p->trace) {
+                    if (hipExtLaunchKernel(nd.func, nd.grid, nd.block, p->argv.data() + p->argv_off[o.a], nd.shmem, nd.stream,
+                                           p->tr[0][o.a], p->tr[1][o.a], 0) != hipSuccess) {
+                        (void)hipGetLastError();
+                        return MGN_ELAUNCH;
+                    }
+                } else if (hipLaunchKernel(nd.func, nd.grid, nd.block, p->argv.data() + p->argv_off[o.a], nd.shmem, nd.stream) != hipSuccess) {
                     (void)hipGetLastError();
                     return MGN_ELAUNCH;
                 }
@@ -219,6 +237,56 @@ int mgn_plan_set_stream(void* plan, int i, void* stream) {
     return MGN_OK;
 }
 
+/* In-situ kernel trace: with on != 0 every launch of the following replays carries a hipEvent pair bound to the dispatch
+ * (hipExtLaunchKernel), so that one un-profiled replay yields begin / end of each of its kernels on the device clock. */
+int mgn_plan_trace(void* plan, int on) {
+    Plan* p = (Plan*)plan;
+    if (!p) return MGN_EINVAL;
+    if (on && p->tr[0].empty()) {
+        for (int w = 0; w < 2; ++w) {
+            p->tr[w].assign(p->nodes.size(), nullptr);
+            for (size_t i = 0; i < p->nodes.size(); ++i)
+                if (p->nodes[i].type == 0 && hipEventCreate(&p->tr[w][i]) != hipSuccess) return MGN_ELAUNCH;
+        }
+    }
+    p->trace = on != 0;
+    return MGN_OK;
+}
+
+/* After a traced replay has completed: for every node i (n = node count) times in ms relative to the BEGIN of node `ref`:
+ * t_a[i] = elapsed(begin event of ref, begin event of i), t_b[i] = elapsed(begin event of ref, end event of i),
+ * dur[i] = elapsed(begin event of i, end event of i); NaN for marks, skipped and never-launched nodes.  (For events bound to
+ * dispatches the runtime evaluates elapsed(x, y) as END(y's dispatch) - BEGIN(x's dispatch): t_a == t_b and begin = t_b - dur;
+ * the caller checks which of the two conventions the installed runtime follows.) */
+int mgn_plan_trace_read(void* plan, int ref, int n, float* t_a, float* t_b, float* dur) {
+    Plan* p = (Plan*)plan;
+    if (!p || !t_a || !t_b || !dur || n != (int)p->nodes.size() || p->tr[0].empty() || ref < 0 || ref >= n || !p->tr[0][ref])
+        return MGN_EINVAL;
+    const float nan = __builtin_nanf("");
+    for (int i = 0; i < n; ++i) {
+        t_a[i] = t_b[i] = dur[i] = nan;
+        if (!p->tr[0][i] || (!p->skip.empty() && p->skip[i] == 1)) continue;
+        float a, b, d;
+        if (hipEventElapsedTime(&a, p->tr[0][ref], p->tr[0][i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (hipEventElapsedTime(&b, p->tr[0][ref], p->tr[1][i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (hipEventElapsedTime(&d, p->tr[0][i], p->tr[1][i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        t_a[i] = a; t_b[i] = b; dur[i] = d;
+    }
+    return MGN_OK;
+}
+
+/* What-if replays.  skip = 1: node i is not launched (its outputs keep whatever they held -- the step's RESULTS are then
+ * meaningless, its timing is that of the step without the node); skip = 2: node i is launched TWICE back to back (what the node
+ * costs, measured as an increase, with the step's data left intact wherever the kernel is a pure function of its inputs);
+ * skip = 0: as recorded. */
+int mgn_plan_set_skip(void* plan, int i, int skip) {
+    Plan* p = (Plan*)plan;
+    if (!p || i < 0 || i >= (int)p->nodes.size() || skip < 0 || skip > 2) return MGN_EINVAL;
+    if (p->skip.empty()) p->skip.assign(p->nodes.size(), 0);
+    p->skip[i] = (unsigned char)skip;
+    return MGN_OK;
+}
+
 int mgn_plan_prof_elapsed(void* plan, int slot, float* ms) {
     Plan* p = (Plan*)plan;
     if (!p || !ms || slot < 0 || slot >= (int)p->prof[0].size()) return MGN_EINVAL;
@@ -229,8 +297,10 @@ int mgn_plan_free(void* plan) {
     Plan* p = (Plan*)plan;
     if (!p) return MGN_OK;
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < 2; ++w) {
         for (hipEvent_t e : p->prof[w]) (void)hipEventDestroy(e);
+        for (hipEvent_t e : p->tr[w]) if (e) (void)hipEventDestroy(e);
+    }
     delete p;
     return MGN_OK;
 }

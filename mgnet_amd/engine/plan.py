@@ -470,6 +470,9 @@ class StepPlan:
         for node, st in moved_nodes:
             _C.check(lib.mgn_plan_set_stream(self.handle, node, st), "mgn_plan_set_stream")
         self.main, self.n_ops = main, n
+        # what tools/critical_path.py reads: the schedule and, per item, what it is (no tensors)
+        self.ops = ops
+        self.items = [dict(kind=it["kind"], node=it.get("node", -1), stream=it["stream"], name=it["name"]) for it in items]
         kernels = sum(1 for it in items if it["kind"] == 0)
         by_name = {}
         for it in items:
@@ -498,6 +501,39 @@ class StepPlan:
         k = run(h, k, prof_slot)
         if k != self.n_ops:
             _C.check(k if k < 0 else -5, "mgn_plan_run")
+
+    # ---- measuring the step from inside un-profiled replays (tools/critical_path.py) -------------------------------------------------
+    def trace(self, on=True):
+        """the launches of the following replays carry a hipEvent pair bound to the dispatch itself (csrc/plan.hip mgn_plan_trace)"""
+        _C.check(_C.lib().mgn_plan_trace(self.handle, 1 if on else 0), "mgn_plan_trace")
+
+    def trace_read(self):
+        """after a traced replay has completed: (begin_ms, end_ms) per recorded node relative to the first launch's begin; NaN where the
+        node is a mark or was skipped"""
+        lib = _C.lib()
+        n = lib.mgn_plan_node_count(self.handle)
+        ref = next(it["node"] for it in self.items if it["kind"] == 0 and not (getattr(self, "_skipped", None) and it["node"] in self._skipped))
+        a, b, d = (np.zeros(n, dtype=np.float32) for _ in range(3))
+        fp = ctypes.POINTER(ctypes.c_float)
+        _C.check(lib.mgn_plan_trace_read(self.handle, ref, n, a.ctypes.data_as(fp), b.ctypes.data_as(fp), d.ctypes.data_as(fp)), "mgn_plan_trace_read")
+        ok = ~np.isnan(b)
+        # the runtime evaluates elapsed(x, y) between dispatch-bound events as END(y) - BEGIN(x): then t_a == t_b; a runtime that
+        # distinguishes the begin event would give t_b - t_a == dur
+        if np.allclose(a[ok], b[ok], atol=1e-4):
+            begin, end = b - d, b
+        else:
+            begin, end = a, b
+        return begin.astype(np.float64), end.astype(np.float64)
+
+    def set_skip(self, nodes, skip=True):
+        """what-if replays: these recorded nodes are not launched (skip True / 1: results meaningless, timing = the step without them) or
+        launched twice (skip 2: what they cost, as an increase, with the data intact for pure kernels); False / 0 = as recorded"""
+        lib = _C.lib()
+        self._skipped = getattr(self, "_skipped", set())
+        mode = int(skip)
+        for i in nodes:
+            _C.check(lib.mgn_plan_set_skip(self.handle, int(i), mode), "mgn_plan_set_skip")
+            (self._skipped.add if mode == 1 else self._skipped.discard)(int(i))
 
     def prof_elapsed_ms(self, slot):
         ms = ctypes.c_float()

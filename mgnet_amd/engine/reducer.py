@@ -23,10 +23,24 @@ def ready_order(model, params):
     """`params` in the order in which the backward of an MGNet step hands their gradients over: reverse registration order,
     except for the pose network -- its forward is issued FIRST (lowest autograd sequence numbers, mg_net.py:262-265), so the
     engine replays its backward LAST, after the backbone's.  With plain reverse order the first bucket (log_vars + pose_net)
-    completes at the very end of backward and every other bucket's all-reduce queues up behind it: no overlap."""
+    completes at the very end of backward and every other bucket's all-reduce queues up behind it: no overlap.
+    By default the two trunks are issued side by side (MGNet.interleaved_trunks) and their gradients arrive alternately."""
     pose = getattr(model, "pose_net", None)
     late = {id(p) for p in pose.parameters()} if pose is not None else set()
     rev = list(reversed(list(params)))
+    if pose is not None and getattr(model, "interleaved_trunks", lambda: False)():
+        # MGNet.forward issues pose encoder and backbone block by block beside each other (pose block k, then backbone block k), so
+        # backward hands over: heads / decoders, the pose network's own convs, then backbone block k, pose block k for k = last .. stem
+        wanted = {id(p) for p in rev}
+        pe, bb = pose.pose_encoder, model.backbone
+        units = lambda net: [net.stem] + [blk for n in net.stage_names for blk in getattr(net, n)]
+        trunk = []
+        for ub, up in zip(reversed(units(bb)), reversed(units(pe))):
+            for u in (ub, up):
+                trunk += [p for p in reversed(list(u.parameters())) if id(p) in wanted]
+        in_trunk = {id(p) for p in trunk}
+        assert len(in_trunk) == len(trunk)
+        return [p for p in rev if id(p) not in in_trunk and id(p) not in late] + [p for p in rev if id(p) in late and id(p) not in in_trunk] + trunk
     return [p for p in rev if id(p) not in late] + [p for p in rev if id(p) in late]
 
 

@@ -208,7 +208,10 @@ class PoseCNN(nn.Module):  # layers.py:130-167
             mgnet_xavier_fill(m)
 
     def forward(self, image_list):
-        out = self.pose_encoder(image_list)["res5"]
+        return self.head(self.pose_encoder(image_list)["res5"])
+
+    def head(self, out):
+        """what follows the encoder (MGNet.forward calls it by itself when it issues the encoder block by block beside the backbone)"""
         out = self.conv1(out, relu=True)   # layers.py:158-163: relu_(conv(x))
         out = self.conv2(out, relu=True)
         out = self.conv3(out, relu=True)

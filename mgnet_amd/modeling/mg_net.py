@@ -180,8 +180,18 @@ class MGNet(nn.Module):
             return None
         st = self.__dict__.get("_streams")
         if st is None:
-            st = self.__dict__["_streams"] = [torch.cuda.Stream(self.device) for _ in range(2)]
+            # (a third one for the pose network: MGNET_POSE_STREAM=1 -- its backward then is not queued behind the instance head's)
+            st = self.__dict__["_streams"] = [torch.cuda.Stream(self.device) for _ in range(3 if os.environ.get("MGNET_POSE_STREAM") == "1" else 2)]
         return st
+
+    def interleaved_trunks(self):
+        """True when the training forward issues pose encoder and backbone block by block beside each other (both are the same
+        ResNet; MGNET_INTERLEAVE=0 restores the reference's order: pose network first, as a whole)"""
+        if not getattr(self, "with_depth", False) or os.environ.get("MGNET_INTERLEAVE", "1") == "0" or getattr(self, "pose_net", None) is None:
+            return False
+        pe, bb = self.pose_net.pose_encoder, self.backbone
+        return (getattr(pe, "stage_names", None) == getattr(bb, "stage_names", 0)
+                and all(len(getattr(pe, n)) == len(getattr(bb, n)) for n in bb.stage_names))
 
     def forward(self, batched_inputs):
         inputs, outputs, targets = {}, {}, {}
@@ -228,15 +238,38 @@ class MGNet(nn.Module):
                 inputs["image_prev"] = self._net_input(batched_inputs, "image_prev")
                 inputs["image_next"] = self._net_input(batched_inputs, "image_next")
                 pose_in = torch.cat(list(inputs.values()), 1)  # mg_net.py:264
+        pk = 2 if (side and len(side) > 2) else 0   # the stream of the pose network
+        features = None
         if pose_in is not None:
-            handover(main, side[0] if side else None, pose_in)
-            with on(0):
-                outputs["poses"] = self.pose_net(pose_in)
+            handover(main, side[pk] if side else None, pose_in)
+            pe, bb = self.pose_net.pose_encoder, self.backbone
+            if self.training and self.interleaved_trunks():
+                # The two ResNets issued block by block beside each other: autograd replays ready nodes in reverse creation order, so
+                # their backward passes alternate as well.  With the pose network issued as a whole FIRST (mg_net.py:262-265 order) its
+                # backward was replayed LAST, behind the backbone's: the final 5.6 ms of the step were one stream running the pose
+                # encoder's small kernels alone (profiles/r05_critical_path.txt); side by side the step is 2.5 ms shorter (28.7 -> 26.1).
+                with on(pk):
+                    xp = pe.stem(pose_in)
+                xb = bb.stem(inputs["image"])
+                features = {"stem": xb} if "stem" in bb._out_features else {}
+                for name in bb.stage_names:
+                    for blk_p, blk_b in zip(getattr(pe, name), getattr(bb, name)):
+                        with on(pk):
+                            xp = blk_p(xp)
+                        xb = blk_b(xb)
+                    if name in bb._out_features:
+                        features[name] = xb
+                with on(pk):
+                    outputs["poses"] = self.pose_net.head(xp)
+            else:
+                with on(pk):
+                    outputs["poses"] = self.pose_net(pose_in)
 
         if self.msc_flip_eval and not self.training:   # mg_net.py:267-268
             norm = (self._stack(batched_inputs, "image", 255.0) - self.pixel_mean) / self.pixel_std
             return self._inference(batched_inputs, self.forward_multi_scale_flip(norm))
-        features = self.backbone(inputs["image"])
+        if features is None:
+            features = self.backbone(inputs["image"])
         features["global_context"] = self.global_context(features[self.bb_features[-1]])
         if not self.training:
             if self.with_panoptic:
@@ -289,7 +322,7 @@ class MGNet(nn.Module):
             with on(1):
                 outputs["depth"] = self.depth_head(f_dep)
                 if side:
-                    handover(side[0], side[1], outputs.get("poses"))
+                    handover(side[pk], side[1], outputs.get("poses"))
                 l_depth.update(self.depth_head.losses(outputs, targets))
 
         if depth_first:
@@ -305,8 +338,8 @@ class MGNet(nn.Module):
         for part in (l_sem, l_ins, l_depth):
             losses.update(part)
         if side:
-            handover(side[0], main, losses)
-            handover(side[1], main, losses)
+            for st in side:
+                handover(st, main, losses)
 
         if self.with_uncertainty:  # mg_net.py:360-372 -- same scalar names, but no .item() host syncs inside forward
             #   loss_k <- tau_k * exp(-log_vars[k]) * loss_k + 0.5 * log_vars[k],  tau = 1 for loss_sem_seg, else 0.5
