@@ -38,12 +38,29 @@ def reproj_roofline(kern_ms, npx, u8, traffic, extra=None):
     r = {"bound": "hbm", "kernel": "reproj_march<true, %s> (fused reprojection loss + photometric gradient)" % ("uint8 RGBX frames" if u8 else "fp32 planar frames"),
          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
          "traffic": traffic, "traffic_source": "profiles/traffic.json: PMC measurement (FETCH_SIZE + WRITE_SIZE, calibrated in the same pass) of this kernel "
-                                                 "in this frame layout, not re-measured in this run", "bytes_per_px": bpp, "bytes_per_launch": bpp * npx, "avg_launch_ms": round(kern_ms, 4),
+                                                 "in this frame layout on the current csrc/reproj_loss.hip (round 5), not re-measured in this run", "bytes_per_px": bpp, "bytes_per_launch": bpp * npx, "avg_launch_ms": round(kern_ms, 4),
          "achieved_at_61_B_per_px": round(FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9, 1),
          "frac_at_61_B_per_px": round(FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
          "limiter": "VALU issue + vector-memory instruction rate, not HBM (DESIGN.md 2.4: counted)"}
     r.update(extra or {})
     return r
+
+
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0   # wave64 instructions per second: 1024 SIMD-32 units, two cycles per wave instruction, 2.4 GHz
+
+
+def valu_ceiling(kern_ms, tj):
+    """the ceiling that binds reproj_march: vector-ALU issue.  Wave-instruction count of one launch from the PMC pass in
+    profiles/traffic.json (a static property of the kernel on this workload shape), time live: `valu_frac` = issued wave instructions per
+    second / (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction) -- a lower bound of the pipe's occupancy (transcendentals, DPP and
+    64-bit operations take more than one pass, and the sustained clock is below 2.4 GHz); `valu_active_frac` is the counted share."""
+    v = (tj or {}).get("valu")
+    if not v:
+        return {}
+    rate = v["wave_instructions_per_launch"] / (kern_ms * 1e-3)
+    return {"valu_frac": round(rate / VALU_ISSUE_PEAK, 4), "valu_wave_instructions_per_launch": v["wave_instructions_per_launch"],
+            "valu_lane_instructions_per_px": v["lane_instructions_per_px"], "valu_issue_peak_per_s": VALU_ISSUE_PEAK,
+            "valu_active_frac": v.get("active_frac"), "valu_source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE, tools/pmc_traffic2.sh)"}
 
 
 def synth_batch(B, H, W, seed, device):
@@ -138,7 +155,8 @@ def cpu_baseline(H, W, state_dict=None, cfg=None):
 
 def conv_roofline(dev, B):
     """Second roofline object (informative): the convolution kernel that takes the largest share of the step -- the 3x3
-    256->256 head/refine layers at 1/8 resolution (conv3x3_win16, csrc/conv_win.hip) -- timed live with events on the launch stream."""
+    256->256 head/refine layers at 1/8 resolution (conv3x3_win8f: the 8-row patch with two blocks per CU, csrc/conv_win.hip:360 picks it
+    for pc * rows >= 1024) -- timed live with events on the launch stream."""
     from mgnet_amd import _C
     x = torch.randn(B, 256, 128, 256, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = torch.nn.Parameter(torch.randn(256, 256, 3, 3, device=dev) * 0.02)
@@ -155,7 +173,7 @@ def conv_roofline(dev, B):
     ms = e0.elapsed_time(e1) / n
     flops = 2.0 * B * 128 * 256 * 256 * 256 * 9
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv3x3_win16 (windowed 3x3, 256->256 channels, 8x128x256 pixels: the layer shape with the largest share of the step)",
+    return {"bound": "mfma", "kernel": "conv3x3_win8f (windowed 3x3, 256->256 channels, 8x128x256 pixels: the layer shape with the largest share of the step)",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
             "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
 
@@ -277,10 +295,14 @@ def full_step_bench(args, world, rank, dev):
         from mgnet_amd.engine import peer as _peer
         if _peer.exchange() is None:
             break
-        for _ in range(2):
-            trainer.run_step(batch)
+        probe_err = None
+        try:   # (Trainer.run_step raises as soon as it sees the mailbox's time-out flag: that must reach the vote below, not end the rank)
+            for _ in range(2):
+                trainer.run_step(batch)
+        except RuntimeError as e:
+            probe_err = str(e)
         torch.cuda.synchronize()
-        bad = torch.tensor([1.0 if _peer.exchange().failed() else 0.0], device=dev)
+        bad = torch.tensor([1.0 if (probe_err is not None or _peer.exchange().failed()) else 0.0], device=dev)
         torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
         if bad.item() == 0.0:
             break
@@ -302,9 +324,11 @@ def full_step_bench(args, world, rank, dev):
     # latency); "graph" (--graph on, one rank only) = the whole step captured once in a hipGraph on ONE stream and replayed.
     # Measured (end of round 2): eager + side streams 30.2 ms, graph 32.5 ms (capturing the side-stream branches crashes hipGraph on ROCm 7.0).
     use_graph = args.graph == "on" and world == 1
-    # (multi-rank runs replay the plan only on request: the path is tested with two processes on one GPU, never across GPUs -- the
-    #  driver's scaling measurement stays on the eager step, whose host cost a GPU-bound multi-rank step hides as well)
-    use_plan = (args.exec == "plan" or (args.exec == "auto" and world == 1)) and not use_graph
+    # Multi-rank runs replay the plan as well (the eager issue costs the host 15-20 ms of a ~27 ms step BEFORE the +136 mailbox launches
+    # and the all-reduce calls of a multi-rank step): the recording needs the SyncBN statistics on the mailbox kernels (probed above) and
+    # succeeds on every rank or is dropped by all of them; otherwise the eager step with the process group's collectives is timed and
+    # `config.step_execution` says why.
+    use_plan = args.exec in ("plan", "auto") and not use_graph
     mode, plan_note = "eager", None
     for _ in range(max(args.warmup, 3) if (use_graph or use_plan) else args.warmup):
         trainer.run_step(batch)
@@ -397,7 +421,7 @@ def full_step_bench(args, world, rank, dev):
     # before each step, none inside), so that it measures the host's own work and not the wait for queue slots -- over the K timed steps
     # the issue loop runs ahead of a GPU-bound step only until the hardware queues are full, and its wall time then equals the GPU's.
     issue_one = []
-    for _ in range(5 if world == 1 else 0):   # (multi-rank: every extra step costs a round of collectives; the loop's wall time is reported)
+    for _ in range(5 if world == 1 else 3):   # (every rank takes part: a multi-rank step is a round of collectives)
         torch.cuda.synchronize()
         ti = time.perf_counter()
         if mode == "plan":
@@ -459,12 +483,12 @@ def full_step_bench(args, world, rank, dev):
         kern_ms = float(np.median([plan.prof_elapsed_ms(k) for k in range(args.steps)] if mode == "plan" else ev.elapsed_ms()))
         npx = B * H * W
         u8_frames = model._orig_frames_u8(batch) is not None     # the layout MGNet.forward hands to the loss for this batch
-        traffic = None
+        traffic, tj_match = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if (tj.get("B"), tj.get("H"), tj.get("W")) == (B, H, W) and bool(tj.get("u8_frames", False)) == u8_frames:
-                traffic = tj.get("hbm_bytes_per_launch")
+                traffic, tj_match = tj.get("hbm_bytes_per_launch"), tj
         img_s = world * B * args.steps / dt
         # forward conv FLOPs per image scale with the pixel count; training ~ 3x forward
         gflop_fwd = 560.2 * (H * W) / (1024 * 2048)
@@ -484,7 +508,7 @@ def full_step_bench(args, world, rank, dev):
                                                   ("on" if model._side_streams() is not None else "off") + ")" + (f"; {plan_note}" if plan_note else "")),
                        **({"step_execution_probe": exec_probe} if exec_probe else {}),
                        "host_issue_ms_per_step": round(host_issue_ms, 2),
-                       "host_issue_is": "wall time of issuing ONE step of this workload into an empty launch queue (median of 5, after the timed region)",
+                       "host_issue_is": "wall time of issuing ONE step of this workload into an empty launch queue (median of 5 -- 3 on multi-rank runs -- after the timed region)",
                        "host_issue_loop_wall_ms_per_step": round(t_issue / args.steps * 1e3, 2),
                        "host_issue_loop_wall_is": "wall time of the K-step issue loop / K: includes waiting for launch-queue slots once the GPU is the bottleneck",
                        "host_issue_ms_per_step_unloaded": None if host_unloaded is None else round(host_unloaded, 2),
@@ -492,6 +516,7 @@ def full_step_bench(args, world, rank, dev):
                        "losses": {k: round(float(v.detach()), 5) for k, v in last.items()},
                        "torch_staging_ops": sorted(__import__("mgnet_amd.modeling.ops", fromlist=["x"]).STAGING_USED)},
             "roofline": reproj_roofline(kern_ms, npx, u8_frames, traffic, {
+                **valu_ceiling(kern_ms, tj_match),
                 "timed_with": "hipEvent pairs around the kernel on its launch stream, " +
                               (f"{args.steps} eager steps run right after the graph-replayed timed region" if mode == "graph"
                                else "recorded by the replayed plan inside the timed steps" if mode == "plan" else "inside the timed steps")}),

@@ -244,8 +244,14 @@ class PinnedStager:
     def __init__(self, depth=3):
         self.depth, self.rings = depth, {}
 
-    def stage(self, src, device, slot=None):
-        """`slot`: one ring per call site (two sites staging equal shapes in the same step must not share buffers)"""
+    def stage(self, src, device, slot=None, data=False):
+        """`slot`: one ring per call site (two sites staging equal shapes in the same step must not share buffers).
+        `data`: the tensor carries per-batch VALUES (e.g. the camera matrices of the dataset mapper), not addresses of the step's own
+        buffers -- a step that is being recorded for replay must not freeze them."""
+        if PLAN_RECORDER[0] is not None and data:
+            from .engine.plan import PlanUnsupported
+            raise PlanUnsupported(f"a per-batch host tensor ('{slot}') is uploaded inside the step: a replay would reuse the recorded batch's values; "
+                                  "hand the step device tensors (Trainer.run_step_planned keeps device copies of host entries and refills them)")
         if PLAN_RECORDER[0] is not None:
             # a step being recorded for replay: the table's content is the same in every replay (addresses of the recorded step), so it is
             # uploaded ONCE, now, into a device tensor the plan keeps alive -- the launch goes to the library directly, past the recorder,

@@ -32,7 +32,10 @@ from .. import _C
 
 
 class PlanUnsupported(RuntimeError):
-    pass
+    """the step cannot be replayed.  `completed`: the recording's body had already run to its end when the recorder's objection surfaced
+    (a torch op it cannot express is only noticed, not refused) -- the step HAS been trained, `result` is what the body returned"""
+    completed = False
+    result = None
 
 
 _ALLOC_ONLY = {"empty.memory_format", "empty_like.default", "empty_strided.default", "new_empty.default", "new_empty_strided.default"}
@@ -182,9 +185,12 @@ class _Recorder(TorchDispatchMode):
                 if p:
                     b = blocks.find(p)
                     if b is None:
+                        # library-owned memory (hipMalloc: ticket counters, workspaces): no extent known -- the address itself is the
+                        # range, so that two launches on different streams holding the SAME pointer (the counter pool wraps after 256
+                        # launches) are ordered as recorded; the p2p mailboxes have one channel per stream and never meet here
                         self.unresolved.add(p)
-                    else:
-                        (reads if kd == 1 else writes).append(b)
+                        b = (p, p + 1)
+                    (reads if kd == 1 else writes).append(b)
             elif sz >= 8:   # by-value struct: every aligned 8-byte word that points into a live block counts as read + written
                 words = np.frombuffer(raw[o:o + (sz // 8) * 8], dtype=np.uint64)
                 for p in words[(words >= lo) & (words < hi)]:
@@ -422,6 +428,7 @@ class StepPlan:
             torch._C._cuda_endAllocateToPool(dev_index, self.pool.id)
         if rec.error is not None:
             lib.mgn_plan_abort()
+            rec.error.completed, rec.error.result = True, result
             raise rec.error
         h = ctypes.c_void_p()
         _C.check(lib.mgn_plan_end(ctypes.byref(h)), "mgn_plan_end")

@@ -129,7 +129,15 @@ class Trainer:
             self.optimizer.launch_step()
             return {k: v.detach() for k, v in loss_dict.items()}
 
-        plan, losses = StepPlan.record(body, dev, prof_slots=prof_slots)
+        try:
+            plan, losses = StepPlan.record(body, dev, prof_slots=prof_slots)
+        except PlanUnsupported as e:
+            if e.completed:   # the body ran to its end before the recorder objected: this step has been trained -- count it
+                self.scheduler.step()
+                self.iter += 1
+                self.storage.step()
+                self._check_peers()
+            raise
         self.scheduler.step()
         self.iter += 1
         self.storage.step()
@@ -150,8 +158,10 @@ class Trainer:
     # ---- the training-loop entry on top of record/replay: a NEW batch every call ------------------------------------------------
     @staticmethod
     def _batch_signature(batched_inputs):
-        return tuple(tuple(sorted((k, (tuple(v.shape), v.dtype) if isinstance(v, torch.Tensor) else repr(v))
-                                  for k, v in d.items())) for d in batched_inputs)
+        """what has to match for a recorded step to be replayed on a new batch: the tensors' shapes / dtypes and the frame size -- not
+        `file_name`, `image_id`, ... which the dataset mapper keeps in every dict (dataset_mapper.py:129-259) and which differ per sample"""
+        return tuple(tuple(sorted((k, (tuple(v.shape), v.dtype) if isinstance(v, torch.Tensor) else v)
+                                  for k, v in d.items() if isinstance(v, torch.Tensor) or k in ("height", "width"))) for d in batched_inputs)
 
     @staticmethod
     def _layout(batched_inputs):
@@ -173,7 +183,9 @@ class Trainer:
         """plan-owned copies of a batch with the SAME view structure, so that the recorded step keeps the zero-copy batch assembly of
         MGNet._stack and a refill is one copy per collated buffer"""
         bases, layout = self._layout(batched_inputs)
-        static_bases = [b.clone(memory_format=torch.preserve_format) for b in bases]
+        # (host entries -- the mapper's camera_matrix -- get DEVICE copies: the recorded step must read memory a refill can rewrite)
+        dev = next(self.model.parameters()).device if getattr(self, "model", None) is not None else None
+        static_bases = [b.clone(memory_format=torch.preserve_format) if (dev is None or b.device == dev) else b.to(dev) for b in bases]
         index = {id(b): k for k, b in enumerate(bases)}
         out = []
         for d in batched_inputs:
@@ -193,13 +205,26 @@ class Trainer:
         one per entry otherwise"""
         bases, layout = self._layout(batched_inputs)
         if layout == self._static_layout:
-            for s, sb in zip(bases, self._static_bases):
-                sb.copy_(s, non_blocking=True)
+            for k, (s, sb) in enumerate(zip(bases, self._static_bases)):
+                self._fill(sb, s, k)
             return
-        for st, d in zip(self._plan_inputs, batched_inputs):
+        for j, (st, d) in enumerate(zip(self._plan_inputs, batched_inputs)):
             for k, v in d.items():
                 if isinstance(v, torch.Tensor):
-                    st[k].copy_(v, non_blocking=True)
+                    self._fill(st[k], v, (j, k))
+
+    def _fill(self, dst, src, slot):
+        """dst (device, plan-owned) <- src; a host source goes through the pinned ring (a copy from pageable memory would hold the host
+        until the queue has drained: the replay's 2.5 ms of host time would then be serialised with the 26 ms of the device)"""
+        if src.is_cuda or not dst.is_cuda:
+            dst.copy_(src, non_blocking=True)
+        elif dst.is_contiguous() and (src.numel() * src.element_size()) % 4 == 0 and src.numel() > 0 and src.dtype == dst.dtype:
+            from .. import _C
+            if getattr(self, "_fill_stager", None) is None:
+                self._fill_stager = _C.PinnedStager()
+            self._fill_stager.stage_into(dst, src.contiguous(), slot=("batch", slot))
+        else:
+            dst.copy_(src)
 
     def run_step_planned(self, batched_inputs, warmup=3):
         """`run_step` for a training loop that wants the recorded step: the first `warmup` calls run eagerly (lazy workspaces, layout cache,
@@ -213,15 +238,34 @@ class Trainer:
                 return self.run_step(batched_inputs)
             from .plan import PlanUnsupported
             static, bases, layout = self._static_copy(batched_inputs)
+            err, losses = None, None
             try:
                 self.record_plan(static)
+                losses = self._plan_losses
             except PlanUnsupported as e:
-                self.plan_note = f"eager steps: {e}"
-                return self.run_step(batched_inputs)
+                err = e
+                if e.completed:        # the step ran (and was counted by record_plan) before the recorder objected: do NOT train the batch again
+                    losses = e.result
+            if self.reducer.world > 1:
+                # every rank replays or none does: a rank on the eager path issues another launch / collective sequence than its peers expect
+                import torch.distributed as dist
+                ok = torch.tensor([0.0 if err is not None else 1.0], device=next(self.model.parameters()).device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() != 1.0 and err is None:
+                    err = PlanUnsupported("the recording failed on another rank")
+                    self._plan.close()
+            if err is not None:
+                self._plan = None
+                self.plan_note = f"eager steps: {err}"
+                return losses if losses is not None else self.run_step(batched_inputs)
             self._static_bases, self._static_layout, self._plan_sig = bases, layout, self._batch_signature(batched_inputs)
-            return self._plan_losses
+            return losses
         if self._batch_signature(batched_inputs) != self._plan_sig:
             self.plan_eager_steps = getattr(self, "plan_eager_steps", 0) + 1
+            if self.plan_eager_steps in (10, 100, 1000):
+                import logging
+                logging.getLogger("mgnet_amd").warning("run_step_planned: %d steps ran eagerly because their batch does not match the recorded "
+                                                       "step's tensor shapes (the plan is kept for the batches that do)", self.plan_eager_steps)
             return self.run_step(batched_inputs)
         self._refill_static(batched_inputs)
         return self.replay_plan()

@@ -163,7 +163,7 @@ class MGNet(nn.Module):
         st = self.__dict__.get("_stager")
         if st is None:
             st = self.__dict__["_stager"] = _C.PinnedStager()
-        return st.stage(t, self.device, slot)
+        return st.stage(t, self.device, slot, data=True)
 
     def _net_input(self, batched_inputs, key):
         x = (self._stack(batched_inputs, key, 255.0) - self.pixel_mean) / self.pixel_std

@@ -102,16 +102,19 @@ def _check_vs_torch_bf16(rows, tb_rows, what, worse_frac=0.05, labels=("HIP bf16
     assert len(far) <= 0.2 * worse_frac * len(common) + 1, (what, far[:10])
 
 
-@pytest.mark.parametrize("H,W", [(64, 96), (192, 640)])
+# bf16 at 64x96 was a row of this test until round 4, passing only on `worse_frac=0.5`.  Dropped like the same row of
+# tests/test_step_composed_gpu.py, for the reason measured there (profiles/r04_composed_64x96_diagnosis.txt): with a 64x96 input the deepest
+# layers normalise over 2..12 samples, 64 % of the squared gradient norm is `backbone.stem.conv1.weight`, and that tensor is rounding
+# noise in EVERY 16-bit evaluation at this size (the product: cosine -0.03 at 0.94x the norm; the fp32 twin: 0.46 at 2.3x) -- a bound ten
+# times looser than the other rows' asserts nothing.  The size at which the comparison means something is asserted at the strict bound.
+@pytest.mark.parametrize("H,W", [(192, 640)])
 def test_every_parameter_gradient_bf16(H, W):
     """bf16 activations (the benchmark's dtype): losses within SURVEY 8(d)'s rel 2e-2, every parameter gradient at least as close
     to the fp32 oracle as a plain-torch bf16 evaluation of the same network (see _check_vs_torch_bf16)"""
     ref, got, rows, tb = _grads(H, W, amp=True, torch_bf16=True)
     for k in ref:
         assert float(got[k]) == pytest.approx(float(ref[k]), rel=2e-2, abs=2e-4), k
-    # (at 64x96 the deepest layers normalise over 2..12 samples and BOTH bf16 evaluations sit at the noise floor -- relative error
-    #  ~0.5 -- so the per-tensor comparison is only meaningful in aggregate there)
-    _check_vs_torch_bf16(rows, tb, f"bf16 {H}x{W}", worse_frac=0.5 if H * W < 100000 else 0.05)
+    _check_vs_torch_bf16(rows, tb, f"bf16 {H}x{W}", worse_frac=0.05)
 
 
 def test_every_parameter_gradient_fp32(monkeypatch):

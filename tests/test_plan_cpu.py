@@ -128,4 +128,46 @@ def test_static_batch_copy_keeps_the_view_structure_and_refills():
                 if isinstance(v, torch.Tensor):
                     assert torch.equal(v, o[k]), k
     assert Trainer._batch_signature(b) == Trainer._batch_signature(loose) != Trainer._batch_signature(synthetic_batch(2, 32, 96, "cpu"))
+    # what the dataset mapper adds per sample (file names, ids) is not part of the signature: the plan is replayed for them
+    named = [dict(d, file_name=f"f{j}.png", image_id=j) for j, d in enumerate(b)]
+    assert Trainer._batch_signature(named) == Trainer._batch_signature(b)
 
+
+
+def test_critical_path_tool_reads_the_schedule_edges_and_walks_the_last_chain():
+    """tools/critical_path.py: the dependency edges it reconstructs from the op list (same-stream order + record / wait pairs) and the
+    chain it walks back from the kernel that ends last, on a synthetic two-stream step with a host-issued torch op in the middle"""
+    import importlib.util
+    import os
+    import types
+
+    import numpy as np
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("critical_path", os.path.join(root, "tools", "critical_path.py"))
+    cp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cp)
+    items = [item(0, MAIN, writes=[A]),              # producer
+             item(1, S1, reads=[A], writes=[B]),     # side stream: waits for 0
+             item(2, MAIN, writes=[C]),              # independent of 1
+             item(-1, MAIN, reads=[C], writes=[C], kind=1),   # a torch op between plan segments (no events of its own)
+             item(3, MAIN, reads=[B, C], writes=[D])]         # joins both: waits for 1 (event) and follows the closure
+    items[3]["name"] = "add.Tensor"
+    ops, n_ev, n_cross, ns, _ = derive_schedule(items, MAIN)
+    plan = types.SimpleNamespace(ops=ops, items=[dict(kind=it["kind"], node=it["node"], stream=it["stream"], name=it["name"]) for it in items],
+                                 main=types.SimpleNamespace(cuda_stream=MAIN), handle=None)
+    preds = cp.schedule_edges(plan)
+    assert preds[0] == [] and preds[1] == [0] and preds[2] == [0] and preds[3] == [2] and sorted(preds[4]) == [1, 3]
+    # node times (ms): 0: 0-1, 1: 1.1-5 (the long one), 2: 1.05-2, 3: 5.2-6
+    begins = [np.array([0.0, 1.1, 1.05, 5.2])]
+    ends = [np.array([1.0, 5.0, 2.0, 6.0])]
+    cp.plan_grid = lambda *a: ""
+    out = []
+    res = cp.analyse(plan, begins, ends, cp.FAMILIES, out)
+    txt = "\n".join(out)
+    assert abs(res["trace_span_ms"] - 6.0) < 1e-9 and res["kernels"] == 4
+    chain = txt[txt.index("(b) the dependency chain"):]
+    rows = [ln.split() for ln in chain.splitlines() if ln[:9].strip().replace(".", "").isdigit()]
+    names = [r[-1] if not r[-1].startswith("(") else r[-2] for r in rows]
+    assert names == ["k0", "k1", "k3"], (names, chain)       # 0 -> 1 (cross-stream) -> 3; k2 and the torch op are off the chain
+    assert abs(res["no_kernel_ms"] - (0.05 + 0.2)) < 1e-6        # 1.0-1.05 and 5.0-5.2

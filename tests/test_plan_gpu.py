@@ -106,3 +106,64 @@ def test_run_step_planned_is_run_step_with_a_new_batch_every_call():
     torch.cuda.synchronize()
     for (na, pa), (nb, pb) in zip(ta.model.named_parameters(), tb.model.named_parameters()):
         assert torch.equal(pa, pb), na
+
+
+def _mapper_like(batch, k):
+    """what the reference's dataset mapper hands over (dataset_mapper.py:129-259): the camera matrix as a HOST tensor whose values change
+    with every sample's augmentation, plus per-sample strings / ids the step never reads"""
+    out = []
+    for j, d in enumerate(batch):
+        d = dict(d)
+        cam = d["camera_matrix"].detach().cpu().clone()
+        cam[0, 0] *= 1.0 + 0.05 * k + 0.01 * j     # a resize-augmented focal length
+        cam[0, 2] += 3.0 * k
+        d["camera_matrix"] = cam
+        d["file_name"], d["image_id"] = f"frame_{k}_{j}.png", 100 * k + j
+        out.append(d)
+    return out
+
+
+def test_run_step_planned_follows_host_camera_matrices_that_change_per_batch():
+    """a per-batch HOST tensor must not be frozen into the recording.  The mapper's camera_matrix arrives on the CPU and
+    differs per batch; file_name / image_id differ per sample and must not stop the replay.  Same trajectory as run_step, bit for bit."""
+    from mgnet_amd.data import synthetic_batch
+    ta, _, _ = _trainer()
+    tb, _, _ = _trainer()
+    dev = torch.device("cuda:0")
+    batches = [_mapper_like(synthetic_batch(2, 128, 256, dev, seed=60 + k), k) for k in range(7)]
+    la = [{n: float(v) for n, v in ta.run_step(b).items()} for b in batches]
+    lb = [{n: float(v) for n, v in tb.run_step_planned(b).items()} for b in batches]
+    assert tb._plan is not None and getattr(tb, "plan_note", None) is None and getattr(tb, "plan_eager_steps", 0) == 0
+    assert la == lb
+    assert len({a["loss_photometric"] for a in la[4:]}) == 3, "the batches were meant to differ in their photometric loss"
+    for (na, pa), (nb, pb) in zip(ta.model.named_parameters(), tb.model.named_parameters()):
+        assert torch.equal(pa, pb), na
+    # recording such a batch directly (no device copies) is refused before anything is frozen
+    from mgnet_amd.engine.plan import PlanUnsupported
+    tc, _, _ = _trainer()
+    for b in batches[:3]:
+        tc.run_step(b)
+    with pytest.raises(PlanUnsupported, match="per-batch host tensor"):
+        tc.record_plan(batches[3])
+
+
+def test_a_step_the_recorder_refuses_after_it_ran_is_counted_once():
+    """a `.item()` inside the step is noticed by the recorder while the body keeps running -- the step has been trained
+    when the refusal surfaces; run_step_planned must not train the batch a second time (iteration, LR schedule and Adam's step count stay
+    in line with an eager run)"""
+    ta, batch_a, _ = _trainer()
+    tb, batch_b, _ = _trainer()
+    fwd = tb.model.forward
+
+    def forward_with_a_host_read(batched_inputs):
+        losses = fwd(batched_inputs)
+        losses["loss_sem_seg"].item()
+        return losses
+    tb.model.forward = forward_with_a_host_read
+    la = [{n: float(v) for n, v in ta.run_step(batch_a).items()} for _ in range(6)]
+    lb = [{n: float(v) for n, v in tb.run_step_planned(batch_b).items()} for _ in range(6)]
+    assert tb._plan is None and "device -> host read" in tb.plan_note
+    assert ta.iter == tb.iter == 6
+    assert la == lb
+    for (na, pa), (nb, pb) in zip(ta.model.named_parameters(), tb.model.named_parameters()):
+        assert torch.equal(pa, pb), na

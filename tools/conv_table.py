@@ -60,24 +60,30 @@ for sig, cnt in calls.items():
         x = cl(xs); w = (torch.randn(*ws, device=dev) * 0.05).to(torch.bfloat16)
         kh, kw = khw if khw else ws[1:3]
         gf = 2.0 * xs[0] * osz[0] * osz[1] * ws[0] * xs[1] * kh * kw / 1e9 / (up * up)
+        # the stems run on channel-padded input (3 -> 8, 9 -> 16: csrc/prep.hip): the padding is not work
+        real = gf * ({8: 3, 16: 9}.get(xs[1], xs[1]) / xs[1] if (kh, kw) == (7, 7) else 1.0)
         t = timeit(lambda: o_ig(x, w, osz, None, s, p, up, False, odt, khw))
         desc = f"igemm x{xs} w{ws} out{osz} s{s} p{p} up{up}{' packed' if khw else ''}{' f32' if odt == torch.float32 else ''}"
     elif sig[0] == "up2":
         _, dys, ws, osz, lo = sig
         dy = cl(dys); w = (torch.randn(*ws, device=dev) * 0.05).to(torch.bfloat16)
         res = cl((dys[0], ws[0], dys[2], dys[3])) if lo else None
-        gf = 2.0 * dys[0] * dys[2] * dys[3] * dys[1] * ws[0] * ws[1] * ws[2] / 1e9
+        gf = real = 2.0 * dys[0] * dys[2] * dys[3] * dys[1] * ws[0] * ws[1] * ws[2] / 1e9
         t = timeit(lambda: o_up2(dy, w, osz, res, lo))
         desc = f"up2   dy{dys} w{ws} out{osz} s2 data gradient (conv_up2.hip){' + low-res shortcut gradient' if lo else ''}"
     else:
         _, dys, xs, kh, kw, s, p, cr = sig
         dy = cl(dys); x = cl(xs)
         gf = 2.0 * dys[0] * dys[2] * dys[3] * dys[1] * xs[1] * kh * kw / 1e9
+        real = gf * ((cr / xs[1]) if cr else 1.0)
         t = timeit(lambda: o_wg(dy, x, kh, kw, s, p, cr))
         desc = f"wgrad dy{dys} x{xs} k{kh}x{kw} s{s} p{p} cin_real={cr}"
-    rows.append((cnt * t, cnt, t, gf, desc))
+    rows.append((cnt * t, cnt, t, gf, real, desc))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
-print(f"total conv time per step: {tot:.2f} ms, {sum(r[1] for r in rows)} calls, {sum(r[1]*r[3] for r in rows)/1e3:.2f} TFLOP")
-for tt, cnt, t, gf, desc in rows:
-    print(f"{tt:7.3f} ms  {cnt:2d} x {t*1e3:7.1f} us  {gf:7.1f} GF {gf/t:6.0f} TF/s  {desc}")
+tf_issued, tf_real = sum(r[1] * r[3] for r in rows) / 1e3, sum(r[1] * r[4] for r in rows) / 1e3
+print(f"total conv time per step: {tot:.2f} ms, {sum(r[1] for r in rows)} calls, {tf_real:.2f} TFLOP of real work = {tf_real / tot * 1e3:.0f} TF/s = "
+      f"{tf_real / tot * 1e3 / 2500 * 100:.1f} % of the 2.5 PF dense bf16 peak ({tf_issued:.2f} TFLOP issued incl. the stems' channel padding)")
+print("   total      calls x each      issued GF  TF/s | real GF  TF/s  signature")
+for tt, cnt, t, gf, real, desc in rows:
+    print(f"{tt:7.3f} ms  {cnt:2d} x {t*1e3:7.1f} us  {gf:7.1f} GF {gf/t:6.0f} | {real:7.1f} {real/t:6.0f}  {desc}")

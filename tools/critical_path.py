@@ -203,7 +203,13 @@ def analyse(plan, begins, ends, fams, out):
             if g > 0:
                 gaps.append((g, p, q))
         gaps.sort(reverse=True)
-        gtxt = "; ".join(f"{g * 1e3:.0f}: {short(items[p]['name'])} -> {short(items[q]['name'])}" for g, p, q in gaps[:3])
+        def released_by(q):   # the predecessor of q (schedule edges) that ended last: what the stream was waiting for
+            cand = [r for r in preds[q] if ok[r]]
+            if not cand:
+                return "?"
+            r = max(cand, key=lambda r: ee[r])
+            return f"{short(items[r]['name'])}@{'main' if items[r]['stream'] == main else hex(items[r]['stream'])[-4:]}"
+        gtxt = "; ".join(f"{g * 1e3:.0f}: {short(items[p]['name'])} -> {short(items[q]['name'])} [released by {released_by(q)}]" for g, p, q in gaps[:4])
         name = "main" if st == main else hex(st)[-6:]
         out.append(f"{name:>18s} {len(idx):8d} {busy:9.3f} {first:8.3f} {last:8.3f} {last - first - busy:15.3f}  {gtxt}")
     any_busy = union_len(all_iv)
