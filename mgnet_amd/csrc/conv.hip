@@ -42,6 +42,7 @@ struct ConvParams {
     float* stat_part;     // [pixel tiles][Cout][2]: per-tile sums of r, r^2 over the ROUNDED outputs (statistics of the InPlaceABNSync that
                           // follows; only without bias / ReLU / residual / fp32 output), or null
 };
+MGN_PLAN_RO(ConvParams, MGN_RO(in) MGN_RO(w) MGN_RO(bias) MGN_RO(residual))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 // Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8, observed; MI355X_MICROARCH.md) and every XCD has its
 // own 4 MB L2.  With tile = blockIdx.x each L2 ends up loading (nearly) the whole input: vertically adjacent tiles share
@@ -498,6 +499,7 @@ struct Conv1Params {
     long M;               // N * OH * OW
     int ntiles;
 };
+MGN_PLAN_RO(Conv1Params, MGN_RO(in) MGN_RO(w))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 template <int CIN, int NT, int WN>
 struct C1 {
@@ -833,6 +835,7 @@ struct Conv64Params {
     int N, H, W, Cout;
     int strips, chunks, rows_per_chunk, nslices, co_tiles;
 };
+MGN_PLAN_RO(Conv64Params, MGN_RO(in) MGN_RO(w) MGN_RO(residual))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 constexpr int C64_NR = 8;   // ring of input rows: r-1 .. r+2 in use by the two output rows of a step, r+3 .. r+6 in flight
 constexpr int C64_INROW = 136 * 128, C64_LDS = C64_NR * C64_INROW;
 
@@ -1067,6 +1070,7 @@ struct WgradParams {
     float* partial;        // [gridDim.z][Cout][taps*Cin] per-split partial results (plain stores, no atomics)
     int remap_tiles, co_tiles;   // remap_tiles > 0: 1-D grid, see wgrad_block
 };
+MGN_PLAN_RO(WgradParams, MGN_RO(dout) MGN_RO(in))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 // Which (output-channel tile, tap x input-channel tile, pixel split) a block of the split-K tile kernels works on.  With the plain 3-D
 // grid the tile blocks of ONE pixel split -- which read the same dOut / input pixels -- have consecutive linear ids and therefore land
@@ -1252,6 +1256,7 @@ struct Wgrad3Params {
     int N, H, W, Cin, Cout;
     int co_tiles, ci_tiles, strips, chunks, rows_per_chunk, nslices, ng;
 };
+MGN_PLAN_RO(Wgrad3Params, MGN_RO(dout) MGN_RO(in))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
@@ -1514,6 +1519,7 @@ struct WgradStemParams {
     int N, IH, IW, OH, OW, Cout;
     int strips, chunks, rows_per_chunk, nslices, co_tiles;
 };
+MGN_PLAN_RO(WgradStemParams, MGN_RO(dout) MGN_RO(in))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 template <int CP>
 struct WS {
     static constexpr int PIN = CP == 16 ? 9 : 5;      // 1-KB pieces per input row of the strip (262 pixels)

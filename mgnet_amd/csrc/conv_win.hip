@@ -43,6 +43,7 @@ struct WinParams {
     int py, px;                // patches per image (rows, columns)
     int xcd;                   // 1: deal contiguous bands of patches to the XCDs
 };
+MGN_PLAN_RO(WinParams, MGN_RO(in) MGN_RO(w) MGN_RO(residual) MGN_RO(stat_shift))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 constexpr int PW = 32, WW = PW + 2;
 constexpr int WIN_PIECES = 40;                 // 1-KB DMA pieces of 16 pixels x 64 B: 5 per wave (612 of the 640 pixels are real)

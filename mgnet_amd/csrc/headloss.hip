@@ -432,6 +432,7 @@ struct InsMaps {
     const float* ow;   // [B,1,H,W]
     float oscale;      // common_stride multiplier applied after the upsampling (mg_net.py:682-694)
 };
+MGN_PLAN_RO(InsMaps, MGN_RO(center) MGN_RO(center_f) MGN_RO(offset) MGN_RO(ct) MGN_RO(cw) MGN_RO(ot) MGN_RO(ow))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 __device__ __forceinline__ float interp1f(const float* m, const Corner& c) {
     return c.w00 * m[c.o00] + c.w10 * m[c.o10] + c.w01 * m[c.o01] + c.w11 * m[c.o11];

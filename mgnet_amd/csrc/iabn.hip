@@ -214,6 +214,7 @@ struct StatsOut {
     float* running_mean; float* running_var;
     float eps, momentum;
 };
+MGN_PLAN_RO(StatsOut, MGN_RO(weight) MGN_RO(bias))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 template <typename T>
 __global__ __launch_bounds__(TPB) void iabn_stats_kernel(const T* __restrict__ x, long M, int C, int SC, float* ws, unsigned* counter, StatsOut o) {

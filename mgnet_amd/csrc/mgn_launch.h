@@ -20,9 +20,27 @@ namespace mgn_plan {
 constexpr int MAX_ARGS = 48;
 constexpr int MAX_ARG_BYTES = 1024;
 
+// which 8-byte words of a by-value struct argument hold pointers the kernel only READS through (structs up to 1 KiB).  A struct
+// says so with MGN_PLAN_RO right behind its definition; without it every pointer found in the struct counts as written -- which
+// orders, e.g., the three decoders' first convolutions (all readers of one backbone feature map) one after the other on replay.
+struct RoBits {
+    unsigned long long w[2] = {0, 0};
+    constexpr RoBits operator|(RoBits o) const { RoBits r; r.w[0] = w[0] | o.w[0]; r.w[1] = w[1] | o.w[1]; return r; }
+};
+constexpr RoBits ro_field(size_t offset, size_t size) {
+    RoBits r;
+    for (size_t b = offset / 8; b < (offset + size + 7) / 8 && b < 128; ++b) r.w[b / 64] |= 1ull << (b % 64);
+    return r;
+}
+constexpr RoBits mgn_plan_ro(const void*) { return RoBits{}; }   // (argument types that declare nothing)
+#define MGN_RO(f) | mgn_plan::ro_field(offsetof(S_, f), sizeof(S_::f))
+#define MGN_PLAN_RO(T, fields) \
+    constexpr mgn_plan::RoBits mgn_plan_ro(const T*) { using S_ = T; return mgn_plan::RoBits{} fields; }
+
 struct ArgDesc {
     unsigned short offset, size;
     unsigned char kind;   // 0 opaque bytes, 1 pointer to const (read), 2 pointer (read / written)
+    RoBits ro;            // kind 0: the struct's read-only pointer words
 };
 
 extern "C" int g_mgn_plan_recording;   // csrc/plan.hip
@@ -48,7 +66,9 @@ struct Packer {
         bytes = (bytes + al - 1) / al * al;
         if (n < MAX_ARGS && bytes + (int)sizeof(T) <= MAX_ARG_BYTES) {
             std::memcpy(blob + bytes, &v, sizeof(T));
-            desc[n] = ArgDesc{(unsigned short)bytes, (unsigned short)sizeof(T), arg_kind<T>()};
+            RoBits ro;
+            if constexpr (!std::is_pointer<T>::value && std::is_class<T>::value) ro = mgn_plan_ro(static_cast<const T*>(nullptr));
+            desc[n] = ArgDesc{(unsigned short)bytes, (unsigned short)sizeof(T), arg_kind<T>(), ro};
         }
         bytes += (int)sizeof(T);
         ++n;

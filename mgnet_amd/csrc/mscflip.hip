@@ -49,6 +49,7 @@ struct AccParams {
     int dtype, mode, flip, first;
     float stride, scale, divide;   // mode 2: (v * stride) / scale; divide > 0: acc = (acc + v) / divide (the last pass)
 };
+MGN_PLAN_RO(AccParams, MGN_RO(lr))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 __device__ __forceinline__ float msc_post(float v, int mode, int c, const AccParams& p) {
     if (mode == 2) {           // offsets: * stride / scale; x component (channel 1) mirrored on flipped passes
@@ -149,6 +150,7 @@ struct InParams {
     uint16_t* dst;      // [N,h,w,8] 16-bit
     int N, H, W, h, w, flip, f16;
 };
+MGN_PLAN_RO(InParams, MGN_RO(src))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 __global__ __launch_bounds__(256) void msc_input(InParams p) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), n = blockIdx.z;

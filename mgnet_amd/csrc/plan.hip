@@ -150,6 +150,20 @@ int mgn_plan_node_args(const void* plan, int i, int max_args, int* offsets, int*
     return n.nargs;
 }
 
+/* per argument of node i: the read-only pointer words of a by-value struct (two 64-bit masks per argument: bit w = the struct's
+ * 8-byte word w is a pointer the kernel only reads through; csrc/mgn_launch.h MGN_PLAN_RO) */
+int mgn_plan_node_ro(const void* plan, int i, int max_args, unsigned long long* ro) {
+    const Plan* p = (const Plan*)plan;
+    if (!p || i < 0 || i >= (int)p->nodes.size() || !ro) return MGN_EINVAL;
+    const Node& n = p->nodes[i];
+    if (n.nargs > max_args) return MGN_ENOSPC;
+    for (int k = 0; k < n.nargs; ++k) {
+        ro[2 * k] = p->args[n.arg_off + k].ro.w[0];
+        ro[2 * k + 1] = p->args[n.arg_off + k].ro.w[1];
+    }
+    return n.nargs;
+}
+
 /* the replay schedule: ops[k] = (type, a, stream).  LAUNCH a = node; RECORD / WAIT a = event index (n_events are created here);
  * BREAK = return to the host (mgn_plan_run stops in front of it).  prof_slots > 0 creates that many hipEvent pairs for the prof marks. */
 int mgn_plan_compile(void* plan, int n_ops, const int* types, const int* a, void* const* streams, int n_events, int prof_slots) {

@@ -307,6 +307,7 @@ struct AbnBwd {
     float inv_n, eps, slope;
     int leaky;
 };
+MGN_PLAN_RO(AbnBwd, MGN_RO(scale) MGN_RO(offset) MGN_RO(weight) MGN_RO(bias) MGN_RO(rstd) MGN_RO(sums))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 __global__ __launch_bounds__(256) void abn_maxpool_bwd(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                        const uint8_t* __restrict__ idx, uint16_t* __restrict__ dx, AbnBwd q, int N, int IH,

@@ -18,6 +18,7 @@ struct PrepParams {
     int nf, B, H, W, Cp;
     uint16_t* out;             // [B, H, W, Cp] bf16
 };
+MGN_PLAN_RO(PrepParams, MGN_RO(frames))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 __device__ __forceinline__ uint32_t f2bf(float f) { return mgn_f2h(f); }   // this TU's 16-bit format (h16.h)
 
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
 // uint8 frames -> fp32 in [0,1] (x.float() / 255, mg_net.py:320-335: the un-jittered frames of the photometric loss), stacked
 // into one batch tensor: replaces torch.stack + a type-promoting division (two passes, the second at 2.4 TB/s)
 struct U8Frames { const uint8_t* f[16]; };
+MGN_PLAN_RO(U8Frames, MGN_RO(f))
 __global__ __launch_bounds__(256) void u8_frames_to_f32(U8Frames fr, long n16, float divisor, float* __restrict__ out) {
     const uint8_t* src = fr.f[blockIdx.y];
     float4* dst = reinterpret_cast<float4*>(out) + (long)blockIdx.y * n16 * 4;
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void u8_frames_to_f32_nhwc4(U8Frames fr, long 
 // uint8 planes -> packed uint8 RGBX pixels (the frames stay bytes; the reprojection kernels convert in registers): each thread packs 4
 // consecutive pixels from three dword loads into one 16-byte store
 struct U8Frames48 { const uint8_t* f[48]; };
+MGN_PLAN_RO(U8Frames48, MGN_RO(f))
 __global__ __launch_bounds__(256) void u8_frames_to_rgbx(U8Frames48 fr, long hw4, uint4* __restrict__ out) {
     const uint8_t* src = fr.f[blockIdx.y];
     uint4* dst = out + (long)blockIdx.y * hw4;

@@ -68,6 +68,7 @@ struct Params {
     int reduce_mean;  // loss.py:242-243 photometric_reduce_op "mean": mean over the warped maps instead of their min (automask must be 0)
     int pad_mode;     // F.grid_sample padding_mode of the warp (camera_utils.py:24-55): 0 "zeros", 1 "border", 2 "reflection"
 };
+MGN_PLAN_RO(Params, MGN_RO(inv) MGN_RO(img) MGN_RO(prev) MGN_RO(nxt) MGN_RO(mask) MGN_RO(cam))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 // bound_ctrl=1: lanes without a source read 0, so no "old" operand has to be materialised (saves a v_mov per shift)
 __device__ __forceinline__ float dpp_from_left(float x) {  // lane i <- lane i-1 (lane 0 <- 0)
@@ -930,6 +931,7 @@ struct BwdParams {
     float* d_pose_out;
     int B, H, W, n;
 };
+MGN_PLAN_RO(BwdParams, MGN_RO(inv) MGN_RO(img) MGN_RO(mask) MGN_RO(grad_losses) MGN_RO(hdr) MGN_RO(stats) MGN_RO(d_pose))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 template <bool U8>
 __global__ __launch_bounds__(256) void reproj_bwd(BwdParams p) {

@@ -11,6 +11,7 @@
 namespace {
 
 struct UncPtrs { const float* p[MGN_MAX_TASKS]; };
+MGN_PLAN_RO(UncPtrs, MGN_RO(p))
 
 __global__ void uncertainty_fwd(UncPtrs raw, int n, const float* __restrict__ log_vars, unsigned tau_one_mask, float* __restrict__ weighted,
                                 float* __restrict__ unc) {

@@ -143,6 +143,7 @@ class _Recorder(TorchDispatchMode):
         self.in_host_call = 0
         self._info = _C.PlanNodeInfo()
         self._offs, self._sizes, self._kinds = (ctypes.c_int * 64)(), (ctypes.c_int * 64)(), (ctypes.c_int * 64)()
+        self._ro = (ctypes.c_ulonglong * 128)()
 
     # ---- library calls -------------------------------------------------------------------------------------------------
     def wrap(self, name, fn):
@@ -172,14 +173,27 @@ class _Recorder(TorchDispatchMode):
         if info.type != 0:
             return info.stream or 0, [], [], "prof"
         n = lib.mgn_plan_node_args(plan, i, len(offs), offs, sizes, kinds)
-        if n < 0:
+        if n < 0 or lib.mgn_plan_node_ro(plan, i, len(offs), self._ro) != n:
             raise PlanUnsupported("a kernel with more arguments than the recorder holds")
+        ro = self._ro
+        if os.environ.get("MGN_PLAN_NO_RO"):   # (A/B: every pointer found in a struct argument counts as written, as before round 5)
+            ctypes.memset(ro, 0, ctypes.sizeof(ro))
         raw = ctypes.string_at(info.blob, info.nbytes) if info.nbytes else b""
         lo = blocks.starts[0] if blocks.starts else 0
         hi = blocks.ends[-1] if blocks.ends else 0
         reads, writes = [], []
+        dbg = self.__dict__.setdefault("arg_debug", {}) if os.environ.get("MGN_PLAN_DEBUG") else None
         for k in range(n):
             o, sz, kd = offs[k], sizes[k], kinds[k]
+            if dbg is not None:
+                if kd:
+                    pp = int.from_bytes(raw[o:o + 8], "little")
+                    dbg.setdefault(i, []).append((k, "const*" if kd == 1 else "ptr", pp, blocks.find(pp) if pp else None))
+                elif sz >= 8:
+                    for wi, pp in enumerate(np.frombuffer(raw[o:o + (sz // 8) * 8], dtype=np.uint64)):
+                        if lo <= int(pp) < hi and blocks.find(int(pp)) is not None:
+                            is_ro = wi < 128 and (self._ro[2 * k + wi // 64] >> (wi % 64)) & 1
+                            dbg.setdefault(i, []).append((k, "struct, read-only word" if is_ro else "struct", int(pp), blocks.find(int(pp))))
             if kd:
                 p = int.from_bytes(raw[o:o + 8], "little")
                 if p:
@@ -191,12 +205,14 @@ class _Recorder(TorchDispatchMode):
                         self.unresolved.add(p)
                         b = (p, p + 1)
                     (reads if kd == 1 else writes).append(b)
-            elif sz >= 8:   # by-value struct: every aligned 8-byte word that points into a live block counts as read + written
+            elif sz >= 8:   # by-value struct: every aligned 8-byte word that points into a live block counts as read + written --
+                # unless the struct declares the word a pointer its kernel only reads through (MGN_PLAN_RO in csrc/)
                 words = np.frombuffer(raw[o:o + (sz // 8) * 8], dtype=np.uint64)
-                for p in words[(words >= lo) & (words < hi)]:
-                    b = blocks.find(int(p))
+                for wi in np.nonzero((words >= lo) & (words < hi))[0]:
+                    b = blocks.find(int(words[wi]))
                     if b is not None:
-                        writes.append(b)
+                        wi = int(wi)
+                        (reads if (wi < 128 and (ro[2 * k + wi // 64] >> (wi % 64)) & 1) else writes).append(b)
         return info.stream or 0, reads, writes, info.name.decode() if info.name else "?"
 
     def host_call(self, fn, name, reads=(), writes=()):
@@ -479,6 +495,8 @@ class StepPlan:
         self.main, self.n_ops = main, n
         # what tools/critical_path.py reads: the schedule and, per item, what it is (no tensors)
         self.ops = ops
+        if os.environ.get("MGN_PLAN_DEBUG"):   # (tools/plan_why.py: which memory range orders two launches of different streams)
+            self.debug_items, self.arg_debug = items, getattr(rec, "arg_debug", {})
         self.items = [dict(kind=it["kind"], node=it.get("node", -1), stream=it["stream"], name=it["name"]) for it in items]
         kernels = sum(1 for it in items if it["kind"] == 0)
         by_name = {}

@@ -273,12 +273,23 @@ class Trainer:
     def _backward(self, loss_dict):
         """sum of the loss dict -> backward; with fp16 activations the sum is multiplied by the dynamic loss scale first
         (GradScaler.scale(losses).backward(), detectron2 AMPTrainer.run_step)"""
-        losses = sum(loss_dict.values())
         scale = self.optimizer.loss_scale() if hasattr(self.optimizer, "loss_scale") else None
         # split-K sums of a bucket's convs as one launch (reducer._pack); not under hipGraph capture (the table upload uses events)
         self.reducer.lazy_wgrad(not os.environ.get("MGN_NO_LAZY_WGRAD") and not getattr(self.model, "_no_side_streams", False))
+        # d(sum of the losses [* scale]) / d loss_k = 1 [* scale] for every k: the backward starts from the task losses themselves with that
+        # value as their gradient instead of from a sum node -- the same gradients, but no head's backward chain begins with a tensor that
+        # was computed from ALL heads' losses (on replay the heads then run forward -> loss -> backward without waiting for each other)
+        vals = [v for v in loss_dict.values()]
+        if vals and vals[0].is_cuda:
+            g = scale.detach().reshape(()) if scale is not None else self.__dict__.get("_one")
+            if g is None:
+                g = self._one = torch.ones((), dtype=torch.float32, device=vals[0].device)
+            roots, grads = vals, [g.to(v.dtype) if v.dtype != g.dtype else g for v in vals]
+        else:
+            total = sum(vals)
+            roots, grads = [total if scale is None else total * scale], None
         try:
-            (losses if scale is None else losses * scale).backward()
+            torch.autograd.backward(roots, grad_tensors=grads)
         except BaseException:
             self.reducer.abort()
             raise

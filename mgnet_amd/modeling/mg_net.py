@@ -317,6 +317,23 @@ class MGNet(nn.Module):
         # reference's order (mg_net.py:290-358: sem_seg, center, offset, photometric, smoothness) -- the uncertainty weights are indexed by it.
         l_sem, l_ins, l_depth = {}, {}, {}
         depth_first = self.with_depth and os.environ.get("MGN_HEAD_ORDER", "depth_first") != "sem_first"
+        # Uncertainty weighting (mg_net.py:360-372: loss_k <- tau_k * exp(-log_vars[k]) * loss_k + 0.5 * log_vars[k], tau = 1 for
+        # loss_sem_seg, else 0.5; same scalar names, no .item() host syncs) PER HEAD, on the head's own stream, right behind its losses:
+        # [HIP] one launch forward, one backward per head (ops.uncertainty_weighting).  Weighted in one launch over the whole dictionary
+        # at the end of forward (rounds 1-4), every head's backward had to wait for the slowest head's forward -- on replay the instance
+        # and semantic branches sat idle for 2.5 - 4 ms per step (profiles/r05_critical_path_interleaved.txt).  Task index = position in
+        # the reference's loss dictionary (sem_seg, center, offset, photometric, smoothness).
+        k0 = {"sem": 0, "ins": 1 if self.with_panoptic else 0, "depth": 3 if self.with_panoptic else 0}
+        storage = get_event_storage() if self.with_uncertainty else None
+
+        def weigh(part, first):
+            if not self.with_uncertainty or not part:
+                return
+            weighted, raw, unc = ops.uncertainty_weighting(part, self.log_vars, k0=first)
+            for key in list(part):
+                storage.put_scalar(key + "_raw", raw[key])
+                storage.put_scalar(key + "_uncertainty", unc[key])
+                part[key] = weighted[key]
 
         def run_depth():
             with on(1):
@@ -324,6 +341,7 @@ class MGNet(nn.Module):
                 if side:
                     handover(side[pk], side[1], outputs.get("poses"))
                 l_depth.update(self.depth_head.losses(outputs, targets))
+                weigh(l_depth, k0["depth"])
 
         if depth_first:
             run_depth()
@@ -331,25 +349,18 @@ class MGNet(nn.Module):
             with on(0):
                 outputs["center"], outputs["offset"] = self.ins_embed_head(f_ins)
                 l_ins.update(self.ins_embed_head.losses(outputs, targets))
+                weigh(l_ins, k0["ins"])
             outputs["sem_seg"] = self.sem_seg_head(f_sem)
             l_sem.update(self.sem_seg_head.losses(outputs, targets))
+            weigh(l_sem, k0["sem"])
         if self.with_depth and not depth_first:
             run_depth()
+        assert len(l_sem) <= 1 and len(l_ins) in (0, 2), "task indices of the uncertainty weights assume one semantic and two instance losses"
         for part in (l_sem, l_ins, l_depth):
             losses.update(part)
         if side:
             for st in side:
                 handover(st, main, losses)
-
-        if self.with_uncertainty:  # mg_net.py:360-372 -- same scalar names, but no .item() host syncs inside forward
-            #   loss_k <- tau_k * exp(-log_vars[k]) * loss_k + 0.5 * log_vars[k],  tau = 1 for loss_sem_seg, else 0.5
-            # for all tasks at once: [HIP] one launch forward, one backward (ops.uncertainty_weighting)
-            storage = get_event_storage()
-            weighted, raw, unc = ops.uncertainty_weighting(losses, self.log_vars)
-            for key in list(losses):
-                storage.put_scalar(key + "_raw", raw[key])
-                storage.put_scalar(key + "_uncertainty", unc[key])
-                losses[key] = weighted[key]
         return losses
 
 

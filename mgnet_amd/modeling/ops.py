@@ -1065,40 +1065,49 @@ def upsampled_ins_losses(center, offset, targets):
 # uncertainty weighting of the task losses (mg_net.py:360-372)
 # ---------------------------------------------------------------------------------------------------------------
 class _UncertaintyFn(torch.autograd.Function):
-    """[HIP] csrc/scalars.hip: weighted_k = tau_k exp(-log_vars[k]) raw_k + 0.5 log_vars[k] for all tasks in one launch; one output per
-    task (views of one buffer), one launch for the backward -- the launches carry the pointers of the loss scalars where they lie."""
+    """[HIP] csrc/scalars.hip: weighted_k = tau_k exp(-log_vars[k]) raw_k + 0.5 log_vars[k] for the tasks k0 .. k0 + n - 1 in one launch;
+    one output per task (views of one buffer), one launch for the backward -- the launches carry the pointers of the loss scalars where
+    they lie.  A call covers the tasks of ONE head (k0 = its first task), so that nothing in a head's forward -> loss -> backward chain
+    reads another head's results."""
 
     @staticmethod
-    def forward(ctx, log_vars, tau_mask, *raws):
+    def forward(ctx, log_vars, tau_mask, k0, *raws):
         from .. import _C
         raws = [r.detach().float().reshape(()).contiguous() for r in raws]
         lv = log_vars.detach().contiguous()
-        weighted, unc = _C.uncertainty_fwd(raws, lv, tau_mask)
-        ctx.raws, ctx.lv, ctx.tau_mask = raws, lv, tau_mask
+        weighted, unc = _C.uncertainty_fwd(raws, lv[k0:k0 + len(raws)], tau_mask >> k0)
+        ctx.raws, ctx.lv, ctx.tau_mask, ctx.k0 = raws, lv, tau_mask, k0
         ctx.mark_non_differentiable(unc)
         return (unc,) + tuple(weighted.unbind(0))
 
     @staticmethod
     def backward(ctx, _g_unc, *gs):
         from .. import _C
+        k0, n, nt = ctx.k0, len(ctx.raws), ctx.lv.numel()
         gs = [None if g is None else g.float().reshape(()).contiguous() for g in gs]
-        d_raw, d_lv = _C.uncertainty_bwd(ctx.raws, gs, ctx.lv, ctx.tau_mask)
-        return (d_lv, None) + tuple(d_raw.unbind(0))
+        # one launch over ALL of log_vars: the other tasks carry no gradient here (their d log_vars entries come out as exact zeros; any
+        # finite scalar stands in for their raw loss)
+        n_all = min(nt, _C.MGN_MAX_TASKS)
+        raws = [ctx.raws[k - k0] if k0 <= k < k0 + n else ctx.raws[0] for k in range(n_all)]
+        grads = [gs[k - k0] if k0 <= k < k0 + n else None for k in range(n_all)]
+        d_raw, d_lv = _C.uncertainty_bwd(raws, grads, ctx.lv, ctx.tau_mask)
+        return (d_lv, None, None) + tuple(d_raw[k0:k0 + n].unbind(0))
 
 
 _TAU_CACHE = {}
 
 
-def uncertainty_weighting(losses, log_vars):
-    """mg_net.py:360-372 for a dict of task losses (in task order): -> (weighted dict, raw dict, uncertainty dict) of device scalars"""
+def uncertainty_weighting(losses, log_vars, k0=0):
+    """mg_net.py:360-372 for a dict of task losses (in task order, the first one being task `k0` of log_vars): -> (weighted dict, raw
+    dict, uncertainty dict) of device scalars"""
     keys = list(losses)
-    if log_vars.is_cuda and len(keys) <= 8 and all(v.is_cuda for v in losses.values()) and not os.environ.get("MGN_NO_UNC_FUSE"):
-        mask = sum(1 << i for i, k in enumerate(keys) if k == "loss_sem_seg")
-        out = _UncertaintyFn.apply(log_vars, mask, *[losses[k] for k in keys])
+    if log_vars.is_cuda and k0 + len(keys) <= 8 and all(v.is_cuda for v in losses.values()) and not os.environ.get("MGN_NO_UNC_FUSE"):
+        mask = sum(1 << (k0 + i) for i, k in enumerate(keys) if k == "loss_sem_seg")
+        out = _UncertaintyFn.apply(log_vars, mask, k0, *[losses[k] for k in keys])
         unc, weighted = out[0], out[1:]
         return ({k: weighted[i] for i, k in enumerate(keys)}, {k: losses[k].detach() for k in keys}, {k: unc[i] for i, k in enumerate(keys)})
     raw = torch.stack([losses[k].float().reshape(()) for k in keys])
-    lv = log_vars[:len(keys)]
+    lv = log_vars[k0:k0 + len(keys)]
     ck = (tuple(keys), str(raw.device))
     tau = _TAU_CACHE.get(ck)   # (uploaded once: a copy from pageable host memory stalls the host until the queue has drained)
     if tau is None:

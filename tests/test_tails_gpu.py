@@ -61,6 +61,23 @@ def test_uncertainty_weighting_matches_reference_formula():
             assert float(raw[k]) == float(raw0[i]) and float(unc[k]) == pytest.approx(float(torch.exp(lv0[i])), rel=2e-6)
             assert float(raws[i].grad) == pytest.approx(float(r2[i].grad), rel=2e-6)
         assert torch.allclose(lv.grad.double(), l2.grad, rtol=2e-6, atol=1e-7) and float(lv.grad[n:].abs().sum()) == 0.0
+    # per head (MGNet.forward: the tasks of one head per call, k0 = its first task): bit-identical values and gradients to the one call
+    # over the whole dictionary, started from the task losses themselves (Trainer._backward) as from their weighted sum
+    raw0 = [torch.rand((), device="cuda") * 3 for _ in range(5)]
+    ra, rb = [r.clone().requires_grad_(True) for r in raw0], [r.clone().requires_grad_(True) for r in raw0]
+    la, lb = lv0.clone().requires_grad_(True), lv0.clone().requires_grad_(True)
+    wa, _, ua = ops.uncertainty_weighting(dict(zip(keys, ra)), la)
+    sum(wa.values()).backward()
+    wb, ub = {}, {}
+    for k0, n in ((3, 2), (1, 2), (0, 1)):   # (the depth head's tasks first, as the forward issues them)
+        w, _, u = ops.uncertainty_weighting({k: r for k, r in zip(keys[k0:k0 + n], rb[k0:k0 + n])}, lb, k0=k0)
+        wb.update(w)
+        ub.update(u)
+    one = torch.ones((), device="cuda")
+    torch.autograd.backward([wb[k] for k in keys], grad_tensors=[one] * 5)
+    for i, k in enumerate(keys):
+        assert float(wa[k]) == float(wb[k]) and float(ua[k]) == float(ub[k]) and float(ra[i].grad) == float(rb[i].grad), k
+    assert torch.equal(la.grad, lb.grad)
     # an unused output gets no gradient; the others are unaffected
     raws = [r.clone().requires_grad_(True) for r in raw0[:3]]
     lv = lv0.clone().requires_grad_(True)
