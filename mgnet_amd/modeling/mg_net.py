@@ -228,10 +228,15 @@ class MGNet(nn.Module):
             from .. import _C
             mean, std = self._mean01, self._std01   # (host constants: reading the device buffers would sync every step)
             frames = [self._stack(batched_inputs, "image")]
-            inputs["image"] = _C.prep_input(frames, mean, std, 8, self.amp_dtype)
             if self.training and self.with_depth:
-                frames += [self._stack(batched_inputs, "image_prev"), self._stack(batched_inputs, "image_next")]
-                pose_in = _C.prep_input(frames, mean, std, 16, self.amp_dtype)   # channels: image, prev, next (:264)
+                # the pose network's input is made on the pose network's stream, beside the backbone's (two HBM-bound launches, the larger
+                # of which only the pose stem waits for)
+                pframes = frames + [self._stack(batched_inputs, "image_prev"), self._stack(batched_inputs, "image_next")]
+                if side:
+                    handover(main, side[2 if len(side) > 2 else 0], pframes)
+                with on(2 if (side and len(side) > 2) else 0):
+                    pose_in = _C.prep_input(pframes, mean, std, 16, self.amp_dtype)   # channels: image, prev, next (:264)
+            inputs["image"] = _C.prep_input(frames, mean, std, 8, self.amp_dtype)
         else:
             inputs["image"] = self._net_input(batched_inputs, "image")
             if self.training and self.with_depth:
@@ -241,7 +246,8 @@ class MGNet(nn.Module):
         pk = 2 if (side and len(side) > 2) else 0   # the stream of the pose network
         features = None
         if pose_in is not None:
-            handover(main, side[pk] if side else None, pose_in)
+            if not fused_prep:
+                handover(main, side[pk] if side else None, pose_in)
             pe, bb = self.pose_net.pose_encoder, self.backbone
             if self.training and self.interleaved_trunks():
                 # The two ResNets issued block by block beside each other: autograd replays ready nodes in reverse creation order, so
