@@ -696,6 +696,27 @@ int mgn_bcast_rows(const float* g, int N, long HW, int C, float scale, void* dx,
 int mgn_scale_channels(const void* x, const float* s, int N, long HW, int C, int mode, const float* add /* nullable:
                        y += add[n,c] (the pooled branch of the attention backward) */, const void* addt /* nullable: y += addt[n,r,c], a
                        16-bit tensor of x's shape: `arm(x) + last` of the decoder, layers.py:87, in the same pass */, void* y, void* stream);
+
+/* InPlaceABNSync followed by a channel-attention module (mgnet/modeling/layers.py:221-267 AttentionRefinementModule, :270-322
+ * FeatureFusionModule: `fm = conv+norm(x); fm * sigmoid(attention(avg_pool(fm)))` / `fm + fm * ...`), the norm's and the attention's
+ * passes over the activation fused (csrc/eltwise.hip): forward 2 R + 2 W instead of 3 R + 2 W, backward 4 R + 1 W instead of 7 R + 2 W.
+ * x, z, g, dy: 16-bit [N, HW, C] channels-last, C % 8 == 0; act 0 identity / 1 leaky_relu(slope).
+ * mgn_abn_apply_pool: z = act(scale[c] x + offset[c]) (z may be x: in place) and pooled[n][c] = pool_scale * sum_rows(rounded z);
+ *   workspace >= N * 256 * C floats.
+ * mgn_att_abn_bwd_stats: S[5][N][C] (quantity-major) = sums over the image's rows of {g z, g m, g m xh, m, m xh}, m = act'(z), xh = (act^-1(z) - bias) /
+ *   (|weight| + eps); workspace >= N * 64 * 5 * C floats.
+ * mgn_att_abn_bwd_sums: sums[2][C] = {sum dz, sum dz xh} of the norm's backward for dz = (g base + dpool) m, base = s (mode 0) | 1 + s
+ *   (mode 1), dpool[N][C] = the pooled branch's gradient per element (NULL = 0); dwb[2][C] = {d weight, d bias} or NULL.
+ * mgn_att_abn_bwd_apply: dy = (|w| + eps) rstd (dz - sums[0] inv_n) - (act^-1(z) - bias) rstd sums[1] inv_n  (sums global over ranks). */
+int mgn_abn_apply_pool(const void* x, void* z, const float* scale, const float* offset, int act, float slope, int N, long HW, int C,
+                       float pool_scale, float* pooled, float* workspace, size_t workspace_bytes, void* stream);
+int mgn_att_abn_bwd_stats(const void* g, const void* z, const float* weight, const float* bias, float eps, int act, float slope, int N, long HW,
+                          int C, float* S, float* workspace, size_t workspace_bytes, void* stream);
+int mgn_att_abn_bwd_sums(const float* S, const float* s, const float* dpool, int mode, int N, int C, const float* weight, float* sums, float* dwb,
+                         void* stream);
+int mgn_att_abn_bwd_apply(const void* g, const void* z, void* dy, const float* s, const float* dpool, int mode, const float* weight,
+                          const float* bias, const float* rstd, const float* sums, float inv_n, float eps, int act, float slope, int N, long HW,
+                          int C, void* stream);
 int mgn_nearest_fwd(const void* x, int N, int h, int w, int H, int W, int C, void* y, void* stream);
 int mgn_nearest_bwd(const void* dy, int N, int h, int w, int H, int W, int C, void* dx, void* stream);
 int mgn_concat2(const void* a, const void* b, long rows, int Ca, int Cb, void* y, void* stream);
@@ -756,6 +777,13 @@ int mgn_conv3x3_up2_win_f16(const void* in, const void* w, void* out, int N, int
     int ksize, const void* residual, int residual_lowres, void* stream);
 int mgn_conv_wgrad_partial_f16(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
     int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
+int mgn_abn_apply_pool_f16(const void* x, void* z, const float* scale, const float* offset, int act, float slope, int N, long HW, int C,
+                           float pool_scale, float* pooled, float* workspace, size_t workspace_bytes, void* stream);
+int mgn_att_abn_bwd_stats_f16(const void* g, const void* z, const float* weight, const float* bias, float eps, int act, float slope, int N, long HW,
+                              int C, float* S, float* workspace, size_t workspace_bytes, void* stream);
+int mgn_att_abn_bwd_apply_f16(const void* g, const void* z, void* dy, const float* s, const float* dpool, int mode, const float* weight,
+                              const float* bias, const float* rstd, const float* sums, float inv_n, float eps, int act, float slope, int N, long HW,
+                              int C, void* stream);
 int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);
 int mgn_sum3_f16(const void* a, const void* b, const void* c, void* y, long n_elems, void* stream);
 int mgn_abn_add_relu_fwd_f16(const void* x, const float* scale, const float* offset, const void* shortcut, void* y,

@@ -30,8 +30,9 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd",
            "mgn_plan_begin", "mgn_plan_recorded", "mgn_plan_current", "mgn_plan_end", "mgn_plan_abort", "mgn_plan_node_count", "mgn_plan_node_info", "mgn_plan_node_args",
            "mgn_plan_compile", "mgn_plan_set_stream", "mgn_plan_run", "mgn_plan_prof_elapsed", "mgn_plan_free",
-           "mgn_plan_trace", "mgn_plan_trace_read", "mgn_plan_set_skip", "mgn_plan_node_ro"]
-SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']]
+           "mgn_plan_trace", "mgn_plan_trace_read", "mgn_plan_set_skip", "mgn_plan_node_ro",
+           "mgn_abn_apply_pool", "mgn_att_abn_bwd_stats", "mgn_att_abn_bwd_sums", "mgn_att_abn_bwd_apply"]
+SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']]
 DEPTH_MAX_FILTER_IDS = 16
 MGN_MAX_TASKS = 8   # include/mgnet_hip.h
 
@@ -84,7 +85,7 @@ def plan_touch(reads=(), writes=()):
 
 
 H16 = (torch.bfloat16, torch.float16)   # the 16-bit activation formats: bf16 entry points, or their _f16 twins (csrc/h16.h)
-F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x']
+F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']
 
 
 def _fn(name, t):
@@ -222,6 +223,10 @@ def lib():
         L.mgn_plan_trace_read.argtypes = [vp, ci, ci, ctypes.POINTER(cf), ctypes.POINTER(cf), ctypes.POINTER(cf)]
         L.mgn_plan_set_skip.argtypes = [vp, ci, ci]
         L.mgn_plan_node_ro.argtypes = [vp, ci, ci, ctypes.POINTER(ctypes.c_ulonglong)]
+        L.mgn_abn_apply_pool.argtypes = [vp, vp, vp, vp, ci, cf, ci, cl, ci, cf, vp, vp, sz, vp]
+        L.mgn_att_abn_bwd_stats.argtypes = [vp, vp, vp, vp, cf, ci, cf, ci, cl, ci, vp, vp, sz, vp]
+        L.mgn_att_abn_bwd_sums.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]
+        L.mgn_att_abn_bwd_apply.argtypes = [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, cf, cf, ci, cf, ci, cl, ci, vp]
         for n in SYMBOLS[4:]:
             getattr(L, n).restype = ci
         L.mgn_p2p_mailbox_bytes.restype = sz
@@ -1298,6 +1303,44 @@ def colsum(x, x2, scale):
     check(_fn("mgn_colsum", x)(x.data_ptr(), None if x2 is None else x2.data_ptr(), N, H * W, C, scale, out.data_ptr(), ws.data_ptr(),
                            ws.numel() * 4, _stream()), "mgn_colsum")
     return out
+
+
+def abn_apply_pool(x, z, scale, offset, activation, slope, pool_scale):
+    """z = act(scale * x + offset) (z may be x) and pooled [N, C] = pool_scale * column sums of the rounded z per image, in ONE pass"""
+    N, C, H, W = x.shape
+    pooled = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    ws = torch.empty(N * 256 * C, dtype=torch.float32, device=x.device)
+    check(_fn("mgn_abn_apply_pool", x)(x.data_ptr(), z.data_ptr(), scale.data_ptr(), offset.data_ptr(), activation, slope, N, H * W, C, pool_scale,
+                                       pooled.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()), "mgn_abn_apply_pool")
+    return pooled
+
+
+def att_abn_bwd_stats(g, z, weight, bias, eps, activation, slope):
+    """S [5, N, C]: per-(image, channel) sums {g z, g m, g m xh, m, m xh} of the fused attention + norm backward (csrc/eltwise.hip)"""
+    N, C, H, W = z.shape
+    S = torch.empty((5, N, C), dtype=torch.float32, device=z.device)
+    ws = torch.empty(N * 64 * 5 * C, dtype=torch.float32, device=z.device)
+    check(_fn("mgn_att_abn_bwd_stats", z)(g.data_ptr(), z.data_ptr(), weight.data_ptr(), bias.data_ptr(), eps, activation, slope, N, H * W, C,
+                                          S.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()), "mgn_att_abn_bwd_stats")
+    return S
+
+
+def att_abn_bwd_sums(S, s, dpool, mode, weight):
+    """-> (sums [2, C], d_weight [C], d_bias [C]) of the norm's backward from the per-image sums, the attention factor and the pooled gradient"""
+    _, N, C = S.shape
+    out = torch.empty((4, C), dtype=torch.float32, device=S.device)
+    check(lib().mgn_att_abn_bwd_sums(S.data_ptr(), s.data_ptr(), None if dpool is None else dpool.data_ptr(), mode, N, C, weight.data_ptr(),
+                                     out.data_ptr(), out[2].data_ptr(), _stream()), "mgn_att_abn_bwd_sums")
+    return out[:2], out[2], out[3]
+
+
+def att_abn_bwd_apply(g, z, s, dpool, mode, weight, bias, rstd, sums, total_count, eps, activation, slope):
+    N, C, H, W = z.shape
+    dy = _cl_like(z)
+    check(_fn("mgn_att_abn_bwd_apply", z)(g.data_ptr(), z.data_ptr(), dy.data_ptr(), s.data_ptr(), None if dpool is None else dpool.data_ptr(), mode,
+                                          weight.data_ptr(), bias.data_ptr(), rstd.data_ptr(), sums.data_ptr(), 1.0 / float(total_count), eps,
+                                          activation, slope, N, H * W, C, _stream()), "mgn_att_abn_bwd_apply")
+    return dy
 
 
 def colsum_all(x):

@@ -269,8 +269,216 @@ __global__ __launch_bounds__(TPB) void split2(const uint4* __restrict__ dy, int 
     }
 }
 
+
+// ---- InPlaceABNSync followed by a channel-attention module (layers.py:221-322: ARM / FFM on the output of conv + norm), fused ------------
+// The attention factor s[n, c] depends on the global average of the normalised map z, and the pooled branch's gradient dpool[n, c] on
+// sum(g * z): two-pass problems like the norm itself.  Done as separate ops the chain costs, per module,
+//   forward : apply (R y, W z) + pool (R z) + scale (R z, W out)                                  = 3 R + 2 W
+//   backward: sum g*z (R g, R z) + scale (R g, W dx) + norm reduce (R dx, R z) + norm apply (R dx, R z, W dy) = 7 R + 2 W
+// of activation-sized traffic.  dx = g * base + dpool (base = s or 1 + s) is linear in g with per-(image, channel) coefficients, so the
+// norm's two sums follow from five per-(image, channel) sums taken in ONE pass over (g, z),
+//   P = sum g z,  B1 = sum g m,  B2 = sum g m xh,  M1 = sum m,  M2 = sum m xh      (m = act'(z), xh = (act^-1(z) - beta) / gamma')
+//   sum dz = sum_n base B1 + dpool M1,     sum dz xh = sum_n base B2 + dpool M2
+// and the norm's input gradient dy from a second pass over (g, z): 4 R + 1 W; forward 2 R + 2 W with the pool taken while z is written.
+template <int NQ>
+__device__ __forceinline__ void block_colsums(float (&acc)[NQ][8], float* sh, int tx, int ty, int cv, int rl, float* dst, int C) {
+    // sh: [rl][cv][8] floats per quantity, one quantity after the other (TPB * 8 floats)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sh[(ty * cv + tx) * 8 + k] = acc[q][k];
+        __syncthreads();
+        if (ty == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float t = 0.f;
+                for (int y = 0; y < rl; ++y) t += sh[(y * cv + tx) * 8 + k];
+                dst[(long)q * C + tx * 8 + k] = t;
+            }
+        }
+    }
+}
+
+// z = act(scale * x + offset) (x and z may be the same tensor) + partial[n][chunk][C] = sums of the ROUNDED z over the chunk's rows
+__global__ __launch_bounds__(TPB) void abn_apply_pool(const uint16_t* x, uint16_t* z, const float* __restrict__ scale,
+                                                      const float* __restrict__ offset, int leaky, float slope, long HW, int C, float* partial) {
+    __shared__ float sh[TPB * 8];
+    const int cv = C / 8, rl = TPB / cv;
+    const int tx = threadIdx.x % cv, ty = threadIdx.x / cv;
+    const int n = blockIdx.y, chunks = gridDim.x;
+    const long r0 = HW * blockIdx.x / chunks, r1 = HW * (blockIdx.x + 1) / chunks;
+    float sc[8], of[8], acc[1][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[tx * 8 + k]; of[k] = offset[tx * 8 + k]; acc[0][k] = 0.f; }
+    auto body = [&](const uint4& q, long r) {
+        float v[8];
+        unpack8(q, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = fmaf(v[k], sc[k], of[k]);
+            v[k] = leaky ? (t > 0.f ? t : t * slope) : t;   // (the expression of iabn_apply, csrc/iabn.hip)
+        }
+        const uint4 o = pack8(v);
+        *reinterpret_cast<uint4*>(z + ((long)n * HW + r) * C + tx * 8) = o;
+        unpack8(o, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[0][k] += v[k];
+    };
+    long r = r0 + ty;
+    for (; r + 3 * rl < r1; r += 4 * rl) {
+        const uint16_t* b = x + ((long)n * HW + r) * C + tx * 8;
+        const uint4 q0 = *reinterpret_cast<const uint4*>(b), q1 = *reinterpret_cast<const uint4*>(b + (long)rl * C);
+        const uint4 q2 = *reinterpret_cast<const uint4*>(b + 2L * rl * C), q3 = *reinterpret_cast<const uint4*>(b + 3L * rl * C);
+        body(q0, r); body(q1, r + rl); body(q2, r + 2 * rl); body(q3, r + 3 * rl);
+    }
+    for (; r < r1; r += rl) body(*reinterpret_cast<const uint4*>(x + ((long)n * HW + r) * C + tx * 8), r);
+    block_colsums<1>(acc, sh, tx, ty, cv, rl, partial + ((long)n * chunks + blockIdx.x) * C, C);
+}
+
+// the five per-(image, channel) sums of the backward (see above): partial[n][chunk][5][C]
+__global__ __launch_bounds__(TPB) void att_abn_bwd_stats(const uint16_t* __restrict__ g, const uint16_t* __restrict__ z,
+                                                         const float* __restrict__ weight, const float* __restrict__ bias, float eps, int leaky,
+                                                         float slope, long HW, int C, float* partial) {
+    __shared__ float sh[TPB * 8];
+    const int cv = C / 8, rl = TPB / cv;
+    const int tx = threadIdx.x % cv, ty = threadIdx.x / cv;
+    const int n = blockIdx.y, chunks = gridDim.x;
+    const long r0 = HW * blockIdx.x / chunks, r1 = HW * (blockIdx.x + 1) / chunks;
+    const float inv_slope = 1.f / slope;
+    float bk[8], igk[8], acc[5][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        bk[k] = bias[tx * 8 + k];
+        igk[k] = 1.f / (fabsf(weight[tx * 8 + k]) + eps);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[q][k] = 0.f;
+    }
+    auto body = [&](const uint4& qg, const uint4& qz) {
+        float gv[8], zv[8];
+        unpack8(qg, gv);
+        unpack8(qz, zv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float zl = zv[k], m = 1.f;
+            if (leaky && (__float_as_uint(zl) >> 31)) { zl *= inv_slope; m = slope; }   // (sign bit: -0 is a negative pre-activation, csrc/iabn.hip)
+            const float xh = (zl - bk[k]) * igk[k], gm = gv[k] * m;
+            acc[0][k] = fmaf(gv[k], zv[k], acc[0][k]);
+            acc[1][k] += gm;
+            acc[2][k] = fmaf(gm, xh, acc[2][k]);
+            acc[3][k] += m;
+            acc[4][k] = fmaf(m, xh, acc[4][k]);
+        }
+    };
+    long r = r0 + ty;
+    for (; r + rl < r1; r += 2 * rl) {
+        const long o = ((long)n * HW + r) * C + tx * 8;
+        const uint4 g0 = *reinterpret_cast<const uint4*>(g + o), z0 = *reinterpret_cast<const uint4*>(z + o);
+        const uint4 g1 = *reinterpret_cast<const uint4*>(g + o + (long)rl * C), z1 = *reinterpret_cast<const uint4*>(z + o + (long)rl * C);
+        body(g0, z0);
+        body(g1, z1);
+    }
+    if (r < r1) {
+        const long o = ((long)n * HW + r) * C + tx * 8;
+        body(*reinterpret_cast<const uint4*>(g + o), *reinterpret_cast<const uint4*>(z + o));
+    }
+    block_colsums<5>(acc, sh, tx, ty, cv, rl, partial + ((long)n * chunks + blockIdx.x) * 5 * C, C);
+}
+
+// dy = A (dz - m1) - (zlin - beta) Bc   with dz = (g base[n, c] + dpool[n, c]) m      (iabn_bwd_apply of csrc/iabn.hip on the fused dz)
+__global__ __launch_bounds__(TPB) void att_abn_bwd_apply(const uint16_t* __restrict__ g, const uint16_t* __restrict__ z, uint16_t* __restrict__ dy,
+                                                         const float* __restrict__ s, const float* __restrict__ dpool, int mode,
+                                                         const float* __restrict__ weight, const float* __restrict__ bias,
+                                                         const float* __restrict__ rstd, const float* __restrict__ sums, float inv_n, float eps,
+                                                         int leaky, float slope, long HW, int C) {
+    const int cv = C / 8, rl = TPB / cv;
+    const int tx = threadIdx.x % cv, ty = threadIdx.x / cv;
+    const int n = blockIdx.y, chunks = gridDim.x;
+    const long r0 = HW * blockIdx.x / chunks, r1 = HW * (blockIdx.x + 1) / chunks;
+    const float inv_slope = 1.f / slope;
+    float A[8], m1[8], Bc[8], bk[8], bs[8], dp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = tx * 8 + k;
+        const float gm = fabsf(weight[c]) + eps, rs = rstd[c];
+        A[k] = gm * rs;
+        m1[k] = sums[c] * inv_n;
+        Bc[k] = rs * sums[C + c] * inv_n;
+        bk[k] = bias[c];
+        bs[k] = (mode ? 1.f : 0.f) + s[(long)n * C + c];
+        dp[k] = dpool ? dpool[(long)n * C + c] : 0.f;
+    }
+    auto body = [&](const uint4& qg, const uint4& qz, long r) {
+        float gv[8], zv[8];
+        unpack8(qg, gv);
+        unpack8(qz, zv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float zl = zv[k], dz = fmaf(gv[k], bs[k], dp[k]);
+            if (leaky && (__float_as_uint(zl) >> 31)) { zl *= inv_slope; dz *= slope; }
+            gv[k] = A[k] * (dz - m1[k]) - (zl - bk[k]) * Bc[k];
+        }
+        *reinterpret_cast<uint4*>(dy + ((long)n * HW + r) * C + tx * 8) = pack8(gv);
+    };
+    long r = r0 + ty;
+    for (; r + 3 * rl < r1; r += 4 * rl) {
+        const long o = ((long)n * HW + r) * C + tx * 8, st = (long)rl * C;
+        const uint4 g0 = *reinterpret_cast<const uint4*>(g + o), z0 = *reinterpret_cast<const uint4*>(z + o);
+        const uint4 g1 = *reinterpret_cast<const uint4*>(g + o + st), z1 = *reinterpret_cast<const uint4*>(z + o + st);
+        const uint4 g2 = *reinterpret_cast<const uint4*>(g + o + 2 * st), z2 = *reinterpret_cast<const uint4*>(z + o + 2 * st);
+        const uint4 g3 = *reinterpret_cast<const uint4*>(g + o + 3 * st), z3 = *reinterpret_cast<const uint4*>(z + o + 3 * st);
+        body(g0, z0, r); body(g1, z1, r + rl); body(g2, z2, r + 2 * rl); body(g3, z3, r + 3 * rl);
+    }
+    for (; r < r1; r += rl) {
+        const long o = ((long)n * HW + r) * C + tx * 8;
+        body(*reinterpret_cast<const uint4*>(g + o), *reinterpret_cast<const uint4*>(z + o), r);
+    }
+}
+
+// partial[n][chunk][5][C] -> S[5][N][C] (quantity-major: S[0] = sum g z is the [N][C] matrix the attention branch's backward consumes)
+__global__ void att_abn_stats_final(const float* __restrict__ partial, int chunks, int C, int N, float* __restrict__ S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 5 * C) return;
+    const int n = i / (5 * C), qc = i % (5 * C), q = qc / C, c = qc % C;
+    const float* p = partial + (long)n * chunks * 5 * C + qc;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < chunks; k += 4) {
+        s0 += p[(long)k * 5 * C]; s1 += p[(long)(k + 1) * 5 * C]; s2 += p[(long)(k + 2) * 5 * C]; s3 += p[(long)(k + 3) * 5 * C];
+    }
+    for (; k < chunks; ++k) s0 += p[(long)k * 5 * C];
+    S[((long)q * N + n) * C + c] = (s0 + s1) + (s2 + s3);
+}
+#ifndef MGN_F16
+
+// the norm's two sums (and its parameter gradients) from the per-(image, channel) sums S[5][N][C], s and dpool: one thread per channel,
+// images in a fixed order
+__global__ void att_abn_bwd_sums(const float* __restrict__ S, const float* __restrict__ s, const float* __restrict__ dpool, int mode, int N, int C,
+                                 const float* __restrict__ weight, float* __restrict__ sums, float* __restrict__ dwb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* q = S + (long)n * C + c;
+        const long Q = (long)N * C;
+        const float base = (mode ? 1.f : 0.f) + s[(long)n * C + c], dp = dpool ? dpool[(long)n * C + c] : 0.f;
+        a += fmaf(base, q[Q], dp * q[3 * Q]);
+        b += fmaf(base, q[2 * Q], dp * q[4 * Q]);
+    }
+    sums[c] = a;
+    sums[C + c] = b;
+    if (dwb) {
+        const float w = weight[c];
+        dwb[c] = b * (float)((w > 0.f) - (w < 0.f));
+        dwb[C + c] = a;
+    }
+}
+#endif
+
 inline bool c_ok(int C) { return C >= 8 && C % 8 == 0 && C / 8 <= TPB && TPB % (C / 8) == 0; }
 inline int chunks_for(long HW) { long c = HW / 512; return (int)(c < 1 ? 1 : (c > 64 ? 64 : c)); }
+// passes that also WRITE the tensor want the whole chip: up to 256 chunks per image (>= 128 rows each)
+inline int chunks_wide(long HW) { long c = HW / 128; return (int)(c < 1 ? 1 : (c > 256 ? 256 : c)); }
 
 }  // namespace
 
@@ -348,6 +556,53 @@ int mgn_concat2(const void* a, const void* b, long rows, int Ca, int Cb, void* y
 int mgn_split2(const void* dy, long rows, int Ca, int Cb, void* da, void* db, void* stream) {
     if (!dy || !da || !db || rows < 1 || Ca < 8 || Cb < 8 || Ca % 8 || Cb % 8) return MGN_EINVAL;
     hipLaunchKernelGGL(split2, dim3(blocks_for(rows * ((Ca + Cb) / 8))), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)dy, Ca, Cb, (uint4*)da, (uint4*)db, rows);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+#endif
+
+/* InPlaceABNSync + channel attention, fused passes (see the kernels' header comment).
+ * mgn_abn_apply_pool: z = act(scale[c] * x + offset[c]) (x == z allowed: in place) and pooled[n][c] = pool_scale * sum over the image's rows
+ *   of the rounded z.  workspace: N * 256 * C floats.
+ * mgn_att_abn_bwd_stats: S[5][N][C] = per-(image, channel) sums {g z, g m, g m xh, m, m xh} over (g, z) (m = act'(z), xh from z, weight, bias).
+ *   workspace: N * 64 * 5 * C floats.
+ * mgn_att_abn_bwd_sums (fp32 only): sums[2][C] = {sum dz, sum dz xh} of the norm's backward (+ dwb[2][C] = {d weight, d bias}) from S, the
+ *   attention factor s[N][C], the pooled branch's gradient dpool[N][C] (1 / HW included; NULL = 0) and mode (0: z s, 1: z (1 + s)).
+ * mgn_att_abn_bwd_apply: dy = the norm's input gradient for dz = (g base + dpool) m; sums are GLOBAL over the ranks, inv_n = 1 / (total rows). */
+int MGN_SYM(mgn_abn_apply_pool)(const void* x, void* z, const float* scale, const float* offset, int act, float slope, int N, long HW, int C,
+                                float pool_scale, float* pooled, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !z || !scale || !offset || !pooled || !workspace || N < 1 || HW < 1 || !c_ok(C) || act < 0 || act > 1) return MGN_EINVAL;
+    const int chunks = chunks_wide(HW);
+    if (workspace_bytes < sizeof(float) * (size_t)N * chunks * C) return MGN_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(abn_apply_pool, dim3(chunks, N), dim3(TPB), 0, st, (const uint16_t*)x, (uint16_t*)z, scale, offset, act, slope, HW, C, workspace);
+    hipLaunchKernelGGL(colsum_final, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)workspace, chunks, C, N, pool_scale, pooled);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int MGN_SYM(mgn_att_abn_bwd_stats)(const void* g, const void* z, const float* weight, const float* bias, float eps, int act, float slope, int N,
+                                   long HW, int C, float* S, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!g || !z || !weight || !bias || !S || !workspace || N < 1 || HW < 1 || !c_ok(C) || act < 0 || act > 1) return MGN_EINVAL;
+    const int chunks = chunks_for(HW);
+    if (workspace_bytes < sizeof(float) * (size_t)N * chunks * 5 * C) return MGN_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(att_abn_bwd_stats, dim3(chunks, N), dim3(TPB), 0, st, (const uint16_t*)g, (const uint16_t*)z, weight, bias, eps, act, slope, HW, C,
+                       workspace);
+    hipLaunchKernelGGL(att_abn_stats_final, dim3((N * 5 * C + 255) / 256), dim3(256), 0, st, (const float*)workspace, chunks, C, N, S);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+int MGN_SYM(mgn_att_abn_bwd_apply)(const void* g, const void* z, void* dy, const float* s, const float* dpool, int mode, const float* weight,
+                                   const float* bias, const float* rstd, const float* sums, float inv_n, float eps, int act, float slope, int N,
+                                   long HW, int C, void* stream) {
+    if (!g || !z || !dy || !s || !weight || !bias || !rstd || !sums || N < 1 || HW < 1 || !c_ok(C) || mode < 0 || mode > 1 || act < 0 || act > 1)
+        return MGN_EINVAL;
+    hipLaunchKernelGGL(att_abn_bwd_apply, dim3(chunks_wide(HW), N), dim3(TPB), 0, (hipStream_t)stream, (const uint16_t*)g, (const uint16_t*)z,
+                       (uint16_t*)dy, s, dpool, mode, weight, bias, rstd, sums, inv_n, eps, act, slope, HW, C);
+    return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+#ifndef MGN_F16
+int mgn_att_abn_bwd_sums(const float* S, const float* s, const float* dpool, int mode, int N, int C, const float* weight, float* sums, float* dwb,
+                         void* stream) {
+    if (!S || !s || !weight || !sums || N < 1 || C < 1 || mode < 0 || mode > 1) return MGN_EINVAL;
+    hipLaunchKernelGGL(att_abn_bwd_sums, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, S, s, dpool, mode, N, C, weight, sums, dwb);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 #endif

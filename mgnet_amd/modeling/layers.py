@@ -126,8 +126,8 @@ class AttentionRefinementModule(nn.Module):  # layers.py:221-267
 
     def forward(self, x, addend=None):
         """addend: a tensor added to the result (`arm(x) + last`, layers.py:87) inside the scaling pass on the GPU path"""
-        fm = self.conv(x)
-        return ops.channel_attention(fm, self.channel_attention, "arm", addend=addend)
+        # conv -> norm -> attention; on the GPU path the norm's and the attention's passes over the map are fused (ops._AbnAttentionFn)
+        return ops.conv_abn_attention(self.conv, x, self.channel_attention, "arm", addend=addend)
 
 
 class FeatureFusionModule(nn.Module):  # layers.py:270-322
@@ -145,8 +145,7 @@ class FeatureFusionModule(nn.Module):  # layers.py:270-322
             mgnet_xavier_fill(self.channel_attention[2])
 
     def forward(self, fsp, fcp):
-        fm = self.conv(ops.concat_channels(fsp, fcp))
-        return ops.channel_attention(fm, self.channel_attention, "ffm", residual=True)
+        return ops.conv_abn_attention(self.conv, ops.concat_channels(fsp, fcp), self.channel_attention, "ffm", residual=True)
 
 
 class MGNetDecoder(nn.Module):  # layers.py:22-94

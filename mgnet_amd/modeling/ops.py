@@ -883,6 +883,106 @@ def channel_attention(x, attention, kind, residual=False, addend=None):
     return y if addend is None else y + addend
 
 
+class _AbnAttentionFn(torch.autograd.Function):
+    """[HIP] conv output -> InPlaceABNSync -> channel attention (ARM layers.py:221-267 / FFM :270-322) as ONE autograd node whose passes over
+    the activation are fused (csrc/eltwise.hip `abn_apply_pool`, `att_abn_bwd_*`): the pool is taken while the normalised map is written,
+    and in the backward the five per-(image, channel) sums of one pass over (g, z) give both the pooled branch's input and the norm's two
+    sums -- 2 R + 2 W forward and 4 R + 1 W backward of activation-sized traffic instead of 3 R + 2 W and 7 R + 2 W for the separate
+    _IABNFn and _ChannelAttentionFn nodes.  Same formulas; the gradient g * base + dpool is no longer rounded to 16 bit in between."""
+
+    @staticmethod
+    def forward(ctx, y, pstats, nw, nb, nrm, nrv, training, momentum, eps, activation, slope, group,
+                kind, residual, w1, p2, p3, a_rm, a_rv, a_training, a_momentum, a_eps, addend=None):
+        from .. import _C
+        N, C, H, W = y.shape
+        M = N * H * W
+        act = {"identity": 0, "leaky_relu": 1}[activation]
+        w32, b32 = nw.detach().float().contiguous(), nb.detach().float().contiguous()
+        world = dist.get_world_size(group) if _dist_active(group) else 1
+        if training:
+            coef = _train_coef(y, M, C, w32, b32, eps, momentum, nrm, nrv, world, group, pstats)
+        else:
+            coef = _C.iabn_eval_coeffs(w32, b32, nrm, nrv, eps)
+        pooled = _C.abn_apply_pool(y, y, coef[0], coef[1], act, slope, 1.0 / (H * W))   # in place: y now holds z
+        z = y
+        w1c = w1.detach().reshape(w1.shape[0], -1)
+        if kind == "arm":
+            s, xhat, rstd = _C.vec_linear_fwd(pooled, w1c, "sigmoid", (p2.detach(), p3.detach(), a_rm, a_rv, a_training, a_momentum, a_eps))
+            ctx.save_for_backward(z, pooled, s, w1c, w32, b32, coef, p2.detach(), xhat, rstd)
+        else:
+            w2c = p2.detach().reshape(p2.shape[0], -1)
+            h, _, _ = _C.vec_linear_fwd(pooled, w1c, "relu")
+            s, _, _ = _C.vec_linear_fwd(h, w2c, "sigmoid")
+            ctx.save_for_backward(z, pooled, s, w1c, w32, b32, coef, w2c, h)
+        # (y is overwritten through the raw kernel and never used again: the producing conv keeps its inputs, not its output)
+        ctx.cfg = (kind, residual, eps, act, slope, group, world, training, float(M) * world, nw.dtype, a_eps, tuple(w1.shape),
+                   None if p2 is None else tuple(p2.shape), addend is not None)
+        return _C.scale_channels(z, s, 1 if residual else 0, addt=addend)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _C
+        kind, residual, eps, act, slope, group, world, training, total, wdtype, a_eps, w1s, p2s, has_addend = ctx.cfg
+        if not training:
+            raise NotImplementedError("backward through eval-mode InPlaceABNSync is not on the training path")
+        z = ctx.saved_tensors[0]
+        g = _cl(g, z)
+        mode = 1 if residual else 0
+        if kind == "arm":
+            z, pooled, s, w1c, w32, b32, coef, bnw, xhat, rstd = ctx.saved_tensors
+        else:
+            z, pooled, s, w1c, w32, b32, coef, w2c, h = ctx.saved_tensors
+        S = _C.att_abn_bwd_stats(g, z, w32, b32, eps, act, slope)
+        ds = S[0]     # sum g z per (image, channel): the gradient of the attention factor
+        hw = z.shape[2] * z.shape[3]
+        if kind == "arm":
+            dW1, dpool, dbw, dbb = _C.vec_linear_bwd(ds, s, pooled, w1c, "sigmoid", bnw, xhat, rstd, a_eps, dv_scale=1.0 / hw)
+            d2, d3 = dbw, dbb
+        else:
+            dW2, dh, _, _ = _C.vec_linear_bwd(ds, s, h, w2c, "sigmoid")
+            dW1, dpool, _, _ = _C.vec_linear_bwd(dh, h, pooled, w1c, "relu", dv_scale=1.0 / hw)
+            d2, d3 = dW2.view(p2s), None
+        sums, d_nw, d_nb = _C.att_abn_bwd_sums(S, s, dpool, mode, w32)
+        if world > 1:
+            sums = _allreduce_sums(sums, group)
+        dy = _C.att_abn_bwd_apply(g, z, s, dpool, mode, w32, b32, coef[3], sums, total, eps, act, slope)
+        return (dy, None, d_nw.to(wdtype), d_nb.to(wdtype), None, None, None, None, None, None, None, None,
+                None, None, dW1.view(w1s), d2, d3, None, None, None, None, None, (g if has_addend else None))
+
+
+def conv_abn_attention(conv, x, attention, kind, residual=False, addend=None):
+    """`fm = conv(x)` (a layers.Conv2d with an InPlaceABNSync norm) followed by ops.channel_attention(fm, attention, kind, ...): on the GPU
+    path one fused node behind the convolution (_AbnAttentionFn), otherwise exactly those two calls"""
+    from .. import _C
+    norm = getattr(conv, "norm", None)
+    a1 = attention[1]
+    ok = (x.is_cuda and x.dtype in _C.H16 and norm is not None and type(norm).__name__ == "InPlaceABNSync" and conv.activation is None
+          and conv.out_channels % 8 == 0 and conv.out_channels // 8 <= 256 and 256 % (conv.out_channels // 8) == 0 and x.shape[0] <= 64
+          and a1.bias is None and (norm.training or not torch.is_grad_enabled()) and not os.environ.get("MGN_NO_ATTN_FUSE")
+          and not os.environ.get("MGN_NO_ABN_ATTN"))
+    add_ok = addend is None or (not os.environ.get("MGN_NO_ARMADD") and addend.dtype == x.dtype and addend.is_contiguous(memory_format=torch.channels_last))
+    if kind == "arm":
+        bn = a1.norm
+        ok = ok and not _dist_active(bn.group) and (bn.training or not torch.is_grad_enabled())
+    else:
+        ok = ok and attention[2].bias is None
+    if ok and add_ok:
+        y = conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, stats_for=norm)
+        if _C.elt_supported(y) and (addend is None or addend.shape == y.shape):
+            ps = _pstats(y)
+            if kind == "arm":
+                bn = a1.norm
+                return _AbnAttentionFn.apply(y, ps, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.training, norm.momentum,
+                                             norm.eps, norm.activation, norm.activation_param, norm.group, "arm", residual, a1.weight,
+                                             bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, addend)
+            return _AbnAttentionFn.apply(y, ps, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.training, norm.momentum,
+                                         norm.eps, norm.activation, norm.activation_param, norm.group, "ffm", residual, a1.weight,
+                                         attention[2].weight, None, None, None, True, 0.0, 0.0, addend)
+        fm = norm(y)   # (not a shape for the fused kernels: the ordinary norm consumes the conv's statistics)
+        return channel_attention(fm, attention, kind, residual=residual, addend=addend)
+    return channel_attention(conv(x), attention, kind, residual=residual, addend=addend)
+
+
 class _CatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -141,3 +141,60 @@ def test_posecnn_tail_matches_torch(monkeypatch):
     for name, got, ref in (("dx", x.grad, xd.grad), ("dw1", w1.grad, p[0].grad), ("db1", b1.grad, p[1].grad), ("dw4", w4.grad, p[2].grad),
                            ("db4", b4.grad, p[3].grad)):
         assert rel(got, ref) < 1.5e-2, (name, rel(got, ref))
+
+
+@pytest.mark.parametrize("kind,dtype", [("arm", torch.bfloat16), ("ffm", torch.bfloat16), ("arm", torch.float16), ("ffm", torch.float16)])
+def test_norm_and_attention_fused_node_vs_separate_nodes_and_fp64(kind, dtype, monkeypatch):
+    """ops._AbnAttentionFn (conv output -> InPlaceABNSync -> ARM / FFM attention with the passes over the map fused: pool inside the norm's
+    apply pass; in the backward five per-(image, channel) sums of ONE pass over (g, z) feed both the attention branch and the norm's sums)
+    against (a) the two separate nodes it replaces (MGN_NO_ABN_ATTN=1) and (b) the oracle's fp64 evaluation of layers.py:221-322 on the
+    same 16-bit inputs: at least as close to fp64 as the separate nodes (it rounds the intermediate gradient once less)"""
+    import oracle.network_oracle as NO
+    from mgnet_amd.modeling.layers import AttentionRefinementModule, FeatureFusionModule
+    torch.manual_seed(5)
+    N, H, W = 3, 20, 36
+    if kind == "arm":
+        mod, prefix = AttentionRefinementModule(64, 128).cuda().train(), "m"
+        ins0 = [torch.randn(N, 64, H, W, device="cuda")]
+    else:
+        mod, prefix = FeatureFusionModule(128 + 128, 256).cuda().train(), "m"
+        ins0 = [torch.randn(N, 128, H, W, device="cuda"), torch.randn(N, 128, H, W, device="cuda")]
+    with torch.no_grad():
+        for n_, p in mod.named_parameters():
+            if n_.endswith("norm.weight"):
+                p.copy_(torch.randn_like(p) * 0.5 + 1.0)      # (signed: the norm uses |weight| + eps and d weight carries the sign)
+            elif n_.endswith("norm.bias"):
+                p.copy_(torch.randn_like(p) * 0.3)
+    ins0 = [t.to(dtype).contiguous(memory_format=torch.channels_last) for t in ins0]
+    Cout = 128 if kind == "arm" else 256
+    g = torch.randn(N, Cout, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for tag in ("fused", "separate"):
+        if tag == "separate":
+            monkeypatch.setenv("MGN_NO_ABN_ATTN", "1")
+        for p in mod.parameters():
+            p.grad = None
+        ins = [t.clone().requires_grad_(True) for t in ins0]
+        y = mod(*ins)
+        y.backward(g)
+        res[tag] = (y.detach().double(), [t.grad.double() for t in ins], {n_: p.grad.double().clone() for n_, p in mod.named_parameters()})
+    monkeypatch.delenv("MGN_NO_ABN_ATTN")
+    # fp64 oracle on the same (16-bit rounded) inputs
+    sd = {f"{prefix}.{k}": v.detach().double().clone().requires_grad_(v.dtype.is_floating_point) for k, v in mod.state_dict().items()}
+    ins = [t.double().clone().requires_grad_(True) for t in ins0]
+    yr = NO.arm(sd, prefix, ins[0]) if kind == "arm" else NO.ffm(sd, prefix, ins[0], ins[1])
+    yr.backward(g.double())
+    spacing = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    yf, ys = res["fused"][0], res["separate"][0]
+    assert float((yf - yr).abs().max()) <= 3 * spacing * float(yr.abs().max())
+    assert float((yf - ys).abs().max()) <= 2.02 * spacing * float(yr.abs().max())
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+    rows = [("input%d" % i, res["fused"][1][i], res["separate"][1][i], ins[i].grad) for i in range(len(ins))]
+    rows += [(n_, res["fused"][2][n_], res["separate"][2][n_], sd[f"{prefix}.{n_}"].grad) for n_ in res["fused"][2]]
+    for name, gf, gs, gr in rows:
+        ef, es = rel(gf, gr), rel(gs, gr)
+        tol = 4e-2 if dtype == torch.bfloat16 else 2e-2   # (the conv's own 16-bit weights and gradients bound both paths: 1.05e-2 in fp16)
+        assert ef <= tol, (kind, name, ef, es)
+        assert ef <= 1.25 * es + 1e-3, (kind, name, ef, es)
