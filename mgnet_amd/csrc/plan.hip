@@ -52,8 +52,36 @@ struct Plan {
     std::vector<hipEvent_t> tr[2];
     bool trace = false;
     std::vector<unsigned char> skip;   // what-if replays (mgn_plan_set_skip): node not launched
+    // race hunting (mgn_plan_set_jitter): random delay kernels in front of launches shake the relative timing of the streams -- a replay
+    // whose cross-stream edges are complete gives the same bits under any timing
+    // data probes (mgn_plan_probe): after node i, a checksum of a memory range is written to a caller-owned slot -- two replays of
+    // the same step can then be compared range by range to find the first buffer that differs
+    struct Probe { int node; const void* ptr; size_t nwords; unsigned long long* out; int copy; };
+    std::vector<Probe> probes;
+    std::vector<unsigned char> fence_after;   // debugging (mgn_plan_set_skip mode 3): an event record + self-wait behind the node
+    hipEvent_t fence_ev = nullptr;
+    unsigned long long jitter_state = 0;
+    int jitter_permille = 0, jitter_max_us = 0;
     bool overflow = false;
 };
+
+__global__ void plan_checksum_kernel(const unsigned* __restrict__ p, size_t nwords, unsigned long long* out) {
+    __shared__ unsigned long long sh[256];
+    unsigned long long a = 0;
+    for (size_t i = threadIdx.x; i < nwords; i += 256) a += (unsigned long long)p[i] * (2 * (i % 8191) + 1);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int k = 0; k < 256; ++k) t += sh[k];
+        *out = t;
+    }
+}
+
+__global__ void plan_delay_kernel(long long ticks) {   // wall_clock64: 100 MHz on gfx950
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 
 static Plan* g_rec = nullptr;
 static std::mutex g_rec_mutex;   // launches are recorded from the caller's thread AND from the autograd thread of the backward pass
@@ -214,6 +242,14 @@ int mgn_plan_run(void* plan, int from, int prof_slot) {
             const Node& nd = p->nodes[o.a];
             if (nd.type == 0) {
                 if (!p->skip.empty() && p->skip[o.a] == 1) continue;
+                if (p->jitter_permille > 0) {
+                    p->jitter_state = p->jitter_state * 6364136223846793005ull + 1442695040888963407ull;
+                    const unsigned r = (unsigned)(p->jitter_state >> 33);
+                    if ((int)(r % 1000u) < p->jitter_permille) {
+                        const long long us = 1 + (long long)((r / 1000u) % (unsigned)p->jitter_max_us);
+                        plan_delay_kernel<<<1, 64, 0, nd.stream>>>(us * 100);
+                    }
+                }
                 if (!p->skip.empty() && p->skip[o.a] == 2 &&   // what-if "twice": the extra launch first, the traced / ordinary one after it
                     hipLaunchKernel(nd.func, nd.grid, nd.block, p->argv.data() + p->argv_off[o.a], nd.shmem, nd.stream) != hipSuccess) {
                     (void)hipGetLastError();
@@ -229,6 +265,16 @@ int mgn_plan_run(void* plan, int from, int prof_slot) {
                     (void)hipGetLastError();
                     return MGN_ELAUNCH;
                 }
+                if (!p->fence_after.empty() && p->fence_after[o.a]) {
+                    if (!p->fence_ev) (void)hipEventCreateWithFlags(&p->fence_ev, hipEventDisableTiming);
+                    (void)hipEventRecord(p->fence_ev, nd.stream);
+                    (void)hipStreamWaitEvent(nd.stream, p->fence_ev, 0);
+                }
+                for (const Plan::Probe& pr : p->probes)
+                    if (pr.node == o.a) {
+                        if (pr.copy) (void)hipMemcpyAsync(pr.out, pr.ptr, pr.nwords * 4, hipMemcpyDeviceToDevice, nd.stream);
+                        else plan_checksum_kernel<<<1, 256, 0, nd.stream>>>((const unsigned*)pr.ptr, pr.nwords, pr.out);
+                    }
             } else if (prof_slot >= 0 && prof_slot < (int)p->prof[nd.which].size()) {
                 (void)hipEventRecord(p->prof[nd.which][prof_slot], nd.stream);
             }
@@ -295,9 +341,38 @@ int mgn_plan_trace_read(void* plan, int ref, int n, float* t_a, float* t_b, floa
  * skip = 0: as recorded. */
 int mgn_plan_set_skip(void* plan, int i, int skip) {
     Plan* p = (Plan*)plan;
-    if (!p || i < 0 || i >= (int)p->nodes.size() || skip < 0 || skip > 2) return MGN_EINVAL;
+    if (!p || i < 0 || i >= (int)p->nodes.size() || skip < 0 || skip > 3) return MGN_EINVAL;
+    if (skip == 3) {   // (debugging: an event record + wait on the node's own stream behind it: a barrier packet with fences)
+        if (p->fence_after.empty()) p->fence_after.assign(p->nodes.size(), 0);
+        p->fence_after[i] = 1;
+        return MGN_OK;
+    }
     if (p->skip.empty()) p->skip.assign(p->nodes.size(), 0);
     p->skip[i] = (unsigned char)skip;
+    return MGN_OK;
+}
+
+/* Race hunting: from now on every launch of a replay is preceded, with probability permille / 1000, by a kernel that idles its stream for
+ * 1 .. max_us microseconds (pseudo-random from `seed`).  permille = 0 switches it off. */
+int mgn_plan_set_jitter(void* plan, unsigned long long seed, int permille, int max_us) {
+    Plan* p = (Plan*)plan;
+    if (!p || permille < 0 || permille > 1000 || (permille > 0 && max_us < 1)) return MGN_EINVAL;
+    p->jitter_state = seed * 2654435761ull + 1;
+    p->jitter_permille = permille;
+    p->jitter_max_us = max_us;
+    return MGN_OK;
+}
+
+/* debugging: after node i of every following replay, the checksum of [ptr, ptr + nbytes) (device memory, nbytes % 4 == 0) is written to
+ * *out (device memory, 8 bytes) on the node's stream; node < 0 clears all probes */
+int mgn_plan_probe(void* plan, int node, const void* ptr, size_t nbytes, void* out) {
+    Plan* p = (Plan*)plan;
+    if (!p) return MGN_EINVAL;
+    if (node < 0) { p->probes.clear(); return MGN_OK; }
+    const bool copy = node >= (1 << 24);   // node | 1 << 24: copy the range to `out` (nbytes of device memory) instead of a checksum
+    node &= (1 << 24) - 1;
+    if (node >= (int)p->nodes.size() || !ptr || !out || nbytes % 4) return MGN_EINVAL;
+    p->probes.push_back(Plan::Probe{node, ptr, nbytes / 4, (unsigned long long*)out, copy ? 1 : 0});
     return MGN_OK;
 }
 

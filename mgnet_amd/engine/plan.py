@@ -22,6 +22,7 @@ import bisect
 import ctypes
 import gc
 import os
+import sys
 import threading
 
 import numpy as np
@@ -176,11 +177,18 @@ class _Recorder(TorchDispatchMode):
         if n < 0 or lib.mgn_plan_node_ro(plan, i, len(offs), self._ro) != n:
             raise PlanUnsupported("a kernel with more arguments than the recorder holds")
         ro = self._ro
-        if os.environ.get("MGN_PLAN_NO_RO"):   # (A/B: every pointer found in a struct argument counts as written, as before round 5)
+        # Which struct arguments' read-only declarations are honoured (MGN_PLAN_RO = conv | all | none; default conv).  With ALL of them
+        # honoured the three heads' forward passes overlap fully -- 1.1 ms faster per step -- but two replays of one step then differ, in
+        # 1.5 - 8 % of the steps, by what one stale 128-pixel tile is worth (profiles/r05_plan_determinism.txt: a later kernel of the SAME stream
+        # reads a tile its predecessor wrote in the previous replay; every pointer of the pair is declared, plain HIP kernels do not
+        # reproduce it (tools/probe/l2_probe.hip), any extra event nearby hides it).  Root cause not found; until it is, only the
+        # convolution family's declarations are used: 0 differing steps in 1200 replays (as with none), tests/test_plan_gpu.py keeps watch.
+        mode = "none" if os.environ.get("MGN_PLAN_NO_RO") else os.environ.get("MGN_PLAN_RO", "conv")
+        nm_ = info.name.decode() if info.name else ""
+        if mode == "none" or (mode == "conv" and not any(x in nm_ for x in ("conv", "up2", "wgrad", "stem"))):
             ctypes.memset(ro, 0, ctypes.sizeof(ro))
-        raw = ctypes.string_at(info.blob, info.nbytes) if info.nbytes else b""
-        lo = blocks.starts[0] if blocks.starts else 0
-        hi = blocks.ends[-1] if blocks.ends else 0
+        elif os.environ.get("MGN_PLAN_NO_RO_FOR") and any(x and x in nm_ for x in os.environ["MGN_PLAN_NO_RO_FOR"].split(",")):
+            ctypes.memset(ro, 0, ctypes.sizeof(ro))   # (bisecting: ... not for kernels whose name contains one of these substrings)
         reads, writes = [], []
         dbg = self.__dict__.setdefault("arg_debug", {}) if os.environ.get("MGN_PLAN_DEBUG") else None
         for k in range(n):
@@ -483,6 +491,27 @@ class StepPlan:
             self.report_split = getattr(self, "report_split", {})
             self.report_split[sub] = moved
         main_id = int(main.cuda_stream)
+        if os.environ.get("MGN_PLAN_CLOSURE_BARRIERS"):   # (debugging: every host-issued torch op joins all streams before and after itself)
+            sel = os.environ["MGN_PLAN_CLOSURE_BARRIERS"]
+            for it in items:
+                if it["kind"] == 1 and (sel == "1" or any(x in it["name"] for x in sel.split(","))):
+                    it["writes"] = list(it["writes"]) + [(1, 2)]
+                else:
+                    it["reads"] = list(it["reads"]) + [(1, 2)]
+        if os.environ.get("MGN_PLAN_BARRIER_AT"):   # (debugging: a full join of all streams in front of the first launch of that name)
+            sub, hit, G = os.environ["MGN_PLAN_BARRIER_AT"], False, (1, 2)
+            mode = os.environ.get("MGN_PLAN_BARRIER_MODE", "both")   # both | wait (X waits for everything before it) | release (everything after waits for X)
+            only = os.environ.get("MGN_PLAN_BARRIER_STREAMS")       # optional: only items whose stream index (sorted handles) is listed take part
+            sidx = {st: k for k, st in enumerate(sorted({it["stream"] for it in items}))}
+            lo_, hi_ = int(os.environ.get("MGN_PLAN_BARRIER_FROM", 0)), int(os.environ.get("MGN_PLAN_BARRIER_TO", 1 << 30))
+            for ii, it in enumerate(items):
+                if not hit and it["kind"] == 0 and sub in it["name"]:
+                    hit = True
+                    it["writes"] = list(it["writes"]) + [G]
+                    print(f"[plan barrier] at item {ii} {it['name'][:40]} stream index {sidx[it['stream']]}", file=sys.stderr)
+                elif (only is None or str(sidx[it["stream"]]) in only.split(",")) and lo_ <= ii < hi_:
+                    if (not hit and mode in ("both", "wait")) or (hit and mode in ("both", "release")):
+                        it["reads"] = list(it["reads"]) + [G]
         ops, n_ev, n_cross, ns, moved_nodes = derive_schedule(items, main_id, serial=bool(os.environ.get("MGN_PLAN_SERIAL")))
         self.closures = [it["closure"] for it in items if it["kind"] == 1]
         n = len(ops)
@@ -559,6 +588,10 @@ class StepPlan:
         for i in nodes:
             _C.check(lib.mgn_plan_set_skip(self.handle, int(i), mode), "mgn_plan_set_skip")
             (self._skipped.add if mode == 1 else self._skipped.discard)(int(i))
+
+    def set_jitter(self, seed, permille=100, max_us=200):
+        """race hunting: random idle kernels in front of the replayed launches (csrc/plan.hip mgn_plan_set_jitter); permille 0 = off"""
+        _C.check(_C.lib().mgn_plan_set_jitter(self.handle, int(seed), int(permille), int(max_us)), "mgn_plan_set_jitter")
 
     def prof_elapsed_ms(self, slot):
         ms = ctypes.c_float()
