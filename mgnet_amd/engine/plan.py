@@ -189,6 +189,9 @@ class _Recorder(TorchDispatchMode):
             ctypes.memset(ro, 0, ctypes.sizeof(ro))
         elif os.environ.get("MGN_PLAN_NO_RO_FOR") and any(x and x in nm_ for x in os.environ["MGN_PLAN_NO_RO_FOR"].split(",")):
             ctypes.memset(ro, 0, ctypes.sizeof(ro))   # (bisecting: ... not for kernels whose name contains one of these substrings)
+        raw = ctypes.string_at(info.blob, info.nbytes) if info.nbytes else b""
+        lo = blocks.starts[0] if blocks.starts else 0
+        hi = blocks.ends[-1] if blocks.ends else 0
         reads, writes = [], []
         dbg = self.__dict__.setdefault("arg_debug", {}) if os.environ.get("MGN_PLAN_DEBUG") else None
         for k in range(n):
