@@ -13,6 +13,15 @@ __global__ void R(const float* x, int n, float v, unsigned* err, int shift) {
     for (int i = b * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) bad += x[i] != v;
     if (bad) atomicAdd(err, bad);
 }
+// per-block partial rows of `row` floats (16 bytes for row = 4): neighbouring BLOCKS -- usually on different XCDs -- write into one 128-byte line
+__global__ void Wp(float* x, int row, float v) {
+    if (threadIdx.x < row) x[(size_t)blockIdx.x * row + threadIdx.x] = v + threadIdx.x;
+}
+__global__ void Rp(const float* x, int nblk, int row, float v, unsigned* err) {
+    unsigned bad = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nblk * row; i += gridDim.x * blockDim.x) bad += x[i] != v + (i % row);
+    if (bad) atomicAdd(err, bad);
+}
 struct WP { float* x; int n; float v; };
 struct RP { const float* x; int n; float v; unsigned* err; int shift; };
 // the same two kernels with their pointers INSIDE by-value structs (as most kernels of libmgnet_hip.so take them): the runtime's
@@ -37,13 +46,17 @@ int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 20000, n = argc > 2 ? atoi(argv[2]) : 1 << 16, with_busy = argc > 3 ? atoi(argv[3]) : 1;
     const int in_struct = argc > 4 ? atoi(argv[4]) : 0;
     float *x, *y; unsigned* err;
-    hipMalloc(&x, n * sizeof(float)); hipMalloc(&y, (4 << 20) * sizeof(float)); hipMalloc(&err, 4);
+    hipMalloc(&x, (size_t)n * 128 * sizeof(float)); hipMalloc(&y, (4 << 20) * sizeof(float)); hipMalloc(&err, 4);
     hipMemset(err, 0, 4); hipMemset(y, 0, (4 << 20) * sizeof(float));
     hipStream_t s, t, u;
     hipStreamCreateWithFlags(&s, hipStreamNonBlocking); hipStreamCreateWithFlags(&t, hipStreamNonBlocking); hipStreamCreateWithFlags(&u, hipStreamNonBlocking);
     for (int it = 1; it <= iters; ++it) {
         if (with_busy && it % 4 == 0) { busy<<<300, 256, 0, t>>>(y, 4 << 20, 64); busy<<<77, 256, 0, u>>>(y + (2 << 20), 1 << 20, 200); }
-        if (in_struct) {
+        if (in_struct >= 2) {   // partial rows: in_struct = 2 + log2(row floats) -> 2: 1 float, 4: 4 floats (16 B), 7: 32 floats (128 B)
+            const int row = 1 << (in_struct - 2), nblk = n;
+            Wp<<<nblk, 64, 0, s>>>(x, row, (float)it);
+            Rp<<<argc > 5 ? atoi(argv[5]) : 1, 256, 0, s>>>(x, nblk, row, (float)it, err);
+        } else if (in_struct) {
             Ws<<<256, 256, 0, s>>>(WP{x, n, (float)it});
             Rs<<<256, 256, 0, s>>>(RP{x, n, (float)it, err, 37 + it % 101});
         } else {
