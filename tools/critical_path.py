@@ -49,7 +49,7 @@ FAMILIES = [   # first match wins
     ("reproj", r"reproj_"),
     ("head losses", r"upce_|ohem_|ins_fwd|ins_bwd|uncertainty|head_act|sum3_kernel|sum4_kernel"),
     ("upsample depth", r"up1_|adjoint_gather"),
-    ("attention / small vec", r"vec_linear|vec_sum|scale_channels|bcast_rows"),
+    ("attention / small vec (+ fused norm passes)", r"vec_linear|vec_sum|scale_channels|bcast_rows|att_abn|abn_apply_pool"),
     ("eltwise (nearest, concat, sum3, relu)", r"nearest_|concat2|split2|sum3_h16|relu_mask|add_relu"),
     ("input prep / weight layout", r"prep_kernel|u8_frames|weight_layout|copy_from_host"),
     ("optimizer", r"adam_kernel|sqnorm|clip_coef|optim"),
