@@ -133,6 +133,11 @@ class _Recorder(TorchDispatchMode):
         self.blocks = _Blocks()
         self.blocks.load_snapshot()
         self.keep = []              # tensors / buffers the plan refers to
+        # MGN_PLAN_NO_REUSE = <bytes> | all: storages up to that size stay allocated until the recording ends, so that no two tensors of
+        # the step share an address (debugging aid for stale-cache-line hunts: profiles/r05_plan_determinism.txt)
+        nr = os.environ.get("MGN_PLAN_NO_REUSE", "")
+        self.hold_max = (1 << 62) if nr == "all" else int(nr or 0)
+        self.hold = []
         self.pending_touch = ([], [])
         self.lock = threading.RLock()
         self.unresolved = set()
@@ -275,6 +280,8 @@ class _Recorder(TorchDispatchMode):
             for t in cuda_out:
                 if t.untyped_storage().nbytes():
                     self.blocks.add(*_extent(t))
+                    if t.untyped_storage().nbytes() <= self.hold_max:
+                        self.hold.append(t.untyped_storage())
         sch = func._schema
         name = sch.name.split("::")[-1] + "." + (func._overloadname or "default")
         if sch.name == "aten::_local_scalar_dense":
