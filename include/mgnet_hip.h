@@ -333,9 +333,10 @@ int mgn_plan_probe(void* plan, int node, const void* ptr, size_t nbytes, void* o
 int mgn_plan_free(void* plan);
 
 /* The 7x7 / stride 2 / pad 3 stems with 64 output channels (res_net.py:96-104 BasicStem conv1; the 9-channel pose-net stem,
- * res_net.py:169-181) on the channel-padded input of mgn_prep_input (Cin = 8 | 16) and the layout-mode-2 weights of
+ * res_net.py:169-181) on the channel-padded input of mgn_prep_input (Cin = 4 | 8 | 16) and the layout-mode-2 weights of
  * mgn_weight_layout: persistent windowed kernel with the weights in registers (csrc/conv_stem.hip); mgn_conv_igemm dispatches
- * here.  stat_partials: NULL or [mgn_conv_stem7_blocks(...)][64][2] sums of r, r^2 over the rounded outputs.  MGN_ENOTSUP for
+ * here.  Cin = 4 (3 real channels, IW even) is the backbone stem at its dense reduction: a kernel row is one run of 8 column
+ * slots x 4 channels (K = 224 for 147 real products, against 392 on the 8-channel input).  stat_partials: NULL or [mgn_conv_stem7_blocks(...)][64][2] sums of r, r^2 over the rounded outputs.  MGN_ENOTSUP for
  * other shapes (mgn_conv_stem7_blocks == 0). */
 int mgn_conv_stem7(const void* in, const void* w_packed, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout,
                    float* stat_partials, void* stream);
@@ -345,7 +346,8 @@ int mgn_conv_stem7_blocks(int N, int IH, int IW, int Cin, int OH, int OW, int Co
 /* patch height mgn_conv_igemm picks for a 3x3 / stride 1 / pad 1 layer of this shape: 16, 8, or 0 (= it uses another kernel) */
 int mgn_conv_win_patch_rows(int N, int OH, int OW, int Cin, int Cout);
 /* fp32 OIHW master weights -> bf16 kernel layout. mode 0: [Cout][KH][KW][Cin]; 1: [Cin][KH][KW][Cout] with flipped taps
- * (data gradient); 2: packed-tap stem layout [Cout][ceil(KH*KW*Cp/32)*32] for a Cp-channel (8|16) padded input */
+ * (data gradient); 2: packed-tap stem layout [Cout][ceil(KH*KW*Cp/32)*32] for a Cp-channel (8|16) padded input; Cp = 4 (7x7 only):
+ * the dense-row layout [Cout][224], k = kh*32 + (kw+1)*4 + c */
 int mgn_weight_layout(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp,
                       int cout_pad /* > Cout: output channels zero-padded to cout_pad in the layout (few-class predictors) */, void* stream);
 /* every conv weight of a model in one launch (after the optimizer step): table_dev = n_entries rows of 8 x int64 on the
@@ -402,9 +404,10 @@ int mgn_ins_loss_bwd(const float* center_lr, long csb, long csh, long csw, const
  * Network input assembly -- replaces mg_net.py:250-264 (`.float()/255`, mean/std normalisation of image, image_prev,
  * image_next and their channel concatenation for PoseCNN).
  * frames_u8: HOST array of n_frames (1..3) device pointers to [B,3,H,W] uint8; pixel_mean3/std3: HOST floats in the 0..1
- * domain (cfg value / 255); out: [B,H,W,Cp] bf16 channels-last, Cp = 8 or 16, channels 3f..3f+2 = frame f, rest zero.
+ * domain (cfg value / 255); out: [B,H,W,Cp] bf16 channels-last, Cp = 4 (one frame), 8 or 16, channels 3f..3f+2 = frame f, rest zero.
  * mgn_conv_igemm / mgn_conv_wgrad accept such Cin = 8 | 16 inputs ("packed taps": k = tap*Cin + c, weights
- * [Cout][ceil(KH*KW*Cin/32)*32] bf16, dw [Cout][KH*KW*Cin] fp32).
+ * [Cout][ceil(KH*KW*Cin/32)*32] bf16, dw [Cout][KH*KW*Cin] fp32) and, for the 7x7 / stride 2 / pad 3 / 64-channel stem on even widths
+ * only, Cin = 4 ("dense rows": k = kh*32 + (kw+1)*4 + c, weights [Cout][224]).
  * ---------------------------------------------------------------------------------------------- */
 int mgn_prep_input(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
                    const float* pixel_std3, void* out_bf16, int Cp, void* stream);

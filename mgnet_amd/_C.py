@@ -600,8 +600,17 @@ def optim_step_dev(kind, p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, nest
 # convolution (implicit GEMM, bf16 MFMA).  Tensors are logical NCHW in channels_last memory format.
 # ---------------------------------------------------------------------------------------------------------------
 def conv_supported(x, weight):
-    """Cin % 32 == 0, or a channel-padded stem input (Cin 8/16 holding the weight's 3/9 real channels)"""
-    return x.is_cuda and x.dtype in H16 and (weight.shape[1] % 32 == 0 or (x.shape[1] in (8, 16) and weight.shape[1] <= x.shape[1]))
+    """Cin % 32 == 0, or a channel-padded stem input (Cin 4/8/16 holding the weight's 3/9 real channels)"""
+    return x.is_cuda and x.dtype in H16 and (weight.shape[1] % 32 == 0 or (x.shape[1] in (4, 8, 16) and weight.shape[1] <= x.shape[1]))
+
+
+def stem_input_channels(N, H, W, real=3):
+    """channel padding of the 7x7 / stride-2 stem's input: 4 where the dense-row kernel takes the shape (3 real channels, even width:
+    csrc/conv_stem.hip CP = 4), else 8 (16 for the 9-channel pose stem)"""
+    if real > 3:
+        return 16 if real > 8 else 8
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    return 4 if lib().mgn_conv_stem7_blocks(N, H, W, 4, OH, OW, 64) > 0 else 8
 
 
 def u8_frames_to_f32(frames, divisor):
@@ -726,7 +735,7 @@ def msc_accumulate(acc, lr, mode, flip, first, stride=1.0, scale=1.0, divide=0.0
 
 
 def prep_input(frames_u8, mean3, std3, Cp, dtype=torch.bfloat16):
-    """frames: list of [B,3,H,W] uint8 CUDA tensors -> [B,Cp,H,W] bf16 / fp16 channels_last (normalised, zero-padded channels)"""
+    """frames: list of [B,3,H,W] uint8 CUDA tensors -> [B,Cp,H,W] bf16 / fp16 channels_last (normalised, zero-padded channels; Cp = 4 | 8 | 16)"""
     B, _, H, W = frames_u8[0].shape
     frames_u8 = [f.contiguous() for f in frames_u8]
     out = torch.empty((B, Cp, H, W), dtype=dtype, device=frames_u8[0].device, memory_format=torch.channels_last)

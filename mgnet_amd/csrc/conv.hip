@@ -1522,10 +1522,11 @@ struct WgradStemParams {
 MGN_PLAN_RO(WgradStemParams, MGN_RO(dout) MGN_RO(in))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 template <int CP>
 struct WS {
-    static constexpr int PIN = CP == 16 ? 9 : 5;      // 1-KB pieces per input row of the strip (262 pixels)
+    static constexpr int PIN = CP == 16 ? 9 : (CP == 8 ? 5 : 3);      // 1-KB pieces per input row of the strip (262 pixels)
     static constexpr int INROW = PIN * 1024, OUTROW = 128 * 128, POUT = 16;
     static constexpr int NIN = 11, NOUT = 3, LDS = NIN * INROW + NOUT * OUTROW;
-    static constexpr int PXG = CP == 16 ? 1 : 2, TPK = CP == 16 ? 4 : 2;   // pixel groups, 32-column tiles per kernel row
+    static constexpr int PXG = 16 / CP, TPK = CP / 4;   // pixel groups, 32-column tiles per kernel row
+    static constexpr int COL0 = CP == 4 ? 4 : 3;      // image column of slot 0 relative to 2*ow (CP = 4: slot 0 is the padding slot, kw = slot - 1)
     static constexpr int KSW = 8 / PXG;               // 16-pixel k-steps per wave and row
     static constexpr int PXB = CP * 2;                // bytes per input pixel
 };
@@ -1537,7 +1538,7 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1;
-    const int ngrp = CP == 16 ? wave >> 1 : (wave >> 1) & 1, pxg = CP == 16 ? 0 : wave >> 2;
+    const int ngrp = CP == 16 ? wave >> 1 : (CP == 8 ? (wave >> 1) & 1 : 0), pxg = CP == 16 ? 0 : (CP == 8 ? wave >> 2 : wave >> 1);
     const int L = blockIdx.x, q8 = L >> 3;
     const int slice = (q8 / p.co_tiles) * 8 + (L & 7), tile = q8 % p.co_tiles;
     if (slice >= p.nslices) return;
@@ -1568,7 +1569,7 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
         vout[i] = ow < p.OW ? (ow * p.Cout + co0 + seg * 8) * 2 : OOB;
     }
     (void)vin;
-    const int iw_base = 2 * ow0 - 3;
+    const int iw_base = 2 * ow0 - C::COL0;
     auto issue_in = [&](int ih, int slot, int rot) {
         const bool ok = ih >= 0 && ih < p.IH;
         const int soff = ok ? ((n * p.IH + ih) * p.IW) * C::PXB : 0;
@@ -1602,7 +1603,7 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
     // fragment addresses.  A (dOut): pixel rows, co columns.  B (input): rows = output pixels -> input pixel 2*px (+kw
     // through the column block), columns = 32-byte blocks of the kernel row.
     const int g = lane >> 4, i4 = lane & 15;
-    const int prow = pxg * 64 + 8 * (g >> 1) + (i4 >> 2);
+    const int prow = pxg * (128 / C::PXG) + 8 * (g >> 1) + (i4 >> 2);
     auto lds_off = [](int px, int ch) { return px * 128 + ((((ch >> 3) ^ (((px >> 1) & 1) << 2))) << 4) + (ch & 7) * 2; };
     const int aA = C::NIN * C::INROW + lds_off(prow, wm * 32 + (g & 1) * 16 + 4 * (i4 & 3));
     const int bB = 2 * prow * C::PXB + 32 * (g & 1) + 8 * (i4 & 3);
@@ -1667,7 +1668,9 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
         } else if (r == r0 + 1) {
             // the prologue's rows of step r0+1 must have landed; this group's pieces of step r0 (>= LMIN per wave) may stay in flight
             if (LMIN == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (LMIN == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            static_assert(LMIN == 8 || LMIN == 6 || LMIN == 5, "counted wait of the second step");
         }
         __builtin_amdgcn_s_barrier();
         if (loader) {   // rows of step r+2 (always issued: out-of-range rows read as zeros into slots nobody uses)
@@ -1709,30 +1712,33 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
         s0 = s0 + 2 >= 11 ? s0 - 9 : s0 + 2;
         so = so + 1 >= 3 ? 0 : so + 1;
     }
-    if (C::PXG == 2) {  // sum the two pixel halves: 3 tiles at a time through the (now idle) ring memory
+    if (C::PXG > 1) {  // sum the pixel groups (fixed order 1, 2, ..): 3 tiles at a time through the (now idle) ring memory
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float* red = reinterpret_cast<float*>(wssm);
-        const int t256 = tid & 255;
+        constexpr int GT = 512 / C::PXG;          // threads of a pixel group
+        const int tg = tid & (GT - 1);
 #pragma unroll
-        for (int tb = 0; tb < 7; tb += 3) {
-            __syncthreads();
-            if (pxg == 1) {
+        for (int src = 1; src < C::PXG; ++src)
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    if (tb + t < 7)
+            for (int tb = 0; tb < 7; tb += 3) {
+                __syncthreads();
+                if (pxg == src) {
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) red[(t * 16 + e) * 256 + t256] = acc[tb + t][e];
+                    for (int t = 0; t < 3; ++t)
+                        if (tb + t < 7)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) red[(t * 16 + e) * GT + tg] = acc[tb + t][e];
+                }
+                __syncthreads();
+                if (pxg == 0) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        if (tb + t < 7)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[tb + t][e] += red[(t * 16 + e) * GT + tg];
+                }
             }
-            __syncthreads();
-            if (pxg == 0) {
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    if (tb + t < 7)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[tb + t][e] += red[(t * 16 + e) * 256 + t256];
-            }
-        }
-        if (pxg == 1) return;
+        if (pxg != 0) return;
     }
     const size_t rowf = (size_t)7 * 8 * CP;                      // floats per output channel
     float* dst = p.partial + (size_t)slice * p.Cout * rowf;
@@ -1748,6 +1754,7 @@ __device__ __forceinline__ void wgrad_stem_body(const WgradStemParams& p) {
 }
 __global__ __launch_bounds__(512, 1) void conv_wgrad_stem16(WgradStemParams p) { wgrad_stem_body<16>(p); }
 __global__ __launch_bounds__(512, 1) void conv_wgrad_stem8(WgradStemParams p) { wgrad_stem_body<8>(p); }
+__global__ __launch_bounds__(512, 1) void conv_wgrad_stem4(WgradStemParams p) { wgrad_stem_body<4>(p); }
 
 // dw[co][c][kh][kw] (torch layout, c < cin_real) = sum over the slices of partial[s][co][kh][kw*CP + c]
 // block = one (co, kh) row of 8*CP floats: 32 lanes x 16 bytes along the row times 8 groups along the slices, combined in a
@@ -1783,8 +1790,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_reduce(const float* __res
         const float v[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int e = el * 4 + k, kw = e / CP, c = e - kw * CP;   // row position = kw * CP + c
-            if (kw < 7 && c < cin_real) dw[(((size_t)co * cin_real + c) * 7 + kh) * 7 + kw] = v[k];
+            const int e = el * 4 + k, slot = e / CP, c = e - slot * CP;   // row position = slot * CP + c
+            const int kw = CP == 4 ? slot - 1 : slot;                      // (CP = 4: slot 0 is the padding slot)
+            if (kw >= 0 && kw < 7 && c < cin_real) dw[(((size_t)co * cin_real + c) * 7 + kh) * 7 + kw] = v[k];
         }
     }
 }
@@ -2003,7 +2011,8 @@ static inline dim3 wgrad_reduce_grid(int Cout, int taps, int Cin) { return dim3(
 // fp32 OIHW master weights -> bf16 kernel layouts, one launch per conv
 //   mode 0: [Cout][KH][KW][Cin]                      (forward)
 //   mode 1: [Cin][KH][KW][Cout], taps flipped        (data gradient: w'[ci][kh][kw][co] = w[co][ci][KH-1-kh][KW-1-kw])
-//   mode 2: [Cout][Kpad], k = tap*Cp + c, zero padded (packed-tap stems; Cp = padded input channels)
+//   mode 2: [Cout][Kpad], k = tap*Cp + c, zero padded (packed-tap stems; Cp = padded input channels);
+//           Cp = 4 (7x7 only): k = kh*32 + (kw+1)*4 + c, Kpad = 224 -- the dense-row stem kernel
 // element i of the bf16 layout (CoutP >= Cout: output channels zero-padded to CoutP, e.g. the few-class predictors to 32)
 __device__ __forceinline__ float layout_value(const float* __restrict__ w, long i, int Cout, int CoutP, int Cin, int KH, int KW, int mode, int Cp) {
     if (mode == 0) {
@@ -2020,6 +2029,10 @@ __device__ __forceinline__ float layout_value(const float* __restrict__ w, long 
     }
     const int Kpad = (KH * KW * Cp + 31) / 32 * 32;
     const int k = (int)(i % Kpad), co = (int)(i / Kpad);
+    if (Cp == 4) {   // dense kernel rows (7x7 stems, csrc/conv_stem.hip CP = 4): k = kh*32 + slot*4 + c, slot = kw + 1 (slot 0 is zero)
+        const int kh = k >> 5, slot = (k >> 2) & 7, c = k & 3;
+        return (co < Cout && kh < KH && slot >= 1 && slot <= KW && c < Cin) ? w[(((long)co * Cin + c) * KH + kh) * KW + slot - 1] : 0.f;
+    }
     const int tap = k / Cp, c = k - tap * Cp;
     return (co < Cout && tap < KH * KW && c < Cin) ? w[(((long)co * Cin + c) * KH + tap / KW) * KW + tap % KW] : 0.f;
 }
@@ -2089,7 +2102,7 @@ extern "C" {
 
 int MGN_SYM(mgn_weight_layout)(const float* w_oihw, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode, int Cp, int cout_pad, void* stream) {
     if (!w_oihw || !out_bf16 || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || mode < 0 || mode > 2) return MGN_EINVAL;
-    if (mode == 2 && (Cp < Cin || (Cp != 8 && Cp != 16))) return MGN_EINVAL;
+    if (mode == 2 && (Cp < Cin || (Cp != 4 && Cp != 8 && Cp != 16) || (Cp == 4 && (KH != 7 || KW != 7)))) return MGN_EINVAL;
     const int CoutP = cout_pad > Cout ? cout_pad : Cout;
     const int Kpad = mode == 2 ? (KH * KW * Cp + 31) / 32 * 32 : 0;
     const long n = mode == 2 ? (long)CoutP * Kpad : (long)CoutP * Cin * KH * KW;
@@ -2128,6 +2141,13 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
     if (plan_rows) *plan_rows = 0;
     if ((!plan_rows && (!in || !w || !out)) || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || up < 1)
         return MGN_EINVAL;
+    if (Cin == 4) {   // the dense-row stem layout: only the persistent stem kernel (csrc/conv_stem.hip) takes it
+        if (KH != 7 || KW != 7 || stride != 2 || pad != 3 || up != 1 || bias || relu || out_f32 || residual) return MGN_ENOTSUP;
+        const int sb = mgn_conv_stem7_blocks(N, IH, IW, Cin, OH, OW, Cout);
+        if (sb <= 0) return MGN_ENOTSUP;
+        if (plan_rows) { *plan_rows = sb; return MGN_OK; }
+        return MGN_SYM(mgn_conv_stem7)(in, w, out, N, IH, IW, Cin, OH, OW, Cout, stat_part, stream);
+    }
     const bool pack = (Cin == 8 || Cin == 16);            // small-Cin stems: taps packed into the k-slab
     if (!pack && (Cin < 32 || Cin % 32 != 0)) return MGN_ENOTSUP;  // k-slab = 32 or 64 input channels of one tap
     if (pack && up != 1) return MGN_ENOTSUP;
@@ -2345,7 +2365,8 @@ static void wgrad_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW,
 // 7x7 / stride 2 / pad 3 on a channel-padded (8 | 16) input -> the stem row-march kernel
 static bool wgrad_stem_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW, int stride, int pad, int IH, int IW, WgradStemParams* p) {
     if (getenv("MGN_WGRAD_NOSTEM")) return false;
-    if (KH != 7 || KW != 7 || stride != 2 || pad != 3 || (Cin != 8 && Cin != 16) || Cout % 64) return false;
+    if (KH != 7 || KW != 7 || stride != 2 || pad != 3 || (Cin != 4 && Cin != 8 && Cin != 16) || Cout % 64) return false;
+    if (Cin == 4 && (IW & 1)) return false;   // (aligned pixel pairs)
     if (OH != (IH - 1) / 2 + 1 || OW != (IW - 1) / 2 + 1) return false;
     if ((size_t)N * OH * OW * Cout * 2 >= 0x7fffffffu || (size_t)N * IH * IW * Cin * 2 >= 0x7fffffffu) return false;
     p->N = N; p->IH = IH; p->IW = IW; p->OH = OH; p->OW = OW; p->Cout = Cout;
@@ -2408,7 +2429,7 @@ int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int
 static int wgrad_impl(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
                       int KW, int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc, void* stream) {
     if (!dout || !in || (!dw && !desc) || !workspace || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || KH < 1 || KW < 1 || stride < 1) return MGN_EINVAL;
-    if (Cin % 8 != 0 || Cout % 8 != 0) return MGN_ENOTSUP;
+    if ((Cin % 8 != 0 && Cin != 4) || Cout % 8 != 0) return MGN_ENOTSUP;
     WgradParams p;
     p.dout = (const uint16_t*)dout; p.in = (const uint16_t*)in; p.dw = dw;
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
@@ -2425,11 +2446,13 @@ static int wgrad_impl(const void* dout, const void* in, float* dw, int N, int IH
         if (!attrs) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_stem16), hipFuncAttributeMaxDynamicSharedMemorySize, WS<16>::LDS);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_stem8), hipFuncAttributeMaxDynamicSharedMemorySize, WS<8>::LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_stem4), hipFuncAttributeMaxDynamicSharedMemorySize, WS<4>::LDS);
             attrs = true;
         }
         const unsigned nblk = (unsigned)((ps.nslices + 7) / 8) * 8 * ps.co_tiles;
         if (Cin == 16) hipLaunchKernelGGL(conv_wgrad_stem16, dim3(nblk), dim3(512), WS<16>::LDS, st, ps);
-        else hipLaunchKernelGGL(conv_wgrad_stem8, dim3(nblk), dim3(512), WS<8>::LDS, st, ps);
+        else if (Cin == 8) hipLaunchKernelGGL(conv_wgrad_stem8, dim3(nblk), dim3(512), WS<8>::LDS, st, ps);
+        else hipLaunchKernelGGL(conv_wgrad_stem4, dim3(nblk), dim3(512), WS<4>::LDS, st, ps);
         hipLaunchKernelGGL(conv_wgrad_stem_reduce, dim3((unsigned)Cout * 7), dim3(256), 0, st, (const float*)workspace, ps.nslices, Cout, Cin,
                            oihw_cin, dw);
         return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;

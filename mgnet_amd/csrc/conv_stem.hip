@@ -23,6 +23,14 @@
 //   stores : 16-byte buffer stores (out-of-range pixels dropped by the bounds check: the instruction count per patch is
 //            constant, so `s_waitcnt vmcnt(8)` at the top of the next patch waits for the window DMA but not for the stores)
 //   stats  : per-lane running sums over ALL patches of the block, one partial row per block at the end
+//
+// CP = 4 (round 5, the backbone stem at its dense K): the input is [N, IH, IW, 4] (3 real channels, 8 bytes per pixel, IW even) and a
+// kernel ROW is one dense run of 8 column slots x 4 channels = 32 k-values: slot kw' = kw + 1 (slot 0 has zero weights), so that the
+// window starts at the EVEN image column 2 ox0 - 4 and a 16-byte LDS element is an aligned PAIR of pixels = the eight k-values
+// (slots 2j, 2j + 1) a lane feeds to one MFMA.  Output column ox and slot pair j read element (ox - ox0) + j of the window row: no
+// parity planes, 32 lanes x 16 contiguous bytes.  K = 7 x 32 = 224 instead of 49 x 8 = 392 (147 real): 14 slabs instead of 25, a
+// 21 x 36-element window (12 KB) instead of 24 KB.  A wave owns 4 output rows x 32 channels (56 weight registers, 64 accumulators):
+// under 256 registers, so TWO blocks share a CU and one block's window DMA latency hides behind the other's MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -55,10 +63,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 template <int CP> struct Stem {
     static constexpr int NH = CP / 8;                  // 16-byte channel halves per pixel
-    static constexpr int S = CP == 8 ? 25 : 49;        // k-slabs of 16
+    static constexpr int S = CP == 4 ? 14 : (CP == 8 ? 25 : 49);   // k-slabs of 16
+    static constexpr int SPR = CP == 4 ? 4 : 7;        // slabs two window rows further down (CP = 4 | 8: the shared fragment stream)
     static constexpr int CB = CP == 8 ? 2 : 1;         // 32-channel blocks per wave
-    static constexpr int RW = CP == 8 ? 2 : 4;         // output rows per wave
-    static constexpr int ROWP = NH * 2 * PLANE;        // 16-byte elements per window row
+    static constexpr int RW = CP == 8 ? 2 : 4;         // output rows per wave  (CB = 1: 2 row groups x 2 channel halves of waves)
+    static constexpr int BPC = CP == 4 ? 2 : 1;        // resident blocks per CU the kernel is built for
+    static constexpr int ROWP = CP == 4 ? PLANE : NH * 2 * PLANE;   // 16-byte elements per window row
     static constexpr int ELEMS = WROWS * ROWP;
     static constexpr int CHUNKS = (ELEMS + 63) / 64;   // 1-KB DMA pieces: 24 / 48
     static constexpr int CPW = CHUNKS / 4;             // per wave
@@ -80,7 +90,7 @@ __device__ __forceinline__ void stem_body(const StemParams& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
-    const int wr = CP == 8 ? wave : (wave >> 1), wc = CP == 8 ? 0 : (wave & 1);   // row group / channel half of the wave
+    const int wr = CB == 1 ? (wave >> 1) : wave, wc = CB == 1 ? (wave & 1) : 0;   // row group / channel half of the wave
 
     const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * CP * 2), out_bytes = (uint32_t)((size_t)p.N * p.OH * p.OW * 64 * 2);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, in_bytes, 0x00020000);
@@ -92,6 +102,10 @@ __device__ __forceinline__ void stem_body(const StemParams& p) {
     for (int j = 0; j < G::CPW; ++j) {
         const int e = (wave + 4 * j) * 64 + lane;
         const int rowl = e / G::ROWP, rem = e - rowl * G::ROWP;
+        if (CP == 4) {   // element = the pixel pair at window columns 2 rem, 2 rem + 1 (35 pairs are real)
+            desc[j] = (e < G::ELEMS && rem <= SPW + 2) ? ((rowl << 16) | (2 * rem << 1)) : -1;
+            continue;
+        }
         const int h = rem / (2 * PLANE), r2 = rem - h * 2 * PLANE;
         const int plane = r2 / PLANE, idx = r2 - plane * PLANE;
         const int lc = 2 * idx + plane;
@@ -101,7 +115,7 @@ __device__ __forceinline__ void stem_body(const StemParams& p) {
     const int ppi = p.py * p.px;
     auto issue = [&](int patch, int buf) {
         const int n = patch / ppi, prem = patch - n * ppi, pyi = prem / p.px, pxi = prem - pyi * p.px;
-        const int iy0 = 2 * SPH * pyi - 3, ix0 = 2 * SPW * pxi - 3;
+        const int iy0 = 2 * SPH * pyi - 3, ix0 = 2 * SPW * pxi - (CP == 4 ? 4 : 3);
         unsigned char* dst = sm + buf * G::WBUF + wave * 1024;
 #pragma unroll
         for (int j = 0; j < G::CPW; ++j) {
@@ -155,13 +169,15 @@ __device__ __forceinline__ void stem_body(const StemParams& p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][cb][e] = 0.f;
         const unsigned char* win = sm + buf * G::WBUF + lbase;
-        if (CP == 8) {
-            // slab = two taps (lane halves).  Output row i at slab s reads what output row 0 reads at slab s + 7 (two window rows =
+        if (CP != 16) {
+            // slab = two taps (lane halves); CP = 4: two slot pairs of a kernel row (element (t & 1) * 2 + hi of window row t >> 1).  Output row i at slab s reads what output row 0 reads at slab s + 7 (two window rows =
             // 14 taps further down): ONE fragment stream F(t), t = s + 7 i, serves all rows -- 25 + 7 (RW - 1) reads for 25 RW CB
             // MFMAs.  The odd tap of the last slab (tap 49) has zero weights: any finite window element will do.
-            constexpr int T = S + 7 * (RW - 1), PF = 2;   // PF: fragments in flight ahead of the matrix cores
+            constexpr int SPR = G::SPR;
+            constexpr int T = S + SPR * (RW - 1), PF = 2;   // PF: fragments in flight ahead of the matrix cores
             constexpr int RMAX = 6 + 2 * (RW - 1);        // last window row of a wave
             auto sfrag = [&](int t) {
+                if (CP == 4) return *reinterpret_cast<const h16x8*>(win + ((t >> 1) * G::ROWP + (t & 1) * 2 + hi) * 16);
                 const int u0 = 2 * t, u1 = (2 * t + 1) / 7 <= RMAX ? 2 * t + 1 : 2 * t;
                 return *reinterpret_cast<const h16x8*>(win + (hi ? tap_off<CP>(u1) : tap_off<CP>(u0)));
             };
@@ -173,7 +189,7 @@ __device__ __forceinline__ void stem_body(const StemParams& p) {
                 if (t + PF < T) a[(t + PF) % (PF + 1)] = sfrag(t + PF);
 #pragma unroll
                 for (int i = 0; i < RW; ++i) {
-                    const int sl = t - 7 * i;
+                    const int sl = t - SPR * i;
                     if (sl >= 0 && sl < S) {
 #pragma unroll
                         for (int cb = 0; cb < CB; ++cb) acc[i][cb] = MGN_MFMA_32x32x16(wf[sl][cb], a[t % (PF + 1)], acc[i][cb]);
@@ -256,7 +272,7 @@ __device__ __forceinline__ void stem_body(const StemParams& p) {
             v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
             return v;
         };
-        constexpr int NP = (CP == 8 ? 4 : 2) * 2;
+        constexpr int NP = (CB == 1 ? 2 : 4) * 2;
         float* red = reinterpret_cast<float*>(sm + 2 * G::WBUF);   // [NP][64 channels][2]
         const int rw = (lane >> 4) & 1;
 #pragma unroll
@@ -281,6 +297,7 @@ __device__ __forceinline__ void stem_body(const StemParams& p) {
     }
 }
 
+__global__ __launch_bounds__(256, 2) void conv_stem7_d4(StemParams p) { stem_body<4>(p); }
 __global__ __launch_bounds__(256, 1) void conv_stem7_c8(StemParams p) { stem_body<8>(p); }
 __global__ __launch_bounds__(256, 1) void conv_stem7_c16(StemParams p) { stem_body<16>(p); }
 
@@ -291,7 +308,8 @@ extern "C" {
 #ifndef MGN_F16
 /* number of blocks (= statistics rows) the persistent stem kernel uses for this layer, 0 = not a layer for it */
 int mgn_conv_stem7_blocks(int N, int IH, int IW, int Cin, int OH, int OW, int Cout) {
-    if ((Cin != 8 && Cin != 16) || Cout != 64 || N < 1 || IH < 1 || IW < 1) return 0;
+    if ((Cin != 4 && Cin != 8 && Cin != 16) || Cout != 64 || N < 1 || IH < 1 || IW < 1) return 0;
+    if (Cin == 4 && ((IW & 1) || getenv("MGN_CONV_NOSTEM4"))) return 0;   // (pixel pairs: even rows; the caller then pads to 8 channels)
     if (OH != (IH + 6 - 7) / 2 + 1 || OW != (IW + 6 - 7) / 2 + 1) return 0;
     if ((size_t)N * IH * IW * Cin * 2 >= 0x7fffffffu || (size_t)N * OH * OW * 64 * 2 >= 0x7fffffffu) return 0;
     if (getenv("MGN_CONV_NOSTEM7")) return 0;
@@ -303,11 +321,12 @@ int mgn_conv_stem7_blocks(int N, int IH, int IW, int Cin, int OH, int OW, int Co
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                   ? prop.multiProcessorCount : 256;
     }
-    return (int)(np < cus ? np : cus);
+    const long cap = (long)cus * (Cin == 4 ? Stem<4>::BPC : 1);
+    return (int)(np < cap ? np : cap);
 }
 #endif
 
-/* 7x7 / stride 2 / pad 3, Cin = 8 | 16 (channel-padded), Cout = 64: see the header of this file.  MGN_ENOTSUP for other shapes. */
+/* 7x7 / stride 2 / pad 3, Cin = 4 | 8 | 16 (channel-padded), Cout = 64: see the header of this file.  MGN_ENOTSUP for other shapes. */
 int MGN_SYM(mgn_conv_stem7)(const void* in, const void* w_packed, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout,
                             float* stat_partials, void* stream) {
     const int blocks = mgn_conv_stem7_blocks(N, IH, IW, Cin, OH, OW, Cout);
@@ -321,11 +340,13 @@ int MGN_SYM(mgn_conv_stem7)(const void* in, const void* w_packed, void* out, int
     hipStream_t st = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7_d4), hipFuncAttributeMaxDynamicSharedMemorySize, Stem<4>::LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7_c8), hipFuncAttributeMaxDynamicSharedMemorySize, Stem<8>::LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7_c16), hipFuncAttributeMaxDynamicSharedMemorySize, Stem<16>::LDS);
         attr = true;
     }
-    if (Cin == 8) hipLaunchKernelGGL(conv_stem7_c8, dim3(blocks), dim3(256), Stem<8>::LDS, st, p);
+    if (Cin == 4) hipLaunchKernelGGL(conv_stem7_d4, dim3(blocks), dim3(256), Stem<4>::LDS, st, p);
+    else if (Cin == 8) hipLaunchKernelGGL(conv_stem7_c8, dim3(blocks), dim3(256), Stem<8>::LDS, st, p);
     else hipLaunchKernelGGL(conv_stem7_c16, dim3(blocks), dim3(256), Stem<16>::LDS, st, p);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }

@@ -2,7 +2,7 @@
 //
 // Replaces mgnet/modeling/mg_net.py:250-264: `x.float()/255`, `(x - pixel_mean)/pixel_std` for image / image_prev /
 // image_next and the channel concatenation fed to PoseCNN -- ~12 elementwise torch kernels and three fp32 copies of every
-// frame in the reference.  One pass: reads 3 bytes per frame and pixel, writes one 16- or 32-byte NHWC pixel whose padding
+// frame in the reference.  One pass: reads 3 bytes per frame and pixel, writes one 8-, 16- or 32-byte NHWC pixel whose padding
 // channels are zero (the layout the packed-tap stem convolution consumes).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,6 +36,10 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
         const uint8_t* src = p.frames[f] + (b * 3) * hw + px;
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[f * 3 + c] = f2bf((float)src[c * hw] * p.scale[c] + p.shift[c]);
+    }
+    if (p.Cp == 4) {   // the dense-row backbone stem (csrc/conv_stem.hip CP = 4): 8 bytes per pixel
+        *reinterpret_cast<uint2*>(p.out + i * 4) = make_uint2(v[0] | (v[1] << 16), v[2]);
+        return;
     }
     uint4* dst = reinterpret_cast<uint4*>(p.out + i * p.Cp);
     dst[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
@@ -142,7 +146,7 @@ extern "C" int mgn_u8_frames_to_f32(const void* const* frames_u8, int n_frames, 
 extern "C" int MGN_SYM(mgn_prep_input)(const void* const* frames_u8, int n_frames, int B, int H, int W, const float* pixel_mean3,
                               const float* pixel_std3, void* out_bf16, int Cp, void* stream) {
     if (!frames_u8 || n_frames < 1 || n_frames > 3 || B < 1 || H < 1 || W < 1 || !pixel_mean3 || !pixel_std3 || !out_bf16) return MGN_EINVAL;
-    if ((Cp != 8 && Cp != 16) || n_frames * 3 > Cp) return MGN_EINVAL;
+    if ((Cp != 4 && Cp != 8 && Cp != 16) || n_frames * 3 > Cp) return MGN_EINVAL;
     PrepParams p;
     for (int f = 0; f < 3; ++f) p.frames[f] = f < n_frames ? (const uint8_t*)frames_u8[f] : nullptr;
     for (int c = 0; c < 3; ++c) {  // pixel_mean / pixel_std are in the 0..1 domain (mg_net.py:86-91: cfg value / 255)

@@ -236,7 +236,9 @@ class MGNet(nn.Module):
                     handover(main, side[2 if len(side) > 2 else 0], pframes)
                 with on(2 if (side and len(side) > 2) else 0):
                     pose_in = _C.prep_input(pframes, mean, std, 16, self.amp_dtype)   # channels: image, prev, next (:264)
-            inputs["image"] = _C.prep_input(frames, mean, std, 8, self.amp_dtype)
+            # 3 -> 4 channels where the dense-row stem kernel takes the shape (csrc/conv_stem.hip CP = 4), else 3 -> 8
+            cp = _C.stem_input_channels(*[frames[0].shape[i] for i in (0, 2, 3)])
+            inputs["image"] = _C.prep_input(frames, mean, std, cp, self.amp_dtype)
         else:
             inputs["image"] = self._net_input(batched_inputs, "image")
             if self.training and self.with_depth:

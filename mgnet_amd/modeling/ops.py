@@ -300,12 +300,12 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, pad, relu, with_skip=False, cout_pad=0, stats=None, keep_pad=False):
         from .. import _C
 
-        N, Cin, IH, IW = x.shape   # Cin of the ACTIVATION (8/16 = channel-padded stem input)
+        N, Cin, IH, IW = x.shape   # Cin of the ACTIVATION (4/8/16 = channel-padded stem input)
         Cout, _, KH, KW = weight.shape
         OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
         xs = x.contiguous(memory_format=torch.channels_last)
         b = None if bias is None else bias.detach().float().contiguous()
-        packed = Cin in (8, 16)
+        packed = Cin in (4, 8, 16)
         if packed:  # stem on a channel-padded input: k = tap*Cin + c, row padded to a multiple of 32
             out = _C.conv_igemm(xs, _C.weight_layout(weight, 2, Cin, dtype=xs.dtype), (OH, OW), b, stride, pad, 1, relu, khw=(KH, KW), stats=stats)
         else:

@@ -81,7 +81,8 @@ def test_mfma_fragment_layout_is_not_transposed():
     assert torch.equal(y[0, :, 0, :], ref)
 
 
-@pytest.mark.parametrize("cfg", [(2, 3, 8, 64, 40, 56), (1, 9, 16, 64, 33, 47), (2, 3, 8, 128, 32, 32)])
+@pytest.mark.parametrize("cfg", [(2, 3, 8, 64, 40, 56), (1, 9, 16, 64, 33, 47), (2, 3, 8, 128, 32, 32), (2, 3, 4, 64, 40, 56),
+                                 (1, 3, 4, 64, 33, 46), (3, 3, 4, 64, 70, 300)])
 def test_stem_7x7_packed_taps(cfg):
     """7x7 stride-2 stems on the channel-padded input of csrc/prep.hip (3 -> 8, 9 -> 16 channels): forward + wgrad."""
     from mgnet_amd.modeling import ops
@@ -148,6 +149,66 @@ def test_stem_persistent_window_kernel(cfg, dtype, monkeypatch):
     assert float(((st[2] - m2) / m2).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(2, 40, 56), (3, 17, 130), (1, 7, 10), (5, 50, 200), (3, 256, 512), (2, 1024, 2048), (1, 21, 66), (2, 35, 62)])
+def test_stem_dense_rows_kernel(cfg, dtype):
+    """csrc/conv_stem.hip CP = 4 (the backbone stem at K = 7 x 32 = 224: 4-channel pixels, kernel rows as dense runs of 8 column slots):
+    ragged shapes, several patches per block, both formats; against fp64, against the 8-channel kernel on the same values (same
+    products, another summation order: a few fp32 ulps before the rounding to 16 bits), its statistics rows against the fp64 statistics;
+    and the weight gradient of the same layout (conv_wgrad_stem4) against the 8-channel kernel and fp64."""
+    from mgnet_amd import _C
+
+    N, H, W = cfg
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    torch.manual_seed(H + W)
+    x8 = torch.zeros(N, 8, H, W, device="cuda")
+    x8[:, :3] = torch.randn(N, 3, H, W, device="cuda") + 0.3
+    x8 = x8.to(dtype).contiguous(memory_format=torch.channels_last)
+    x4 = x8[:, :4].contiguous(memory_format=torch.channels_last)
+    assert _C.stem_input_channels(N, H, W) == 4
+    w = torch.nn.Parameter(torch.randn(64, 3, 7, 7, device="cuda") / (3 * 49) ** 0.5)
+    wl4, wl8 = _C.weight_layout(w, 2, 4, dtype=dtype), _C.weight_layout(w, 2, 8, dtype=dtype)
+    assert wl4.shape == (64, 224)
+    rows = _C.lib().mgn_conv_stem7_blocks(N, H, W, 4, OH, OW, 64)
+    assert rows > 0 and rows == _C.lib().mgn_conv_stat_rows(N, H, W, 4, OH, OW, 64, 7, 7, 2, 3, None)
+    holder = []
+    y = _C.conv_igemm(x4, wl4, (OH, OW), None, 2, 3, khw=(7, 7), stats=(None, holder))
+    part = holder[0][0]
+    assert part.shape == (rows, 64, 2)
+    assert torch.equal(y, _C.conv_igemm(x4, wl4, (OH, OW), None, 2, 3, khw=(7, 7)))
+    y8 = _C.conv_igemm(x8, wl8, (OH, OW), None, 2, 3, khw=(7, 7))
+    scale = float(y8.float().abs().max())
+    assert float((y.float() - y8.float()).abs().max()) <= 2 ** -7 * scale          # one 16-bit ulp at the largest magnitude
+    assert float((y != y8).float().mean()) < 0.05
+    if N * H * W <= 2 ** 21:
+        ref = F.conv2d(x8[:, :3].double(), w.detach().to(dtype).double(), stride=2, padding=3)
+        assert float((y.double() - ref).abs().max() / ref.abs().max()) < 6e-3
+    st = _C.iabn_from_partials(part, 64, N * OH * OW, None, stats_only=True).double()
+    yd = y.permute(1, 0, 2, 3).reshape(64, -1).double()
+    mean = yd.mean(1)
+    m2 = ((yd - mean[:, None]) ** 2).sum(1)
+    assert float((st[1] - mean).abs().max()) < 2e-6 * float(yd.abs().max())
+    assert float(((st[2] - m2) / m2).abs().max()) < 2e-5
+    # weight gradient
+    g = torch.randn(N, 64, OH, OW, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    dw4 = _C.conv_wgrad(g, x4, 7, 7, 2, 3, cin_real=3)
+    dw8 = _C.conv_wgrad(g, x8, 7, 7, 2, 3, cin_real=3)
+    assert dw4.shape == (64, 3, 7, 7)
+    assert float((dw4 - dw8).abs().max()) <= 2e-5 * float(dw8.abs().max()) + 1e-6 * (N * OH * OW) ** 0.5
+    if N * H * W <= 2 ** 19:
+        xr = x8[:, :3].double().requires_grad_(False)
+        wr = w.detach().double().requires_grad_(True)
+        (F.conv2d(xr, wr, stride=2, padding=3) * g.double()).sum().backward()
+        assert float((dw4.double() - wr.grad).abs().max() / wr.grad.abs().max()) < 1e-5
+
+
+def test_dense_stem_falls_back_to_eight_channels_on_odd_widths(monkeypatch):
+    from mgnet_amd import _C
+    assert _C.stem_input_channels(2, 40, 57) == 8 and _C.stem_input_channels(2, 40, 56, real=9) == 16
+    monkeypatch.setenv("MGN_CONV_NOSTEM4", "1")
+    assert _C.stem_input_channels(2, 40, 56) == 8
+
+
 def test_prep_input_matches_reference_normalisation():
     """mg_net.py:250-264: x/255, (x-mean)/std, cat(image, prev, next) -- against torch ops."""
     from mgnet_amd import _C
@@ -163,6 +224,9 @@ def test_prep_input_matches_reference_normalisation():
     assert float(out16[:, 9:].abs().max()) == 0.0
     out8 = _C.prep_input([frames[0].cuda()], mean, std, 8)
     assert torch.equal(out8[:, :3], out16[:, :3]) and float(out8[:, 3:].abs().max()) == 0.0
+    out4 = _C.prep_input([frames[0].cuda()], mean, std, 4)
+    assert out4.shape == (2, 4, 24, 40) and out4.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out4[:, :3], out16[:, :3]) and float(out4[:, 3:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("big,case", [("256", (1, 64, 256, 19, 23, 3, 1, 1)), ("256", (2, 128, 512, 9, 14, 3, 2, 1)),
