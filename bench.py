@@ -244,13 +244,55 @@ def fp16_leg(args, dev, B, H, W, steps=None):
             "losses_finite": bool(all(torch.isfinite(v.detach()).item() for v in last.values()))}
 
 
+def eval_leg(args, dev, H, W):
+    """Inference throughput of the same network (mg_net.py:375-520: eval-mode forward + the per-image post-processing -- panoptic
+    fusion, depth scaling -- at full resolution): single-scale at B = 1 and B = 8, and the 14-pass multi-scale + flip protocol
+    (TEST.MSC_FLIP_EVAL) at B = 1.  Informative (not the headline metric): wall clock around a few calls, device synchronised on both
+    sides, inputs resident in HBM.  The norm layers run their eval form (one affine + activation pass per layer, no statistics)."""
+    from mgnet_amd import add_mgnet_config, get_cfg
+    from mgnet_amd.data import synthetic_batch
+    from mgnet_amd.registry import build_model
+    cfg = get_cfg()
+    add_mgnet_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "bench-c4-cityscapes-videosequence.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", str(dev)])
+    torch.manual_seed(0)
+    model = build_model(cfg).eval()
+
+    def timed(batch, n, warm):
+        with torch.no_grad():
+            for _ in range(warm):
+                model(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                out = model(batch)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        assert len(out) == len(batch) and all(torch.isfinite(r["depth"][0]).all().item() for r in out)
+        return {"ms_per_call": round(dt * 1e3, 2), "img_per_s": round(len(batch) / dt, 2), "calls": n}
+    res = {"what": f"model.eval()(batch): forward + panoptic / depth post-processing per image at {H}x{W}, bf16, random-init weights, synthetic frames",
+           "post_processing": "on the device (csrc/postproc.hip), per image like the reference"}
+    def frames(B):   # the inference fields of the dataset mapper: image, 3x3 camera matrix, camera height (mg_net.py:404-417)
+        batch = synthetic_batch(B, H, W, dev, seed=77)
+        for d in batch:
+            d["camera_matrix"] = d["camera_matrix"][:3, :3].cpu()
+            d["camera_height"] = torch.tensor([1.22])
+        return batch
+    for B, n in ((1, 10), (8, 4)):
+        res[f"single_scale_B{B}"] = timed(frames(B), n, 2)
+    model.msc_flip_eval = True
+    res["msc_flip_14_passes_B1"] = timed(frames(1), 2, 1)
+    return res
+
+
 def fp16_leg_child(args):
     """The fp16 leg as a CHILD process running this script with --dtype fp16 (a fresh process, started -- not exec'ed -- after the
     bf16 measurement): inside the parent, behind its other legs, the same steps ran 1-1.5 ms slower than as a run of their own (so did the
     conv roofline leg: 289 vs 249 us for the same launch), which is what round 3 reported as the 'fp16 gap'.  Two stand-alone runs per dtype
     on one box differ by +0.44 ms (profiles/r04_fp16_vs_bf16.txt)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp16", "--no-fp16-leg", "--no-cpu-baseline", "--no-host-probe", "--steps",
+    cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp16", "--no-fp16-leg", "--no-eval-leg", "--no-cpu-baseline", "--no-host-probe", "--steps",
            str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width),
            "--exec", args.exec, "--timeout", str(min(args.timeout, 600.0))]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(args.timeout, 600.0) + 30)
@@ -540,6 +582,12 @@ def full_step_bench(args, world, rank, dev):
             except Exception as e:  # noqa: BLE001
                 line["fp16"] = {"error": f"{type(e).__name__}: {e}"}
             model = None
+        if world == 1 and args.dtype == "bf16" and not args.no_eval_leg:
+            try:
+                line["eval"] = eval_leg(args, dev, H, W)
+            except Exception as e:  # noqa: BLE001 -- informative only
+                line["eval"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(H, W, state_dict_cpu, cfg)
         print(json.dumps(line), flush=True)
@@ -626,6 +674,7 @@ def main():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="on: replay the captured step as a hipGraph (1 GPU, one stream); auto/off: issue every launch from Python "
                          "with the independent branches on side streams (the faster mode)")
+    ap.add_argument("--no-eval-leg", action="store_true", help="skip the inference-throughput object (`eval`) measured after the training step (N = 1)")
     ap.add_argument("--no-fp16-leg", action="store_true", help="skip the 5 fp16 + loss-scaling steps run after the bf16 measurement (N = 1)")
     ap.add_argument("--timeout", type=float, default=1500.0,
                     help="seconds after which a rank (and, with --gpus N self-launch, the whole child job) is stopped and the bench exits non-zero")

@@ -242,6 +242,20 @@ int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int
 int mgn_conv_wgrad_partial(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
                            int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
 int mgn_conv_wgrad_reduce_batch(const void* table_dev, int n_entries, long total_blocks, void* stream);
+/* The FeatureFusionModule's 1x1 convolution over torch.cat([fsp, fcp], dim=1) (layers.py:316-317) WITHOUT the concatenated map -- the
+ * three decoders each copied 2 x 67 MB into it and split its gradient again (mgn_concat2 / mgn_split2, 0.28 ms per step):
+ *   mgn_conv1x1_cat   out = conv1x1(in0 | in1, w): in0, in1 [N,H,W,128], w [Cout][256] (layout mode 0), Cout % 256 == 0; the rows of the
+ *                     streaming kernel's LDS tile arrive as two half rows from the two maps;
+ *   mgn_conv1x1_split (out0 | out1) = conv1x1(in, w): in [N,H,W,256] = the output gradient, w [256][256] (layout mode 1): the data
+ *                     gradient, its two channel halves written to maps of their own;
+ *   mgn_conv_wgrad_cat weight gradient against (in0 | in1), Cin % 256 == 0: dw != NULL reduces at once (like mgn_conv_wgrad), desc8 !=
+ *                     NULL leaves the split partials for mgn_conv_wgrad_reduce_batch (like mgn_conv_wgrad_partial); exactly one of them.
+ * Same arithmetic in the same order as the plain kernels on the concatenated map: bit-identical results (tests/test_conv_gpu.py).
+ * MGN_ENOTSUP: other channel counts or maps too small for the streaming kernel (the caller concatenates). */
+int mgn_conv1x1_cat(const void* in0, const void* in1, const void* w, void* out, int N, int H, int W, int Cin, int Cout, void* stream);
+int mgn_conv1x1_split(const void* in, const void* w, void* out0, void* out1, int N, int H, int W, int Cin, int Cout, void* stream);
+int mgn_conv_wgrad_cat(const void* dout, const void* in0, const void* in1, float* dw, int N, int H, int W, int Cin, int Cout,
+                       void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution (forward, or data gradient on flipped+transposed weights) with Cin % 32 == 0 and
  * Cout % 128 == 0 as a WINDOWED implicit GEMM (csrc/conv_win.hip): a block owns a patch of patch_rows (8 | 16) x 32 output pixels
  * and keeps the input window in LDS for all nine taps.  Same tensors as mgn_conv_igemm (which dispatches here for the
@@ -787,6 +801,10 @@ int mgn_conv3x3_up2_win_f16(const void* in, const void* w, void* out, int N, int
     int ksize, const void* residual, int residual_lowres, void* stream);
 int mgn_conv_wgrad_partial_f16(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
     int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
+int mgn_conv1x1_cat_f16(const void* in0, const void* in1, const void* w, void* out, int N, int H, int W, int Cin, int Cout, void* stream);
+int mgn_conv1x1_split_f16(const void* in, const void* w, void* out0, void* out1, int N, int H, int W, int Cin, int Cout, void* stream);
+int mgn_conv_wgrad_cat_f16(const void* dout, const void* in0, const void* in1, float* dw, int N, int H, int W, int Cin, int Cout,
+                           void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
 int mgn_abn_apply_pool_f16(const void* x, void* z, const float* scale, const float* offset, int act, float slope, int N, long HW, int C,
                            float pool_scale, float* pooled, float* workspace, size_t workspace_bytes, void* stream);
 int mgn_att_abn_bwd_stats_f16(const void* g, const void* z, const float* weight, const float* bias, float eps, int act, float slope, int N, long HW,

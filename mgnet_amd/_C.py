@@ -16,7 +16,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_optim_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv3x3_up2_win", "mgn_conv_win_patch_rows", "mgn_conv_stem7", "mgn_conv_stem7_blocks", "mgn_iabn_coeffs_from_partials", "mgn_iabn_partials_reduce", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_optim_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv3x3_up2_win", "mgn_conv_win_patch_rows", "mgn_conv_stem7", "mgn_conv_stem7_blocks", "mgn_iabn_coeffs_from_partials", "mgn_iabn_partials_reduce", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv1x1_cat", "mgn_conv1x1_split", "mgn_conv_wgrad_cat", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_adjoint_footprint_floats", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_sum3", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -32,7 +32,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_plan_compile", "mgn_plan_set_stream", "mgn_plan_run", "mgn_plan_prof_elapsed", "mgn_plan_free",
            "mgn_plan_trace", "mgn_plan_trace_read", "mgn_plan_set_skip", "mgn_plan_node_ro", "mgn_plan_set_jitter", "mgn_plan_probe",
            "mgn_abn_apply_pool", "mgn_att_abn_bwd_stats", "mgn_att_abn_bwd_sums", "mgn_att_abn_bwd_apply"]
-SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']]
+SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_conv1x1_cat', 'mgn_conv1x1_split', 'mgn_conv_wgrad_cat', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']]
 DEPTH_MAX_FILTER_IDS = 16
 MGN_MAX_TASKS = 8   # include/mgnet_hip.h
 
@@ -85,7 +85,7 @@ def plan_touch(reads=(), writes=()):
 
 
 H16 = (torch.bfloat16, torch.float16)   # the 16-bit activation formats: bf16 entry points, or their _f16 twins (csrc/h16.h)
-F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']
+F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_conv1x1_cat', 'mgn_conv1x1_split', 'mgn_conv_wgrad_cat', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']
 
 
 def _fn(name, t):
@@ -138,6 +138,10 @@ def lib():
         L.mgn_iabn_partials_reduce.argtypes = [vp, ci, ci, ci, vp, vp]
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
+        for sfx in ("", "_f16"):
+            getattr(L, "mgn_conv1x1_cat" + sfx).argtypes = [vp, vp, vp, vp] + [ci] * 5 + [vp]
+            getattr(L, "mgn_conv1x1_split" + sfx).argtypes = [vp, vp, vp, vp] + [ci] * 5 + [vp]
+            getattr(L, "mgn_conv_wgrad_cat" + sfx).argtypes = [vp, vp, vp, vp] + [ci] * 5 + [vp, sz, vp, vp]
         L.mgn_conv_wgrad_partial.argtypes = [vp, vp] + [ci] * 12 + [vp, sz, ctypes.POINTER(ctypes.c_longlong), vp]
         L.mgn_conv_wgrad_reduce_batch.argtypes = [vp, ci, cl, vp]
         L.mgn_weight_layout.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
@@ -1034,6 +1038,54 @@ def conv_wgrad(dy, x, kh, kw, stride, pad, cin_real=None, lazy=False):
             check(rc, "mgn_conv_wgrad_partial")
     check(_fn("mgn_conv_wgrad", dy)(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, IH, IW, Cin, OH, OW, Cout, kh, kw, stride, pad,
                                cin_real, ws.data_ptr(), nb.value, _stream()), "mgn_conv_wgrad")
+    return dw
+
+
+def conv1x1_cat(a, b, w_ohwi):
+    """conv1x1(cat([a, b], 1), w) without the concatenated map: a, b [N,128,H,W] channels_last 16-bit, w_ohwi [Cout,1,1,256]; None if the
+    shape is not one the two-source streaming kernel takes (mgn_conv1x1_cat)"""
+    N, Ca, H, W = a.shape
+    Cout = w_ohwi.shape[0]
+    if not (Ca == 128 and b.shape == a.shape and Cout % 256 == 0 and a.dtype == b.dtype == w_ohwi.dtype and w_ohwi.shape[1:] == (1, 1, 256)):
+        return None
+    out = torch.empty((N, Cout, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
+    rc = _fn("mgn_conv1x1_cat", a)(a.data_ptr(), b.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), N, H, W, 256, Cout, _stream())
+    if rc == -95:
+        return None
+    check(rc, "mgn_conv1x1_cat")
+    return out
+
+
+def conv1x1_split(dy, w_ihwo):
+    """the data gradient of conv1x1_cat: dy [N,256,H,W], w_ihwo [256,1,1,256] (layout mode 1) -> (da, db) [N,128,H,W] each, or None"""
+    N, C, H, W = dy.shape
+    if not (C == 256 and tuple(w_ihwo.shape) == (256, 1, 1, 256) and dy.dtype == w_ihwo.dtype):
+        return None
+    da = torch.empty((N, 128, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    db = torch.empty_like(da)
+    rc = _fn("mgn_conv1x1_split", dy)(dy.data_ptr(), w_ihwo.data_ptr(), da.data_ptr(), db.data_ptr(), N, H, W, 256, 256, _stream())
+    if rc == -95:
+        return None
+    check(rc, "mgn_conv1x1_split")
+    return da, db
+
+
+def conv_wgrad_cat(dy, a, b, lazy=False):
+    """weight gradient of conv1x1_cat: dy [N,Cout,H,W], a / b [N,C/2,H,W] -> dw fp32 [Cout, C, 1, 1] (lazy: as conv_wgrad)"""
+    N, Cout, H, W = dy.shape
+    Cin = a.shape[1] + b.shape[1]
+    dw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=dy.device)
+    nb = ctypes.c_size_t(0)
+    check(lib().mgn_conv_wgrad_workspace_bytes(N, H, W, Cin, Cout, 1, 1, ctypes.byref(nb)), "mgn_conv_wgrad_workspace_bytes")
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=dy.device)
+    if lazy and WGRAD_LAZY[0]:
+        desc = (ctypes.c_longlong * 8)()
+        check(_fn("mgn_conv_wgrad_cat", dy)(dy.data_ptr(), a.data_ptr(), b.data_ptr(), None, N, H, W, Cin, Cout, ws.data_ptr(), nb.value, desc, _stream()),
+              "mgn_conv_wgrad_cat")
+        WGRAD_PENDING[dw.data_ptr()] = (list(desc), ws, tuple(dw.shape), WGRAD_LAZY[0])
+        return dw
+    check(_fn("mgn_conv_wgrad_cat", dy)(dy.data_ptr(), a.data_ptr(), b.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, ws.data_ptr(), nb.value, None,
+                                         _stream()), "mgn_conv_wgrad_cat")
     return dw
 
 

@@ -492,14 +492,16 @@ __global__ __launch_bounds__(256) void conv_igemm_glds(ConvParams p) {
 //   * D = W-rows x pixels (lane = pixel) with the v_permlane32_swap epilogue: 16-byte stores of 8 consecutive channels.
 // Grid: (min(tiles, 256), Cout / (32*NT*WN)).  No bias / ReLU / residual / fp32 output (those layers keep the generic kernel).
 struct Conv1Params {
-    const uint16_t* in;   // [N, IH, IW, CIN]
+    const uint16_t* in;   // [N, IH, IW, CIN]   (in2 != null: channels [0, CIN/2) only, [N, IH, IW, CIN/2])
     const uint16_t* w;    // [Cout, CIN]
-    uint16_t* out;        // [N, OH, OW, Cout]
+    uint16_t* out;        // [N, OH, OW, Cout]  (out2 != null: channels [0, Cout/2) only, [N, OH, OW, Cout/2])
     int N, IH, IW, OH, OW, Cout, stride;
     long M;               // N * OH * OW
     int ntiles;
+    const uint16_t* in2;  // the input is the channel concatenation (in | in2) of two maps, never materialised (FeatureFusionModule)
+    uint16_t* out2;       // the output's upper half of the channels goes to a map of its own (the concatenation's data gradient)
 };
-MGN_PLAN_RO(Conv1Params, MGN_RO(in) MGN_RO(w))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO(Conv1Params, MGN_RO(in) MGN_RO(w) MGN_RO(in2))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 template <int CIN, int NT, int WN>
 struct C1 {
@@ -520,9 +522,13 @@ struct C1 {
     static __device__ __forceinline__ int swz(int r) { return PITCH >= 256 ? (r & 7) : (PITCH == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3)); }
 };
 
-template <int CIN, int NT, int WN>
+// TWO: the input rows come from two maps of CIN / 2 channels each (p.in, p.in2).  The LDS tile is then [2 halves][BM rows][CIN bytes]
+// (a 1-KB DMA piece stays inside one half, so the source is fixed per piece at compile time); k-step kk reads half kk / (KK / 2).
+template <int CIN, int NT, int WN, bool TWO = false>
 __device__ __forceinline__ void conv1x1_body(const Conv1Params& p) {
     using C = C1<CIN, NT, WN>;
+    constexpr int HP = C::PITCH / 2, HTILE = C::BM * HP;   // TWO: bytes per half row / per half tile
+    static_assert(!TWO || (HP >= 256 && C::NP % 8 == 0), "two-source rows: 256-byte halves, whole pieces per half");
     extern __shared__ __attribute__((aligned(16))) unsigned char c1sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
     const int wn = wave % WN, wm = wave / WN;
@@ -537,8 +543,9 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Params& p) {
         for (int kk = 0; kk < C::KK; ++kk) wr[t][kk] = *reinterpret_cast<const h16x8*>(wp + kk * 16);
     }
 
-    const __amdgpu_buffer_rsrc_t rsI =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, (uint32_t)((size_t)p.N * p.IH * p.IW * CIN * 2), 0x00020000);
+    const uint32_t in_bytes = (uint32_t)((size_t)p.N * p.IH * p.IW * (TWO ? CIN / 2 : CIN) * 2);
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsI2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(TWO ? p.in2 : p.in), 0, in_bytes, 0x00020000);
     constexpr int OOB = (int)0x80000000;
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -549,8 +556,10 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Params& p) {
 #pragma unroll
         for (int i = 0; i < C::NPW; ++i) {
             const int j = wave + 4 * i;
-            const int o = j * 1024 + lane * 16;
-            const int r = o / C::PITCH, pc = (o % C::PITCH) >> 4;
+            constexpr int PITCH_L = TWO ? HP : C::PITCH;                 // row pitch of the LDS (half) tile this piece lands in
+            const bool second = TWO && i >= C::NPW / 2;                  // (j >= NP / 2 <=> i >= NPW / 2: wave < 4)
+            const int o = (TWO ? (j - (second ? C::NP / 2 : 0)) : j) * 1024 + lane * 16;
+            const int r = o / PITCH_L, pc = (o % PITCH_L) >> 4;
             const long m = (long)tile * C::BM + r;
             int voff = OOB;
             if (m < p.M) {
@@ -561,9 +570,10 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Params& p) {
                     const int oh = (int)(t2 % p.OH), n = (int)(t2 / p.OH);
                     pix = ((long)n * p.IH + (long)oh * p.stride) * p.IW + (long)ow * p.stride;
                 }
-                voff = (int)(pix * C::PITCH) + ((pc ^ C::swz(r)) << 4);
+                voff = (int)(pix * PITCH_L) + ((pc ^ C::swz(r)) << 4);
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(base + j * 1024), 16, voff, 0, 0, 0);
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI2, (lds_ptr)(base + j * 1024), 16, voff, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(base + j * 1024), 16, voff, 0, 0, 0);
         }
     };
 
@@ -589,7 +599,7 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Params& p) {
 #pragma unroll
         for (int g = 0; g < C::PG; ++g) {
             const int r = (wm * C::PG + g) * 32 + (lane & 31);
-            const unsigned char* row = a + r * C::PITCH;
+            const unsigned char* row = a + r * (TWO ? HP : C::PITCH);
             const int sw = C::swz(r);
             f32x16 acc[NT];
 #pragma unroll
@@ -598,7 +608,8 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Params& p) {
                 for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < C::KK; ++kk) {
-                const h16x8 x = *reinterpret_cast<const h16x8*>(row + (((2 * kk + hi) ^ sw) << 4));
+                const h16x8 x = TWO ? *reinterpret_cast<const h16x8*>(row + (kk >= C::KK / 2 ? HTILE : 0) + ((((2 * kk + hi) & (HP / 16 - 1)) ^ sw) << 4))
+                                    : *reinterpret_cast<const h16x8*>(row + (((2 * kk + hi) ^ sw) << 4));
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = MGN_MFMA_32x32x16(wr[t][kk], x, acc[t]);
             }
@@ -606,7 +617,10 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Params& p) {
             // groups so that each lane stores 8 consecutive channels (16 bytes)
             const long m = (long)tile * C::BM + r;
             const bool ok = m < p.M;
-            uint16_t* opix = p.out + (size_t)(ok ? m : 0) * p.Cout + co_w;
+            // (out2: this wave's channels lie in one half of the output channels -- 32 NT divides Cout / 2)
+            const int ohalf = p.Cout >> 1;
+            uint16_t* opix = !p.out2 ? p.out + (size_t)(ok ? m : 0) * p.Cout + co_w
+                                     : (co_w >= ohalf ? p.out2 + (size_t)(ok ? m : 0) * ohalf + (co_w - ohalf) : p.out + (size_t)(ok ? m : 0) * ohalf + co_w);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -629,6 +643,7 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Params& p) {
     }
 }
 __global__ __launch_bounds__(256, 1) void conv1x1_s_256_2_4(Conv1Params p) { conv1x1_body<256, 2, 4>(p); }
+__global__ __launch_bounds__(256, 1) void conv1x1_s_256_2_4_cat(Conv1Params p) { conv1x1_body<256, 2, 4, true>(p); }
 __global__ __launch_bounds__(256, 1) void conv1x1_s_256_1_1(Conv1Params p) { conv1x1_body<256, 1, 1>(p); }
 __global__ __launch_bounds__(256, 1) void conv1x1_s_32_2_4(Conv1Params p) { conv1x1_body<32, 2, 4>(p); }
 __global__ __launch_bounds__(256, 1) void conv1x1_s_64_1_4(Conv1Params p) { conv1x1_body<64, 1, 4>(p); }
@@ -1069,8 +1084,9 @@ struct WgradParams {
     int oihw, cin_real;    // final layout of dw: [Cout][cin_real][KH][KW] (torch parameter layout) or [Cout][KH][KW][Cin]
     float* partial;        // [gridDim.z][Cout][taps*Cin] per-split partial results (plain stores, no atomics)
     int remap_tiles, co_tiles;   // remap_tiles > 0: 1-D grid, see wgrad_block
+    const uint16_t* in2;   // != null (conv_wgrad only): the input is the channel concatenation (in | in2) of two maps of Cin / 2 channels
 };
-MGN_PLAN_RO(WgradParams, MGN_RO(dout) MGN_RO(in))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO(WgradParams, MGN_RO(dout) MGN_RO(in) MGN_RO(in2))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 // Which (output-channel tile, tap x input-channel tile, pixel split) a block of the split-K tile kernels works on.  With the plain 3-D
 // grid the tile blocks of ONE pixel split -- which read the same dOut / input pixels -- have consecutive linear ids and therefore land
@@ -1124,6 +1140,10 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
     const int cseg = t & 15, pg = t >> 4;  // 8-channel segment, 8-pixel group
     int c0 = (isB ? bci * 64 * NT : bco * 64 * MT) + cseg * 8;
     bool vc = c0 < (isB ? p.Cin : p.Cout) && cseg * 8 < 64 * (isB ? NT : MT);
+    // two-source input (64 NT divides Cin / 2: a block's column tile lies in one of the maps)
+    const int cpitch = p.in2 ? p.Cin >> 1 : p.Cin;
+    const bool second = p.in2 && bci * 64 * NT >= cpitch;
+    if (isB && second) c0 -= cpitch;
     if (PACK && isB) {  // c0 is a packed column: split into (tap, channel)
         const int tap = c0 / p.Cin;
         vc = tap < p.KH * p.KW && cseg * 8 < 64 * NT;
@@ -1147,7 +1167,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dout), 0, (uint32_t)((size_t)M * p.Cout * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.in), 0, (uint32_t)((size_t)p.N * p.IH * p.IW * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(second ? p.in2 : p.in), 0, (uint32_t)((size_t)p.N * p.IH * p.IW * cpitch * 2), 0x00020000);
     constexpr int OOB = (int)0x80000000;
     uint4 rg[8];
     auto load = [&]() {  // loads the k-step starting at pixel mcur (out-of-range -> 0 via the buffer bounds), advances by WBK
@@ -1162,7 +1182,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
             // fast path: the 8 pixels lie in one output row -> one row test, offsets differ by a constant step
             const int ih = poh * p.stride - p.pad + kh, iw0 = pow_ * p.stride - p.pad + kw;
             const bool rowok = vc && ih >= 0 && ih < p.IH;
-            const int base = (((pn * p.IH + ih) * p.IW + iw0) * p.Cin + c0) * 2, step = p.stride * p.Cin * 2;
+            const int base = (((pn * p.IH + ih) * p.IW + iw0) * cpitch + c0) * 2, step = p.stride * cpitch * 2;
             const int rem = (int)(m_end - mcur < 8 ? m_end - mcur : 8);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -1177,7 +1197,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradParams p) {
             for (int q = 0; q < 8; ++q) {
                 const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
                 const bool ok = vc && mcur + q < m_end && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
-                const int off = ok ? (((n * p.IH + ih) * p.IW + iw) * p.Cin + c0) * 2 : OOB;
+                const int off = ok ? (((n * p.IH + ih) * p.IW + iw) * cpitch + c0) * 2 : OOB;
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
                 rg[q] = make_uint4(v.x, v.y, v.z, v.w);
                 const bool wrap = (ow + 1 == p.OW);
@@ -2171,7 +2191,7 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
         !getenv("MGN_CONV_NO1X1") && !stat_part) {
         Conv1Params q;
         q.in = p.in; q.w = p.w; q.out = (uint16_t*)out; q.N = N; q.IH = IH; q.IW = IW; q.OH = OH; q.OW = OW; q.Cout = Cout;
-        q.stride = stride; q.M = M; q.ntiles = 0;
+        q.stride = stride; q.M = M; q.ntiles = 0; q.in2 = nullptr; q.out2 = nullptr;
         int rc1 = 1;   // 1 = not taken (shape without an instantiation, or too small): fall through to the generic kernels
         const bool pl = plan_rows != nullptr;   // (planning: 2 = would be taken -- the streaming kernel has no statistics epilogue)
         if (Cin == 256 && Cout % 256 == 0) rc1 = launch_conv1x1<256, 2, 4>(conv1x1_s_256_2_4, q, st, pl);
@@ -2427,14 +2447,18 @@ int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int
 // desc != null: "partial only" -- the split-K partials stay in the workspace, no reduction is launched, desc[0..7] = {partial,
 // 0, splits, Cout, taps, Cin, oihw, cin_real} describes the reduction for mgn_conv_wgrad_reduce_batch (dw is not written)
 static int wgrad_impl(const void* dout, const void* in, float* dw, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,
-                      int KW, int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc, void* stream) {
+                      int KW, int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc, void* stream,
+                      const void* in2 = nullptr) {
     if (!dout || !in || (!dw && !desc) || !workspace || N < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || KH < 1 || KW < 1 || stride < 1) return MGN_EINVAL;
     if ((Cin % 8 != 0 && Cin != 4) || Cout % 8 != 0) return MGN_ENOTSUP;
     WgradParams p;
     p.dout = (const uint16_t*)dout; p.in = (const uint16_t*)in; p.dw = dw;
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.oihw = oihw_cin > 0; p.cin_real = oihw_cin > 0 ? oihw_cin : Cin;
+    p.in2 = (const uint16_t*)in2;
     if (oihw_cin > Cin) return MGN_EINVAL;
+    // two-source input (in | in2): the 1x1 layers of the split-K tile kernel only, column tiles of 128 inside one map
+    if (in2 && (KH != 1 || KW != 1 || stride != 1 || pad != 0 || Cin % 256 != 0 || (size_t)N * IH * IW * Cin >= 0x7fffffffu)) return MGN_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
     const size_t wsize = (size_t)Cout * KH * KW * Cin;
     WgradStemParams ps;
@@ -2536,6 +2560,41 @@ int MGN_SYM(mgn_conv_wgrad_partial)(const void* dout, const void* in, int N, int
                                     int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream) {
     if (!desc8) return MGN_EINVAL;
     return wgrad_impl(dout, in, nullptr, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, oihw_cin, workspace, workspace_bytes, desc8, stream);
+}
+
+/* weight gradient of a 1x1 convolution whose input is the channel concatenation (in0 | in1) of two [N, H, W, Cin / 2] maps (never
+ * materialised); dw / desc8 as in mgn_conv_wgrad / mgn_conv_wgrad_partial (exactly one of them non-null).  Cin % 256 == 0. */
+int MGN_SYM(mgn_conv_wgrad_cat)(const void* dout, const void* in0, const void* in1, float* dw, int N, int H, int W, int Cin, int Cout,
+                                void* workspace, size_t workspace_bytes, long long* desc8, void* stream) {
+    if (!in1 || (!dw) == (!desc8)) return MGN_EINVAL;
+    return wgrad_impl(dout, in0, dw, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, Cin, workspace, workspace_bytes, desc8, stream, in1);
+}
+
+/* out = conv1x1(in0 | in1, w): the FeatureFusionModule's convolution over the concatenation of its two inputs (layers.py:316-317)
+ * without the concatenated map.  in0, in1: [N, H, W, 128]; w: [Cout][256] (layout mode 0); out: [N, H, W, Cout], Cout % 256 == 0.
+ * MGN_ENOTSUP: other channel counts, or a map too small for the streaming kernel (the caller concatenates). */
+int MGN_SYM(mgn_conv1x1_cat)(const void* in0, const void* in1, const void* w, void* out, int N, int H, int W, int Cin, int Cout, void* stream) {
+    if (!in0 || !in1 || !w || !out || N < 1 || H < 1 || W < 1) return MGN_EINVAL;
+    const long M = (long)N * H * W;
+    if (Cin != 256 || Cout % 256 != 0 || (size_t)M * 128 * 2 >= 0x7fffffffu || M >= 0x7fffffffL || getenv("MGN_CONV_NO1X1")) return MGN_ENOTSUP;
+    Conv1Params q;
+    q.in = (const uint16_t*)in0; q.in2 = (const uint16_t*)in1; q.w = (const uint16_t*)w; q.out = (uint16_t*)out; q.out2 = nullptr;
+    q.N = N; q.IH = H; q.IW = W; q.OH = H; q.OW = W; q.Cout = Cout; q.stride = 1; q.M = M; q.ntiles = 0;
+    const int rc = launch_conv1x1<256, 2, 4>(conv1x1_s_256_2_4_cat, q, (hipStream_t)stream);
+    return rc == 1 ? MGN_ENOTSUP : rc;
+}
+
+/* (out0 | out1) = conv1x1(in, w): the data gradient of the convolution above -- in: [N, H, W, 256] (the output gradient), w: [Cout = 256]
+ * [256] (layout mode 1), out0 / out1: [N, H, W, 128] each = the gradients of the two concatenated maps, written directly. */
+int MGN_SYM(mgn_conv1x1_split)(const void* in, const void* w, void* out0, void* out1, int N, int H, int W, int Cin, int Cout, void* stream) {
+    if (!in || !w || !out0 || !out1 || N < 1 || H < 1 || W < 1) return MGN_EINVAL;
+    const long M = (long)N * H * W;
+    if (Cin != 256 || Cout != 256 || (size_t)M * 256 * 2 >= 0x7fffffffu || M >= 0x7fffffffL || getenv("MGN_CONV_NO1X1")) return MGN_ENOTSUP;
+    Conv1Params q;
+    q.in = (const uint16_t*)in; q.in2 = nullptr; q.w = (const uint16_t*)w; q.out = (uint16_t*)out0; q.out2 = (uint16_t*)out1;
+    q.N = N; q.IH = H; q.IW = W; q.OH = H; q.OW = W; q.Cout = Cout; q.stride = 1; q.M = M; q.ntiles = 0;
+    const int rc = launch_conv1x1<256, 2, 4>(conv1x1_s_256_2_4, q, (hipStream_t)stream);
+    return rc == 1 ? MGN_ENOTSUP : rc;
 }
 
 #ifndef MGN_F16

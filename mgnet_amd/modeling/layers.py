@@ -145,7 +145,7 @@ class FeatureFusionModule(nn.Module):  # layers.py:270-322
             mgnet_xavier_fill(self.channel_attention[2])
 
     def forward(self, fsp, fcp):
-        return ops.conv_abn_attention(self.conv, ops.concat_channels(fsp, fcp), self.channel_attention, "ffm", residual=True)
+        return ops.conv_abn_attention(self.conv, (fsp, fcp), self.channel_attention, "ffm", residual=True)
 
 
 class MGNetDecoder(nn.Module):  # layers.py:22-94

@@ -367,6 +367,51 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, None
 
 
+class _ConvCatFn(torch.autograd.Function):
+    """[HIP] conv1x1(torch.cat([a, b], 1), weight) (FeatureFusionModule, layers.py:316-317) without the concatenated map: the streaming
+    1x1 kernel reads its pixel rows as two half rows (mgn_conv1x1_cat), its data gradient writes the two halves of its output channels to
+    two maps (mgn_conv1x1_split), the weight gradient gathers from both (mgn_conv_wgrad_cat).  Bit-identical to `_CatFn` + `_ConvFn`
+    (same kernels, same summation order); saves the copy into the concatenation and the split of its gradient, 2 x 134 MB per decoder."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight):
+        from .. import _C
+        out = _C.conv1x1_cat(a, b, _C.weight_layout(weight, 0, 0, 0, dtype=a.dtype))
+        assert out is not None   # (conv_cat_supported is the gate)
+        ctx.save_for_backward(a, b, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _C
+        a, b, weight = ctx.saved_tensors
+        dy = dy.to(a.dtype).contiguous(memory_format=torch.channels_last)
+        da = db = dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            r = _C.conv1x1_split(dy, _C.weight_layout(weight, 1, 0, 0, dtype=a.dtype))
+            if r is None:    # (not reachable for the shapes the forward accepted; kept as the definition)
+                dcat = _C.conv_igemm(dy, _C.weight_layout(weight, 1, 0, 0, dtype=a.dtype), a.shape[2:], None, 1, 0)
+                r = dcat[:, :a.shape[1]], dcat[:, a.shape[1]:]
+            da, db = r
+        if ctx.needs_input_grad[2]:
+            dw = _C.conv_wgrad_cat(dy, a, b, lazy=True)
+        return da, db, dw
+
+
+def conv_cat_supported(a, b, weight, conv=None):
+    from .. import _C
+    if os.environ.get("MGN_NO_CONVCAT") or not (a.is_cuda and a.dtype in _C.H16 and a.dtype == b.dtype and a.shape == b.shape and a.shape[1] == 128):
+        return False
+    if tuple(weight.shape[1:]) != (256, 1, 1) or weight.shape[0] % 256 or weight.dtype != torch.float32:
+        return False
+    if conv is not None and (conv.bias is not None or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (0, 0)):
+        return False
+    if not (a.is_contiguous(memory_format=torch.channels_last) and b.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    N, _, H, W = a.shape
+    return (N * H * W + 127) // 128 * (weight.shape[0] // 256) >= 512    # (the streaming kernel's own size gate: tiles x channel groups)
+
+
 class _ShortcutS2Fn(torch.autograd.Function):
     """The 1x1 / stride 2 / pad 0 shortcut conv of a down-sampling BasicBlock (res_net.py:52-60 `downsample`) next to a conv1 that
     returned `xsub` (with_skip = 2).  Forward: the ordinary strided 1x1 conv on the full input.  Backward: the gradient goes to `xsub`
@@ -956,6 +1001,9 @@ def conv_abn_attention(conv, x, attention, kind, residual=False, addend=None):
     from .. import _C
     norm = getattr(conv, "norm", None)
     a1 = attention[1]
+    pair = x if isinstance(x, tuple) else None      # (fsp, fcp) of the FeatureFusionModule: the conv reads both maps, no concatenation
+    if pair is not None:
+        x = pair[0]
     ok = (x.is_cuda and x.dtype in _C.H16 and norm is not None and type(norm).__name__ == "InPlaceABNSync" and conv.activation is None
           and conv.out_channels % 8 == 0 and conv.out_channels // 8 <= 256 and 256 % (conv.out_channels // 8) == 0 and x.shape[0] <= 64
           and a1.bias is None and (norm.training or not torch.is_grad_enabled()) and not os.environ.get("MGN_NO_ATTN_FUSE")
@@ -966,8 +1014,10 @@ def conv_abn_attention(conv, x, attention, kind, residual=False, addend=None):
         ok = ok and not _dist_active(bn.group) and (bn.training or not torch.is_grad_enabled())
     else:
         ok = ok and attention[2].bias is None
+    if pair is not None and not (ok and add_ok and conv_cat_supported(pair[0], pair[1], conv.weight, conv)):
+        x, pair = concat_channels(*pair), None
     if ok and add_ok:
-        y = conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, stats_for=norm)
+        y = _ConvCatFn.apply(pair[0], pair[1], conv.weight) if pair is not None else conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, stats_for=norm)
         if _C.elt_supported(y) and (addend is None or addend.shape == y.shape):
             ps = _pstats(y)
             if kind == "arm":

@@ -202,6 +202,42 @@ def test_stem_dense_rows_kernel(cfg, dtype):
         assert float((dw4.double() - wr.grad).abs().max() / wr.grad.abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(8, 128, 256), (2, 256, 257), (2, 128, 256)])
+def test_conv1x1_over_a_concatenation_without_the_concatenation(shape, dtype, monkeypatch):
+    """ops._ConvCatFn (FeatureFusionModule's conv over cat([fsp, fcp], 1), layers.py:316-317): output, both data gradients and the weight
+    gradient are BIT-identical to concat2 -> conv -> split2 (same kernels and summation order, only the addressing differs), and match
+    fp64 on a small case."""
+    from mgnet_amd import _C
+    from mgnet_amd.modeling import ops
+
+    N, H, W = shape
+    torch.manual_seed(H)
+    a0 = torch.randn(N, 128, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    b0 = torch.randn(N, 128, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(256, 256, 1, 1, device="cuda") / 16)
+    g = torch.randn(N, 256, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    assert ops.conv_cat_supported(a0, b0, w)
+    a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    y = ops._ConvCatFn.apply(a, b, w)
+    y.backward(g)
+    da, db, dw = a.grad.clone(), b.grad.clone(), w.grad.clone()
+    w.grad = None
+    a2, b2 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    y2 = ops.conv2d(ops.concat_channels(a2, b2), w, None, 1, 0)
+    y2.backward(g)
+    assert torch.equal(y, y2) and torch.equal(da, a2.grad) and torch.equal(db, b2.grad) and torch.equal(dw, w.grad)
+    if N * H * W <= 2 ** 16:
+        ad, bd = a0.double().requires_grad_(True), b0.double().requires_grad_(True)
+        wd = w.detach().to(dtype).double().requires_grad_(True)
+        yd = F.conv2d(torch.cat([ad, bd], 1), wd)
+        yd.backward(g.double())
+        rel = lambda u, v: float((u.double() - v).abs().max() / v.abs().max())
+        assert rel(y, yd.detach()) < 1e-2 and rel(da, ad.grad) < 1e-2 and rel(db, bd.grad) < 1e-2 and rel(dw, wd.grad) < 2e-3
+    monkeypatch.setenv("MGN_NO_CONVCAT", "1")
+    assert not ops.conv_cat_supported(a0, b0, w)
+
+
 def test_dense_stem_falls_back_to_eight_channels_on_odd_widths(monkeypatch):
     from mgnet_amd import _C
     assert _C.stem_input_channels(2, 40, 57) == 8 and _C.stem_input_channels(2, 40, 56, real=9) == 16

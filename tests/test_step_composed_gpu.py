@@ -280,9 +280,18 @@ def test_composed_step_is_as_close_to_the_rounding_matched_reference_as_its_fp32
     ref_losses, ref = _step(m, batch, scale)                     # (b) fp64 nodes, 16-bit rounding at the product's points
     assert calls["conv"] >= 70 and calls["norm"] >= 53, calls    # ... and the run really went through the substituted nodes
     monkeypatch.setattr(sys.modules[__name__], "ACC", torch.float32)
-    twin_losses, twin = _step(m, batch, scale)                   # (c) the same nodes in fp32 arithmetic: the control
+    # (c) the same nodes in fp32 arithmetic: the control.  It runs through torch's fp32 convolutions, which are NOT reproducible on this stack
+    # (round 5, six runs of this test: the product's numbers identical to four digits every time, the control's median cosine 0.940 ...
+    # 0.958, its loss_center 25.690 ... 25.696 against the reference's 25.690) -- so it is evaluated three times and each tensor / loss
+    # is given its WORST result, like the torch-bf16 yardstick of test_grad_parity_gpu.py: the question is whether the product lies inside
+    # the spread of fp32 evaluations, not whether it beats one lucky draw
+    twins = [_step(m, batch, scale) for _ in range(3)]
+    twin_losses, twin = twins[0]
     assert set(hip) == set(ref) == set(twin) and len(hip) > 200
-    rows, rows_twin = _rows(hip, ref), _rows(twin, ref)
+    rows = _rows(hip, ref)
+    runs = [{r[0]: r for r in _rows(t[1], ref)} for t in twins]
+    rows_twin = [(n, min(b[n][1] for b in runs), max(b[n][2] for b in runs), runs[0][n][3]) for n in runs[0]]
+    twin_dist = {k: max(abs(t[0][k] - v) for t in twins) for k, v in ref_losses.items()}
     med = lambda v: sorted(v)[len(v) // 2]
     sig = {r[0] for r in _significant(rows)}
     whole = lambda a: float((torch.cat([a[n] for n in sorted(ref)]) @ torch.cat([ref[n] for n in sorted(ref)])) /
@@ -302,7 +311,7 @@ def test_composed_step_is_as_close_to_the_rounding_matched_reference_as_its_fp32
     for k, v in ref_losses.items():
         assert hip_losses[k] == pytest.approx(v, rel=2e-2, abs=2e-4), (k, hip_losses[k], v)
         # the product's losses are as close to the reference's as the control's are (3x its distance + a floor of 1e-3 relative)
-        assert abs(hip_losses[k] - v) <= 3 * abs(twin_losses[k] - v) + 1e-3 * abs(v) + 1e-5, (k, hip_losses[k], v, twin_losses[k])
+        assert abs(hip_losses[k] - v) <= 3 * twin_dist[k] + 1e-3 * abs(v) + 1e-5, (k, hip_losses[k], v, [t[0][k] for t in twins])
     # (strict: the yardstick here is deterministic torch fp32 arithmetic, not MIOpen's bf16 convolutions -- measured 0 worse, 0 far worse)
     _check_vs_torch_bf16(rows, rows_twin, f"composed {str(dtype)[6:]} {H}x{W} ", worse_frac=0.05, strict=True,
                          labels=("HIP", "fp32 twin", "the fp64 rounding-matched reference"))

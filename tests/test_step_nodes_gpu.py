@@ -210,7 +210,7 @@ def test_every_conv_and_norm_node_of_a_full_step_matches_fp64(dtype, monkeypatch
             seen["skip"] += bool(n["ins"][6])
             seen["cout_pad"] += bool(n["ins"][7])
             seen["stats"] += len(n["ins"]) > 8 and n["ins"][8] is not None
-            seen["stem"] += n["ins"][0].shape[1] in (8, 16)
+            seen["stem"] += n["ins"][0].shape[1] in (4, 8, 16)
             seen["bias"] += n["ins"][2] is not None
             seen["skip_lowres"] += n["ins"][6] == 2
         elif n["kind"] == "_ShortcutS2Fn":
