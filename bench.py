@@ -270,9 +270,26 @@ def eval_leg(args, dev, H, W):
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         assert len(out) == len(batch) and all(torch.isfinite(r["depth"][0]).all().item() for r in out)
-        return {"ms_per_call": round(dt * 1e3, 2), "img_per_s": round(len(batch) / dt, 2), "calls": n}
+        # the network alone (backbone, decoders, heads; the per-image post-processing replaced by a stub for these calls)
+        model._inference = lambda bi, outputs: [None] * len(bi)
+        try:
+            with torch.no_grad():
+                model(batch)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    model(batch)
+                torch.cuda.synchronize()
+        finally:
+            del model._inference
+        dn = (time.perf_counter() - t0) / n
+        return {"ms_per_call": round(dt * 1e3, 2), "img_per_s": round(len(batch) / dt, 2), "calls": n,
+                "network_only_ms_per_call": round(dn * 1e3, 2), "network_only_img_per_s": round(len(batch) / dn, 2)}
     res = {"what": f"model.eval()(batch): forward + panoptic / depth post-processing per image at {H}x{W}, bf16, random-init weights, synthetic frames",
-           "post_processing": "on the device (csrc/postproc.hip), per image like the reference"}
+           "post_processing": "on the device (csrc/postproc.hip), per image like the reference; its cost is data-dependent -- the centre grouping visits "
+                              "every centre candidate per thing pixel, and random-init heads yield thousands of candidates (a trained model: tens) -- "
+                              "so `network_only_*` (same calls with the post-processing stubbed out) is the figure that transfers",
+           "norm_layers": "folded into the convolutions (ops.conv_abn_eval; MGN_NO_EVALFOLD=1 restores the separate eval pass)"}
     def frames(B):   # the inference fields of the dataset mapper: image, 3x3 camera matrix, camera height (mg_net.py:404-417)
         batch = synthetic_batch(B, H, W, dev, seed=77)
         for d in batch:

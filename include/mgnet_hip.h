@@ -266,6 +266,17 @@ int mgn_conv3x3_win(const void* in, const void* w, void* out, int N, int H, int 
                                             (r - shift)^2 over the ROUNDED outputs r, the input of mgn_iabn_coeffs_from_partials: the
                                             statistics pass of the InPlaceABNSync that follows the conv (res_net.py:35,49,59) */,
                     const float* stat_shift /* [Cout] or NULL (= 0): e.g. the layer's running_mean */, void* stream);
+/* the same with the epilogue out = act(conv + bias + residual) (bias [Cout] fp32 or NULL; act 0 none | 1 ReLU | 2 leaky ReLU with
+ * `slope`): not together with the statistics rows.  mgn_conv_igemm_act dispatches here. */
+int mgn_conv3x3_win_act(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
+                        int patch_rows, float* stat_partials, const float* stat_shift, const float* bias, int act, float slope, void* stream);
+/* out = act(conv(in, w) + bias + residual): mgn_conv_igemm (up = 1, 16-bit output) with the activation as a parameter (0 none | 1 ReLU |
+ * 2 leaky ReLU with `slope`) and the bias / activation epilogue in every forward kernel it dispatches to except the 1x1 streaming
+ * kernel (those layers take the generic kernel).  Inference (mg_net.py:375-425, the reference's InPlaceABN -> ABN swap for deployment,
+ * tools/onnx_trt_export.py:19): `conv -> InPlaceABNSync(eval)` is a fixed affine + activation, so the caller folds the scale into the
+ * weights, passes the shift as `bias`, and a residual block's `+ shortcut -> ReLU` as `residual` / act = 1: no norm pass at all. */
+int mgn_conv_igemm_act(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
+                       int Cout, int KH, int KW, int stride, int pad, int act, float slope, const void* residual, void* stream);
 /* Data gradient of a 3x3 / stride 2 / pad 1 convolution (res_net.py:28-60 with stride 2: conv1 of the down-sampling BasicBlocks) as a
  * windowed implicit GEMM over the LOW-resolution gradient (csrc/conv_up2.hip): in = d(conv output) [N,H,W,Cin], w = the flipped /
  * transposed weights [Cout][3][3][Cin] (mgn_weight_layout mode 1), out = d(conv input) [N,OH,OW,Cout] with OH in {2H-1, 2H}, OW alike;
@@ -801,6 +812,10 @@ int mgn_conv3x3_up2_win_f16(const void* in, const void* w, void* out, int N, int
     int ksize, const void* residual, int residual_lowres, void* stream);
 int mgn_conv_wgrad_partial_f16(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
     int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
+int mgn_conv3x3_win_act_f16(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
+                            int patch_rows, float* stat_partials, const float* stat_shift, const float* bias, int act, float slope, void* stream);
+int mgn_conv_igemm_act_f16(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
+                           int Cout, int KH, int KW, int stride, int pad, int act, float slope, const void* residual, void* stream);
 int mgn_conv1x1_cat_f16(const void* in0, const void* in1, const void* w, void* out, int N, int H, int W, int Cin, int Cout, void* stream);
 int mgn_conv1x1_split_f16(const void* in, const void* w, void* out0, void* out1, int N, int H, int W, int Cin, int Cout, void* stream);
 int mgn_conv_wgrad_cat_f16(const void* dout, const void* in0, const void* in1, float* dw, int N, int H, int W, int Cin, int Cout,

@@ -16,7 +16,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_optim_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv3x3_up2_win", "mgn_conv_win_patch_rows", "mgn_conv_stem7", "mgn_conv_stem7_blocks", "mgn_iabn_coeffs_from_partials", "mgn_iabn_partials_reduce", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv1x1_cat", "mgn_conv1x1_split", "mgn_conv_wgrad_cat", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_optim_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv3x3_up2_win", "mgn_conv_win_patch_rows", "mgn_conv_stem7", "mgn_conv_stem7_blocks", "mgn_iabn_coeffs_from_partials", "mgn_iabn_partials_reduce", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv1x1_cat", "mgn_conv1x1_split", "mgn_conv_wgrad_cat", "mgn_conv3x3_win_act", "mgn_conv_igemm_act", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_adjoint_footprint_floats", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_sum3", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -32,7 +32,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_plan_compile", "mgn_plan_set_stream", "mgn_plan_run", "mgn_plan_prof_elapsed", "mgn_plan_free",
            "mgn_plan_trace", "mgn_plan_trace_read", "mgn_plan_set_skip", "mgn_plan_node_ro", "mgn_plan_set_jitter", "mgn_plan_probe",
            "mgn_abn_apply_pool", "mgn_att_abn_bwd_stats", "mgn_att_abn_bwd_sums", "mgn_att_abn_bwd_apply"]
-SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_conv1x1_cat', 'mgn_conv1x1_split', 'mgn_conv_wgrad_cat', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']]
+SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_conv1x1_cat', 'mgn_conv1x1_split', 'mgn_conv_wgrad_cat', 'mgn_conv3x3_win_act', 'mgn_conv_igemm_act', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']]
 DEPTH_MAX_FILTER_IDS = 16
 MGN_MAX_TASKS = 8   # include/mgnet_hip.h
 
@@ -85,7 +85,7 @@ def plan_touch(reads=(), writes=()):
 
 
 H16 = (torch.bfloat16, torch.float16)   # the 16-bit activation formats: bf16 entry points, or their _f16 twins (csrc/h16.h)
-F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_conv1x1_cat', 'mgn_conv1x1_split', 'mgn_conv_wgrad_cat', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']
+F16_TWINS = ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_conv1x1_cat', 'mgn_conv1x1_split', 'mgn_conv_wgrad_cat', 'mgn_conv3x3_win_act', 'mgn_conv_igemm_act', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']
 
 
 def _fn(name, t):
@@ -139,6 +139,8 @@ def lib():
         L.mgn_conv_wgrad.argtypes = [vp, vp, vp] + [ci] * 12 + [vp, sz, vp]
         L.mgn_conv_wgrad_workspace_bytes.argtypes = [ci] * 7 + [ctypes.POINTER(sz)]
         for sfx in ("", "_f16"):
+            getattr(L, "mgn_conv_igemm_act" + sfx).argtypes = [vp, vp, vp, vp] + [ci] * 12 + [cf, vp, vp]
+            getattr(L, "mgn_conv3x3_win_act" + sfx).argtypes = [vp, vp, vp] + [ci] * 5 + [vp, ci, vp, vp, vp, ci, cf, vp]
             getattr(L, "mgn_conv1x1_cat" + sfx).argtypes = [vp, vp, vp, vp] + [ci] * 5 + [vp]
             getattr(L, "mgn_conv1x1_split" + sfx).argtypes = [vp, vp, vp, vp] + [ci] * 5 + [vp]
             getattr(L, "mgn_conv_wgrad_cat" + sfx).argtypes = [vp, vp, vp, vp] + [ci] * 5 + [vp, sz, vp, vp]
@@ -1041,6 +1043,21 @@ def conv_wgrad(dy, x, kh, kw, stride, pad, cin_real=None, lazy=False):
     return dw
 
 
+def conv_igemm_act(x, w_ohwi, out_shape, bias, stride, pad, act=0, slope=0.0, residual=None):
+    """act(conv(x, w) + bias + residual) in one launch (mgn_conv_igemm_act; act 0 none | 1 ReLU | 2 leaky ReLU): the inference form of
+    conv -> InPlaceABNSync [-> + shortcut -> ReLU] with the norm folded into w_ohwi / bias.  None where no kernel has the epilogue."""
+    N, Cin, IH, IW = x.shape
+    Cout, KH, KW, _ = w_ohwi.shape
+    OH, OW = out_shape
+    out = torch.empty((N, Cout, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = _fn("mgn_conv_igemm_act", x)(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(), N, IH, IW, Cin,
+                                      OH, OW, Cout, KH, KW, stride, pad, act, float(slope), None if residual is None else residual.data_ptr(), _stream())
+    if rc == -95:
+        return None
+    check(rc, "mgn_conv_igemm_act")
+    return out
+
+
 def conv1x1_cat(a, b, w_ohwi):
     """conv1x1(cat([a, b], 1), w) without the concatenated map: a, b [N,128,H,W] channels_last 16-bit, w_ohwi [Cout,1,1,256]; None if the
     shape is not one the two-source streaming kernel takes (mgn_conv1x1_cat)"""
@@ -1173,6 +1190,7 @@ class _WeightCache:
 
     def refresh(self):
         """re-derive every registered layout from the current parameter values (one launch per 16-bit format in use)"""
+        self.epoch = getattr(self, "epoch", 0) + 1   # (parameters changed behind torch's version counter: ops.conv_abn_eval's folds expire)
         for e in self.entries.values():
             w = e["ref"]()
             if w is None or e["ptr"] != w.data_ptr():   # a collected parameter's row must leave the table (its memory is gone)

@@ -37,7 +37,8 @@ struct ConvParams {
     void* out;            // [N, OH, OW, Cout] bf16 or fp32
     const float* bias;    // [Cout] or null
     const uint16_t* residual;  // [N, OH, OW, Cout] bf16 added to the result before rounding, or null
-    int N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32;
+    int N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32;   // relu: 0 none, 1 ReLU, 2 leaky ReLU with `slope`
+    float slope;
     int xcd_bands;        // 1: remap blockIdx.x so that every XCD works on one contiguous band of pixel tiles (see xcd_tile)
     float* stat_part;     // [pixel tiles][Cout][2]: per-tile sums of r, r^2 over the ROUNDED outputs (statistics of the InPlaceABNSync that
                           // follows; only without bias / ReLU / residual / fp32 output), or null
@@ -91,7 +92,8 @@ __device__ __forceinline__ void emit4(const ConvParams& p, long m, int co, float
     for (int e = 0; e < 4; ++e) {
         v[e] += (p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
         if (p.residual && !vec_ok && co + e < p.Cout) v[e] += mgn_h2f(p.residual[m * p.Cout + co + e]);
-        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+        if (p.relu == 1) v[e] = fmaxf(v[e], 0.f);
+        else if (p.relu == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
     }
     if (vec_ok) {
         if (p.out_f32)
@@ -849,12 +851,15 @@ struct Conv64Params {
                                // InPlaceABNSync that follows, see conv_win.hip / mgn_iabn_coeffs_from_partials), or null
     int N, H, W, Cout;
     int strips, chunks, rows_per_chunk, nslices, co_tiles;
+    const float* bias;     // ACT kernels: out = act(conv + bias + residual), act 0 none | 1 ReLU | 2 leaky ReLU with `slope` (the eval-mode
+    int act;               // fold of the InPlaceABNSync that follows, mgn_conv_igemm_act)
+    float slope;
 };
-MGN_PLAN_RO(Conv64Params, MGN_RO(in) MGN_RO(w) MGN_RO(residual))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO(Conv64Params, MGN_RO(in) MGN_RO(w) MGN_RO(residual) MGN_RO(bias))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 constexpr int C64_NR = 8;   // ring of input rows: r-1 .. r+2 in use by the two output rows of a step, r+3 .. r+6 in flight
 constexpr int C64_INROW = 136 * 128, C64_LDS = C64_NR * C64_INROW;
 
-template <bool STATS, bool RES>
+template <bool STATS, bool RES, bool ACT = false>
 __device__ __forceinline__ void conv3x3_c64_body(const Conv64Params& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char c64sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpx = wave >> 1, wco = wave & 1;
@@ -947,6 +952,13 @@ __device__ __forceinline__ void conv3x3_c64_body(const Conv64Params& p) {
             }
         }
     };
+    float bv[4][4];   // ACT: this lane's 16 bias values (channel = co_w + 8 qd + 4 hi + e)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ACT && p.bias) t = *reinterpret_cast<const float4*>(p.bias + co_w + 8 * qd + 4 * hi);
+        bv[qd][0] = t.x; bv[qd][1] = t.y; bv[qd][2] = t.z; bv[qd][3] = t.w;
+    }
     auto store_rows = [&](int r) {
         // D = W-rows x pixels: col = lane & 31 -> pixel, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output channel.
         // v_permlane32_swap exchanges the 4-channel groups between lane l and lane l+32 so that every lane owns 8 CONSECUTIVE
@@ -975,9 +987,14 @@ __device__ __forceinline__ void conv3x3_c64_body(const Conv64Params& p) {
                             const int qd = 2 * qp + u;
                             float v0 = rr2 ? acc1[qd * 4 + 0] : acc0[qd * 4 + 0], v1 = rr2 ? acc1[qd * 4 + 1] : acc0[qd * 4 + 1];
                             float v2 = rr2 ? acc1[qd * 4 + 2] : acc0[qd * 4 + 2], v3 = rr2 ? acc1[qd * 4 + 3] : acc0[qd * 4 + 3];
+                            if (ACT) { v0 += bv[qd][0]; v1 += bv[qd][1]; v2 += bv[qd][2]; v3 += bv[qd][3]; }
                             if (RES) {
                                 v0 += mgn_lo2f(rp[u][0]); v1 += mgn_hi2f(rp[u][0]);
                                 v2 += mgn_lo2f(rp[u][1]); v3 += mgn_hi2f(rp[u][1]);
+                            }
+                            if (ACT && p.act) {
+                                const float sl = p.act == 1 ? 0.f : p.slope;
+                                v0 = v0 > 0.f ? v0 : v0 * sl; v1 = v1 > 0.f ? v1 : v1 * sl; v2 = v2 > 0.f ? v2 : v2 * sl; v3 = v3 > 0.f ? v3 : v3 * sl;
                             }
                             pk[u][0] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
                             pk[u][1] = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
@@ -1069,6 +1086,8 @@ __device__ __forceinline__ void conv3x3_c64_body(const Conv64Params& p) {
 __global__ __launch_bounds__(512, 1) void conv3x3_c64(Conv64Params p) { conv3x3_c64_body<false, false>(p); }
 __global__ __launch_bounds__(512, 1) void conv3x3_c64_res(Conv64Params p) { conv3x3_c64_body<false, true>(p); }
 __global__ __launch_bounds__(512, 1) void conv3x3_c64_stats(Conv64Params p) { conv3x3_c64_body<true, false>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_c64_act(Conv64Params p) { conv3x3_c64_body<false, false, true>(p); }
+__global__ __launch_bounds__(512, 1) void conv3x3_c64_act_res(Conv64Params p) { conv3x3_c64_body<false, true, true>(p); }
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2155,7 +2174,8 @@ static bool c64_eligible(int N, int IH, int IW, int Cin, int OH, int OW, int Cou
 
 static int conv_igemm_impl(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
                            int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, const void* residual,
-                           float* stat_part, const float* stat_shift, int* plan_rows, void* stream) {
+                           float* stat_part, const float* stat_shift, int* plan_rows, void* stream, float slope = 0.f) {
+    // relu: the activation of the epilogue -- 0 none, 1 ReLU, 2 leaky ReLU with `slope` (act(conv + bias + residual))
     // plan_rows != null: nothing is launched; *plan_rows = number of statistics rows the kernel chosen for this layer would write
     // (0 = that kernel has no statistics epilogue).  One decision path for launching and planning.
     if (plan_rows) *plan_rows = 0;
@@ -2175,7 +2195,7 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
     p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = out; p.bias = bias; p.residual = (const uint16_t*)residual;
     if (residual && out_f32) return MGN_ENOTSUP;
     p.N = N; p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
-    p.stride = stride; p.pad = pad; p.up = up; p.relu = relu; p.out_f32 = out_f32; p.xcd_bands = 0; p.stat_part = stat_part;
+    p.stride = stride; p.pad = pad; p.up = up; p.relu = relu; p.slope = slope; p.out_f32 = out_f32; p.xcd_bands = 0; p.stat_part = stat_part;
     const bool stats_ok = !bias && !relu && !out_f32 && !residual && up == 1;   // what a statistics epilogue may be asked for
     // block -> XCD is (linear block id) % 8: the x-only remap is a per-XCD banding when the x extent is a multiple of 8 or the
     // grid is one-dimensional
@@ -2203,7 +2223,7 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
         if (rc1 == 2) return MGN_OK;
         if (rc1 <= 0) return rc1;
     }
-    if (!pack && KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 1 && IH == OH && IW == OW && !bias && !relu && !out_f32) {
+    if (!pack && KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 1 && IH == OH && IW == OW && !out_f32 && !((bias || relu) && (stat_part || plan_rows))) {
         // windowed kernel (csrc/conv_win.hip): the input window of a 2-D pixel patch stays in LDS for all nine taps
         const int pr = mgn_conv_win_patch_rows(N, OH, OW, Cin, Cout);
         if (pr > 0 && plan_rows) {
@@ -2211,7 +2231,7 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
             return MGN_OK;
         }
         if (pr > 0) {
-            const int rcw = MGN_SYM(mgn_conv3x3_win)(in, w, out, N, OH, OW, Cin, Cout, residual, pr, stat_part, stat_shift, stream);
+            const int rcw = MGN_SYM(mgn_conv3x3_win_act)(in, w, out, N, OH, OW, Cin, Cout, residual, pr, stat_part, stat_shift, bias, relu, slope, stream);
             if (rcw != MGN_ENOTSUP || stat_part) return rcw;
         }
     }
@@ -2222,7 +2242,7 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
         const int rcu = MGN_SYM(mgn_conv3x3_up2_win)(in, w, out, N, IH, IW, Cin, Cout, OH, OW, KH, residual, 0, stream);
         if (rcu != MGN_ENOTSUP) return rcu;
     }
-    const bool c64 = !pack && !bias && !relu && !out_f32 && c64_eligible(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up);
+    const bool c64 = !pack && !out_f32 && !((bias || relu) && (stat_part || plan_rows)) && c64_eligible(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up);
     if (stat_part && !stats_ok) return MGN_ENOTSUP;   // (mgn_conv_stat_rows says which layers leave statistics behind)
     if (pack && KH == 7 && KW == 7 && stride == 2 && pad == 3 && stats_ok) {
         // the 64-channel stems: persistent windowed kernel with the weights in registers (csrc/conv_stem.hip), one statistics row per block
@@ -2248,6 +2268,7 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
     } else if (c64) {
         Conv64Params q;
         q.in = p.in; q.w = p.w; q.out = (uint16_t*)out; q.residual = p.residual; q.stat_part = stat_part;
+        q.bias = bias; q.act = relu; q.slope = slope;
         c64_plan(N, OH, OW, Cout, &q);
         if (plan_rows) { *plan_rows = stats_ok ? q.nslices : 0; return MGN_OK; }
         static bool cattr = false;
@@ -2255,9 +2276,17 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_stats), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_res), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_act), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_act_res), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
             cattr = true;
         }
         if (q.stat_part && q.residual) return MGN_ENOTSUP;
+        if (bias || relu) {   // out = act(conv + bias + residual): inference with the following norm folded in (mgn_conv_igemm_act)
+            const dim3 g64((unsigned)((q.nslices + 7) / 8) * 8 * q.co_tiles);
+            if (q.residual) hipLaunchKernelGGL(conv3x3_c64_act_res, g64, dim3(512), C64_LDS, st, q);
+            else hipLaunchKernelGGL(conv3x3_c64_act, g64, dim3(512), C64_LDS, st, q);
+            return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+        }
         if (q.residual) hipLaunchKernelGGL(conv3x3_c64_res, dim3((unsigned)((q.nslices + 7) / 8) * 8 * q.co_tiles), dim3(512), C64_LDS, st, q);
         else if (q.stat_part) hipLaunchKernelGGL(conv3x3_c64_stats, dim3((unsigned)((q.nslices + 7) / 8) * 8 * q.co_tiles), dim3(512), C64_LDS, st, q);
         else hipLaunchKernelGGL(conv3x3_c64, dim3((unsigned)((q.nslices + 7) / 8) * 8 * q.co_tiles), dim3(512), C64_LDS, st, q);
@@ -2332,6 +2361,16 @@ static int conv_igemm_impl(const void* in, const void* w, void* out, const float
 int MGN_SYM(mgn_conv_igemm)(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
                    int Cout, int KH, int KW, int stride, int pad, int up, int relu, int out_f32, const void* residual, void* stream) {
     return conv_igemm_impl(in, w, out, bias, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, up, relu, out_f32, residual, nullptr, nullptr, nullptr, stream);
+}
+
+/* out = act(conv(in, w) + bias + residual), act: 0 none | 1 ReLU | 2 leaky ReLU with `slope` -- mgn_conv_igemm with the activation as a
+ * parameter and the bias / activation epilogue also in the windowed 3x3 and the 64-channel kernels: eval-mode `conv -> InPlaceABNSync`
+ * (and the residual block's `-> + shortcut -> ReLU`) as ONE launch, the norm's fixed affine folded into the weights (scale) and this
+ * bias (shift) by the caller.  16-bit output only. */
+int MGN_SYM(mgn_conv_igemm_act)(const void* in, const void* w, void* out, const float* bias, int N, int IH, int IW, int Cin, int OH, int OW,
+                                int Cout, int KH, int KW, int stride, int pad, int act, float slope, const void* residual, void* stream) {
+    if (act < 0 || act > 2) return MGN_EINVAL;
+    return conv_igemm_impl(in, w, out, bias, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, 1, act, 0, residual, nullptr, nullptr, nullptr, stream, slope);
 }
 
 int MGN_SYM(mgn_conv_igemm_stats)(const void* in, const void* w, void* out, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH,

@@ -42,8 +42,11 @@ struct WinParams {
     const float* stat_shift;   // [Cout] or null (= 0)
     int py, px;                // patches per image (rows, columns)
     int xcd;                   // 1: deal contiguous bands of patches to the XCDs
+    const float* bias;         // [Cout] added before the residual, or null (the eval-mode fold of the InPlaceABNSync that follows, see
+    int act;                   // mgn_conv_igemm_act); act after bias and residual: 0 none, 1 ReLU, 2 leaky ReLU with `slope`
+    float slope;
 };
-MGN_PLAN_RO(WinParams, MGN_RO(in) MGN_RO(w) MGN_RO(residual) MGN_RO(stat_shift))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO(WinParams, MGN_RO(in) MGN_RO(w) MGN_RO(residual) MGN_RO(stat_shift) MGN_RO(bias))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 constexpr int PW = 32, WW = PW + 2;
 constexpr int WIN_PIECES = 40;                 // 1-KB DMA pieces of 16 pixels x 64 B: 5 per wave (612 of the 640 pixels are real)
@@ -247,6 +250,7 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
         for (int q = 0; q < 4; ++q) {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (stats && p.stat_shift) t = *reinterpret_cast<const float4*>(p.stat_shift + bn * 128 + wn * 64 + j * 32 + 8 * q + 4 * hi);
+            if (!stats && p.bias) t = *reinterpret_cast<const float4*>(p.bias + bn * 128 + wn * 64 + j * 32 + 8 * q + 4 * hi);   // (never both)
             sh[j][q][0] = t.x; sh[j][q][1] = t.y; sh[j][q][2] = t.z; sh[j][q][3] = t.w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) s1[j][q][e] = s2[j][q][e] = 0.f;
@@ -280,9 +284,14 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
                 for (int u = 0; u < 2; ++u) {
                     const int q = 2 * qp + u;
                     float v0 = acc[i][j][q * 4 + 0], v1 = acc[i][j][q * 4 + 1], v2 = acc[i][j][q * 4 + 2], v3 = acc[i][j][q * 4 + 3];
+                    if (!stats && p.bias) { v0 += sh[j][q][0]; v1 += sh[j][q][1]; v2 += sh[j][q][2]; v3 += sh[j][q][3]; }
                     if (p.residual) {
                         v0 += mgn_lo2f(rp[u][0]); v1 += mgn_hi2f(rp[u][0]);
                         v2 += mgn_lo2f(rp[u][1]); v3 += mgn_hi2f(rp[u][1]);
+                    }
+                    if (p.act) {
+                        const float sl = p.act == 1 ? 0.f : p.slope;
+                        v0 = v0 > 0.f ? v0 : v0 * sl; v1 = v1 > 0.f ? v1 : v1 * sl; v2 = v2 > 0.f ? v2 : v2 * sl; v3 = v3 > 0.f ? v3 : v3 * sl;
                     }
                     pk[u][0] = mgn_pack2(v0, v1);
                     pk[u][1] = mgn_pack2(v2, v3);
@@ -363,9 +372,21 @@ int mgn_conv_win_patch_rows(int N, int OH, int OW, int Cin, int Cout) {
 }
 #endif
 
+int MGN_SYM(mgn_conv3x3_win_act)(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
+                                 int patch_rows, float* stat_partials, const float* stat_shift, const float* bias, int act, float slope,
+                                 void* stream);
 int MGN_SYM(mgn_conv3x3_win)(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
                              int patch_rows, float* stat_partials, const float* stat_shift, void* stream) {
-    if (!in || !w || !out || N < 1 || H < 1 || W < 1) return MGN_EINVAL;
+    return MGN_SYM(mgn_conv3x3_win_act)(in, w, out, N, H, W, Cin, Cout, residual, patch_rows, stat_partials, stat_shift, nullptr, 0, 0.f, stream);
+}
+
+/* the same with an epilogue out = act(conv + bias + residual) (act: 0 none, 1 ReLU, 2 leaky ReLU with `slope`): inference with the
+ * InPlaceABNSync that follows folded into the weights and this bias (mgn_conv_igemm_act).  Not together with the statistics rows. */
+int MGN_SYM(mgn_conv3x3_win_act)(const void* in, const void* w, void* out, int N, int H, int W, int Cin, int Cout, const void* residual,
+                                 int patch_rows, float* stat_partials, const float* stat_shift, const float* bias, int act, float slope,
+                                 void* stream) {
+    if (!in || !w || !out || N < 1 || H < 1 || W < 1 || act < 0 || act > 2) return MGN_EINVAL;
+    if (stat_partials && (bias || act)) return MGN_ENOTSUP;
     if (Cin < 32 || Cin % 32 != 0 || Cout < 128 || Cout % 128 != 0) return MGN_ENOTSUP;
     if ((size_t)N * H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fffffffu) return MGN_ENOTSUP;   // 32-bit byte offsets
     if (patch_rows != 8 && patch_rows != 16) return MGN_EINVAL;
@@ -373,6 +394,7 @@ int MGN_SYM(mgn_conv3x3_win)(const void* in, const void* w, void* out, int N, in
     p.in = (const uint16_t*)in; p.w = (const uint16_t*)w; p.out = (uint16_t*)out; p.residual = (const uint16_t*)residual;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.stat_part = stat_partials; p.stat_shift = stat_shift;
+    p.bias = bias; p.act = act; p.slope = slope;
     if (stat_partials && residual) return MGN_ENOTSUP;
     p.py = (H + patch_rows - 1) / patch_rows; p.px = (W + PW - 1) / PW;
     const long npatch = (long)N * p.py * p.px;

@@ -32,6 +32,10 @@ class InPlaceABNSync(nn.Module):
         return ops.iabn(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum,
                         self.eps, self.activation, self.activation_param, self.group)
 
+    def train(self, mode=True):
+        self.__dict__.pop("_mgn_eval_fold", None)   # (ops.conv_abn_eval's folded weights: the running statistics are about to move)
+        return super().train(mode)
+
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, activation={self.activation}"
 
@@ -57,6 +61,12 @@ class Conv2d(nn.Conv2d):
     def forward(self, x, with_skip=False, full=None):
         skip = None
         sf = self.norm if isinstance(self.norm, InPlaceABNSync) else None
+        if sf is not None and not sf.training and full is None and not torch.is_grad_enabled():
+            y = ops.conv_abn_eval(x, self)      # inference: the norm folded into the convolution (one launch)
+            if y is not None:
+                if self.activation is not None:
+                    y = self.activation(y)
+                return (y, x[:, :, ::2, ::2] if with_skip == 2 else x) if with_skip else y
         if full is not None:   # a block's 1x1 / stride-2 shortcut conv fed with conv1's `xsub` (ops._ShortcutS2Fn)
             x = ops.conv2d_shortcut_s2(x, full, self.weight, stats_for=sf)
         elif with_skip:   # also hand back the input for a second consumer (its gradient is fused into the conv's backward)

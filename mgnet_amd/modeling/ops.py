@@ -237,6 +237,44 @@ class _AbnAddReluFn(torch.autograd.Function):
         return dx, dm, d_weight.to(wdtype), d_bias.to(wdtype), None, None, None, None, None, None, None
 
 
+def conv_abn_eval(x, conv, residual=None, relu=False):
+    """Inference form of `conv -> InPlaceABNSync` (and of the residual block's `-> + shortcut -> ReLU`): in eval mode the norm is a fixed
+    per-channel affine + activation, so its scale is folded into the convolution's weights, its shift becomes the bias and the activation
+    (after the optional residual) runs in the convolution's epilogue -- one launch, no pass over the activation for the norm (the
+    reference swaps InPlaceABN for a foldable ABN for deployment the same way, tools/onnx_trt_export.py:19).  The folded 16-bit weights
+    are cached on the norm module until a parameter / buffer changes or the module goes back to training mode.
+    Returns None when the call is not such a case (training, gradients enabled, CPU, fp32 trunk, a shape without the epilogue): the
+    caller then runs conv and norm as before."""
+    from .. import _C
+    norm = getattr(conv, "norm", None)
+    if (norm is None or type(norm).__name__ != "InPlaceABNSync" or norm.training or torch.is_grad_enabled() or not x.is_cuda
+            or x.dtype not in _C.H16 or x.dim() != 4 or conv.weight.shape[1] != x.shape[1] or x.shape[1] % 32 or conv.groups != 1
+            or tuple(conv.dilation) != (1, 1) or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]
+            or norm.activation not in ("identity", "leaky_relu") or (relu and norm.activation != "identity")
+            or norm.running_mean.dtype != torch.float32 or os.environ.get("MGN_NO_EVALFOLD")):
+        return None
+    w = conv.weight
+    Cout, Cin, KH, KW = w.shape
+    stride, pad = conv.stride[0], conv.padding[0]
+    N, _, IH, IW = x.shape
+    OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
+    if residual is not None and (tuple(residual.shape) != (N, Cout, OH, OW) or residual.dtype != x.dtype
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    key = (w.data_ptr(), w._version, getattr(_C.weight_cache, "epoch", 0), norm.weight._version, norm.bias._version, norm.running_mean._version,
+           norm.running_var._version, norm.running_mean.data_ptr(), x.dtype, None if conv.bias is None else conv.bias._version)
+    fold = norm.__dict__.get("_mgn_eval_fold")
+    if fold is None or fold[0] != key:
+        coef = _C.iabn_eval_coeffs(norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous(), norm.running_mean,
+                                   norm.running_var, norm.eps)          # [2, C]: y = coef[0] * x + coef[1]
+        w2 = (w.detach().float() * coef[0].view(-1, 1, 1, 1)).contiguous()
+        b2 = (coef[1] if conv.bias is None else coef[1] + coef[0] * conv.bias.detach().float()).contiguous()
+        fold = (key, _C._weight_layout_now(w2, 0, 0, None, 0, x.dtype), b2)
+        norm.__dict__["_mgn_eval_fold"] = fold
+    act, slope = (1, 0.0) if relu else ((2, float(norm.activation_param)) if norm.activation == "leaky_relu" else (0, 0.0))
+    return _C.conv_igemm_act(x.contiguous(memory_format=torch.channels_last), fold[1], (OH, OW), fold[2], stride, pad, act, slope, residual)
+
+
 def abn_add_relu(x, norm, shortcut):
     """`relu_(norm(x) + shortcut)` for an identity-activation InPlaceABNSync (res_net.py:62-79); fused on the GPU path."""
     from .. import _C

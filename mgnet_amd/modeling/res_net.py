@@ -33,6 +33,14 @@ class BasicBlock(nn.Module):  # res_net.py:11-79
                 c2_msra_fill(layer)
 
     def forward(self, x):
+        if not self.training and not torch.is_grad_enabled():
+            # inference: three launches per block -- every norm folded into its convolution, the shortcut add and the ReLU in conv2's
+            # epilogue (ops.conv_abn_eval; each call falls back to conv + norm on its own where no kernel has the epilogue)
+            out = self.conv1(x)
+            sc = x if self.shortcut is None else self.shortcut(x)
+            c2 = self.conv2
+            y = ops.conv_abn_eval(out, c2, residual=sc.contiguous(memory_format=torch.channels_last) if sc.is_cuda else sc, relu=True)
+            return y if y is not None else ops.abn_add_relu(ops.conv2d(out, c2.weight, c2.bias, c2.stride, c2.padding), c2.norm, sc)
         if self.shortcut is not None and self.stride == 2 and ops.sub2_supported(x, self.conv1.weight, self.shortcut.weight):
             # down-sampling block: the shortcut conv's data gradient travels at the LOW resolution into conv1's data-gradient kernel
             out, xsub = self.conv1(x, with_skip=2)

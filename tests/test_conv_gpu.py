@@ -238,6 +238,65 @@ def test_conv1x1_over_a_concatenation_without_the_concatenation(shape, dtype, mo
     assert not ops.conv_cat_supported(a0, b0, w)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [  # (Cin, Cout, k, stride, H, W, activation, with residual + ReLU)   -> the kernel that takes it
+    (128, 128, 3, 1, 64, 128, "leaky_relu", False),   # windowed 3x3
+    (256, 256, 3, 1, 32, 64, "identity", True),       # windowed 3x3, block tail
+    (64, 64, 3, 1, 64, 96, "leaky_relu", False),      # 64-channel row march
+    (64, 64, 3, 1, 63, 97, "identity", True),         # 64-channel row march, block tail, ragged
+    (64, 128, 3, 2, 64, 96, "leaky_relu", False),     # generic (strided)
+    (64, 128, 1, 2, 64, 96, "identity", False),       # generic (the shortcut)
+    (512, 128, 3, 1, 17, 33, "leaky_relu", False)])
+def test_eval_mode_conv_with_the_norm_folded_in(case, dtype, monkeypatch):
+    """ops.conv_abn_eval (inference: conv -> InPlaceABNSync [-> + shortcut -> ReLU] as one launch, scale folded into the weights, shift
+    and activation in the epilogue) against fp64 on the unfolded parameters and against the two-launch path it replaces; the fold is
+    rebuilt when a parameter or running statistic changes."""
+    from mgnet_amd.modeling import layers, ops
+
+    Cin, Cout, k, stride, H, W, activation, tail = case
+    torch.manual_seed(Cin + H)
+    conv = layers.Conv2d(Cin, Cout, kernel_size=k, stride=stride, padding=k // 2, bias=False, norm=layers._abn(Cout, activation)).cuda()
+    with torch.no_grad():
+        conv.norm.weight.uniform_(0.5, 1.5); conv.norm.bias.normal_(0, 0.3)
+        conv.norm.running_mean.normal_(0, 0.2); conv.norm.running_var.uniform_(0.5, 2.0)
+    conv.eval()
+    x = torch.randn(2, Cin, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    OH, OW = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(2, Cout, OH, OW, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last) if tail else None
+
+    def reference():
+        n = conv.norm
+        gamma = n.weight.detach().abs().double() + n.eps
+        scale = gamma / (n.running_var.double() + n.eps).sqrt()
+        y = F.conv2d(x.double(), conv.weight.detach().to(dtype).double(), stride=stride, padding=k // 2)
+        y = y * scale.view(1, -1, 1, 1) + (n.bias.detach().double() - n.running_mean.double() * scale).view(1, -1, 1, 1)
+        if activation == "leaky_relu":
+            y = torch.where(y > 0, y, y * n.activation_param)
+        return torch.relu(y + res.double()) if tail else y
+    with torch.no_grad():
+        y = ops.conv_abn_eval(x, conv, residual=res, relu=tail)
+        assert y is not None and y.shape == (2, Cout, OH, OW) and y.dtype == dtype
+        ref = reference()
+        tol = (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) * 2.5     # weights rounded after the fold + one output rounding
+        assert float((y.double() - ref).abs().max() / ref.abs().max()) < tol
+        monkeypatch.setenv("MGN_NO_EVALFOLD", "1")
+        assert ops.conv_abn_eval(x, conv, residual=res, relu=tail) is None
+        y2 = conv(x.clone())                                                # conv, then the norm's eval pass in place
+        y2 = torch.relu(y2.float() + res.float()).to(dtype) if tail else y2
+        monkeypatch.delenv("MGN_NO_EVALFOLD")
+        assert float((y.float() - y2.float()).abs().max() / ref.abs().max()) < 2 * tol
+        if not tail:
+            assert torch.equal(conv(x.clone()), y)                          # Conv2d.forward takes the folded path by itself
+        # the cached fold follows the parameters
+        conv.norm.running_mean.add_(0.5)
+        y3 = ops.conv_abn_eval(x, conv, residual=res, relu=tail)
+        assert float((y3.double() - reference()).abs().max() / ref.abs().max()) < tol and not torch.equal(y3, y)
+    assert ops.conv_abn_eval(x, conv) is None          # gradients enabled: not an inference call
+    conv.train()
+    with torch.no_grad():
+        assert ops.conv_abn_eval(x, conv) is None and "_mgn_eval_fold" not in conv.norm.__dict__
+
+
 def test_dense_stem_falls_back_to_eight_channels_on_odd_widths(monkeypatch):
     from mgnet_amd import _C
     assert _C.stem_input_channels(2, 40, 57) == 8 and _C.stem_input_channels(2, 40, 56, real=9) == 16
