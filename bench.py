@@ -395,7 +395,9 @@ def full_step_bench(args, world, rank, dev):
         # launch-plan replay (engine/plan.py): one eager step recorded, the timed steps replayed from C with the side streams kept
         plan = None
         try:
-            plan = trainer.record_plan(batch, prof_slots=args.steps)
+            # (one process: three recordings, the fastest kept -- a recording's replay time is fixed when its buffers are placed,
+            #  Trainer.record_plan; the trial steps are training steps like the warm-up's)
+            plan = trainer.record_plan(batch, prof_slots=args.steps, best_of=3 if world == 1 else 1)
         except Exception as e:  # noqa: BLE001 -- report and fall back to the eager step rather than lose the measurement
             plan_note = f"plan recording failed ({type(e).__name__}: {e}); eager steps timed"
             print(f"[bench] {plan_note}", file=sys.stderr, flush=True)
@@ -446,6 +448,8 @@ def full_step_bench(args, world, rank, dev):
             mode = "eager"
             plan_note = "launch-plan replay recorded and available (--exec plan); the calibration found the eager issue faster on this box"
         exec_probe["timed"] = mode
+        if getattr(trainer, "plan_trials", None):
+            exec_probe["plan_recordings_ms"] = trainer.plan_trials   # (6 replays each; the fastest recording is the one probed and timed)
     if use_graph:
         try:
             trainer.capture_step(batch)
