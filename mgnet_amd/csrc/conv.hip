@@ -2406,7 +2406,12 @@ static void wgrad_plan(int N, int OH, int OW, int Cin, int Cout, int KH, int KW,
     const long M = (long)N * OH * OW;
     const int tiles = *co_tiles * (*pack ? 1 : KH * KW) * *ci_tiles;
     long splits = (768 + tiles - 1) / tiles;              // ~768 blocks: 3 resident per CU on 256 CUs
-    long max_splits = (M + 2047) / 2048;                  // >= 2048 pixels (32 k-steps) per block ...
+    // >= 2048 pixels (32 k-steps) per block; the skinny 1x1 layers with one or two tiles (the predictors' 256 <-> 32 channels at
+    // 128 x 256: 151 MB of inputs for 4 GFLOP) take 1024, i.e. two blocks per CU instead of one: 56 -> 43 us (round 5; the 256 -> 256
+    // layer with its four tiles loses with it, 88 -> 112 us).  MGN_WGRAD_PXSPLIT overrides both (A/B)
+    static const int px_env = getenv("MGN_WGRAD_PXSPLIT") ? atoi(getenv("MGN_WGRAD_PXSPLIT")) : 0;
+    const int px_split = px_env > 0 ? px_env : (tiles <= 2 ? 1024 : 2048);
+    long max_splits = (M + px_split - 1) / px_split;
     // ... unless that leaves most of the chip idle (the 1x1 layers of the 32x64 / 64x128 maps: 16-64 blocks, 44-56 us for 0.3-4 GFLOP):
     // then down to 256 pixels per block, up to one block per CU
     static const int min_px = getenv("MGN_WGRAD_MINPX") ? atoi(getenv("MGN_WGRAD_MINPX")) : 256;
