@@ -383,12 +383,17 @@ def full_step_bench(args, world, rank, dev):
     # latency); "graph" (--graph on, one rank only) = the whole step captured once in a hipGraph on ONE stream and replayed.
     # Measured (end of round 2): eager + side streams 30.2 ms, graph 32.5 ms (capturing the side-stream branches crashes hipGraph on ROCm 7.0).
     use_graph = args.graph == "on" and world == 1
-    # Multi-rank runs replay the plan as well (the eager issue costs the host 15-20 ms of a ~27 ms step BEFORE the +136 mailbox launches
-    # and the all-reduce calls of a multi-rank step): the recording needs the SyncBN statistics on the mailbox kernels (probed above) and
-    # succeeds on every rank or is dropped by all of them; otherwise the eager step with the process group's collectives is timed and
-    # `config.step_execution` says why.
-    use_plan = args.exec in ("plan", "auto") and not use_graph
+    # One rank: the recorded step is replayed (--exec auto / plan).  Multi-rank runs: `--exec auto` issues the step EAGERLY and only
+    # `--exec plan` replays it.  The multi-rank replay exists and is tested -- the gradient all-reduces re-issued by the plan at their
+    # place, the SyncBN statistics on the mailbox kernels, every rank or none (tests/test_dist_gpu.py: two ranks on one GPU, plan ==
+    # eager bit for bit) -- but it has never run across GPUs (no multi-GPU box has been available to this repository in any round), and
+    # a wrong cross-stream edge or a hang there would cost the driver's scaling run its numbers.  The eager step is GPU-bound too
+    # (18-20 ms of host issue under a ~26 ms step: +0.2 ms at one rank, config.step_execution_probe), so the default gives up little.
+    use_plan = (args.exec == "plan" or (args.exec == "auto" and world == 1)) and not use_graph
     mode, plan_note = "eager", None
+    if world > 1 and args.exec == "auto":
+        plan_note = ("multi-rank default: eager issue -- the launch-plan replay of a multi-rank step is validated on two ranks sharing one GPU "
+                     "only (bit-identical to eager there), never across GPUs; --exec plan selects it")
     for _ in range(max(args.warmup, 3) if (use_graph or use_plan) else args.warmup):
         trainer.run_step(batch)
     if use_plan:
@@ -397,7 +402,9 @@ def full_step_bench(args, world, rank, dev):
         try:
             # (one process: three recordings, the fastest kept -- a recording's replay time is fixed when its buffers are placed,
             #  Trainer.record_plan; the trial steps are training steps like the warm-up's)
-            plan = trainer.record_plan(batch, prof_slots=args.steps, best_of=3 if world == 1 else 1)
+            #  The two fastest recordings are then replayed from one state and must agree bit for bit (Trainer.record_plan
+            #  verify_steps; on a difference the read-only declarations are dropped and the step is recorded again): config.plan_check
+            plan = trainer.record_plan(batch, prof_slots=args.steps, best_of=3 if world == 1 else 1, verify_steps=args.plan_verify_steps)
         except Exception as e:  # noqa: BLE001 -- report and fall back to the eager step rather than lose the measurement
             plan_note = f"plan recording failed ({type(e).__name__}: {e}); eager steps timed"
             print(f"[bench] {plan_note}", file=sys.stderr, flush=True)
@@ -570,6 +577,7 @@ def full_step_bench(args, world, rank, dev):
                                                   " (launches issued from Python; side streams for the independent branches: " +
                                                   ("on" if model._side_streams() is not None else "off") + ")" + (f"; {plan_note}" if plan_note else "")),
                        **({"step_execution_probe": exec_probe} if exec_probe else {}),
+                       **({"plan_check": trainer.plan_check} if getattr(trainer, "plan_check", None) else {}),
                        "host_issue_ms_per_step": round(host_issue_ms, 2),
                        "host_issue_is": "wall time of issuing ONE step of this workload into an empty launch queue (median of 5 -- 3 on multi-rank runs -- after the timed region)",
                        "host_issue_loop_wall_ms_per_step": round(t_issue / args.steps * 1e3, 2),
@@ -691,7 +699,11 @@ def main():
                     help="16-bit activation format of the trunk: bf16 (default) or the reference's AMP format fp16 with dynamic loss "
                          "scaling (BASELINE C5)")
     ap.add_argument("--exec", choices=["auto", "plan", "eager"], default="auto",
-                    help="how the timed steps are issued on one rank: plan = launch-plan replay from C (default when it records), eager = from Python")
+                    help="how the timed steps are issued: plan = launch-plan replay from C, eager = from Python; auto = plan on one rank (when it "
+                         "records and its calibration is not slower), eager on multi-rank runs (the multi-rank replay has not run across GPUs yet)")
+    ap.add_argument("--plan-verify-steps", type=int, default=12,
+                    help="one rank: the two fastest of the three recordings are replayed this many steps each from the same state and must agree "
+                         "bit for bit (0 = skip the check)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="on: replay the captured step as a hipGraph (1 GPU, one stream); auto/off: issue every launch from Python "
                          "with the independent branches on side streams (the faster mode)")

@@ -334,6 +334,7 @@ int mgn_plan_node_count(const void* plan);
 int mgn_plan_node_info(const void* plan, int i, mgn_plan_node_info_t* out);
 int mgn_plan_node_args(const void* plan, int i, int max_args, int* offsets, int* sizes, int* kinds /*0 opaque, 1 const pointer, 2 pointer*/);
 int mgn_plan_node_ro(const void* plan, int i, int max_args, unsigned long long* ro /*[2 * nargs]: read-only pointer words of struct arguments*/);
+int mgn_plan_node_ro_family(const void* plan, int i, int max_args, int* family /*[nargs]: 0 no declaration, 1 convolution-kernel structs (honoured by default), 2 other*/);
 int mgn_plan_compile(void* plan, int n_ops, const int* types, const int* a, void* const* streams, int n_events, int prof_slots);
 int mgn_plan_run(void* plan, int from_op, int prof_slot);   /* -> index of the BREAK it stopped at, or the op count */
 int mgn_plan_set_stream(void* plan, int node, void* stream);   /* replay a node on another stream (the schedule must order it accordingly) */

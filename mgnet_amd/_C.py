@@ -30,7 +30,7 @@ SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "
            "mgn_reconstruct_bwd", "mgn_project_fwd", "mgn_project_bwd",
            "mgn_plan_begin", "mgn_plan_recorded", "mgn_plan_current", "mgn_plan_end", "mgn_plan_abort", "mgn_plan_node_count", "mgn_plan_node_info", "mgn_plan_node_args",
            "mgn_plan_compile", "mgn_plan_set_stream", "mgn_plan_run", "mgn_plan_prof_elapsed", "mgn_plan_free",
-           "mgn_plan_trace", "mgn_plan_trace_read", "mgn_plan_set_skip", "mgn_plan_node_ro", "mgn_plan_set_jitter", "mgn_plan_probe",
+           "mgn_plan_trace", "mgn_plan_trace_read", "mgn_plan_set_skip", "mgn_plan_node_ro", "mgn_plan_node_ro_family", "mgn_plan_set_jitter", "mgn_plan_probe",
            "mgn_abn_apply_pool", "mgn_att_abn_bwd_stats", "mgn_att_abn_bwd_sums", "mgn_att_abn_bwd_apply"]
 SYMBOLS_F16 = [n + "_f16" for n in ['mgn_weight_layout', 'mgn_weight_layout_batch', 'mgn_conv_igemm', 'mgn_conv_igemm_stats', 'mgn_conv3x3_win', 'mgn_conv3x3_up2_win', 'mgn_conv_stem7', 'mgn_conv_wgrad', 'mgn_conv_wgrad_partial', 'mgn_conv1x1_cat', 'mgn_conv1x1_split', 'mgn_conv_wgrad_cat', 'mgn_conv3x3_win_act', 'mgn_conv_igemm_act', 'mgn_add_relu_fwd', 'mgn_sum3', 'mgn_abn_add_relu_fwd', 'mgn_relu_mask_bwd', 'mgn_colsum', 'mgn_bcast_rows', 'mgn_scale_channels', 'mgn_nearest_fwd', 'mgn_nearest_bwd', 'mgn_abn_maxpool_fwd', 'mgn_abn_maxpool_bwd', 'mgn_maxpool3x3s2_fwd', 'mgn_maxpool3x3s2_bwd', 'mgn_upce_fwd', 'mgn_upce_bwd', 'mgn_ins_loss_fwd', 'mgn_ins_loss_bwd', 'mgn_prep_input', 'mgn_iabn_stats', 'mgn_iabn_train_coeffs', 'mgn_iabn_apply', 'mgn_iabn_bwd_reduce', 'mgn_iabn_bwd_reduce_x', 'mgn_iabn_bwd_reduce_x_relu', 'mgn_iabn_bwd_apply', 'mgn_iabn_bwd_apply_x', 'mgn_abn_apply_pool', 'mgn_att_abn_bwd_stats', 'mgn_att_abn_bwd_apply']]
 DEPTH_MAX_FILTER_IDS = 16
@@ -229,6 +229,7 @@ def lib():
         L.mgn_plan_trace_read.argtypes = [vp, ci, ci, ctypes.POINTER(cf), ctypes.POINTER(cf), ctypes.POINTER(cf)]
         L.mgn_plan_set_skip.argtypes = [vp, ci, ci]
         L.mgn_plan_node_ro.argtypes = [vp, ci, ci, ctypes.POINTER(ctypes.c_ulonglong)]
+        L.mgn_plan_node_ro_family.argtypes = [vp, ci, ci, ctypes.POINTER(ci)]
         L.mgn_plan_set_jitter.argtypes = [vp, ctypes.c_ulonglong, ci, ci]
         L.mgn_plan_probe.argtypes = [vp, ci, vp, sz, vp]
         L.mgn_abn_apply_pool.argtypes = [vp, vp, vp, vp, ci, cf, ci, cl, ci, cf, vp, vp, sz, vp]
@@ -606,8 +607,15 @@ def optim_step_dev(kind, p, g, m, v, chunk_lr, chunk_wd, beta1, beta2, eps, nest
 # convolution (implicit GEMM, bf16 MFMA).  Tensors are logical NCHW in channels_last memory format.
 # ---------------------------------------------------------------------------------------------------------------
 def conv_supported(x, weight):
-    """Cin % 32 == 0, or a channel-padded stem input (Cin 4/8/16 holding the weight's 3/9 real channels)"""
-    return x.is_cuda and x.dtype in H16 and (weight.shape[1] % 32 == 0 or (x.shape[1] in (4, 8, 16) and weight.shape[1] <= x.shape[1]))
+    """Cin % 32 == 0, or a channel-padded stem input (Cin 4/8/16 holding the weight's 3/9 real channels); 8-byte pixels (4 channels)
+    exist for the 7x7 dense-row stem only (csrc/conv_stem.hip; weight_layout mode 2 with Cp = 4 refuses other kernel sizes)"""
+    if not (x.is_cuda and x.dtype in H16):
+        return False
+    if weight.shape[1] % 32 == 0:
+        return True
+    if x.shape[1] == 4:
+        return weight.shape[1] <= 4 and tuple(weight.shape[2:]) == (7, 7)
+    return x.shape[1] in (8, 16) and weight.shape[1] <= x.shape[1]
 
 
 def stem_input_channels(N, H, W, real=3):

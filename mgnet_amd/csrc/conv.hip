@@ -43,7 +43,7 @@ struct ConvParams {
     float* stat_part;     // [pixel tiles][Cout][2]: per-tile sums of r, r^2 over the ROUNDED outputs (statistics of the InPlaceABNSync that
                           // follows; only without bias / ReLU / residual / fp32 output), or null
 };
-MGN_PLAN_RO(ConvParams, MGN_RO(in) MGN_RO(w) MGN_RO(bias) MGN_RO(residual))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO_CONV(ConvParams, MGN_RO(in) MGN_RO(w) MGN_RO(bias) MGN_RO(residual))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 // Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8, observed; MI355X_MICROARCH.md) and every XCD has its
 // own 4 MB L2.  With tile = blockIdx.x each L2 ends up loading (nearly) the whole input: vertically adjacent tiles share
@@ -503,7 +503,7 @@ struct Conv1Params {
     const uint16_t* in2;  // the input is the channel concatenation (in | in2) of two maps, never materialised (FeatureFusionModule)
     uint16_t* out2;       // the output's upper half of the channels goes to a map of its own (the concatenation's data gradient)
 };
-MGN_PLAN_RO(Conv1Params, MGN_RO(in) MGN_RO(w) MGN_RO(in2))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO_CONV(Conv1Params, MGN_RO(in) MGN_RO(w) MGN_RO(in2))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 template <int CIN, int NT, int WN>
 struct C1 {
@@ -655,10 +655,15 @@ __global__ __launch_bounds__(256, 1) void conv1x1_s_512_1_4(Conv1Params p) { con
 template <int CIN, int NT, int WN, typename K>
 static int launch_conv1x1(K kernel, Conv1Params& q, hipStream_t st, bool plan_only = false) {
     using C = C1<CIN, NT, WN>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-        attr = true;
+    // per KERNEL, not per instantiation of this function: conv1x1_s_256_2_4 and its two-source twin share <256, 2, 4, K>
+    static const void* attr_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    const void* kp = reinterpret_cast<const void*>(kernel);
+    bool seen = false;
+    for (const void* d : attr_done) seen = seen || d == kp;
+    if (!seen) {
+        (void)hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        for (const void*& d : attr_done)
+            if (!d) { d = kp; break; }
     }
     const long tiles = (q.M + C::BM - 1) / C::BM;
     if (tiles > 0x7fffffffL) return MGN_EINVAL;
@@ -855,7 +860,7 @@ struct Conv64Params {
     int act;               // fold of the InPlaceABNSync that follows, mgn_conv_igemm_act)
     float slope;
 };
-MGN_PLAN_RO(Conv64Params, MGN_RO(in) MGN_RO(w) MGN_RO(residual) MGN_RO(bias))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO_CONV(Conv64Params, MGN_RO(in) MGN_RO(w) MGN_RO(residual) MGN_RO(bias))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 constexpr int C64_NR = 8;   // ring of input rows: r-1 .. r+2 in use by the two output rows of a step, r+3 .. r+6 in flight
 constexpr int C64_INROW = 136 * 128, C64_LDS = C64_NR * C64_INROW;
 
@@ -1105,7 +1110,7 @@ struct WgradParams {
     int remap_tiles, co_tiles;   // remap_tiles > 0: 1-D grid, see wgrad_block
     const uint16_t* in2;   // != null (conv_wgrad only): the input is the channel concatenation (in | in2) of two maps of Cin / 2 channels
 };
-MGN_PLAN_RO(WgradParams, MGN_RO(dout) MGN_RO(in) MGN_RO(in2))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO_CONV(WgradParams, MGN_RO(dout) MGN_RO(in) MGN_RO(in2))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 // Which (output-channel tile, tap x input-channel tile, pixel split) a block of the split-K tile kernels works on.  With the plain 3-D
 // grid the tile blocks of ONE pixel split -- which read the same dOut / input pixels -- have consecutive linear ids and therefore land
@@ -1295,7 +1300,7 @@ struct Wgrad3Params {
     int N, H, W, Cin, Cout;
     int co_tiles, ci_tiles, strips, chunks, rows_per_chunk, nslices, ng;
 };
-MGN_PLAN_RO(Wgrad3Params, MGN_RO(dout) MGN_RO(in))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO_CONV(Wgrad3Params, MGN_RO(dout) MGN_RO(in))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
@@ -1558,7 +1563,7 @@ struct WgradStemParams {
     int N, IH, IW, OH, OW, Cout;
     int strips, chunks, rows_per_chunk, nslices, co_tiles;
 };
-MGN_PLAN_RO(WgradStemParams, MGN_RO(dout) MGN_RO(in))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO_CONV(WgradStemParams, MGN_RO(dout) MGN_RO(in))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 template <int CP>
 struct WS {
     static constexpr int PIN = CP == 16 ? 9 : (CP == 8 ? 5 : 3);      // 1-KB pieces per input row of the strip (262 pixels)
@@ -2525,6 +2530,9 @@ static int wgrad_impl(const void* dout, const void* in, float* dw, int N, int IH
                            oihw_cin, dw);
         return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
     }
+    // 8-byte pixels (Cin == 4) exist for the dense-row stem kernel only: every kernel below reads 16-byte segments of 8 channels and
+    // would take two pixels for one
+    if (Cin == 4) return MGN_ENOTSUP;
     Wgrad3Params p3;
     if (wgrad3_plan(N, OH, OW, Cin, Cout, KH, KW, stride, pad, IH, IW, &p3)) {
         if (workspace_bytes < sizeof(float) * p3.nslices * wsize) return MGN_ENOSPC;

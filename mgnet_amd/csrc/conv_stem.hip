@@ -52,7 +52,7 @@ struct StemParams {
     int py, px, npatch;   // patches per image (rows of 8, columns of 32) and in total
     int kpad;
 };
-MGN_PLAN_RO(StemParams, MGN_RO(in) MGN_RO(w))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO_CONV(StemParams, MGN_RO(in) MGN_RO(w))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 constexpr int SPH = 8, SPW = 32;   // output patch
 constexpr int WROWS = 2 * SPH + 5; // 21 input rows

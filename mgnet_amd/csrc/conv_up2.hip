@@ -39,7 +39,7 @@ struct Up2Params {
     int py, px, cot;           // patches per image (rows, columns), 64-channel output tiles
     int nitems;                // N * py * px * cot
 };
-MGN_PLAN_RO(Up2Params, MGN_RO(in) MGN_RO(w) MGN_RO(residual))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO_CONV(Up2Params, MGN_RO(in) MGN_RO(w) MGN_RO(residual))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 constexpr int PH = 8, PW = 32, RPW = 2, WW = PW + 1, WPX = (PH + 1) * WW;   // 297 window pixels
 constexpr int NWP = (WPX + 15) / 16;                                          // 19 window pieces of 16 pixels

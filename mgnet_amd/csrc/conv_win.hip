@@ -46,7 +46,7 @@ struct WinParams {
     int act;                   // mgn_conv_igemm_act); act after bias and residual: 0 none, 1 ReLU, 2 leaky ReLU with `slope`
     float slope;
 };
-MGN_PLAN_RO(WinParams, MGN_RO(in) MGN_RO(w) MGN_RO(residual) MGN_RO(stat_shift) MGN_RO(bias))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
+MGN_PLAN_RO_CONV(WinParams, MGN_RO(in) MGN_RO(w) MGN_RO(residual) MGN_RO(stat_shift) MGN_RO(bias))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
 constexpr int PW = 32, WW = PW + 2;
 constexpr int WIN_PIECES = 40;                 // 1-KB DMA pieces of 16 pixels x 64 B: 5 per wave (612 of the 640 pixels are real)

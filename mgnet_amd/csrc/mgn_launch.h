@@ -33,13 +33,25 @@ constexpr RoBits ro_field(size_t offset, size_t size) {
     return r;
 }
 constexpr RoBits mgn_plan_ro(const void*) { return RoBits{}; }   // (argument types that declare nothing)
+constexpr int mgn_plan_ro_family(const void*) { return 0; }
+// A declaration belongs to a FAMILY, fixed here in the source next to the struct -- not derived from kernel names at run time:
+//   MGN_RO_FAMILY_CONV  (1)  argument structs of the convolution kernels (forward, data gradient, weight gradient, stems): the
+//                            declarations the replay honours by default (engine/plan.py MGN_PLAN_RO=conv)
+//   MGN_RO_FAMILY_OTHER (2)  every other declared struct: honoured with MGN_PLAN_RO=all only (profiles/r05_plan_determinism.txt)
+// A new kernel joins the default set only by declaring its struct with MGN_PLAN_RO_CONV.
+#define MGN_RO_FAMILY_CONV 1
+#define MGN_RO_FAMILY_OTHER 2
 #define MGN_RO(f) | mgn_plan::ro_field(offsetof(S_, f), sizeof(S_::f))
-#define MGN_PLAN_RO(T, fields) \
-    constexpr mgn_plan::RoBits mgn_plan_ro(const T*) { using S_ = T; return mgn_plan::RoBits{} fields; }
+#define MGN_PLAN_RO_IN(T, family, fields) \
+    constexpr mgn_plan::RoBits mgn_plan_ro(const T*) { using S_ = T; return mgn_plan::RoBits{} fields; } \
+    constexpr int mgn_plan_ro_family(const T*) { return family; }
+#define MGN_PLAN_RO(T, fields) MGN_PLAN_RO_IN(T, MGN_RO_FAMILY_OTHER, fields)
+#define MGN_PLAN_RO_CONV(T, fields) MGN_PLAN_RO_IN(T, MGN_RO_FAMILY_CONV, fields)
 
 struct ArgDesc {
     unsigned short offset, size;
     unsigned char kind;   // 0 opaque bytes, 1 pointer to const (read), 2 pointer (read / written)
+    unsigned char family; // kind 0: MGN_RO_FAMILY_* of the struct's declaration, 0 = none
     RoBits ro;            // kind 0: the struct's read-only pointer words
 };
 
@@ -67,8 +79,12 @@ struct Packer {
         if (n < MAX_ARGS && bytes + (int)sizeof(T) <= MAX_ARG_BYTES) {
             std::memcpy(blob + bytes, &v, sizeof(T));
             RoBits ro;
-            if constexpr (!std::is_pointer<T>::value && std::is_class<T>::value) ro = mgn_plan_ro(static_cast<const T*>(nullptr));
-            desc[n] = ArgDesc{(unsigned short)bytes, (unsigned short)sizeof(T), arg_kind<T>(), ro};
+            int family = 0;
+            if constexpr (!std::is_pointer<T>::value && std::is_class<T>::value) {
+                ro = mgn_plan_ro(static_cast<const T*>(nullptr));
+                family = mgn_plan_ro_family(static_cast<const T*>(nullptr));
+            }
+            desc[n] = ArgDesc{(unsigned short)bytes, (unsigned short)sizeof(T), arg_kind<T>(), (unsigned char)family, ro};
         }
         bytes += (int)sizeof(T);
         ++n;

@@ -192,6 +192,17 @@ int mgn_plan_node_ro(const void* plan, int i, int max_args, unsigned long long* 
     return n.nargs;
 }
 
+/* per argument of node i: the family of its struct's read-only declaration (csrc/mgn_launch.h: 0 none, MGN_RO_FAMILY_CONV 1 = argument
+ * structs of the convolution kernels, MGN_RO_FAMILY_OTHER 2): which declarations a replay honours is decided per family */
+int mgn_plan_node_ro_family(const void* plan, int i, int max_args, int* family) {
+    const Plan* p = (const Plan*)plan;
+    if (!p || i < 0 || i >= (int)p->nodes.size() || !family) return MGN_EINVAL;
+    const Node& n = p->nodes[i];
+    if (n.nargs > max_args) return MGN_ENOSPC;
+    for (int k = 0; k < n.nargs; ++k) family[k] = p->args[n.arg_off + k].family;
+    return n.nargs;
+}
+
 /* the replay schedule: ops[k] = (type, a, stream).  LAUNCH a = node; RECORD / WAIT a = event index (n_events are created here);
  * BREAK = return to the host (mgn_plan_run stops in front of it).  prof_slots > 0 creates that many hipEvent pairs for the prof marks. */
 int mgn_plan_compile(void* plan, int n_ops, const int* types, const int* a, void* const* streams, int n_events, int prof_slots) {

@@ -32,6 +32,32 @@ from torch.utils._python_dispatch import TorchDispatchMode
 from .. import _C
 
 
+RO_FAMILY_CONV, RO_FAMILY_OTHER = 1, 2   # csrc/mgn_launch.h MGN_RO_FAMILY_*
+_RO_MODES = ("conv", "all", "none")
+_ro_override = None                       # set_ro_mode(): a process-wide override of MGN_PLAN_RO (Trainer.verify_plans falls back to "none")
+
+
+def _ro_mode():
+    if _ro_override is not None:
+        return _ro_override
+    mode = "none" if os.environ.get("MGN_PLAN_NO_RO") else os.environ.get("MGN_PLAN_RO", "conv")
+    if mode not in _RO_MODES:
+        raise ValueError(f"MGN_PLAN_RO={mode!r}: one of {_RO_MODES}")
+    return mode
+
+
+def set_ro_mode(mode):
+    """which read-only declarations later recordings honour (None: back to the environment's MGN_PLAN_RO / the default `conv`)"""
+    global _ro_override
+    if mode is not None and mode not in _RO_MODES:
+        raise ValueError(f"read-only mode {mode!r}: one of {_RO_MODES}")
+    _ro_override = mode
+
+
+def ro_mode():
+    return _ro_mode()
+
+
 class PlanUnsupported(RuntimeError):
     """the step cannot be replayed.  `completed`: the recording's body had already run to its end when the recorder's objection surfaced
     (a torch op it cannot express is only noticed, not refused) -- the step HAS been trained, `result` is what the body returned"""
@@ -150,6 +176,7 @@ class _Recorder(TorchDispatchMode):
         self._info = _C.PlanNodeInfo()
         self._offs, self._sizes, self._kinds = (ctypes.c_int * 64)(), (ctypes.c_int * 64)(), (ctypes.c_int * 64)()
         self._ro = (ctypes.c_ulonglong * 128)()
+        self._fam = (ctypes.c_int * 64)()
 
     # ---- library calls -------------------------------------------------------------------------------------------------
     def wrap(self, name, fn):
@@ -182,18 +209,24 @@ class _Recorder(TorchDispatchMode):
         if n < 0 or lib.mgn_plan_node_ro(plan, i, len(offs), self._ro) != n:
             raise PlanUnsupported("a kernel with more arguments than the recorder holds")
         ro = self._ro
-        # Which struct arguments' read-only declarations are honoured (MGN_PLAN_RO = conv | all | none; default conv).  With ALL of them
-        # honoured the three heads' forward passes overlap fully -- 1.1 ms faster per step -- but two replays of one step then differ, in
-        # 1.5 - 8 % of the steps, by what one stale 128-pixel tile is worth (profiles/r05_plan_determinism.txt: a later kernel of the SAME stream
-        # reads a tile its predecessor wrote in the previous replay; every pointer of the pair is declared, plain HIP kernels do not
-        # reproduce it (tools/probe/l2_probe.hip), any extra event nearby hides it).  Root cause not found; until it is, only the
-        # convolution family's declarations are used: 0 differing steps in 1200 replays (as with none), tests/test_plan_gpu.py keeps watch.
-        mode = "none" if os.environ.get("MGN_PLAN_NO_RO") else os.environ.get("MGN_PLAN_RO", "conv")
+        # Which struct arguments' read-only declarations are honoured: MGN_PLAN_RO = conv (default) | all | none, decided per FAMILY of the
+        # declaration -- a constant the struct's own MGN_PLAN_RO_CONV / MGN_PLAN_RO macro fixes in csrc/ (mgn_plan_node_ro_family), not a
+        # match on kernel names: a kernel joins the default set only if its argument struct is declared with MGN_PLAN_RO_CONV.
+        # With ALL declarations honoured the three heads' forward passes overlap fully -- 0.3-0.7 ms faster per step -- but two replays of
+        # one step then differ, in 1.5 - 8 % of the steps, by what one stale 128-pixel tile is worth (profiles/r05_plan_determinism.txt:
+        # a later kernel of the SAME stream reads a tile its predecessor wrote in the previous replay; every pointer of the pair is
+        # declared, plain HIP kernels do not reproduce it, any extra event nearby hides it).  Root cause not found; until it is, only the
+        # convolution structs' declarations are used (0 differing steps in 3000 replays, as with none); Trainer.verify_plans() checks two
+        # recordings of the real step against each other and falls back to `none` (bench.py runs it), tests/test_plan_gpu.py keeps watch.
+        mode = _ro_mode()
         nm_ = info.name.decode() if info.name else ""
-        if mode == "none" or (mode == "conv" and not any(x in nm_ for x in ("conv", "up2", "wgrad", "stem"))):
-            ctypes.memset(ro, 0, ctypes.sizeof(ro))
-        elif os.environ.get("MGN_PLAN_NO_RO_FOR") and any(x and x in nm_ for x in os.environ["MGN_PLAN_NO_RO_FOR"].split(",")):
-            ctypes.memset(ro, 0, ctypes.sizeof(ro))   # (bisecting: ... not for kernels whose name contains one of these substrings)
+        fam = self._fam
+        if lib.mgn_plan_node_ro_family(plan, i, len(fam), fam) != n:
+            raise PlanUnsupported("a kernel with more arguments than the recorder holds")
+        no_for = [x for x in os.environ.get("MGN_PLAN_NO_RO_FOR", "").split(",") if x]   # (bisecting: not for kernels named like this)
+        for k in range(n):
+            if mode == "none" or (mode == "conv" and fam[k] != RO_FAMILY_CONV) or any(x in nm_ for x in no_for):
+                ro[2 * k] = ro[2 * k + 1] = 0
         raw = ctypes.string_at(info.blob, info.nbytes) if info.nbytes else b""
         lo = blocks.starts[0] if blocks.starts else 0
         hi = blocks.ends[-1] if blocks.ends else 0

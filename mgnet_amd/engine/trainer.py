@@ -2,8 +2,8 @@
 sum of the loss dict -> backward (bucketed all-reduce overlapped) -> full-model clip -> Adam -> poly LR.
 SOLVER.AMP: bf16 activations by default (no loss scaling needed); SOLVER.AMP.DTYPE "float16" runs the reference's fp16 with
 GradScaler's dynamic loss scaling evaluated on the device (solver/fused_adam.py, csrc/optim.hip: no host synchronisation)."""
+import copy
 import os
-
 import time
 
 import torch
@@ -101,37 +101,132 @@ class Trainer:
     # ~29 ms GPU-bound step.  One eager step is recorded as a table of launches with by-value arguments (side streams included, their
     # dependencies derived from the memory each launch touches) and replayed from C; per replay the host uploads the learning-rate
     # tables and walks the table.  Unlike the hipGraph above it keeps the concurrent branches and costs a few ms of host time per step.
-    def record_plan(self, batched_inputs, prof_slots=0, best_of=1, trial_steps=6):
+    def record_plan(self, batched_inputs, prof_slots=0, best_of=1, trial_steps=6, verify_steps=0):
         """Record the step as a launch plan (see _record_plan_once).  best_of > 1 (one process only): record that many plans, run
         `trial_steps` replays of each -- every one of them a real training step -- and keep the fastest.  Why: the same step recorded twice
         in one process replays at 26.3 or at 26.7 ms, stable for the life of the recording (profiles/r05_plan_recordings.txt); what differs
         between two recordings is where the private pool's buffers landed in memory, nothing a schedule could express.  The trial timings
-        are kept in `self.plan_trials`."""
+        are kept in `self.plan_trials`.
+
+        verify_steps > 0 (with best_of >= 2): the two fastest recordings are replayed `verify_steps` steps each FROM THE SAME STATE
+        (parameters, buffers, optimizer moments, loss scale, schedule) and must agree bit for bit in every step's losses and in the final
+        gradients and parameters -- two recordings place their buffers differently and therefore run with different timing, so a
+        dependency the schedule misses shows up as a difference (profiles/r05_plan_determinism.txt).  If they differ, the read-only
+        declarations are switched off for this process (engine.plan.set_ro_mode("none"): every struct pointer counts as written), the step
+        is recorded again and checked again; a difference that survives raises.  `self.plan_check` reports what was done."""
         if best_of <= 1 or self.reducer.world != 1:
             self.plan_trials = None
+            self.plan_check = None
             return self._record_plan_once(batched_inputs, prof_slots)
-        best, trials = None, []
-        for _ in range(best_of):
-            plan = self._record_plan_once(batched_inputs, prof_slots)
-            state = (self._plan, self._plan_losses, self._plan_inputs, self._plan_keep)
-            for _ in range(2):
-                self.replay_plan()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(trial_steps):
-                self.replay_plan()
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / trial_steps * 1e3
-            trials.append(round(ms, 3))
-            if best is None or ms < best[0]:
-                if best is not None:
-                    best[1][0].close()
-                best = (ms, state)
-            else:
-                plan.close()
-        self._plan, self._plan_losses, self._plan_inputs, self._plan_keep = best[1]
-        self.plan_trials = trials
+        from . import plan as plan_mod
+        self.plan_check = None
+        for attempt in range(2):
+            cands, trials = [], []
+            for _ in range(best_of):
+                plan = self._record_plan_once(batched_inputs, prof_slots)
+                state = (self._plan, self._plan_losses, self._plan_inputs, self._plan_keep)
+                for _ in range(2):
+                    self.replay_plan()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(trial_steps):
+                    self.replay_plan()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / trial_steps * 1e3
+                trials.append(round(ms, 3))
+                cands.append((ms, state))
+            cands.sort(key=lambda c: c[0])
+            check = None
+            if verify_steps > 0:
+                check = self._verify_plans(cands[0][1], cands[1][1], verify_steps)
+                check["read_only_declarations"] = plan_mod.ro_mode()
+            for _, st in cands[1:]:
+                st[0].close()
+            self._plan, self._plan_losses, self._plan_inputs, self._plan_keep = cands[0][1]
+            self.plan_trials = trials
+            if check is None or check["identical"]:
+                if check is not None:
+                    check["fallback"] = self.plan_check   # (None, or the failed check of the first attempt)
+                self.plan_check = check
+                return self._plan
+            # two recordings of one step disagree: no schedule this process derives with the declarations honoured is trusted any more
+            self.plan_check = check
+            self._plan.close()
+            self._plan = None
+            if attempt == 1 or plan_mod.ro_mode() == "none":
+                raise RuntimeError(f"two recordings of the training step replay to different results ({check}); run with --exec eager")
+            plan_mod.set_ro_mode("none")
         return self._plan
+
+    # ---- the state a step changes, for checks that run the same steps twice ------------------------------------------------------
+    @torch.no_grad()
+    def state_snapshot(self):
+        """copies of everything a training step changes: flat parameters, module buffers (running statistics), optimizer moments / step
+        count / loss scale, learning rates, schedule and iteration"""
+        opt = self.optimizer
+        snap = {"params": [p.detach().clone() for p in self.model.parameters()],
+                "buffers": [b.detach().clone() for b in self.model.buffers()],
+                "iter": self.iter, "sched": copy.deepcopy(self.scheduler.state_dict()), "lr": [g["lr"] for g in opt.param_groups]}
+        if hasattr(opt, "launch_step"):
+            snap["opt"] = {"t": opt._t, "m": [m.clone() for m in opt._m], "v": [None if v is None else v.clone() for v in opt._v],
+                           "scaler": None if opt.scaler is None else opt.scaler.clone()}
+        else:
+            snap["opt_sd"] = copy.deepcopy(opt.state_dict())
+        return snap
+
+    @torch.no_grad()
+    def state_restore(self, snap):
+        opt = self.optimizer
+        for p, q in zip(self.model.parameters(), snap["params"]):
+            p.copy_(q)
+        for b, q in zip(self.model.buffers(), snap["buffers"]):
+            b.copy_(q)
+        if "opt" in snap:
+            o = snap["opt"]
+            opt._t = o["t"]
+            for m, q in zip(opt._m, o["m"]):
+                m.copy_(q)
+            for v, q in zip(opt._v, o["v"]):
+                if v is not None:
+                    v.copy_(q)
+            if opt.scaler is not None:
+                opt.scaler.copy_(o["scaler"])
+            from .. import _C
+            _C.weight_cache.refresh()   # the 16-bit kernel layouts are derived from the parameters at the end of every step
+        else:
+            opt.load_state_dict(snap["opt_sd"])
+        self.scheduler.load_state_dict(copy.deepcopy(snap["sched"]))
+        for g, lr in zip(opt.param_groups, snap["lr"]):
+            g["lr"] = lr
+        self.iter = snap["iter"]
+
+    def _verify_plans(self, a, b, steps):
+        """`steps` replays of recording `a`, then -- from the same state -- of recording `b`: every step's losses, the final gradient
+        buckets and the final parameters bit for bit.  The trainer is left in the state after the steps of `b`."""
+        snap = self.state_snapshot()
+        out = []
+        for st in (a, b):
+            self.state_restore(snap)
+            self._plan, self._plan_losses, self._plan_inputs, self._plan_keep = st
+            losses = []
+            for _ in range(steps):
+                ld = self.replay_plan()
+                losses.append(torch.stack([v.detach().float().reshape(()) for v in ld.values()]).clone())
+            torch.cuda.synchronize()
+            out.append((torch.stack(losses).cpu(), [x["flat_g"].clone() for x in self.reducer.buckets],
+                        [p.detach().clone() for p in self.model.parameters()]))
+        (la, ga, pa), (lb, gb, pb) = out
+        same_l = la.view(torch.int32) == lb.view(torch.int32)
+        first = None
+        if not bool(same_l.all()):
+            k = int((~same_l.all(dim=1)).nonzero()[0])
+            names = list(self._plan_losses.keys())
+            first = {"step": k, "losses": {names[j]: (float(la[k, j]), float(lb[k, j])) for j in range(len(names)) if not bool(same_l[k, j])}}
+        grads = all(torch.equal(x, y) for x, y in zip(ga, gb))
+        params = all(torch.equal(x, y) for x, y in zip(pa, pb))
+        return {"what": "two recordings of the step, replayed from the same state", "steps": steps,
+                "identical": first is None and grads and params, "first_difference": first, "final_gradients_equal": grads,
+                "final_parameters_equal": params}
 
     def _record_plan_once(self, batched_inputs, prof_slots=0):
         """Record forward + backward + clip + Adam for `batched_inputs` (device tensors that stay alive and are refilled in place between
@@ -314,11 +409,14 @@ class Trainer:
         # value as their gradient instead of from a sum node -- the same gradients, but no head's backward chain begins with a tensor that
         # was computed from ALL heads' losses (on replay the heads then run forward -> loss -> backward without waiting for each other)
         vals = [v for v in loss_dict.values()]
-        if vals and vals[0].is_cuda:
+        # (terms that carry no gradient -- a constant or detached entry of the dict -- add nothing to the sum's backward and are left out;
+        #  a model whose losses are not all 0-dim takes the summed root below, as the reference's trainer does)
+        live = [v for v in vals if isinstance(v, torch.Tensor) and v.requires_grad]
+        if live and live[0].is_cuda and all(v.dim() == 0 for v in vals if isinstance(v, torch.Tensor)):
             g = scale.detach().reshape(()) if scale is not None else self.__dict__.get("_one")
-            if g is None:
-                g = self._one = torch.ones((), dtype=torch.float32, device=vals[0].device)
-            roots, grads = vals, [g.to(v.dtype) if v.dtype != g.dtype else g for v in vals]
+            if g is None or g.device != live[0].device:
+                g = self._one = torch.ones((), dtype=torch.float32, device=live[0].device)
+            roots, grads = live, [g.to(v.dtype) if v.dtype != g.dtype else g for v in live]
         else:
             total = sum(vals)
             roots, grads = [total if scale is None else total * scale], None

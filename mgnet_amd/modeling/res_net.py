@@ -83,7 +83,20 @@ class ResNet(nn.Module):
             self._out_feature_strides[name] = stride
             self._out_feature_channels[name] = blocks[-1].out_channels
         self._out_features = list(out_features)
-        assert freeze_at == 0, "FREEZE_AT > 0 is not used by any MGNet config"
+        self.freeze(freeze_at)
+
+    def freeze(self, freeze_at=0):
+        """detectron2 `ResNet.freeze` (res_net.py:165 hands MODEL.BACKBONE.FREEZE_AT to it): 1 freezes the stem, k >= 2 also res2..res<k>.
+        `CNNBlockBase.freeze` sets requires_grad = False on the block's parameters and converts BatchNorm modules to FrozenBatchNorm2d --
+        InPlaceABNSync is not a BatchNorm subclass, so the norms of a frozen block keep normalising with the batch statistics and keep
+        updating their running statistics in training mode; only their affine parameters stop training."""
+        units = [(1, [self.stem])] + [(idx, list(getattr(self, name).children())) for idx, name in enumerate(self.stage_names, start=2)]
+        for idx, blocks in units:
+            if freeze_at >= idx:
+                for blk in blocks:
+                    for p in blk.parameters():
+                        p.requires_grad = False
+        return self
 
     @property
     def size_divisibility(self):

@@ -120,6 +120,9 @@ class FusedAdam(torch.optim.Optimizer):
             steps = int(sc[2])
         for g in self.param_groups:
             for p in g["params"]:
+                if p not in where:   # a frozen parameter (MODEL.BACKBONE.FREEZE_AT): torch.optim keeps no state for a tensor without gradients
+                    idx += 1
+                    continue
                 k, o = where[p]
                 if self._t and self.kind == "SGD":   # torch.optim.SGD's state layout
                     state[idx] = {"momentum_buffer": self._m[k][o:o + p.numel()].view(p.shape).clone()}
@@ -141,6 +144,8 @@ class FusedAdam(torch.optim.Optimizer):
                     g[key] = val
             for p in g["params"]:
                 st = sd["state"].get(idx, sd["state"].get(str(idx)))
+                if p not in where:
+                    st = None
                 if st is not None and self.kind == "SGD":
                     k, o = where[p]
                     if st.get("momentum_buffer") is not None:

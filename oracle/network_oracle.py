@@ -52,9 +52,12 @@ def resnet18(sd, p, x):  # res_net.py:107-110, 113-165
     x = conv_abn(sd, p + ".stem.conv1", x, 2, 3)
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     feats = {}
-    for s in range(2, 6):
-        for k in range(2):
+    for s in range(2, 6):   # blocks per stage as the state dict has them: [2, 2, 2, 2] for depth 18, [3, 4, 6, 3] for 34 (res_net.py:137-146)
+        k = 0
+        while f"{p}.res{s}.{k}.conv1.weight" in sd:
             x = basic_block(sd, f"{p}.res{s}.{k}", x, 2 if (k == 0 and s > 2) else 1)
+            k += 1
+        assert k >= 2
         feats[f"res{s}"] = x
     return feats
 

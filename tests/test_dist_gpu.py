@@ -374,27 +374,30 @@ def test_rccl_single_rank_statistics_exchange():
     assert ok is True, ok
 
 
-@pytest.mark.parametrize("gpus", [2, 8])
-def test_bench_self_launch_end_to_end_on_gloo(gpus):
+@pytest.mark.parametrize("gpus,how", [(2, "auto"), (2, "plan"), (8, "auto")])
+def test_bench_self_launch_end_to_end_on_gloo(gpus, how):
     """`python bench.py --gpus N` as the driver runs it (self-launch of the N ranks, barrier + max-over-ranks timing, one JSON line with
     config.distributed) -- here with MGNET_DIST_BACKEND=gloo and all ranks on the one GPU (RCCL refuses that): a functional check of the
-    whole multi-rank path including the mailbox SyncBN, the launch-plan replay and the time-out plumbing, not a measurement"""
+    whole multi-rank path including the mailbox SyncBN and the time-out plumbing, not a measurement.  `--exec auto` (the driver's
+    command) issues a multi-rank step eagerly; `--exec plan` replays the recorded step on every rank."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MGNET_DIST_BACKEND="gloo", MGNET_P2P_TIMEOUT_S="120")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2" if gpus == 2 else "1", "--warmup", "1", "--batch", "2", "--height", "128",
-           "--width", "256", "--no-cpu-baseline", "--timeout", "500"]   # (--exec auto: multi-rank runs replay the plan by default)
+           "--width", "256", "--no-cpu-baseline", "--timeout", "500", "--exec", how]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     d = json.loads(lines[-1])
     assert d["n_gpus"] == gpus and d["value"] > 0 and d["scaling"] == "weak", d
     dist_cfg = d["config"]["distributed"]
-    if "p2p" in dist_cfg["syncbn_exchange"]["mode"]:
+    if how == "auto":
+        assert d["config"]["step_execution"].startswith("eager") and "--exec plan" in d["config"]["step_execution"], d["config"]["step_execution"]
+    elif "p2p" in dist_cfg["syncbn_exchange"]["mode"]:
         assert d["config"]["step_execution"].startswith("plan"), d["config"]["step_execution"]
-        assert d["config"]["host_issue_ms_per_step"] > 0
+    assert d["config"]["host_issue_ms_per_step"] > 0
     assert dist_cfg["rccl_world_size"] == gpus and dist_cfg["grad_allreduce_calls_per_step"] >= 1, dist_cfg
     if "p2p" in dist_cfg["syncbn_exchange"]["mode"]:
         assert dist_cfg["syncbn_collectives_per_step"] == 0 and dist_cfg["syncbn_p2p_exchanges_per_step"] >= 100, dist_cfg

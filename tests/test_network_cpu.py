@@ -62,14 +62,39 @@ def test_cfg_semantics():
     assert "DEPTH_HEAD" in cfg.dump()
 
 
-def small_model(with_depth=True, with_panoptic=True, seed=0):
+def small_model(with_depth=True, with_panoptic=True, seed=0, **over):
     from mgnet_amd.registry import build_model
 
     torch.manual_seed(seed)
     cfg = make_cfg(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "bench-c4-cityscapes-videosequence.yaml"),
                    **{"MODEL.DEVICE": "cpu", "SOLVER.AMP.ENABLED": False, "WITH_DEPTH": with_depth,
-                      "WITH_PANOPTIC": with_panoptic, "MODEL.SEM_SEG_HEAD.OHEM_N_MIN": 1500})
+                      "WITH_PANOPTIC": with_panoptic, "MODEL.SEM_SEG_HEAD.OHEM_N_MIN": 1500, **over})
     return cfg, build_model(cfg)
+
+
+def test_freeze_at_follows_detectron2():
+    """MODEL.BACKBONE.FREEZE_AT (res_net.py:126,165 -> detectron2 ResNet.freeze): 1 = stem, k = stem + res2..res<k>; the backbone AND the
+    pose encoder (layers.py:141-144 builds it from the same registry entry and config); InPlaceABNSync is no BatchNorm subclass, so its
+    buffers stay live and only its affine parameters freeze.  The optimizer's groups still list every parameter (solver/build.py:85-116
+    does not filter); the gradient buckets and the fused optimizer hold the trainable ones."""
+    from mgnet_amd.engine.reducer import GradReducer
+    from mgnet_amd.solver import get_mgnet_optimizer_params
+
+    _, m0 = small_model()
+    _, m = small_model(**{"MODEL.BACKBONE.FREEZE_AT": 3})
+    for trunk in (m.backbone, m.pose_net.pose_encoder):
+        for name, p in trunk.named_parameters():
+            frozen = name.startswith(("stem.", "res2.", "res3."))
+            assert p.requires_grad == (not frozen), name
+    assert all(p.requires_grad for n, p in m.named_parameters() if "backbone" not in n and "pose_encoder" not in n)
+    assert m.backbone.res2[0].conv1.norm.training and m.backbone.res2[0].conv1.norm.running_mean.requires_grad is False
+    groups = get_mgnet_optimizer_params(m, 1e-4)
+    assert len(groups) == len(get_mgnet_optimizer_params(m0, 1e-4))
+    red = GradReducer([p for g in groups for p in (g["params"] if isinstance(g["params"], list) else [g["params"]])])
+    held = {id(p) for b in red.buckets for p in b["params"]}
+    assert held == {id(p) for p in m.parameters() if p.requires_grad}
+    _, m1 = small_model(**{"MODEL.BACKBONE.FREEZE_AT": 1})
+    assert [n for n, p in m1.backbone.named_parameters() if not p.requires_grad] == ["stem.conv1.weight", "stem.conv1.norm.weight", "stem.conv1.norm.bias"]
 
 
 def test_state_dict_keys_and_param_counts():

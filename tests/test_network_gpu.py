@@ -58,3 +58,31 @@ def test_training_reduces_loss_on_fixed_batch(torch_staging):
         first = tot if first is None else first
         last = tot
     assert np.isfinite(last) and last < first, (first, last)
+
+
+def test_trainer_backward_takes_any_loss_dict_a_sum_would():
+    """Trainer._backward starts the backward pass from the task losses themselves (one root per loss).  A registered model may
+    also return a term without a gradient (a constant / detached diagnostic) or a shape-[1] loss: both worked with `sum(losses).backward()`
+    and still do -- gradients equal the summed root's."""
+    from mgnet_amd.engine import Trainer
+
+    x = torch.randn(64, device="cuda")
+    grads = []
+    for variant in ("scalars", "with_detached", "shape_1"):
+        w = torch.nn.Parameter(torch.linspace(-1, 1, 64, device="cuda"))
+        t = Trainer.__new__(Trainer)
+        t.optimizer = type("O", (), {})()
+        t.model = None
+        t.reducer = type("R", (), {"lazy_wgrad": lambda self, on: None, "abort": lambda self: None})()
+        a, b = (w * x).sum(), (w * w).mean()
+        if variant == "scalars":
+            ld = {"a": a, "b": b}
+        elif variant == "with_detached":
+            ld = {"a": a, "b": b, "diag": (w * 3).sum().detach()}
+        else:
+            ld = {"a": a.reshape(1), "b": b.reshape(1)}
+        t._backward(ld)
+        grads.append(w.grad.clone())
+    ref = x + 2 * torch.linspace(-1, 1, 64, device="cuda") / 64
+    for g in grads:
+        assert torch.allclose(g, ref, rtol=1e-6, atol=1e-7)

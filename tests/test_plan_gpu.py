@@ -223,3 +223,103 @@ def test_replay_does_not_read_the_recorded_steps_temporaries():
         assert la == lb, (hex(byte), la, lb)
     for (na, pa), (nb, pb) in zip(ta.model.named_parameters(), tb.model.named_parameters()):
         assert torch.equal(pa, pb), na
+
+
+def test_read_only_declarations_are_honoured_per_family_not_per_kernel_name():
+    """which struct arguments' read-only declarations a replay honours is fixed in csrc/ next to the struct (MGN_PLAN_RO_CONV =
+    family 1, MGN_PLAN_RO = family 2; mgn_plan_node_ro_family), not matched on kernel names at run time.  Default mode `conv`: family 1
+    only.  Checked on a recorded step: every launch whose argument struct is in family 1 is a convolution kernel, the declared structs of
+    the loss / norm / input kernels are family 2, and an undeclared struct has no read-only word at all."""
+    import ctypes
+
+    from mgnet_amd import _C
+    from mgnet_amd.engine import plan as plan_mod
+    assert plan_mod.ro_mode() == "conv"
+    t, b, _ = _trainer(seed=1)
+    for _ in range(3):
+        t.run_step(b)
+    plan = t.record_plan(b)
+    lib = _C.lib()
+    fam, ro = (ctypes.c_int * 64)(), (ctypes.c_ulonglong * 128)()
+    info = _C.PlanNodeInfo()
+    by_family = {0: set(), 1: set(), 2: set()}
+    for i in range(lib.mgn_plan_node_count(plan.handle)):
+        _C.check(lib.mgn_plan_node_info(plan.handle, i, ctypes.byref(info)), "info")
+        if info.type != 0:
+            continue
+        n = lib.mgn_plan_node_ro_family(plan.handle, i, 64, fam)
+        assert n >= 0 and lib.mgn_plan_node_ro(plan.handle, i, 64, ro) == n
+        for k in range(n):
+            assert fam[k] in (0, 1, 2)
+            assert (fam[k] != 0) == bool(ro[2 * k] | ro[2 * k + 1]), (info.name, k)
+            if fam[k]:
+                by_family[fam[k]].add(info.name.decode())
+    conv_like = ("conv", "wgrad", "up2", "stem")
+    assert by_family[1] and all(any(x in nm for x in conv_like) for nm in by_family[1]), sorted(by_family[1])
+    assert any("ins_fwd" in nm for nm in by_family[2]) and any("reproj_march" in nm for nm in by_family[2]), sorted(by_family[2])
+    assert not (by_family[1] & by_family[2])
+    with pytest.raises(ValueError):
+        plan_mod.set_ro_mode("some")
+
+
+def test_two_recordings_are_checked_against_each_other_and_a_difference_drops_the_declarations(monkeypatch):
+    """Trainer.record_plan(best_of, verify_steps): the two fastest recordings replay `verify_steps` steps each from one state snapshot and
+    must agree bit for bit; the check leaves the trainer on the same trajectory as eager steps.  A difference (forced here) switches the
+    read-only declarations off for the process, records again and checks again."""
+    from mgnet_amd.engine import plan as plan_mod
+    ta, ba, _ = _trainer(seed=1)
+    tb, bb, _ = _trainer(seed=1)
+    for _ in range(3):
+        ta.run_step(ba)
+        tb.run_step(bb)
+    tb.record_plan(bb, best_of=2, trial_steps=2, verify_steps=5)
+    chk = tb.plan_check
+    assert chk["identical"] and chk["steps"] == 5 and chk["read_only_declarations"] == "conv" and chk["fallback"] is None, chk
+    # steps taken by B so far: 2 recordings x (1 recorded + 2 + 2 replays), then the check's 5 steps counted ONCE (both runs start
+    # from the same snapshot)
+    n = 2 * 5 + 5
+    assert tb.iter == 3 + n
+    for _ in range(n):
+        ta.run_step(ba)
+    la = {k: float(v) for k, v in ta.run_step(ba).items()}
+    lb = {k: float(v) for k, v in tb.replay_plan().items()}
+    assert la == lb
+    for (na, pa), (nb, pb) in zip(ta.model.named_parameters(), tb.model.named_parameters()):
+        assert torch.equal(pa, pb), na
+    # forced difference -> fallback
+    real = type(tb)._verify_plans
+    calls = []
+
+    def first_one_fails(self, a, b, steps):
+        out = real(self, a, b, steps)
+        calls.append(plan_mod.ro_mode())
+        if len(calls) == 1:
+            out = dict(out, identical=False, first_difference={"step": 0, "losses": {"forced": (0.0, 1.0)}})
+        return out
+    monkeypatch.setattr(type(tb), "_verify_plans", first_one_fails)
+    try:
+        tb._plan.close()
+        tb.record_plan(bb, best_of=2, trial_steps=1, verify_steps=2)
+        assert calls == ["conv", "none"] and plan_mod.ro_mode() == "none"
+        assert tb.plan_check["identical"] and tb.plan_check["read_only_declarations"] == "none" and tb.plan_check["fallback"]["identical"] is False
+        tb.replay_plan()
+    finally:
+        plan_mod.set_ro_mode(None)
+
+
+def test_state_snapshot_restore_repeats_a_step_bit_for_bit():
+    """Trainer.state_snapshot / state_restore (what the recording check stands on): the same eager step run twice from one snapshot gives
+    the same losses, gradients and parameters, fp16 loss-scale state included"""
+    t, b, _ = _trainer(seed=2, dtype="float16")
+    for _ in range(3):
+        t.run_step(b)
+    snap = t.state_snapshot()
+    outs = []
+    for _ in range(2):
+        t.state_restore(snap)
+        ls = [{k: float(v) for k, v in t.run_step(b).items()} for _ in range(3)]
+        outs.append((ls, [x["flat_g"].clone() for x in t.reducer.buckets], [p.detach().clone() for p in t.model.parameters()],
+                     t.optimizer.scaler.clone(), t.iter, [g["lr"] for g in t.optimizer.param_groups]))
+    assert outs[0][0] == outs[1][0] and outs[0][4] == outs[1][4] and outs[0][5] == outs[1][5]
+    assert all(torch.equal(x, y) for x, y in zip(outs[0][1], outs[1][1])) and all(torch.equal(x, y) for x, y in zip(outs[0][2], outs[1][2]))
+    assert torch.equal(outs[0][3], outs[1][3])
