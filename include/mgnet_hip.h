@@ -237,11 +237,13 @@ int mgn_conv_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int
  * cin_real}; MGN_ENOTSUP for the stem shapes (they keep their own reduction).  mgn_conv_wgrad_reduce_batch then performs the
  * reductions of MANY weight gradients in ONE launch from a device table of 10 x int64 per entry: {partial, dst (fp32 gradient in the
  * layout oihw/cin_real select), splits, Cout, taps, Cin, oihw, cin_real, first block, blocks along the (tap, ci) axis =
- * ceil(taps*Cin/256)}, entry k owning blocks [first_k, first_k + Cout_k * gy_k).  Same sums in the same fixed order as mgn_conv_wgrad.
+ * mgn_conv_wgrad_reduce_blocks(splits, taps, Cin)}, entry k owning blocks [first_k, first_k + Cout_k * gy_k).  Same sums in the same
+ * fixed order as mgn_conv_wgrad.
  * The gradient reducer (mgnet_amd/engine/reducer.py) batches a bucket's convolutions this way: ~70 launches per step become ~5. */
 int mgn_conv_wgrad_partial(const void* dout, const void* in, int N, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
                            int stride, int pad, int oihw_cin, void* workspace, size_t workspace_bytes, long long* desc8, void* stream);
 int mgn_conv_wgrad_reduce_batch(const void* table_dev, int n_entries, long total_blocks, void* stream);
+int mgn_conv_wgrad_reduce_blocks(int splits, int taps, int Cin);   /* blocks per output channel of one entry (table column 9); < 0: error */
 /* The FeatureFusionModule's 1x1 convolution over torch.cat([fsp, fcp], dim=1) (layers.py:316-317) WITHOUT the concatenated map -- the
  * three decoders each copied 2 x 67 MB into it and split its gradient again (mgn_concat2 / mgn_split2, 0.28 ms per step):
  *   mgn_conv1x1_cat   out = conv1x1(in0 | in1, w): in0, in1 [N,H,W,128], w [Cout][256] (layout mode 0), Cout % 256 == 0; the rows of the

@@ -16,7 +16,7 @@ _ERR = {-22: "MGN_EINVAL (bad shape / null pointer)", -28: "MGN_ENOSPC (workspac
 SYMBOLS = ["mgn_version", "mgn_reproj_workspace_bytes", "mgn_reproj_loss_fwd", "mgn_reproj_loss_bwd",
            "mgn_iabn_workspace_bytes", "mgn_iabn_stats", "mgn_iabn_train_coeffs", "mgn_iabn_combine", "mgn_iabn_eval_coeffs", "mgn_iabn_apply",
            "mgn_iabn_bwd_reduce", "mgn_iabn_bwd_apply",
-           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_optim_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv3x3_up2_win", "mgn_conv_win_patch_rows", "mgn_conv_stem7", "mgn_conv_stem7_blocks", "mgn_iabn_coeffs_from_partials", "mgn_iabn_partials_reduce", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv1x1_cat", "mgn_conv1x1_split", "mgn_conv_wgrad_cat", "mgn_conv3x3_win_act", "mgn_conv_igemm_act", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
+           "mgn_optim_chunk", "mgn_sqnorm", "mgn_clip_coef", "mgn_adam_step", "mgn_adam_step_dev", "mgn_optim_step_dev", "mgn_clip_coef_scaled", "mgn_conv_igemm", "mgn_conv_igemm_stats", "mgn_conv_stat_rows", "mgn_conv3x3_win", "mgn_conv3x3_up2_win", "mgn_conv_win_patch_rows", "mgn_conv_stem7", "mgn_conv_stem7_blocks", "mgn_iabn_coeffs_from_partials", "mgn_iabn_partials_reduce", "mgn_conv_wgrad", "mgn_conv_wgrad_partial", "mgn_conv1x1_cat", "mgn_conv1x1_split", "mgn_conv_wgrad_cat", "mgn_conv3x3_win_act", "mgn_conv_igemm_act", "mgn_conv_wgrad_reduce_batch", "mgn_conv_wgrad_reduce_blocks", "mgn_conv_wgrad_workspace_bytes", "mgn_weight_layout", "mgn_weight_layout_batch",
            "mgn_upce_partials", "mgn_adjoint_footprint_floats", "mgn_upce_fwd", "mgn_upce_bwd", "mgn_ohem_select_workspace_bytes", "mgn_ohem_select", "mgn_ins_loss_fwd", "mgn_ins_loss_bwd", "mgn_prep_input",
            "mgn_upsample1_fwd", "mgn_upsample1_bwd", "mgn_maxpool3x3s2_fwd", "mgn_maxpool3x3s2_bwd",
            "mgn_add_relu_fwd", "mgn_sum3", "mgn_relu_mask_bwd", "mgn_colsum", "mgn_bcast_rows", "mgn_scale_channels", "mgn_nearest_fwd",
@@ -146,6 +146,7 @@ def lib():
             getattr(L, "mgn_conv_wgrad_cat" + sfx).argtypes = [vp, vp, vp, vp] + [ci] * 5 + [vp, sz, vp, vp]
         L.mgn_conv_wgrad_partial.argtypes = [vp, vp] + [ci] * 12 + [vp, sz, ctypes.POINTER(ctypes.c_longlong), vp]
         L.mgn_conv_wgrad_reduce_batch.argtypes = [vp, ci, cl, vp]
+        L.mgn_conv_wgrad_reduce_blocks.argtypes = [ci, ci, ci]
         L.mgn_weight_layout.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
         L.mgn_weight_layout_batch.argtypes = [vp, ci, cl, vp]
         L.mgn_upce_partials.argtypes = [ci, ci, ci]
@@ -1014,7 +1015,8 @@ def wgrad_reduce_batch(entries):
     global _wgrad_stager
     rows, start = [], 0
     for desc, _ws, dst in entries:
-        gy = (desc[4] * desc[5] // 4 + 63) // 64
+        gy = lib().mgn_conv_wgrad_reduce_blocks(int(desc[2]), int(desc[4]), int(desc[5]))
+        assert gy > 0, desc
         rows.append([desc[0], dst.data_ptr(), desc[2], desc[3], desc[4], desc[5], desc[6], desc[7], start, gy])
         start += desc[3] * gy
     table = torch.tensor(rows, dtype=torch.int64)

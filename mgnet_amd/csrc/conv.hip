@@ -1992,39 +1992,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgradParams p) {
 }
 
 // dw = sum over the pixel splits (fixed order: deterministic), written in the requested layout.
-// Block = 64 lanes x 16 bytes along one output channel's (tap, ci) axis times 4 groups along the splits (group g sums the
-// splits z = g, g+4, ... with two independent accumulators; the groups are combined in a fixed order through LDS): ~8
-// sixteen-byte loads in flight per thread and Cout * ceil(taps*Cin/256) blocks.  (The first version had a thread per element:
-// 4-byte loads in a dependent chain -- 0.6 TB/s, 1.6 ms per training step.)
+// Block = 16 waves.  A wave owns 64 sixteen-byte columns of ONE output channel's (tap, ci) axis and every G-th split, G = 1 .. 16
+// chosen from the split count so that a lane has about four splits to add (four independent accumulators: four 16-byte loads in
+// flight per lane); the G waves of a column group are combined in wave order through LDS, and the 16 / G column groups of a block lie
+// side by side.  Layers with few, large splits (512 -> 512: 8 x 9.4 MB) thus get blocks of 1024 columns x all splits, layers with
+// hundreds of small ones (64 -> 64: 256 x 147 KB) get 16 waves per 64 columns instead of 4 -- the first form of this kernel (4 waves
+// per 64 columns whatever the split count) left those layers with 192 blocks of 64 dependent loads: 0.7 TB/s inside the batched launch.
+// (Round 1 had a thread per element: 4-byte loads in a dependent chain, 0.6 TB/s, 1.6 ms per training step.)
+constexpr int RW = 16;   // waves per block
+__host__ __device__ inline int reduce_groups(int splits) {
+    int g = 1;
+    while (g < RW && g * 4 < splits) g <<= 1;
+    return g;
+}
+// blocks along the (tap, ci) axis of one output channel
+__host__ __device__ inline int reduce_blocks_y(int splits, int taps, int Cin) {
+    const int cols = 64 * (RW / reduce_groups(splits));
+    return (taps * Cin / 4 + cols - 1) / cols;
+}
+__device__ __forceinline__ void f4add(float4& s, const float4& a) { s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw,
                                                   int cin_real, float* __restrict__ dw, int bx, int by) {
-    __shared__ float4 scratch[4][64];
-    const int per = taps * Cin, co = bx, el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    __shared__ float4 scratch[RW][64];
+    const int G = reduce_groups(splits);
+    const int per = taps * Cin, co = bx, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = w % G, sub = w / G;
     const long wsize = (long)Cout * per;
-    const int e4 = by * 64 + el;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    const int e4 = (by * (RW / G) + sub) * 64 + lane;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     if (e4 < per / 4) {
         const float* q = partial + (long)co * per + (long)e4 * 4;
         int z = g;
-        for (; z + 4 < splits; z += 8) {
+        for (; z + 3 * G < splits; z += 4 * G) {
             const float4 a = *reinterpret_cast<const float4*>(q + (long)z * wsize);
-            const float4 c = *reinterpret_cast<const float4*>(q + (long)(z + 4) * wsize);
-            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-            s1.x += c.x; s1.y += c.y; s1.z += c.z; s1.w += c.w;
+            const float4 b = *reinterpret_cast<const float4*>(q + (long)(z + G) * wsize);
+            const float4 c = *reinterpret_cast<const float4*>(q + (long)(z + 2 * G) * wsize);
+            const float4 d = *reinterpret_cast<const float4*>(q + (long)(z + 3 * G) * wsize);
+            f4add(s0, a); f4add(s1, b); f4add(s2, c); f4add(s3, d);
         }
-        if (z < splits) {
-            const float4 a = *reinterpret_cast<const float4*>(q + (long)z * wsize);
-            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-        }
-        s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
+        if (z < splits) { f4add(s0, *reinterpret_cast<const float4*>(q + (long)z * wsize)); z += G; }
+        if (z < splits) { f4add(s1, *reinterpret_cast<const float4*>(q + (long)z * wsize)); z += G; }
+        if (z < splits) { f4add(s2, *reinterpret_cast<const float4*>(q + (long)z * wsize)); }
+        f4add(s0, s1); f4add(s2, s3); f4add(s0, s2);
     }
-    scratch[g][el] = s0;
-    __syncthreads();
-    if (g != 0 || e4 >= per / 4) return;
-    const float4 a = scratch[0][el], b2 = scratch[1][el], c = scratch[2][el], d = scratch[3][el];
-    float4 r;
-    r.x = (a.x + b2.x) + (c.x + d.x); r.y = (a.y + b2.y) + (c.y + d.y);
-    r.z = (a.z + b2.z) + (c.z + d.z); r.w = (a.w + b2.w) + (c.w + d.w);
+    if (G > 1) {
+        scratch[w][lane] = s0;
+        __syncthreads();
+        if (g != 0 || e4 >= per / 4) return;
+        for (int k = 1; k < G; ++k) f4add(s0, scratch[w + k][lane]);   // wave order: fixed
+    } else if (e4 >= per / 4) {
+        return;
+    }
+    const float4 r = s0;
     if (!oihw) { *reinterpret_cast<float4*>(dw + (long)co * per + (long)e4 * 4) = r; return; }
     const int e = e4 * 4, tap = e / Cin, ci = e - tap * Cin;   // 4 consecutive input channels of one tap (Cin % 4 == 0)
     const float v[4] = {r.x, r.y, r.z, r.w};
@@ -2032,14 +2051,15 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
     for (int k = 0; k < 4; ++k)
         if (ci + k < cin_real) dw[((long)co * cin_real + ci + k) * taps + tap] = v[k];
 }
-__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw,
-                                                         int cin_real, float* __restrict__ dw) {
+__global__ __launch_bounds__(64 * RW) void conv_wgrad_reduce(const float* __restrict__ partial, int splits, int Cout, int taps, int Cin, int oihw,
+                                                             int cin_real, float* __restrict__ dw) {
     wgrad_reduce_body(partial, splits, Cout, taps, Cin, oihw, cin_real, dw, blockIdx.x, blockIdx.y);
 }
 // The reductions of MANY weight gradients in one launch (the gradient reducer batches the split-K sums of a bucket's convolutions:
 // 70 launches of ~10 us per training step become one per bucket).  table: 10 x int64 per entry = {partial, dst, splits, Cout, taps,
-// Cin, oihw, cin_real, first block, blocks along the (tap, ci) axis}; a block finds its entry by binary search on `first block`.
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_batch(const long long* __restrict__ table, int n_entries) {
+// Cin, oihw, cin_real, first block, blocks along the (tap, ci) axis = mgn_conv_wgrad_reduce_blocks}; a block finds its entry by binary
+// search on `first block`.
+__global__ __launch_bounds__(64 * RW) void conv_wgrad_reduce_batch(const long long* __restrict__ table, int n_entries) {
     int lo = 0, hi = n_entries - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -2050,7 +2070,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_batch(const long long* 
     wgrad_reduce_body(reinterpret_cast<const float*>(e[0]), (int)e[2], (int)e[3], (int)e[4], (int)e[5], (int)e[6], (int)e[7],
                       reinterpret_cast<float*>(e[1]), local / gy, local % gy);
 }
-static inline dim3 wgrad_reduce_grid(int Cout, int taps, int Cin) { return dim3((unsigned)Cout, (unsigned)((taps * Cin / 4 + 63) / 64)); }
+static inline dim3 wgrad_reduce_grid(int splits, int Cout, int taps, int Cin) { return dim3((unsigned)Cout, (unsigned)reduce_blocks_y(splits, taps, Cin)); }
 
 // fp32 OIHW master weights -> bf16 kernel layouts, one launch per conv
 //   mode 0: [Cout][KH][KW][Cin]                      (forward)
@@ -2550,7 +2570,7 @@ static int wgrad_impl(const void* dout, const void* in, float* dw, int N, int IH
             desc[0] = (long long)(uintptr_t)workspace; desc[1] = 0; desc[2] = p3.nslices; desc[3] = Cout; desc[4] = 9; desc[5] = Cin;
             desc[6] = p.oihw; desc[7] = p.cin_real;
         } else {
-            hipLaunchKernelGGL(conv_wgrad_reduce, wgrad_reduce_grid(Cout, 9, Cin), dim3(256), 0, st, (const float*)workspace, p3.nslices, Cout, 9,
+            hipLaunchKernelGGL(conv_wgrad_reduce, wgrad_reduce_grid(p3.nslices, Cout, 9, Cin), dim3(64 * RW), 0, st, (const float*)workspace, p3.nslices, Cout, 9,
                                Cin, p.oihw, p.cin_real, dw);
         }
         return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
@@ -2596,7 +2616,7 @@ static int wgrad_impl(const void* dout, const void* in, float* dw, int N, int IH
         desc[0] = (long long)(uintptr_t)workspace; desc[1] = 0; desc[2] = gz; desc[3] = Cout; desc[4] = KH * KW; desc[5] = Cin;
         desc[6] = p.oihw; desc[7] = p.cin_real;
     } else {
-        hipLaunchKernelGGL(conv_wgrad_reduce, wgrad_reduce_grid(Cout, KH * KW, Cin), dim3(256), 0, st, (const float*)workspace, (int)gz, Cout,
+        hipLaunchKernelGGL(conv_wgrad_reduce, wgrad_reduce_grid((int)gz, Cout, KH * KW, Cin), dim3(64 * RW), 0, st, (const float*)workspace, (int)gz, Cout,
                            KH * KW, Cin, p.oihw, p.cin_real, dw);
     }
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
@@ -2652,8 +2672,14 @@ int MGN_SYM(mgn_conv1x1_split)(const void* in, const void* w, void* out0, void* 
 #ifndef MGN_F16
 int mgn_conv_wgrad_reduce_batch(const void* table_dev, int n_entries, long total_blocks, void* stream) {
     if (!table_dev || n_entries < 1 || total_blocks < 1 || total_blocks > 0x7fffffffL) return MGN_EINVAL;
-    hipLaunchKernelGGL(conv_wgrad_reduce_batch, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)table_dev, n_entries);
+    hipLaunchKernelGGL(conv_wgrad_reduce_batch, dim3((unsigned)total_blocks), dim3(64 * RW), 0, (hipStream_t)stream, (const long long*)table_dev, n_entries);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
+}
+/* blocks along the (tap, ci) axis of ONE output channel of a reduction with `splits` partial tiles: column 9 of the batch table; an entry
+ * takes Cout x this many blocks */
+int mgn_conv_wgrad_reduce_blocks(int splits, int taps, int Cin) {
+    if (splits < 1 || taps < 1 || Cin < 4 || Cin % 4) return MGN_EINVAL;
+    return reduce_blocks_y(splits, taps, Cin);
 }
 #endif
 

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "mgnet_hip.h"
 
@@ -48,15 +49,29 @@ struct WinParams {
 };
 MGN_PLAN_RO_CONV(WinParams, MGN_RO(in) MGN_RO(w) MGN_RO(residual) MGN_RO(stat_shift) MGN_RO(bias))   // pointers the kernels only read through (launch-plan dependency analysis, csrc/mgn_launch.h)
 
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
 constexpr int PW = 32, WW = PW + 2;
 constexpr int WIN_PIECES = 40;                 // 1-KB DMA pieces of 16 pixels x 64 B: 5 per wave (612 of the 640 pixels are real)
 constexpr int WIN_BYTES = WIN_PIECES * 1024;
 constexpr int WST_BYTES = 128 * 64;            // one weight stage: 128 output channels x 32 input channels
 constexpr int NWST = 8;                        // weight stages (power of two)
 constexpr int PD = 6;                          // W(s + PD) is issued at k-step s (PD + 1 <= NWST)
-constexpr int WIN_LDS = 2 * WIN_BYTES + NWST * WST_BYTES + 1024;   // + one scratch KB for the dummy loads
+constexpr int WIN_LDS = 2 * WIN_BYTES + NWST * WST_BYTES;
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// MGN_WIN_DBG (compile-time, race hunting only; tools/dbg_win_race.py): 1 = every counted wait becomes vmcnt(0); 2 = all of a wave's LDS
+// reads have returned before it enters a barrier; 3 = both
+#ifndef MGN_WIN_DBG
+#define MGN_WIN_DBG 0
+#endif
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if (MGN_WIN_DBG & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    if (MGN_WIN_DBG & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
 __device__ __forceinline__ int xcd_tile(int b, int nb) {   // block b -> XCD b % 8; XCD k works on a contiguous band of tiles
     const int k = b & 7, j = b >> 3, q = nb >> 3, r = nb & 7;
@@ -69,7 +84,7 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {   // block b -> XCD b %
 // 80 KB of LDS, so that TWO independent blocks share a CU, one wave of each per SIMD: what a lone 8-wave block spends outside its
 // k loop (~10 of ~62 us: first window + weight stages, epilogue, block turn-around) runs beside the other
 // block's MFMAs, and a wave stuck issuing LDS-DMA pieces leaves the matrix pipe to its neighbour.  Per k-step a wave issues
-// [window piece | dummy][two weight pieces]; one barrier per k-step (the two waves of a SIMD are not in the same block, so they do
+// [window piece, while the next chunk has one][two weight pieces]; one barrier per k-step (the two waves of a SIMD are not in the same block, so they do
 // not sit in the same bubble), weight ring of 4 stages issued 3 steps ahead.
 template <int PH, int NWM>
 __device__ __forceinline__ void conv_win_body(const WinParams& p) {
@@ -80,16 +95,11 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
     constexpr int WINB = NWM == 4 ? WIN_BYTES : NWP * NW * 1024;          // one window buffer
     constexpr int NST = NWM == 4 ? NWST : 4, PDW = NWM == 4 ? PD : 3;     // weight stages, prefetch distance in k-steps
     constexpr int WPS = 8 / NW;               // weight pieces per wave and k-step
-    constexpr int LPS = 1 + WPS;              // LDS-DMA loads per wave and k-step (window piece or dummy + weight pieces or dummies)
     constexpr int BAR2 = NWM == 4 ? 1 : 0;    // barrier every second k-step (8 waves) / every k-step (4 waves)
-    constexpr int WAITN = BAR2 ? LPS * (PDW - 3) : LPS * (PDW - 2);
+    constexpr int KEEP = BAR2 ? 3 : 1;        // k-steps whose loads may still be in flight behind a wait (everything older has landed)
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
     unsigned char* const winb = wsm;
     unsigned char* const wst = wsm + 2 * WINB;
-    // dummy loads write a KB of zeros: into the scratch KB behind the stages (8 waves), or (4 waves: 80 KB exactly) over the last piece of
-    // window buffer 0, whose 16 pixels lie past the real window and only ever receive the zeros of out-of-range lanes anyway
-    unsigned char* const dummy_kb = NWM == 4 ? wsm + WIN_LDS - 1024 : winb + (NWP * NW - 1) * 1024;
-    static_assert(NWM == 4 || NWP * NW * 16 - 16 >= WPX, "the dummy target must lie past the real window pixels");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
     const int hi = lane >> 5, l31 = lane & 31;
     const int patch = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x, bn = blockIdx.y;
@@ -156,30 +166,36 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // Pipeline.  Every k-step issues exactly TWO LDS-DMA loads per wave, in the order [window piece of the next chunk | dummy]
-    // [W(s + PD) | dummy]; a dummy is an out-of-range load (no memory request, zeros into a scratch KB), which keeps the number
-    // of loads younger than any given one a compile-time constant.  Barriers stand at the even taps of a chunk (5 per 9 k-steps:
-    // with a barrier per step both waves of a SIMD sit in the same bubble); the wait before the barrier of step s is for
-    // W(s + 2), issued at step s + 2 - PD (younger: 2 (PD - 3) loads): the two steps up to the next barrier read W(s), W(s + 1)
-    // and -- the first half (kk = 0) of the NEXT step's fragments is fetched from LDS while the second half of a step's MFMAs
-    // run -- W(s + 2).  Ring hazards: step s writes the stage of step s + PD - NWST = s - 2 and, at taps 0 .. NWP-1, the window
-    // buffer last read in the previous chunk; a barrier separates both from their last readers (tap 0 always has one).
-    auto issue_dummy = [&]() {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)dummy_kb, 16, OOB, 0, 0, 0);
+    // Pipeline.  k-step s issues the LDS-DMA loads [window piece s of the next chunk, while it has one][W(s + PDW), while there is one];
+    // the wait in front of a barrier retires every load issued KEEP or more k-steps ago, i.e. it leaves exactly the loads of the last
+    // KEEP steps in flight -- a compile-time count per (tap, last chunk or not): WinCount::younger().  8 waves: barriers stand at the even
+    // taps of a chunk (5 per 9 k-steps: with a barrier per step both waves of a SIMD sit in the same bubble), KEEP = 3: the wait of even
+    // step s retires W(s + 1), W(s + 2); the two steps up to the next barrier read W(s), W(s + 1) and -- the first half (kk = 0) of the
+    // NEXT step's fragments is fetched from LDS while the second half of a step's MFMAs run -- W(s + 2).  4 waves: a barrier per step,
+    // KEEP = 1.  Ring hazards: step s writes the stage of step s + PDW - NST and, at taps 0 .. NWP-1, the window buffer last read in
+    // the previous chunk; a barrier separates both from their last readers (tap 0 always has one).
+    // (Round 6: until then every step issued a CONSTANT number of loads, padded with out-of-range "dummy" loads into a scratch KB, and
+    //  every wait used one constant.  The compiler merges adjacent identical dummy loads -- stores to the same LDS bytes with nothing it
+    //  can see reading them in between -- so the last taps of the last chunk issued ONE load instead of three, the constant wait then
+    //  retired too little, and the last weight stages could be read before they had landed: rare wrong tiles under memory contention,
+    //  found by tools/dbg_win_race.py at the benchmark's shapes.  No dummies any more: the counts are exact.)
+    struct WinCount {
+        static constexpr int loads(int t, bool last) {   // loads a wave issues at tap t (t < 0: the previous chunk's last taps / the prologue)
+            return t < 0 ? WPS : ((!last && t < NWP) ? 1 : 0) + ((!last || t + PDW <= 8) ? WPS : 0);
+        }
+        static constexpr int younger(int t, bool last) {
+            int n = 0;
+            for (int j = 1; j <= KEEP; ++j) n += loads(t - j, last);
+            return n;
+        }
     };
-    auto issue_w_dummy = [&]() {
-#pragma unroll
-        for (int k = 0; k < WPS; ++k) issue_dummy();
-    };
+    static_assert(NWP <= 9 - KEEP, "the previous chunk's last KEEP taps must carry weight pieces only");
 #pragma unroll
     for (int i = 0; i < NWP; ++i) issue_win(0, i, 0);
 #pragma unroll
-    for (int k = 0; k < PDW; ++k) {   // what steps -PDW .. -1 would have issued (ksteps >= 9 > PDW)
-        issue_dummy();
-        issue_w(0, k, k);
-    }
-    // (8 waves: W(0..2) landed, 2 (PD - 3) younger loads; 4 waves: W(0), W(1) landed -- the first step prefetches W(1) -- LPS younger)
-    wait_vmcnt<WAITN>();
+    for (int k = 0; k < PDW; ++k) issue_w(0, k, k);   // what steps -PDW .. -1 would have issued (ksteps >= 9 > PDW)
+    // (8 waves: W(0..2) landed; 4 waves: W(0), W(1) landed -- the first step prefetches W(1))
+    wait_vmcnt<WPS * KEEP>();
     __builtin_amdgcn_s_barrier();
 
     auto load_frags = [&](const unsigned char* win, const unsigned char* ws, int kh, int kw, int kk, h16x8 (&a)[RPW], h16x8 (&b)[2]) {
@@ -202,20 +218,16 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
         constexpr bool LAST = decltype(last_tag)::value;
         const unsigned char* win = winb + (c & 1) * WINB;
         const unsigned char* win_next = winb + ((c + 1) & 1) * WINB;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (!BAR2 || t % 2 == 0) {   // 8 waves: one barrier per TWO k-steps (taps 0|1, 2|3, 4|5, 6|7, 8): see the pipeline comment
-                wait_vmcnt<WAITN>();
+        static_for<9>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (!BAR2 || t % 2 == 0) {   // 8 waves: one barrier per TWO k-steps (taps 0|1, 2|3, 4|5, 6|7, 8): see the pipeline comment
+                wait_vmcnt<WinCount::younger(t, LAST)>();
                 __builtin_amdgcn_s_barrier();
             }
-            if (!LAST && t < NWP) issue_win(c + 1, t, (c + 1) & 1);
-            else issue_dummy();
-            if (!LAST || t + PDW <= 8) {
-                const int tn = t + PDW >= 9 ? t + PDW - 9 : t + PDW, cn = t + PDW >= 9 ? c + 1 : c;
-                if (LAST || cn < nch) issue_w(cn, tn, (stage + PDW) & (NST - 1));
-                else issue_w_dummy();
-            } else {
-                issue_w_dummy();
+            if constexpr (!LAST && t < NWP) issue_win(c + 1, t, (c + 1) & 1);
+            if constexpr (!LAST || t + PDW <= 8) {   // (a chunk that is not the last always has a next one: c + 1 < nch)
+                constexpr int tn = t + PDW >= 9 ? t + PDW - 9 : t + PDW;
+                issue_w(t + PDW >= 9 ? c + 1 : c, tn, (stage + PDW) & (NST - 1));
             }
             const int kh = t / 3, kw = t - kh * 3;
             const unsigned char* ws = wst + stage * WST_BYTES;
@@ -232,7 +244,7 @@ __device__ __forceinline__ void conv_win_body(const WinParams& p) {
             mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
             stage = (stage + 1) & (NST - 1);
-        }
+        });
     };
     for (int c = 0; c + 1 < nch; ++c) chunk(c, std::false_type{});
     chunk(nch - 1, std::true_type{});

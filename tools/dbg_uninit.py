@@ -39,7 +39,8 @@ def patch():
 
 def run(poison, steps=3):
     ACTIVE[0] = False
-    tr, batch, _ = _trainer(seed=1)
+    B_, H_, W_ = [int(v) for v in os.environ.get("SIZE", "2x128x256").split("x")]
+    tr, batch, _ = _trainer(seed=1, H=H_, W=W_, B=B_)
     out = []
     for k in range(steps):
         ACTIVE[0] = poison
