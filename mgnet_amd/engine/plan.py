@@ -411,7 +411,8 @@ def derive_schedule(items, main_id, serial=False):
             WR = np.concatenate([WR, np.array(acc_w[flushed:], dtype=np.int64)])
             flushed = len(acc_s)
         need = np.zeros(ns, dtype=np.int64)
-        if serial:     # debugging aid: global program order (every launch behind every earlier one)
+        if serial is True or (isinstance(serial, tuple) and serial[0] <= k < serial[1]):
+            # debugging aid: global program order (every launch behind every earlier one); a (lo, hi) tuple: only for items lo <= k < hi
             for t in range(ns):
                 if t != s:
                     need[t] = pos[t]
@@ -555,7 +556,17 @@ class StepPlan:
                 elif (only is None or str(sidx[it["stream"]]) in only.split(",")) and lo_ <= ii < hi_:
                     if (not hit and mode in ("both", "wait")) or (hit and mode in ("both", "release")):
                         it["reads"] = list(it["reads"]) + [G]
-        ops, n_ev, n_cross, ns, moved_nodes = derive_schedule(items, main_id, serial=bool(os.environ.get("MGN_PLAN_SERIAL")))
+        serial = bool(os.environ.get("MGN_PLAN_SERIAL"))
+        if os.environ.get("MGN_PLAN_SERIAL_RANGE"):   # (bisecting a missing edge: "lo:hi" = item indices that replay in program order)
+            lo_s, hi_s = os.environ["MGN_PLAN_SERIAL_RANGE"].split(":")
+            serial = (int(lo_s or 0), int(hi_s or len(items)))
+        if os.environ.get("MGN_PLAN_DUMP"):
+            with open(os.environ["MGN_PLAN_DUMP"], "a") as f:
+                sid = {st: k for k, st in enumerate(sorted({it["stream"] for it in items}))}
+                for k, it in enumerate(items):
+                    f.write(f"{k}\t{sid[it['stream']]}\t{'K' if it['kind'] == 0 else 'T'}\t{it['name'][:90]}\n")
+                f.write("----\n")
+        ops, n_ev, n_cross, ns, moved_nodes = derive_schedule(items, main_id, serial=serial)
         self.closures = [it["closure"] for it in items if it["kind"] == 1]
         n = len(ops)
         types = (ctypes.c_int * n)(*[o[0] for o in ops])

@@ -1,0 +1,53 @@
+"""Race screens at the benchmark's shapes (8 frames of 1024 x 2048): every convolution kernel family and the reprojection-loss kernels,
+launched repeatedly on the same operands while two other streams keep the memory system and the matrix pipes busy, must return the same
+bits every time.  Counted-`vmcnt` LDS-DMA pipelines fail this way when a wait retires too little -- round 6 found csrc/conv_win.hip doing
+so (the compiler had merged its adjacent dummy loads): ~1 % wrong tiles at these shapes, none at the small shapes of the parity tests."""
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_convolution_kernels_are_bit_reproducible_under_load():
+    import race_screen
+    failures = race_screen.screen(reps=5, busy=True, verbose=False)
+    assert not failures, failures
+
+
+def test_windowed_3x3_with_and_without_statistics_rows_agree_under_load():
+    """the statistics epilogue must not change the convolution's output, and neither may a busy chip: alternating launches of both forms
+    against the first result (the form of the screen that found the race: the two epilogues shift the co-resident blocks' timing)"""
+    from mgnet_amd import _C
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    side = [torch.cuda.Stream() for _ in range(2)]
+    big = torch.randn(32 << 20, device=dev)
+    mm = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+    for (N, Cin, H, W, Cout, pr) in [(8, 128, 128, 256, 128, 8), (8, 256, 128, 256, 256, 8), (8, 128, 32, 64, 256, 16), (8, 256, 64, 128, 256, 8)]:
+        x = torch.randn(N, Cin, H, W, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(Cout, 3, 3, Cin, device=dev, generator=g) * 0.05).to(torch.bfloat16).contiguous()
+        shift = torch.zeros(Cout, device=dev)
+        ref = _C.conv3x3_win(x, w, patch_rows=pr)
+        want = torch.nn.functional.conv2d(x[:1].float(), w[:8].float().permute(0, 3, 1, 2).contiguous(), padding=1)
+        assert float((ref[:1, :8].float() - want).abs().max() / want.abs().max()) < 5e-3
+        for r in range(10):
+            for st in side:
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    big.mul_(1.0001)
+                    torch.mm(mm, mm)
+            y = _C.conv3x3_win(x, w, patch_rows=pr, stats_shift=shift, want_stats=True)[0] if r % 2 else _C.conv3x3_win(x, w, patch_rows=pr)
+            assert torch.equal(y, ref), (N, Cin, H, W, Cout, pr, r, int((y != ref).sum()))
+        torch.cuda.synchronize()
+
+
+def test_reprojection_loss_is_bit_reproducible_under_load_at_full_size():
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "reproj_race.py"), "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 of 8 evaluations differ" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

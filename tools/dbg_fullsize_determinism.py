@@ -29,19 +29,24 @@ torch.cuda.synchronize()
 snap = tr.state_snapshot()
 
 
+SUMS = []   # per run: [step][bucket] checksum of the gradient bucket after the step (stream-ordered, no synchronisation)
+
+
 def run(step_fn):
     tr.state_restore(snap)
-    ls = []
+    ls, cs = [], []
     for _ in range(K):
         ld = step_fn()
         ls.append(torch.stack([v.detach().float().reshape(()) for v in ld.values()]).clone())
+        cs.append(torch.stack([b["flat_g"].view(torch.int32).to(torch.int64).sum() for b in tr.reducer.buckets]))
     torch.cuda.synchronize()
-    return torch.stack(ls).cpu(), [b["flat_g"].clone() for b in tr.reducer.buckets], [p.detach().clone() for p in tr.model.parameters()]
+    return (torch.stack(ls).cpu(), [b["flat_g"].clone() for b in tr.reducer.buckets], [p.detach().clone() for p in tr.model.parameters()],
+            torch.stack(cs).cpu())
 
 
 def compare(a, b, names):
-    la, ga, pa = a
-    lb, gb, pb = b
+    la, ga, pa, sa_ = a
+    lb, gb, pb, sb_ = b
     same = la.view(torch.int32) == lb.view(torch.int32)
     out = []
     if not bool(same.all()):
@@ -55,6 +60,8 @@ def compare(a, b, names):
             nm = [n for n, _ in tr.model.named_parameters()]
             bad = [nm[i] for i, (x, y) in enumerate(zip(pa, pb)) if not torch.equal(x, y)]
             out.append("   first / last differing parameters: " + ", ".join(bad[:4]) + " ... " + ", ".join(bad[-4:]))
+    if not torch.equal(sa_, sb_):
+        out.append("gradient buckets differing as [step, bucket]: " + str((sa_ != sb_).nonzero().tolist()[:12]))
     return out
 
 
