@@ -354,8 +354,8 @@ int mgn_plan_set_skip(void* plan, int node, int skip);
 /* race hunting: random idle kernels (1 .. max_us us, probability permille / 1000 per launch) in front of a replay's launches; a complete set
  * of cross-stream edges gives the same bits under any timing (tests/test_plan_gpu.py).  permille 0 = off. */
 int mgn_plan_set_jitter(void* plan, unsigned long long seed, int permille, int max_us);
-/* debugging: after node `node` of every following replay the checksum of [ptr, ptr + nbytes) is written to *out (8 bytes of device memory)
- * on the node's stream -- two replays of one step compared buffer by buffer; node | 1 << 24: the range is COPIED to out (nbytes) instead;
+/* debugging: after node `node` of every following replay an order-independent checksum of [ptr, ptr + nbytes) is ADDED to *out (8 bytes of
+ * device memory the caller zeroes between replays) on the node's stream -- two replays of one step compared buffer by buffer; node | 1 << 24: the range is COPIED to out (nbytes) instead;
  * node < 0 clears the probes */
 int mgn_plan_probe(void* plan, int node, const void* ptr, size_t nbytes, void* out);
 int mgn_plan_free(void* plan);

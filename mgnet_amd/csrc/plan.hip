@@ -65,16 +65,17 @@ struct Plan {
     bool overflow = false;
 };
 
+// order-independent checksum (64-bit integer sums: exact whatever the block order) ADDED to *out -- the caller zeroes the slot
 __global__ void plan_checksum_kernel(const unsigned* __restrict__ p, size_t nwords, unsigned long long* out) {
     __shared__ unsigned long long sh[256];
     unsigned long long a = 0;
-    for (size_t i = threadIdx.x; i < nwords; i += 256) a += (unsigned long long)p[i] * (2 * (i % 8191) + 1);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) a += (unsigned long long)p[i] * (2 * (i % 8191) + 1);
     sh[threadIdx.x] = a;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
         for (int k = 0; k < 256; ++k) t += sh[k];
-        *out = t;
+        atomicAdd(out, t);
     }
 }
 
@@ -284,7 +285,8 @@ int mgn_plan_run(void* plan, int from, int prof_slot) {
                 for (const Plan::Probe& pr : p->probes)
                     if (pr.node == o.a) {
                         if (pr.copy) (void)hipMemcpyAsync(pr.out, pr.ptr, pr.nwords * 4, hipMemcpyDeviceToDevice, nd.stream);
-                        else plan_checksum_kernel<<<1, 256, 0, nd.stream>>>((const unsigned*)pr.ptr, pr.nwords, pr.out);
+                        else plan_checksum_kernel<<<(unsigned)(pr.nwords / 4096 < 1 ? 1 : (pr.nwords / 4096 > 1024 ? 1024 : pr.nwords / 4096)), 256, 0, nd.stream>>>(
+                                (const unsigned*)pr.ptr, pr.nwords, pr.out);
                     }
             } else if (prof_slot >= 0 && prof_slot < (int)p->prof[nd.which].size()) {
                 (void)hipEventRecord(p->prof[nd.which][prof_slot], nd.stream);
@@ -374,8 +376,8 @@ int mgn_plan_set_jitter(void* plan, unsigned long long seed, int permille, int m
     return MGN_OK;
 }
 
-/* debugging: after node i of every following replay, the checksum of [ptr, ptr + nbytes) (device memory, nbytes % 4 == 0) is written to
- * *out (device memory, 8 bytes) on the node's stream; node < 0 clears all probes */
+/* debugging: after node i of every following replay an order-independent checksum of [ptr, ptr + nbytes) (device memory, nbytes % 4 == 0)
+ * is ADDED to *out (device memory, 8 bytes, zeroed by the caller between replays) on the node's stream; node < 0 clears all probes */
 int mgn_plan_probe(void* plan, int node, const void* ptr, size_t nbytes, void* out) {
     Plan* p = (Plan*)plan;
     if (!p) return MGN_EINVAL;

@@ -17,9 +17,12 @@ rgbx = _C.u8_frames_to_rgbx(frames)
 tg = {"image_orig": rgbx[:B], "image_prev_orig": rgbx[B:2 * B], "image_next_orig": rgbx[2 * B:],
       "camera_matrix": torch.stack([x["camera_matrix"] for x in batch]).to(dev), "reprojection_mask": torch.stack([x["reprojection_mask"] for x in batch]).unsqueeze(1)}
 g = torch.Generator(device="cuda").manual_seed(7)
-inv0 = [torch.nn.functional.interpolate(torch.rand(B, 1, H // s, W // s, device=dev, generator=g) * 1.9 + 0.05, size=(H, W), mode="bilinear", align_corners=True)
-        for s in (8, 16, 32)]
-poses0 = 0.01 * torch.randn(B, 2, 6, device=dev, generator=g)
+# DEPTH=flat: what a freshly initialised head predicts (sigmoid(~0) / 0.5 = ~1 everywhere, the warp close to the identity: adjacent lanes'
+# gathers share cache lines); default: smooth random inverse depths in (0.05, 1.95) and poses 0.01 N(0, 1)
+FLAT = os.environ.get("DEPTH") == "flat"
+inv0 = [torch.nn.functional.interpolate((torch.rand(B, 1, H // s, W // s, device=dev, generator=g) * (0.02 if FLAT else 1.9) + (0.99 if FLAT else 0.05)),
+                                        size=(H, W), mode="bilinear", align_corners=True) for s in (8, 16, 32)]
+poses0 = (0.0005 if FLAT else 0.01) * torch.randn(B, 2, 6, device=dev, generator=g)
 crit = MultiViewPhotometricLoss(0.85, 1.0, 0.001, True, "min", "zeros")
 side = [torch.cuda.Stream() for _ in range(2)]
 big = torch.randn(64 << 20, device=dev)
