@@ -38,7 +38,7 @@ def reproj_roofline(kern_ms, npx, u8, traffic, extra=None):
     r = {"bound": "hbm", "kernel": "reproj_march<true, %s> (fused reprojection loss + photometric gradient)" % ("uint8 RGBX frames" if u8 else "fp32 planar frames"),
          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
          "traffic": traffic, "traffic_source": "profiles/traffic.json: PMC measurement (FETCH_SIZE + WRITE_SIZE, calibrated in the same pass) of this kernel "
-                                                 "in this frame layout on the current csrc/reproj_loss.hip (round 5), not re-measured in this run", "bytes_per_px": bpp, "bytes_per_launch": bpp * npx, "avg_launch_ms": round(kern_ms, 4),
+                                                 "in this frame layout on the current csrc/reproj_loss.hip (re-measured in round 6: profiles/r06_traffic.json), not re-measured in this run", "bytes_per_px": bpp, "bytes_per_launch": bpp * npx, "avg_launch_ms": round(kern_ms, 4),
          "achieved_at_61_B_per_px": round(FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9, 1),
          "frac_at_61_B_per_px": round(FWD_BYTES_PER_PX * npx / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
          "limiter": "VALU issue + vector-memory instruction rate, not HBM (DESIGN.md 2.4: counted)"}
