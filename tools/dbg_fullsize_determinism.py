@@ -39,6 +39,8 @@ def run(step_fn):
         ld = step_fn()
         ls.append(torch.stack([v.detach().float().reshape(()) for v in ld.values()]).clone())
         cs.append(torch.stack([b["flat_g"].view(torch.int32).to(torch.int64).sum() for b in tr.reducer.buckets]))
+        if os.environ.get("SYNC_EACH") == "1":   # (the host never runs ahead of the device by more than one step)
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     return (torch.stack(ls).cpu(), [b["flat_g"].clone() for b in tr.reducer.buckets], [p.detach().clone() for p in tr.model.parameters()],
             torch.stack(cs).cpu())
