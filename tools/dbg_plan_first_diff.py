@@ -40,7 +40,8 @@ focus = os.environ.get("FOCUS")
 nprobe_out = len(probes)
 if focus:
     kf = next(k for k, it in enumerate(items) if it["kind"] == 0 and focus in cp.short(it["name"]))
-    prev = max(k for k in range(kf) if items[k]["kind"] == 0 and items[k]["stream"] == items[kf]["stream"])
+    # (the previous LAUNCH on its stream: probes behind a prof mark are never run by mgn_plan_run)
+    prev = max(k for k in range(kf) if items[k]["kind"] == 0 and items[k]["stream"] == items[kf]["stream"] and "prof" not in items[k]["name"])
     seen = set()
     for (a, b) in dbg[kf]["reads"] + dbg[kf]["writes"]:
         if (a, b) not in seen and 1 < b - a <= MAXB:
