@@ -51,3 +51,12 @@ def test_reprojection_loss_is_bit_reproducible_under_load_at_full_size():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "reproj_race.py"), "8"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 of 8 evaluations differ" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_convolution_kernels_match_fp32_torch_at_the_benchmark_shapes():
+    """parity at BASELINE's full sizes (the oracle cannot run them in seconds; the parity tests proper use small shapes): every convolution
+    family of the step at its C4 shape against an fp32 torch convolution of the same 16-bit operands -- forward and data gradients on
+    the first two images, weight gradients over all eight"""
+    import race_screen
+    failures = race_screen.parity(verbose=False)
+    assert not failures, failures

@@ -9,7 +9,7 @@ big = torch.randn(64 << 20, device=dev)
 mm = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
 want = sys.argv[1:] or ["conv1x1 256->256 @128x256", "conv3x3 s1 64->64 @256x512", "stem 7x7 s2 3(4)->64"]
 BUSY = os.environ.get("BUSY", "mm,mul")
-for name, fn in rs.cases(8):
+for name, fn, _ref in rs.cases(8):
     if name not in want:
         continue
     ref = fn(); torch.cuda.synchronize()

@@ -43,7 +43,7 @@ bad = torch.zeros(1, dtype=torch.int32, device=dev)
 cs = torch.cuda.Stream()
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 found = []
-for name, fn in rs.cases(8):
+for name, fn, _ref in rs.cases(8):
     fn(); torch.cuda.synchronize()
     bad.zero_()
     for r in range(ROUNDS):

@@ -26,39 +26,68 @@ def cases(B=8):
     for (cin, cout, h, w) in [(128, 128, 128, 256), (256, 256, 128, 256), (128, 128, 64, 128), (256, 256, 64, 128), (512, 512, 32, 64), (128, 256, 32, 64),
                               (512, 128, 32, 64), (64, 64, 256, 512), (256, 128, 64, 128)]:
         x, wt = cl(B, cin, h, w), wl(cout, 3, cin)
-        out.append((f"conv3x3 s1 {cin}->{cout} @{h}x{w}", lambda x=x, wt=wt, h=h, w=w: _C.conv_igemm(x, wt, (h, w), None, 1, 1)))
+        out.append((f"conv3x3 s1 {cin}->{cout} @{h}x{w}", lambda x=x, wt=wt, h=h, w=w: _C.conv_igemm(x, wt, (h, w), None, 1, 1),
+                    lambda x=x, wt=wt: _ref_conv(x, wt, 1, 1)))
         shift = torch.zeros(cout, device=dev)
         out.append((f"conv3x3 s1 {cin}->{cout} @{h}x{w} + statistics rows",
-                    lambda x=x, wt=wt, h=h, w=w, shift=shift: _stats(x, wt, (h, w), 1, 1, shift)))
+                    lambda x=x, wt=wt, h=h, w=w, shift=shift: _stats(x, wt, (h, w), 1, 1, shift), None))
     # stride-2 forward (3x3 and the 1x1 shortcut) and their data gradients
     for (cin, cout, h, w) in [(64, 128, 256, 512), (128, 256, 128, 256), (256, 512, 64, 128)]:
         x, w3, w1 = cl(B, cin, h, w), wl(cout, 3, cin), wl(cout, 1, cin)
-        out.append((f"conv3x3 s2 {cin}->{cout} @{h}x{w}", lambda x=x, w3=w3, h=h, w=w: _C.conv_igemm(x, w3, (h // 2, w // 2), None, 2, 1)))
-        out.append((f"conv1x1 s2 {cin}->{cout} @{h}x{w}", lambda x=x, w1=w1, h=h, w=w: _C.conv_igemm(x, w1, (h // 2, w // 2), None, 2, 0)))
+        out.append((f"conv3x3 s2 {cin}->{cout} @{h}x{w}", lambda x=x, w3=w3, h=h, w=w: _C.conv_igemm(x, w3, (h // 2, w // 2), None, 2, 1),
+                    lambda x=x, w3=w3: _ref_conv(x, w3, 2, 1)))
+        out.append((f"conv1x1 s2 {cin}->{cout} @{h}x{w}", lambda x=x, w1=w1, h=h, w=w: _C.conv_igemm(x, w1, (h // 2, w // 2), None, 2, 0),
+                    lambda x=x, w1=w1: _ref_conv(x, w1, 2, 0)))
         dy = cl(B, cout, h // 2, w // 2)
         wi = wl(cin, 3, cout)   # layout mode 1: [Cin_fwd][kh][kw][Cout_fwd]
         res = cl(B, cin, h, w)
-        out.append((f"dgrad 3x3 s2 {cout}->{cin} to {h}x{w} (conv_up2 + residual)", lambda dy=dy, wi=wi, h=h, w=w, res=res: _up2(dy, wi, (h, w), res)))
+        out.append((f"dgrad 3x3 s2 {cout}->{cin} to {h}x{w} (conv_up2 + residual)", lambda dy=dy, wi=wi, h=h, w=w, res=res: _up2(dy, wi, (h, w), res),
+                    lambda dy=dy, wi=wi, res=res, h=h, w=w: _ref_dgrad_s2(dy, wi, res, (h, w))))
     # 1x1 layers (streaming kernel / generic)
     for (cin, cout, h, w) in [(256, 256, 128, 256), (256, 32, 128, 256), (32, 256, 128, 256), (512, 256, 32, 64), (128, 64, 128, 256)]:
         x, w1 = cl(B, cin, h, w), wl(cout, 1, cin)
-        out.append((f"conv1x1 {cin}->{cout} @{h}x{w}", lambda x=x, w1=w1, h=h, w=w: _C.conv_igemm(x, w1, (h, w), None, 1, 0)))
+        out.append((f"conv1x1 {cin}->{cout} @{h}x{w}", lambda x=x, w1=w1, h=h, w=w: _C.conv_igemm(x, w1, (h, w), None, 1, 0),
+                    lambda x=x, w1=w1: _ref_conv(x, w1, 1, 0)))
     # stems
     x4, x16 = cl(B, 4, 1024, 2048), cl(B, 16, 1024, 2048)
     w4 = (torch.randn(64, 3, 7, 7, device=dev, generator=g) * 0.05)
     w9 = (torch.randn(64, 9, 7, 7, device=dev, generator=g) * 0.05)
-    out.append(("stem 7x7 s2 3(4)->64", lambda: _C.conv_igemm(x4, _C.weight_layout(w4, 2, 4, dtype=torch.bfloat16), (512, 1024), None, 2, 3, khw=(7, 7))))
-    out.append(("stem 7x7 s2 9(16)->64", lambda: _C.conv_igemm(x16, _C.weight_layout(w9, 2, 16, dtype=torch.bfloat16), (512, 1024), None, 2, 3, khw=(7, 7))))
+    out.append(("stem 7x7 s2 3(4)->64", lambda: _C.conv_igemm(x4, _C.weight_layout(w4, 2, 4, dtype=torch.bfloat16), (512, 1024), None, 2, 3, khw=(7, 7)),
+                lambda: torch.nn.functional.conv2d(x4[:NREF, :3].float(), w4.to(torch.bfloat16).float(), stride=2, padding=3)))
+    out.append(("stem 7x7 s2 9(16)->64", lambda: _C.conv_igemm(x16, _C.weight_layout(w9, 2, 16, dtype=torch.bfloat16), (512, 1024), None, 2, 3, khw=(7, 7)),
+                lambda: torch.nn.functional.conv2d(x16[:NREF, :9].float(), w9.to(torch.bfloat16).float(), stride=2, padding=3)))
     dys = cl(B, 64, 512, 1024)
-    out.append(("wgrad stem 7x7 s2 (4-channel pixels)", lambda: _C.conv_wgrad(dys, x4, 7, 7, 2, 3, cin_real=3)))
-    out.append(("wgrad stem 7x7 s2 (16-channel pixels)", lambda: _C.conv_wgrad(dys, x16, 7, 7, 2, 3, cin_real=9)))
+    out.append(("wgrad stem 7x7 s2 (4-channel pixels)", lambda: _C.conv_wgrad(dys, x4, 7, 7, 2, 3, cin_real=3),
+                lambda: _ref_wgrad(x4[:, :3], dys, 7, 2, 3)))
+    out.append(("wgrad stem 7x7 s2 (16-channel pixels)", lambda: _C.conv_wgrad(dys, x16, 7, 7, 2, 3, cin_real=9),
+                lambda: _ref_wgrad(x16[:, :9], dys, 7, 2, 3)))
     # weight gradients
     for (cin, cout, h, w, k, s) in [(64, 64, 256, 512, 3, 1), (128, 128, 128, 256, 3, 1), (256, 256, 128, 256, 3, 1), (512, 512, 32, 64, 3, 1),
                                     (64, 128, 256, 512, 3, 2), (128, 256, 128, 256, 3, 2), (256, 256, 128, 256, 1, 1), (256, 32, 128, 256, 1, 1),
                                     (64, 128, 256, 512, 1, 2), (512, 128, 32, 64, 3, 1)]:
         x, dy = cl(B, cin, h, w), cl(B, cout, h // s, w // s)
-        out.append((f"wgrad {k}x{k} s{s} {cin}->{cout} @{h}x{w}", lambda x=x, dy=dy, k=k, s=s: _C.conv_wgrad(dy, x, k, k, s, k // 2)))
+        out.append((f"wgrad {k}x{k} s{s} {cin}->{cout} @{h}x{w}", lambda x=x, dy=dy, k=k, s=s: _C.conv_wgrad(dy, x, k, k, s, k // 2),
+                    lambda x=x, dy=dy, k=k, s=s: _ref_wgrad(x, dy, k, s, k // 2)))
     return out
+
+
+NREF = 2   # images of the batch the fp32 reference of a forward / data-gradient case covers (the weight gradients cover all of them)
+
+
+def _ref_conv(x, w_ohwi, stride, pad):
+    """fp32 torch convolution of the first NREF images on the same 16-bit operands (the yardstick: MIOpen fp32)"""
+    return torch.nn.functional.conv2d(x[:NREF].float(), w_ohwi.float().permute(0, 3, 1, 2).contiguous(), stride=stride, padding=pad)
+
+
+def _ref_dgrad_s2(dy, w_ihwo, res, hw):
+    # layout mode 1 = [Cin_fwd][kh][kw][Cout_fwd] with the taps flipped: the forward weight is w[co][ci][KH-1-kh][KW-1-kw]
+    wf = w_ihwo.float().flip(1, 2).permute(3, 0, 1, 2).contiguous()          # [Cout_fwd, Cin_fwd, kh, kw]
+    g = torch.nn.grad.conv2d_input((NREF, wf.shape[1]) + tuple(hw), wf, dy[:NREF].float(), stride=2, padding=1)
+    return g + res[:NREF].float()
+
+
+def _ref_wgrad(x, dy, k, stride, pad):
+    return torch.nn.grad.conv2d_weight(x.float(), (dy.shape[1], x.shape[1], k, k), dy.float(), stride=stride, padding=pad)
 
 
 def _stats(x, wt, hw, stride, pad, shift):
@@ -77,7 +106,7 @@ def screen(reps=8, busy=True, B=8, verbose=True):
     big = torch.randn(64 << 20, device=dev)
     mm = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
     failures = []
-    for name, fn in cases(B):
+    for name, fn, _ref in cases(B):
         ref = fn()
         torch.cuda.synchronize()
         nbad, worst = 0, 0
@@ -100,6 +129,29 @@ def screen(reps=8, busy=True, B=8, verbose=True):
     return failures
 
 
+def parity(B=8, verbose=True, tol=6e-3):
+    """every case against an fp32 torch evaluation on the same 16-bit operands, at the full C4 shapes (first NREF images for the forward /
+    data-gradient cases): max |difference| / max |reference| <= tol (16-bit outputs: 2^-8 rounding; fp32 weight gradients far below)"""
+    failures = []
+    for name, fn, ref in cases(B):
+        if ref is None:
+            continue
+        y, r = fn(), ref()
+        y = y[:r.shape[0]] if y.dim() == 4 and y.shape[0] != r.shape[0] and y.shape[1:] == r.shape[1:] else y
+        assert y.shape == r.shape, (name, y.shape, r.shape)
+        err = float((y.float() - r).abs().max() / r.abs().max().clamp_min(1e-20))
+        if verbose:
+            print(f"{name:62s} max |d| / max |ref| = {err:.2e}", flush=True)
+        if not err <= tol:
+            failures.append((name, err))
+        del y, r
+    return failures
+
+
 if __name__ == "__main__":
+    if "--parity" in sys.argv:
+        f = parity()
+        print(f"cases beyond the tolerance: {f}")
+        sys.exit(1 if f else 0)
     f = screen(int(sys.argv[1]) if len(sys.argv) > 1 else 8, busy=os.environ.get("BUSY", "1") == "1")
     print(f"kernels that are not bit-reproducible under load: {len(f)}   lib={os.environ.get('MGNET_HIP_LIB', 'in-tree')}")
