@@ -25,12 +25,20 @@ items, dbg = plan.items, plan.debug_items
 cp.demangle([it["name"] for it in items])
 MAXB = int(os.environ.get("PROBE_MAX_MB", 600)) << 20
 probes = []   # (item index, range index, a, b)
+# shared workspaces (a block many launches write: the per-stream norm workspace, ...) keep stale bytes of earlier launches in the parts a
+# launch does not rewrite -- their checksums differ after ANY earlier difference and say nothing: skipped
+nwriters = {}
+for it in dbg:
+    if it["kind"] == 0:
+        for r_ in set(it["writes"]):
+            nwriters[r_] = nwriters.get(r_, 0) + 1
+MAXW = int(os.environ.get("PROBE_MAX_WRITERS", 4))
 for k, it in enumerate(dbg):
     if it["kind"] != 0:
         continue
     seen = set()
     for (a, b) in it["writes"]:
-        if (a, b) in seen or b - a <= 1 or b - a > MAXB:
+        if (a, b) in seen or b - a <= 1 or b - a > MAXB or nwriters.get((a, b), 0) > MAXW:
             continue
         seen.add((a, b))
         probes.append((k, a, b - (b - a) % 4))
@@ -53,9 +61,20 @@ if focus:
             probes.append((kf, a, b - (b - a) % 4))
     print(f"focus: #{kf} {cp.short(items[kf]['name'])[:40]}: {len(probes) - nprobe_out} input / output ranges probed behind #{prev} {cp.short(items[prev]['name'])[:30]}")
 slots = torch.zeros(len(probes), dtype=torch.int64, device=dev)
+# FOCUS_COPY=1: the focus kernel's written ranges are also COPIED behind it every replay, to see WHERE in them two replays differ
+copies = []
+if focus and os.environ.get("FOCUS_COPY") == "1":
+    seen = set()
+    for (a, b) in dbg[kf]["writes"]:
+        if (a, b) not in seen and 1 < b - a <= MAXB:
+            seen.add((a, b))
+            buf = torch.zeros((b - a) // 4, dtype=torch.int32, device=dev)
+            copies.append((a, b, buf))
 lib = _C.lib()
 for j, (k, a, b) in enumerate(probes):
     _C.check(lib.mgn_plan_probe(plan.handle, items[k]["node"], ctypes.c_void_p(a), b - a, ctypes.c_void_p(slots.data_ptr() + 8 * j)), "probe")
+for (a, b, buf) in copies:
+    _C.check(lib.mgn_plan_probe(plan.handle, items[kf]["node"] | (1 << 24), ctypes.c_void_p(a), (b - a) // 4 * 4, ctypes.c_void_p(buf.data_ptr())), "probe copy")
 print(f"{len(probes)} probes behind {len({p[0] for p in probes})} launches, {sum(b - a for _, a, b in probes) / 1e9:.2f} GB checksummed per replay", flush=True)
 sid = {st: i for i, st in enumerate(sorted({it['stream'] for it in items}))}
 res = []
@@ -66,6 +85,25 @@ for r in range(R):
     ld = tr.replay_plan()
     torch.cuda.synchronize()
     res.append((slots.cpu().numpy().copy(), {k: float(v) for k, v in ld.items()}))
+    if copies:
+        if r == 0:
+            ref_copies = [buf.clone() for (_a, _b, buf) in copies]
+        else:
+            for (a, b, buf), rc in zip(copies, ref_copies):
+                d = (buf != rc).nonzero().flatten()
+                if d.numel():
+                    off = d * 4
+                    # which other items touch memory right around the differing bytes?
+                    lo_, hi_ = a + int(off[0]), a + int(off[-1]) + 4
+                    near = []
+                    for k2, it2 in enumerate(dbg):
+                        for (x, y) in it2["writes"]:
+                            if k2 != kf and (abs(y - lo_) < (1 << 20) or abs(x - hi_) < (1 << 20) or (x < hi_ and y > lo_)):
+                                near.append(f"#{k2}[s{sid[items[k2]['stream']]}]{cp.short(items[k2]['name'])[:22]}({x - a:+d}..{y - a:+d})")
+                                break
+                    vals = [(int(o), int(rc[o // 4 if False else int(o) // 4]), int(buf[int(o) // 4])) for o in off[:4].tolist()]
+                    print(f"[replay {r}] COPY of {a:#x}+{(b - a) >> 10} KB behind the focus kernel: {d.numel()} words differ, byte offsets {int(off[0])} .. {int(off[-1])} "
+                          f"(first words ref/now: {[(o, hex(x & 0xffffffff), hex(y & 0xffffffff)) for o, x, y in vals]}); writers of nearby memory: {' '.join(near[:10])}", flush=True)
 ref = res[0]
 for r in range(1, R):
     d = np.nonzero(res[r][0] != ref[0])[0]

@@ -29,6 +29,11 @@ big = torch.randn(64 << 20, device=dev)
 mm = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
 
 
+# BUSY=conv: the side streams run the windowed 3x3 kernels of the heads (what shares the chip with this kernel inside the training step)
+cx = [torch.randn(8, c, 128, 256, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for c in (256, 128)]
+cw = [(torch.randn(c, 3, 3, c, device=dev, generator=g) * 0.05).to(torch.bfloat16).contiguous() for c in (256, 128)]
+
+
 def once():
     inv = [x.clone().requires_grad_(True) for x in inv0]
     poses = poses0.clone().requires_grad_(True)
@@ -48,6 +53,12 @@ for r in range(REPS):
             with torch.cuda.stream(st):
                 big.mul_(1.0001)
                 torch.mm(mm, mm)
+    elif os.environ.get("BUSY") == "conv":
+        for k, st in enumerate(side):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                for _ in range(12):
+                    _C.conv3x3_win(cx[k], cw[k], patch_rows=8)
     cur = once()
     torch.cuda.synchronize()
     d = [f"{n}: {int((a != b).sum())} elements" + (f" ({float(a):.9g} / {float(b):.9g})" if a.dim() == 0 else "") for n, a, b in zip(names, ref, cur) if not torch.equal(a, b)]
