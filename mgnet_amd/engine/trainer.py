@@ -355,11 +355,45 @@ class Trainer:
         else:
             dst.copy_(src)
 
-    def run_step_planned(self, batched_inputs, warmup=3):
+    def record_plan_checked(self, batched_inputs, verify_steps=8):
+        """Record the step and accept the recording only if it checks out, WITHOUT training: the state (parameters, buffers, optimizer,
+        schedule, iteration) is the same after the call as before it.  Two recordings are made from that state and replayed `verify_steps`
+        steps each from it; they must agree bit for bit (see record_plan).  Returns the plan (kept as the trainer's), or None with the
+        reason in `self.plan_check` -- the caller then stays on the eager step.  One process only."""
+        assert self.reducer.world == 1
+        from . import plan as plan_mod
+        snap = self.state_snapshot()
+        self.plan_check = None
+        for attempt in range(2):
+            cands = []
+            for _ in range(2):
+                self.state_restore(snap)
+                self._record_plan_once(batched_inputs)
+                cands.append((self._plan, self._plan_losses, self._plan_inputs, self._plan_keep))
+            self.state_restore(snap)
+            check = self._verify_plans(cands[0], cands[1], verify_steps)
+            check["read_only_declarations"] = plan_mod.ro_mode()
+            check["fallback"] = self.plan_check
+            self.plan_check = check
+            cands[1][0].close()
+            self.state_restore(snap)
+            if check["identical"]:
+                self._plan, self._plan_losses, self._plan_inputs, self._plan_keep = cands[0]
+                return self._plan
+            cands[0][0].close()
+            self._plan = None
+            if plan_mod.ro_mode() == "none":
+                break
+            plan_mod.set_ro_mode("none")
+        return None
+
+    def run_step_planned(self, batched_inputs, warmup=3, verify_steps=0):
         """`run_step` for a training loop that wants the recorded step: the first `warmup` calls run eagerly (lazy workspaces, layout cache,
         allocator), the next one records the step on plan-owned copies of the batch, every later call copies its batch into those buffers
         and replays.  A batch of another shape (or a step the recorder refuses) runs eagerly -- `self.plan_note` says why -- so the
-        loop never depends on the plan.  Returns the loss dict of the step like `run_step` (device scalars, overwritten by the next replay)."""
+        loop never depends on the plan.  Returns the loss dict of the step like `run_step` (device scalars, overwritten by the next replay).
+        verify_steps > 0 (one process): the recording is accepted only after `record_plan_checked` -- two recordings replayed from the
+        current state must agree bit for bit; the check itself trains nothing.  Refused recordings leave the loop on eager steps."""
         if getattr(self, "_plan", None) is None:
             # (eager steps THIS process has run, not `self.iter`: a run resumed from a checkpoint still has to warm up)
             if getattr(self, "_eager_steps", 0) < warmup or getattr(self, "plan_note", None):
@@ -369,8 +403,13 @@ class Trainer:
             static, bases, layout = self._static_copy(batched_inputs)
             err, losses = None, None
             try:
-                self.record_plan(static)
-                losses = self._plan_losses
+                if verify_steps > 0 and self.reducer.world == 1:
+                    if self.record_plan_checked(static, verify_steps) is None:
+                        raise PlanUnsupported(f"two recordings of the step replay to different results ({self.plan_check})")
+                    losses = self.replay_plan()   # (the check trained nothing: this is the batch's step)
+                else:
+                    self.record_plan(static)
+                    losses = self._plan_losses
             except PlanUnsupported as e:
                 err = e
                 if e.completed:        # the step ran (and was counted by record_plan) before the recorder objected: do NOT train the batch again

@@ -323,3 +323,20 @@ def test_state_snapshot_restore_repeats_a_step_bit_for_bit():
     assert outs[0][0] == outs[1][0] and outs[0][4] == outs[1][4] and outs[0][5] == outs[1][5]
     assert all(torch.equal(x, y) for x, y in zip(outs[0][1], outs[1][1])) and all(torch.equal(x, y) for x, y in zip(outs[0][2], outs[1][2]))
     assert torch.equal(outs[0][3], outs[1][3])
+
+
+def test_run_step_planned_with_the_recording_check_trains_exactly_the_eager_trajectory():
+    """run_step_planned(verify_steps=k): the recording is checked (two recordings from the current state, k replays each, bit for bit)
+    before it is used, and the check trains nothing -- losses of every call and the parameters afterwards equal plain eager steps"""
+    ta, batch, other = _trainer(seed=3)
+    tb, batch_b, other_b = _trainer(seed=3)
+    la, lb = [], []
+    for k in range(8):
+        x, y = (batch, batch_b) if k % 2 == 0 else (other, other_b)
+        la.append({n: float(v) for n, v in ta.run_step(x).items()})
+        lb.append({n: float(v) for n, v in tb.run_step_planned(y, warmup=3, verify_steps=4).items()})
+    assert tb._plan is not None and tb.plan_check["identical"] and tb.plan_check["steps"] == 4, (getattr(tb, "plan_note", None), tb.plan_check)
+    assert ta.iter == tb.iter == 8
+    assert la == lb
+    for (na, pa), (nb, pb) in zip(ta.model.named_parameters(), tb.model.named_parameters()):
+        assert torch.equal(pa, pb), na
