@@ -535,6 +535,23 @@ class StepPlan:
             self.report_split = getattr(self, "report_split", {})
             self.report_split[sub] = moved
         main_id = int(main.cuda_stream)
+        if os.environ.get("MGN_PLAN_MERGE"):
+            # (experiment: "a>b[,c>d]" -- everything recorded on the a-th stream (handles sorted, as in MGN_PLAN_DUMP) replays on the b-th:
+            #  that pair of streams is serialised in issue order, the others stay concurrent.  The dependency analysis is unchanged.)
+            order = sorted({it["stream"] for it in items} | {main_id})
+            tstream = {int(c["stream"].cuda_stream): c["stream"] for c in (it["closure"] for it in items if it["kind"] == 1)}
+            for pair in os.environ["MGN_PLAN_MERGE"].split(","):
+                a, b = (int(v) for v in pair.split(">"))
+                src, dst = order[a], order[b]
+                for it in items:
+                    if it["stream"] == src:
+                        it["stream"] = dst
+                        if it["kind"] == 0:
+                            it["moved"] = True
+                        else:
+                            it["closure"]["stream"] = tstream.get(dst) or (main if dst == main_id else torch.cuda.ExternalStream(dst, device=main.device))
+                if src == main_id:
+                    raise PlanUnsupported("MGN_PLAN_MERGE: the main stream cannot be merged away")
         if os.environ.get("MGN_PLAN_CLOSURE_BARRIERS"):   # (debugging: every host-issued torch op joins all streams before and after itself)
             sel = os.environ["MGN_PLAN_CLOSURE_BARRIERS"]
             for it in items:
