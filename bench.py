@@ -406,7 +406,14 @@ def full_step_bench(args, world, rank, dev):
             #  verify_steps; on a difference the read-only declarations are dropped and the step is recorded again): config.plan_check
             plan = trainer.record_plan(batch, prof_slots=args.steps, best_of=3 if world == 1 else 1, verify_steps=args.plan_verify_steps)
         except Exception as e:  # noqa: BLE001 -- report and fall back to the eager step rather than lose the measurement
-            plan_note = f"plan recording failed ({type(e).__name__}: {e}); eager steps timed"
+            if "replay to different results" in str(e):
+                chk = getattr(trainer, "plan_check", None) or {}
+                plan_note = ("launch plan refused by the recording check: two recordings of the step, replayed from one state, do not agree bit for bit "
+                             f"(first difference at step {(chk.get('first_difference') or {}).get('step')}: {(chk.get('first_difference') or {}).get('losses')}; "
+                             "with and without the read-only declarations; profiles/r06_determinism.txt section 4) -- eager steps timed; "
+                             "--exec plan --plan-verify-steps 0 times the replay anyway")
+            else:
+                plan_note = f"plan recording failed ({type(e).__name__}: {e}); eager steps timed"
             print(f"[bench] {plan_note}", file=sys.stderr, flush=True)
         ok = torch.tensor([0.0 if plan is None else 1.0], device=dev)
         if world > 1:   # every rank replays, or none does (a rank issuing another launch sequence would leave its peers waiting)
