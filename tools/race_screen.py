@@ -101,7 +101,16 @@ def _up2(dy, wi, hw, res):
     return y if y is not None else _C.conv_igemm(dy, wi, hw, None, 1, 1, up=2, residual=res)
 
 
-def screen(reps=8, busy=True, B=8, verbose=True):
+def _gross(y, ref):
+    """elements of y that differ from ref by more than rounding noise: > 2 ulps of the 16-bit format (> 1e-5 relative for fp32 outputs).
+    A pipeline race gives wrong TILES (errors of order one in thousands of elements); one box of round 6 flipped the last bit of a handful
+    of elements of nearly every kernel under load (profiles/r06_determinism.txt), which is not what this screen is for."""
+    yf, rf = y.float(), ref.float()
+    tol = (2.0 ** -7 if y.dtype in (torch.bfloat16, torch.float16) else 1e-5) * torch.maximum(yf.abs(), rf.abs()) + 1e-30
+    return int(((yf - rf).abs() > tol).sum())
+
+
+def screen(reps=8, busy=True, B=8, verbose=True, strict=True):
     side = [torch.cuda.Stream() for _ in range(2)]
     big = torch.randn(64 << 20, device=dev)
     mm = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
@@ -119,6 +128,12 @@ def screen(reps=8, busy=True, B=8, verbose=True):
                         torch.mm(mm, mm)
             y = fn()
             n = int((y != ref).sum())
+            if n and not strict:   # (tests: last-bit flips of a few elements are reported, not failed)
+                g = _gross(y, ref)
+                if g == 0 and n <= 1e-4 * y.numel():
+                    if verbose:
+                        print(f"{name}: {n} elements differ in the last bits (tolerated)", flush=True)
+                    n = 0
             nbad += n > 0
             worst = max(worst, n)
         torch.cuda.synchronize()
