@@ -20,11 +20,14 @@ def wl(cout, k, cin, scale=0.05):
     return (torch.randn(cout, k, k, cin, device=dev, generator=g) * scale).to(torch.bfloat16).contiguous()
 
 
-def cases(B=8):
+def cases(B=8, div=1):
+    """div: every spatial size divided by it (1: the C4 frame 1024 x 2048; 2: C2's 512 x 1024; 4: C1's 256 x 512)"""
     out = []
+    FH, FW = 1024 // div, 2048 // div
     # forward / data gradient of the 3x3 stride-1 layers (windowed kernels, 64-channel row march, generic)
     for (cin, cout, h, w) in [(128, 128, 128, 256), (256, 256, 128, 256), (128, 128, 64, 128), (256, 256, 64, 128), (512, 512, 32, 64), (128, 256, 32, 64),
                               (512, 128, 32, 64), (64, 64, 256, 512), (256, 128, 64, 128)]:
+        h, w = h // div, w // div
         x, wt = cl(B, cin, h, w), wl(cout, 3, cin)
         out.append((f"conv3x3 s1 {cin}->{cout} @{h}x{w}", lambda x=x, wt=wt, h=h, w=w: _C.conv_igemm(x, wt, (h, w), None, 1, 1),
                     lambda x=x, wt=wt: _ref_conv(x, wt, 1, 1)))
@@ -33,6 +36,7 @@ def cases(B=8):
                     lambda x=x, wt=wt, h=h, w=w, shift=shift: _stats(x, wt, (h, w), 1, 1, shift), None))
     # stride-2 forward (3x3 and the 1x1 shortcut) and their data gradients
     for (cin, cout, h, w) in [(64, 128, 256, 512), (128, 256, 128, 256), (256, 512, 64, 128)]:
+        h, w = h // div, w // div
         x, w3, w1 = cl(B, cin, h, w), wl(cout, 3, cin), wl(cout, 1, cin)
         out.append((f"conv3x3 s2 {cin}->{cout} @{h}x{w}", lambda x=x, w3=w3, h=h, w=w: _C.conv_igemm(x, w3, (h // 2, w // 2), None, 2, 1),
                     lambda x=x, w3=w3: _ref_conv(x, w3, 2, 1)))
@@ -45,18 +49,19 @@ def cases(B=8):
                     lambda dy=dy, wi=wi, res=res, h=h, w=w: _ref_dgrad_s2(dy, wi, res, (h, w))))
     # 1x1 layers (streaming kernel / generic)
     for (cin, cout, h, w) in [(256, 256, 128, 256), (256, 32, 128, 256), (32, 256, 128, 256), (512, 256, 32, 64), (128, 64, 128, 256)]:
+        h, w = h // div, w // div
         x, w1 = cl(B, cin, h, w), wl(cout, 1, cin)
         out.append((f"conv1x1 {cin}->{cout} @{h}x{w}", lambda x=x, w1=w1, h=h, w=w: _C.conv_igemm(x, w1, (h, w), None, 1, 0),
                     lambda x=x, w1=w1: _ref_conv(x, w1, 1, 0)))
     # stems
-    x4, x16 = cl(B, 4, 1024, 2048), cl(B, 16, 1024, 2048)
+    x4, x16 = cl(B, 4, FH, FW), cl(B, 16, FH, FW)
     w4 = (torch.randn(64, 3, 7, 7, device=dev, generator=g) * 0.05)
     w9 = (torch.randn(64, 9, 7, 7, device=dev, generator=g) * 0.05)
-    out.append(("stem 7x7 s2 3(4)->64", lambda: _C.conv_igemm(x4, _C.weight_layout(w4, 2, 4, dtype=torch.bfloat16), (512, 1024), None, 2, 3, khw=(7, 7)),
+    out.append(("stem 7x7 s2 3(4)->64", lambda: _C.conv_igemm(x4, _C.weight_layout(w4, 2, 4, dtype=torch.bfloat16), (FH // 2, FW // 2), None, 2, 3, khw=(7, 7)),
                 lambda: torch.nn.functional.conv2d(x4[:NREF, :3].float(), w4.to(torch.bfloat16).float(), stride=2, padding=3)))
-    out.append(("stem 7x7 s2 9(16)->64", lambda: _C.conv_igemm(x16, _C.weight_layout(w9, 2, 16, dtype=torch.bfloat16), (512, 1024), None, 2, 3, khw=(7, 7)),
+    out.append(("stem 7x7 s2 9(16)->64", lambda: _C.conv_igemm(x16, _C.weight_layout(w9, 2, 16, dtype=torch.bfloat16), (FH // 2, FW // 2), None, 2, 3, khw=(7, 7)),
                 lambda: torch.nn.functional.conv2d(x16[:NREF, :9].float(), w9.to(torch.bfloat16).float(), stride=2, padding=3)))
-    dys = cl(B, 64, 512, 1024)
+    dys = cl(B, 64, FH // 2, FW // 2)
     out.append(("wgrad stem 7x7 s2 (4-channel pixels)", lambda: _C.conv_wgrad(dys, x4, 7, 7, 2, 3, cin_real=3),
                 lambda: _ref_wgrad(x4[:, :3], dys, 7, 2, 3)))
     out.append(("wgrad stem 7x7 s2 (16-channel pixels)", lambda: _C.conv_wgrad(dys, x16, 7, 7, 2, 3, cin_real=9),
@@ -65,6 +70,7 @@ def cases(B=8):
     for (cin, cout, h, w, k, s) in [(64, 64, 256, 512, 3, 1), (128, 128, 128, 256, 3, 1), (256, 256, 128, 256, 3, 1), (512, 512, 32, 64, 3, 1),
                                     (64, 128, 256, 512, 3, 2), (128, 256, 128, 256, 3, 2), (256, 256, 128, 256, 1, 1), (256, 32, 128, 256, 1, 1),
                                     (64, 128, 256, 512, 1, 2), (512, 128, 32, 64, 3, 1)]:
+        h, w = h // div, w // div
         x, dy = cl(B, cin, h, w), cl(B, cout, h // s, w // s)
         out.append((f"wgrad {k}x{k} s{s} {cin}->{cout} @{h}x{w}", lambda x=x, dy=dy, k=k, s=s: _C.conv_wgrad(dy, x, k, k, s, k // 2),
                     lambda x=x, dy=dy, k=k, s=s: _ref_wgrad(x, dy, k, s, k // 2)))
@@ -110,12 +116,12 @@ def _gross(y, ref):
     return int(((yf - rf).abs() > tol).sum())
 
 
-def screen(reps=8, busy=True, B=8, verbose=True, strict=True):
+def screen(reps=8, busy=True, B=8, verbose=True, strict=True, div=1):
     side = [torch.cuda.Stream() for _ in range(2)]
     big = torch.randn(64 << 20, device=dev)
     mm = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
     failures = []
-    for name, fn, _ref in cases(B):
+    for name, fn, _ref in cases(B, div):
         ref = fn()
         torch.cuda.synchronize()
         nbad, worst = 0, 0
@@ -144,11 +150,11 @@ def screen(reps=8, busy=True, B=8, verbose=True, strict=True):
     return failures
 
 
-def parity(B=8, verbose=True, tol=6e-3):
+def parity(B=8, verbose=True, tol=6e-3, div=1):
     """every case against an fp32 torch evaluation on the same 16-bit operands, at the full C4 shapes (first NREF images for the forward /
     data-gradient cases): max |difference| / max |reference| <= tol (16-bit outputs: 2^-8 rounding; fp32 weight gradients far below)"""
     failures = []
-    for name, fn, ref in cases(B):
+    for name, fn, ref in cases(B, div):
         if ref is None:
             continue
         y, r = fn(), ref()
@@ -164,9 +170,10 @@ def parity(B=8, verbose=True, tol=6e-3):
 
 
 if __name__ == "__main__":
+    DIV = int(os.environ.get("DIV", 1))
     if "--parity" in sys.argv:
-        f = parity()
+        f = parity(div=DIV)
         print(f"cases beyond the tolerance: {f}")
         sys.exit(1 if f else 0)
-    f = screen(int(sys.argv[1]) if len(sys.argv) > 1 else 8, busy=os.environ.get("BUSY", "1") == "1")
+    f = screen(int(sys.argv[1]) if len(sys.argv) > 1 else 8, busy=os.environ.get("BUSY", "1") == "1", div=DIV)
     print(f"kernels that are not bit-reproducible under load: {len(f)}   lib={os.environ.get('MGNET_HIP_LIB', 'in-tree')}")
