@@ -163,10 +163,12 @@ int mgn_iabn_bwd_reduce_x(const void* x, const void* dy, int dtype, long M, int 
                           void* ws, size_t ws_bytes, void* stream);
 /* block tail relu(norm_identity(x) + shortcut) (res_net.py:62-79): mgn_iabn_bwd_reduce_x with the ReLU mask folded in.  g = gradient of the
  * tail's output, yrelu = that output (16-bit); writes dm = g * (yrelu > 0) -- the gradient of both summands: the shortcut's gradient and
- * what mgn_iabn_bwd_apply_x reads -- and reduces it in the same pass (replaces mgn_relu_mask_bwd + the re-read of its result). */
-int mgn_iabn_bwd_reduce_x_relu(const void* x, const void* g, const void* yrelu, void* dm, long M, int C, const float* weight,
-                               const float* bias, const float* scale, const float* offset, float eps, float* sums, float* dwb, void* ws,
-                               size_t ws_bytes, void* stream);
+ * what mgn_iabn_bwd_apply_x reads -- and reduces it in the same pass (replaces mgn_relu_mask_bwd + the re-read of its result).
+ * relu_bits (nullable): the mask as one byte per 8 values, bit k = (yrelu[k] > 0), as mgn_abn_add_relu_fwd writes it; when given it is
+ * read instead of yrelu (1/16 of the bytes; yrelu may then be NULL).  Same dm bit for bit. */
+int mgn_iabn_bwd_reduce_x_relu(const void* x, const void* g, const void* yrelu /*nullable with relu_bits*/, const void* relu_bits /*nullable*/,
+                               void* dm, long M, int C, const float* weight, const float* bias, const float* scale, const float* offset,
+                               float eps, float* sums, float* dwb, void* ws, size_t ws_bytes, void* stream);
 int mgn_iabn_bwd_apply_x(const void* x, const void* dy, void* dx, int dtype, long M, int C, const float* weight, const float* bias,
                          const float* scale, const float* offset, const float* saved, const float* sums, float total_count, float eps,
                          int activation, float slope, void* stream);
@@ -724,9 +726,11 @@ int mgn_add_relu_fwd(const void* a, const void* b, void* y, long n_elems, void* 
  * features feed the semantic, instance and depth heads, mg_net.py:290-311) in one pass; c may be NULL */
 int mgn_sum3(const void* a, const void* b, const void* c, void* y, long n_elems, void* stream);
 /* BasicBlock tail (res_net.py:62-79) with the second InPlaceABNSync(identity) folded in:
- * y = relu(bf16(scale[c] * x + offset[c]) + shortcut), x [M,C] bf16 = conv2 output (kept for the backward), C % 8 == 0. */
-int mgn_abn_add_relu_fwd(const void* x, const float* scale, const float* offset, const void* shortcut, void* y, long M, int C,
-                         void* stream);
+ * y = relu(bf16(scale[c] * x + offset[c]) + shortcut), x [M,C] bf16 = conv2 output (kept for the backward), C % 8 == 0.
+ * relu_bits (nullable): [M*C/8] bytes, bit k of byte i = (y[8 i + k] > 0) on the rounded 16-bit output -- the ReLU mask the backward
+ * (mgn_iabn_bwd_reduce_x_relu) then reads instead of y. */
+int mgn_abn_add_relu_fwd(const void* x, const float* scale, const float* offset, const void* shortcut, void* y, void* relu_bits /*nullable*/,
+                         long M, int C, void* stream);
 int mgn_relu_mask_bwd(const void* dy, const void* y, void* dx, long n_elems, void* stream);
 int mgn_colsum(const void* x, const void* x2 /*nullable*/, int N, long HW, int C, float scale, float* out, float* workspace,
                size_t workspace_bytes /* >= N*64*C*4 */, void* stream);
@@ -833,7 +837,7 @@ int mgn_att_abn_bwd_apply_f16(const void* g, const void* z, void* dy, const floa
 int mgn_add_relu_fwd_f16(const void* a, const void* b, void* y, long n_elems, void* stream);
 int mgn_sum3_f16(const void* a, const void* b, const void* c, void* y, long n_elems, void* stream);
 int mgn_abn_add_relu_fwd_f16(const void* x, const float* scale, const float* offset, const void* shortcut, void* y,
-    long M, int C, void* stream);
+    void* relu_bits /*nullable*/, long M, int C, void* stream);
 int mgn_relu_mask_bwd_f16(const void* dy, const void* y, void* dx, long n_elems, void* stream);
 int mgn_colsum_f16(const void* x, const void* x2 /*nullable*/, int N, long HW, int C, float scale, float* out,
     float* workspace, size_t workspace_bytes /* >= N*64*C*4 */, void* stream);
@@ -878,8 +882,9 @@ int mgn_iabn_bwd_reduce_f16(const void* y, const void* dy, int dtype, long M, in
 int mgn_iabn_bwd_reduce_x_f16(const void* x, const void* dy, int dtype, long M, int C, const float* weight, const
     float* bias, const float* scale, const float* offset, float eps, int activation, float slope, float* sums,
     float* dwb, void* ws, size_t ws_bytes, void* stream);
-int mgn_iabn_bwd_reduce_x_relu_f16(const void* x, const void* g, const void* yrelu, void* dm, long M, int C, const float* weight,
-    const float* bias, const float* scale, const float* offset, float eps, float* sums, float* dwb, void* ws, size_t ws_bytes, void* stream);
+int mgn_iabn_bwd_reduce_x_relu_f16(const void* x, const void* g, const void* yrelu, const void* relu_bits, void* dm, long M, int C,
+    const float* weight, const float* bias, const float* scale, const float* offset, float eps, float* sums, float* dwb, void* ws,
+    size_t ws_bytes, void* stream);
 int mgn_iabn_bwd_apply_f16(const void* y, const void* dy, void* dx /*may alias dy*/, int dtype, long M, int C, const
     float* weight, const float* bias, const float* saved, const float* sums, float total_count, float eps, int
     activation, float slope, void* stream);

@@ -193,9 +193,9 @@ def lib():
         L.mgn_msc_input.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.mgn_msc_accumulate.argtypes = [vp, ci, cl, cl, cl, cl] + [ci] * 9 + [cf, cf, cf, vp, vp]
         L.mgn_iabn_bwd_reduce_x.argtypes = [vp, vp, ci, cl, ci, vp, vp, vp, vp, cf, ci, cf, vp, vp, vp, sz, vp]
-        L.mgn_iabn_bwd_reduce_x_relu.argtypes = [vp, vp, vp, vp, cl, ci, vp, vp, vp, vp, cf, vp, vp, vp, sz, vp]
+        L.mgn_iabn_bwd_reduce_x_relu.argtypes = [vp, vp, vp, vp, vp, cl, ci, vp, vp, vp, vp, cf, vp, vp, vp, sz, vp]
         L.mgn_iabn_bwd_apply_x.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp]
-        L.mgn_abn_add_relu_fwd.argtypes = [vp, vp, vp, vp, vp, cl, ci, vp]
+        L.mgn_abn_add_relu_fwd.argtypes = [vp, vp, vp, vp, vp, vp, cl, ci, vp]
         L.mgn_abn_maxpool_fwd.argtypes = [vp, vp, vp, ci, cf, vp, vp, ci, ci, ci, ci, vp]
         L.mgn_abn_maxpool_bwd.argtypes = [vp] * 10 + [cf, cf, ci, cf, ci, ci, ci, ci, vp]
         L.mgn_depth_metrics_workspace_bytes.argtypes = [ci, ci, ctypes.POINTER(sz)]
@@ -526,14 +526,16 @@ def iabn_bwd_reduce_x(x, dy, M, C, weight, bias, coef, eps, activation, slope):
     return out[:2], out[2], out[3]
 
 
-def iabn_bwd_reduce_x_relu(x, g, yrelu, M, C, weight, bias, coef, eps):
-    """block tail: dm = g * (yrelu > 0) written AND reduced in one pass (mgn_iabn_bwd_reduce_x_relu) -> (dm, sums[2,C], d_weight, d_bias)"""
+def iabn_bwd_reduce_x_relu(x, g, yrelu, M, C, weight, bias, coef, eps, relu_bits=None):
+    """block tail: dm = g * (yrelu > 0) written AND reduced in one pass (mgn_iabn_bwd_reduce_x_relu) -> (dm, sums[2,C], d_weight, d_bias);
+    with `relu_bits` (abn_add_relu_fwd(..., want_bits=True)) the mask is read from there instead of yrelu"""
     out = torch.empty((4, C), dtype=torch.float32, device=x.device)
-    dm = _cl_like(yrelu)
+    dm = _cl_like(x)
     ws = _iabn_ws(x.device)
-    check(_fn("mgn_iabn_bwd_reduce_x_relu", x)(x.data_ptr(), g.data_ptr(), yrelu.data_ptr(), dm.data_ptr(), M, C, weight.data_ptr(), bias.data_ptr(),
-                                           coef[0].data_ptr(), coef[1].data_ptr(), eps, out.data_ptr(), out[2].data_ptr(), ws.data_ptr(),
-                                           ws.numel() * 4, _stream()), "mgn_iabn_bwd_reduce_x_relu")
+    check(_fn("mgn_iabn_bwd_reduce_x_relu", x)(x.data_ptr(), g.data_ptr(), None if yrelu is None else yrelu.data_ptr(),
+                                           None if relu_bits is None else relu_bits.data_ptr(), dm.data_ptr(), M, C, weight.data_ptr(),
+                                           bias.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), eps, out.data_ptr(), out[2].data_ptr(),
+                                           ws.data_ptr(), ws.numel() * 4, _stream()), "mgn_iabn_bwd_reduce_x_relu")
     return dm, out[:2], out[2], out[3]
 
 
@@ -543,12 +545,14 @@ def iabn_bwd_apply_x(x, dy, dx, M, C, weight, bias, coef, sums, total_count, eps
                                      float(total_count), eps, activation, slope, _stream()), "mgn_iabn_bwd_apply_x")
 
 
-def abn_add_relu_fwd(x, coef, shortcut):
+def abn_add_relu_fwd(x, coef, shortcut, want_bits=False):
+    """y = relu(norm(x) + shortcut); want_bits: also the ReLU mask, one byte per 8 outputs -> (y, bits)"""
     N, C, H, W = x.shape
     y = torch.empty_like(x)
+    bits = torch.empty(N * H * W * C // 8, dtype=torch.uint8, device=x.device) if want_bits else None
     check(_fn("mgn_abn_add_relu_fwd", x)(x.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), shortcut.data_ptr(), y.data_ptr(),
-                                     N * H * W, C, _stream()), "mgn_abn_add_relu_fwd")
-    return y
+                                     None if bits is None else bits.data_ptr(), N * H * W, C, _stream()), "mgn_abn_add_relu_fwd")
+    return (y, bits) if want_bits else y
 
 
 def iabn_bwd_apply(y, dy, dx, M, C, weight, bias, saved, sums, total_count, eps, activation, slope):

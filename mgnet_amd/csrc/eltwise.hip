@@ -68,10 +68,18 @@ __global__ __launch_bounds__(TPB) void sum3_h16(const uint4* __restrict__ a, con
     }
 }
 // residual-block tail with the second norm folded in: y = relu(bf16(scale[c] * x + offset[c]) + b)  -- the value the separate
-// in-place norm + add_relu_fwd produce, without writing the normalised map (x, the conv output, is kept for the backward)
+// in-place norm + add_relu_fwd produce, without writing the normalised map (x, the conv output, is kept for the backward).
+// BITS: one byte per 8 outputs is written beside y, bit k = (y[k] > 0) taken from the ROUNDED 16-bit value -- the backward's ReLU mask
+// (iabn.hip iabn_bwd_reduce_kernel<.., MASK = 2>) then reads 1/16 of the map instead of the map.
+__device__ __forceinline__ uint32_t positive_bits2(uint32_t w) {   // bit 0 / bit 1: low / high 16-bit value is > 0 (sign clear, magnitude non-zero)
+    const uint32_t t = w & 0x7fff7fffu;
+    const uint32_t pos = (((t + 0x7fff7fffu) | t) & 0x80008000u) & ~w;
+    return ((pos >> 15) & 1u) | ((pos >> 30) & 2u);
+}
+template <bool BITS>
 __global__ __launch_bounds__(TPB) void abn_add_relu_fwd(const uint4* __restrict__ x, const float* __restrict__ scale,
                                                         const float* __restrict__ offset, const uint4* __restrict__ b, uint4* __restrict__ y,
-                                                        long nvec, int cv) {
+                                                        long nvec, int cv, unsigned char* __restrict__ bits) {
     const long i0 = (long)blockIdx.x * TPB + threadIdx.x, stride = (long)gridDim.x * TPB;   // stride % cv == 0 (host)
     const int c0 = (int)(i0 % cv) * 8;
     float sc[8], of[8];
@@ -86,7 +94,10 @@ __global__ __launch_bounds__(TPB) void abn_add_relu_fwd(const uint4* __restrict_
         unpack8(pack8(va), va);   // the bf16 rounding of the stored normalised value
 #pragma unroll
         for (int k = 0; k < 8; ++k) va[k] = fmaxf(va[k] + vb[k], 0.f);
-        y[i] = pack8(va);
+        const uint4 r = pack8(va);
+        y[i] = r;
+        if constexpr (BITS)
+            bits[i] = (unsigned char)(positive_bits2(r.x) | (positive_bits2(r.y) << 2) | (positive_bits2(r.z) << 4) | (positive_bits2(r.w) << 6));
     }
 }
 // dx = dy where y > 0 (the same tensor is the gradient of both summands)
@@ -495,13 +506,18 @@ int MGN_SYM(mgn_sum3)(const void* a, const void* b, const void* c, void* y, long
                        (uint4*)y, n_elems / 8);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
-int MGN_SYM(mgn_abn_add_relu_fwd)(const void* x, const float* scale, const float* offset, const void* b, void* y, long M, int C, void* stream) {
+int MGN_SYM(mgn_abn_add_relu_fwd)(const void* x, const float* scale, const float* offset, const void* b, void* y, void* relu_bits, long M, int C,
+                                  void* stream) {
     if (!x || !scale || !offset || !b || !y || M < 1 || !c_ok(C)) return MGN_EINVAL;
     const long nvec = M * C / 8;
     const int cv = C / 8;
     // c_ok guarantees TPB % cv == 0: with any block count the grid stride stays a multiple of cv (fixed channels per thread)
-    hipLaunchKernelGGL(abn_add_relu_fwd, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)x, scale, offset, (const uint4*)b,
-                       (uint4*)y, nvec, cv);
+    if (relu_bits)
+        hipLaunchKernelGGL(abn_add_relu_fwd<true>, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)x, scale, offset,
+                           (const uint4*)b, (uint4*)y, nvec, cv, (unsigned char*)relu_bits);
+    else
+        hipLaunchKernelGGL(abn_add_relu_fwd<false>, dim3(blocks_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, (const uint4*)x, scale, offset,
+                           (const uint4*)b, (uint4*)y, nvec, cv, (unsigned char*)nullptr);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 int MGN_SYM(mgn_relu_mask_bwd)(const void* dy, const void* y, void* dx, long n_elems, void* stream) {

@@ -346,16 +346,21 @@ __device__ __forceinline__ uint32_t relu_mask2(uint32_t g, uint32_t yv) {
     return g & (((pos >> 15) & 0x00010001u) * 0xffffu);
 }
 
+// two mask bits (bit 0: low, bit 1: high 16-bit value) -> the AND mask of the packed word
+__device__ __forceinline__ uint32_t bits_mask2(uint32_t e) { return ((e & 1u) * 0xffffu) | (((e >> 1) & 1u) * 0xffff0000u); }
+
 // MASK (block tail relu(norm(x) + shortcut), 16-bit only): `dy` is the gradient g of the ReLU's OUTPUT and `yrelu` that output; the
 // gradient of both summands dm = g * (yrelu > 0) is formed here, stored to `dm_out` (the shortcut's gradient, and what the apply pass
 // reads) and reduced in the same pass -- the separate mask pass (read g, y; write dm) and this pass's re-read of dm disappear.
-template <typename T, bool FROMX = false, bool MASK = false>
+// MASK = 2: the mask comes from `rbits`, one byte per 8 values (bit k = yrelu[k] > 0, written by eltwise.hip abn_add_relu_fwd<true>):
+// 1/16 of the map is read instead of the map -- the same dm bit for bit.
+template <typename T, bool FROMX = false, int MASK = 0>
 __global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dy, long M, int C,
                                                               const float* __restrict__ weight, const float* __restrict__ bias,
                                                               float eps, int leaky, float slope, int SC, float* ws, unsigned* counter,
                                                               float* sums, float* dwb, const float* __restrict__ psc = nullptr,
                                                               const float* __restrict__ pof = nullptr, const T* __restrict__ yrelu = nullptr,
-                                                              T* __restrict__ dm_out = nullptr) {
+                                                              T* __restrict__ dm_out = nullptr, const unsigned char* __restrict__ rbits = nullptr) {
     // FROMX: `y` holds the norm's INPUT x and z = psc * x + pof is recomputed instead of inverted from the activated output
     // (used where the normalised map is not kept: fused norm + add + ReLU of the residual blocks).  Compile-time: a run-time
     // test inside the streaming loop cost the ordinary path 30 %.
@@ -374,10 +379,17 @@ __global__ __launch_bounds__(TPB) void iabn_bwd_reduce_kernel(const T* __restric
         [&](long r, int c0, typename Vec<T>::Raw (&q)[2]) {
             q[0] = Vec<T>::load_raw(y + r * C + c0);
             q[1] = Vec<T>::load_raw(dy + r * C + c0);
-            if constexpr (MASK) {
+            if constexpr (MASK == 1) {
                 const uint4 yr = *reinterpret_cast<const uint4*>(yrelu + r * C + c0);
                 uint4 m;
                 m.x = relu_mask2(q[1].x, yr.x); m.y = relu_mask2(q[1].y, yr.y); m.z = relu_mask2(q[1].z, yr.z); m.w = relu_mask2(q[1].w, yr.w);
+                *reinterpret_cast<uint4*>(dm_out + r * C + c0) = m;
+                q[1] = m;
+            }
+            if constexpr (MASK == 2) {
+                const uint32_t e = rbits[(r * C + c0) >> 3];
+                uint4 m;
+                m.x = q[1].x & bits_mask2(e); m.y = q[1].y & bits_mask2(e >> 2); m.z = q[1].z & bits_mask2(e >> 4); m.w = q[1].w & bits_mask2(e >> 6);
                 *reinterpret_cast<uint4*>(dm_out + r * C + c0) = m;
                 q[1] = m;
             }
@@ -706,20 +718,26 @@ int MGN_SYM(mgn_iabn_bwd_reduce_x)(const void* y, const void* dy, int dtype, lon
 }
 
 /* block tail: the reduction of mgn_iabn_bwd_reduce_x (identity activation) with the ReLU mask folded in -- g: gradient of relu(norm(x) +
- * shortcut), yrelu: that output; writes dm = g * (yrelu > 0) (the gradient of both summands) and reduces it in the same pass */
-int MGN_SYM(mgn_iabn_bwd_reduce_x_relu)(const void* x, const void* g, const void* yrelu, void* dm, long M, int C, const float* weight,
-                               const float* bias, const float* scale, const float* offset, float eps, float* sums, float* dwb, void* ws,
-                               size_t ws_bytes, void* stream_) {
+ * shortcut); the mask (output > 0) from `relu_bits` (one byte per 8 values, written by mgn_abn_add_relu_fwd) when given, else from
+ * `yrelu`, that output; writes dm = g * mask (the gradient of both summands) and reduces it in the same pass */
+int MGN_SYM(mgn_iabn_bwd_reduce_x_relu)(const void* x, const void* g, const void* yrelu, const void* relu_bits, void* dm, long M, int C,
+                               const float* weight, const float* bias, const float* scale, const float* offset, float eps, float* sums, float* dwb,
+                               void* ws, size_t ws_bytes, void* stream_) {
     int rc = check_shape(M, C, 1);
     if (rc != MGN_OK) return rc;
-    if (!x || !g || !yrelu || !dm || !weight || !bias || !scale || !offset || !sums || !ws) return MGN_EINVAL;
+    if (!x || !g || (!yrelu && !relu_bits) || !dm || !weight || !bias || !scale || !offset || !sums || !ws) return MGN_EINVAL;
     if (ws_bytes < sizeof(float) * 2 * (size_t)C * 1024) return MGN_ENOSPC;
     const int SC = slab_channels(C), nb = stat_blocks(M, SC, 1);
     unsigned* ctr = next_counter();
     if (!ctr || C / SC > 16) return MGN_ELAUNCH;
-    hipLaunchKernelGGL((iabn_bwd_reduce_kernel<__hip_bfloat16, true, true>), dim3(nb, C / SC), dim3(TPB), 0, (hipStream_t)stream_,
-                       (const __hip_bfloat16*)x, (const __hip_bfloat16*)g, M, C, weight, bias, eps, 0, 0.01f, SC, (float*)ws, ctr, sums, dwb, scale,
-                       offset, (const __hip_bfloat16*)yrelu, (__hip_bfloat16*)dm);
+    if (relu_bits)
+        hipLaunchKernelGGL((iabn_bwd_reduce_kernel<__hip_bfloat16, true, 2>), dim3(nb, C / SC), dim3(TPB), 0, (hipStream_t)stream_,
+                           (const __hip_bfloat16*)x, (const __hip_bfloat16*)g, M, C, weight, bias, eps, 0, 0.01f, SC, (float*)ws, ctr, sums, dwb,
+                           scale, offset, (const __hip_bfloat16*)nullptr, (__hip_bfloat16*)dm, (const unsigned char*)relu_bits);
+    else
+        hipLaunchKernelGGL((iabn_bwd_reduce_kernel<__hip_bfloat16, true, 1>), dim3(nb, C / SC), dim3(TPB), 0, (hipStream_t)stream_,
+                           (const __hip_bfloat16*)x, (const __hip_bfloat16*)g, M, C, weight, bias, eps, 0, 0.01f, SC, (float*)ws, ctr, sums, dwb,
+                           scale, offset, (const __hip_bfloat16*)yrelu, (__hip_bfloat16*)dm, (const unsigned char*)nullptr);
     return hipGetLastError() == hipSuccess ? MGN_OK : MGN_ELAUNCH;
 }
 

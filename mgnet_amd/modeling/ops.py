@@ -210,8 +210,14 @@ class _AbnAddReluFn(torch.autograd.Function):
             coef = _train_coef(x, M, C, w32, b32, eps, momentum, running_mean, running_var, world, group, pstats)
         else:
             coef = _C.iabn_eval_coeffs(w32, b32, running_mean, running_var, eps)
-        y = _C.abn_add_relu_fwd(x, coef, shortcut)
-        ctx.save_for_backward(x, y, w32, b32, coef)
+        # [HIP] training, 16-bit: the ReLU mask leaves as one byte per 8 outputs beside y -- the backward reads it instead of y
+        bits = None
+        if training and x.dtype in _C.H16 and not os.environ.get("MGN_NO_TAILBITS") and not os.environ.get("MGN_NO_TAILMASK_FUSE"):
+            y, bits = _C.abn_add_relu_fwd(x, coef, shortcut, want_bits=True)
+        else:
+            y = _C.abn_add_relu_fwd(x, coef, shortcut)
+        ctx.has_bits = bits is not None
+        ctx.save_for_backward(x, y, w32, b32, coef, *(() if bits is None else (bits,)))
         ctx.cfg = (M, C, eps, group, world, training, float(M) * world, weight.dtype)
         return y
 
@@ -219,14 +225,15 @@ class _AbnAddReluFn(torch.autograd.Function):
     def backward(ctx, g):
         from .. import _C
 
-        x, y, w32, b32, coef = ctx.saved_tensors
+        x, y, w32, b32, coef = ctx.saved_tensors[:5]
+        bits = ctx.saved_tensors[5] if ctx.has_bits else None
         M, C, eps, group, world, training, total, wdtype = ctx.cfg
         if not training:
             raise NotImplementedError("backward through eval-mode InPlaceABNSync is not on the training path")
         g = _cl(g, y)
         if x.dtype in _C.H16 and not os.environ.get("MGN_NO_TAILMASK_FUSE"):
             # [HIP] ReLU mask + reduction in one pass: dm = g * (y > 0) is written (gradient of both summands) while it is reduced
-            dm, sums, d_weight, d_bias = _C.iabn_bwd_reduce_x_relu(x, g, y, M, C, w32, b32, coef, eps)
+            dm, sums, d_weight, d_bias = _C.iabn_bwd_reduce_x_relu(x, g, y, M, C, w32, b32, coef, eps, relu_bits=bits)
         else:
             dm = _C.relu_mask_bwd(g, y)   # gradient of both summands
             sums, d_weight, d_bias = _C.iabn_bwd_reduce_x(x, dm, M, C, w32, b32, coef, eps, 0, 0.01)

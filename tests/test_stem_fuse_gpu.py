@@ -168,3 +168,63 @@ def test_multi_rank_branch_with_two_identical_ranks(monkeypatch):
         assert torch.allclose(s[1], d[1], rtol=1e-3, atol=1e-3 * float(s[1].abs().max()))
         assert torch.allclose(s[2], d[2], rtol=1e-5, atol=1e-6)          # local parameter gradients (DDP averages them later)
         assert torch.allclose(s[3], d[3], rtol=1e-4)                     # running variance: unbiased with the doubled count
+
+
+# ---- the block tail's ReLU mask as one byte per 8 outputs -------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 64, 24, 40), (1, 128, 9, 7), (2, 512, 4, 8), (8, 64, 256, 512)])
+def test_block_tail_mask_bits_equal_the_mask_from_the_output(dtype, shape):
+    """abn_add_relu_fwd(want_bits) leaves bit k of byte i = (y[8 i + k] > 0) on the ROUNDED output (values that round to zero, -0 and the
+    clamped negatives are 0), and the backward that reads those bytes gives the dm, sums and parameter gradients of the backward that
+    reads y -- bit for bit (res_net.py:62-79, BasicBlock tail)."""
+    from mgnet_amd import _C
+    N, C, H, W = shape
+    M = N * H * W
+    torch.manual_seed(11)
+    x = torch.randn(shape, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    sc = torch.randn(shape, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    # exact zeros and sums that vanish or underflow: shortcut = -norm(x) on a slice, tiny values on another
+    coef = torch.stack([torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1, torch.zeros(C, device="cuda"),
+                        torch.ones(C, device="cuda")]).contiguous()
+    z = (x.float() * coef[0].view(1, -1, 1, 1) + coef[1].view(1, -1, 1, 1)).to(dtype)
+    sc[0, :, 0] = (-z[0, :, 0].float()).to(dtype)
+    sc[0, :, 1] = (-z[0, :, 1].float() + (1e-7 if dtype == torch.float16 else 1e-39)).to(dtype)
+    y0 = _C.abn_add_relu_fwd(x, coef, sc)
+    y, bits = _C.abn_add_relu_fwd(x, coef, sc, want_bits=True)
+    assert torch.equal(y, y0)
+    flat = y.permute(0, 2, 3, 1).reshape(-1, 8)
+    want = ((flat > 0).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(bits, want)
+    assert int((flat == 0).sum()) >= C    # the zero slice is in play
+    g = torch.randn(shape, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    w32, b32 = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+    a = _C.iabn_bwd_reduce_x_relu(x, g, y, M, C, w32, b32, coef, 1e-5)
+    b = _C.iabn_bwd_reduce_x_relu(x, g, None, M, C, w32, b32, coef, 1e-5, relu_bits=bits)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert torch.equal(a[0], _C.relu_mask_bwd(g, y))
+
+
+def test_block_tail_module_uses_the_mask_bits(monkeypatch):
+    """ops.abn_add_relu in training mode hands the bytes to its backward; MGN_NO_TAILBITS restores the read of y: same gradients bit for bit"""
+    from mgnet_amd import _C
+    from mgnet_amd.modeling import ops
+    from mgnet_amd.modeling.layers import InPlaceABNSync
+    seen = []
+    real = _C.iabn_bwd_reduce_x_relu
+    monkeypatch.setattr(_C, "iabn_bwd_reduce_x_relu", lambda *a, **k: (seen.append(k.get("relu_bits") is not None), real(*a, **k))[1])
+
+    def grads():
+        torch.manual_seed(4)
+        x = torch.randn(2, 64, 24, 40, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        sc = torch.randn(2, 64, 24, 40, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        norm = InPlaceABNSync(64, momentum=0.01, activation="identity").cuda().train()
+        y = ops.abn_add_relu(x * 1.0, norm, sc)
+        y.backward(torch.randn_like(y))
+        return y.detach(), x.grad, sc.grad, norm.weight.grad, norm.bias.grad
+    a = grads()
+    monkeypatch.setenv("MGN_NO_TAILBITS", "1")
+    b = grads()
+    assert seen == [True, False]
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
